@@ -1,0 +1,202 @@
+"""ctypes mirror of include/c4gpu.h / include/c4m.h (the C ABI of libc4gpu.so).
+
+Only plumbing lives here: struct layouts, function prototypes and the loader.  The product is the shared
+library; this module never computes anything itself and raises loudly when the library is missing.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libc4gpu.so")
+
+MAX_STATES, MAX_TRANSITIONS, MAX_CALCS, MAX_SHADOWS, NAME_LEN = 16, 32, 16, 4, 48
+SPLICE_MAX_LEN = 32
+CELL_MAX = 1 + MAX_SHADOWS + 3
+IMPOSSIBLY_LOW_SCORE = -987654321
+
+SCOPE_ANYWHERE, SCOPE_EDGE, SCOPE_QUERY, SCOPE_TARGET, SCOPE_CORNER = range(5)
+(LABEL_NONE, LABEL_MATCH, LABEL_GAP, LABEL_NER, LABEL_5SS, LABEL_3SS, LABEL_INTRON, LABEL_SPLIT_CODON,
+ LABEL_FRAMESHIFT) = range(9)
+MODE_FIND_SCORE, MODE_FIND_PATH, MODE_FIND_REGION, MODE_FIND_CHECKPOINTS = range(4)
+ALPHABET_DNA, ALPHABET_PROTEIN = 0, 1
+SS5_FORWARD, SS3_FORWARD, SS3_REVERSE, SS5_REVERSE = range(4)
+(CALC_CONST, CALC_MATCH_DNA, CALC_MATCH_PROTEIN, CALC_MATCH_P2D, CALC_SPLICE_PRE, CALC_SPLICE_POST,
+ CALC_PHASE_PRE, CALC_PHASE_POST) = range(8)
+
+
+class Calc(C.Structure):
+    _fields_ = [("name", C.c_char * NAME_LEN), ("kind", C.c_int32), ("value", C.c_int32),
+                ("param", C.c_int32), ("max_score", C.c_int32), ("protect", C.c_int32)]
+
+
+class Transition(C.Structure):
+    _fields_ = [("name", C.c_char * NAME_LEN), ("input", C.c_int32), ("output", C.c_int32),
+                ("advance_query", C.c_int32), ("advance_target", C.c_int32), ("calc", C.c_int32),
+                ("label", C.c_int32), ("dst_shadow_mask", C.c_uint32)]
+
+
+class Shadow(C.Structure):
+    _fields_ = [("name", C.c_char * NAME_LEN), ("designation", C.c_int32), ("on_target", C.c_int32),
+                ("src_state_mask", C.c_uint32), ("dst_transition_mask", C.c_uint32)]
+
+
+class Model(C.Structure):
+    _fields_ = [("name", C.c_char * NAME_LEN),
+                ("n_states", C.c_int32), ("n_transitions", C.c_int32), ("n_calcs", C.c_int32),
+                ("n_shadows", C.c_int32), ("start_state", C.c_int32), ("end_state", C.c_int32),
+                ("start_scope", C.c_int32), ("end_scope", C.c_int32),
+                ("max_query_advance", C.c_int32), ("max_target_advance", C.c_int32),
+                ("total_shadow_designations", C.c_int32),
+                ("query_alphabet", C.c_int32), ("target_alphabet", C.c_int32),
+                ("state_names", (C.c_char * NAME_LEN) * MAX_STATES),
+                ("calcs", Calc * MAX_CALCS),
+                ("transitions", Transition * MAX_TRANSITIONS),
+                ("shadows", Shadow * MAX_SHADOWS)]
+
+
+class SpliceModel(C.Structure):
+    _fields_ = [("model_length", C.c_int32), ("splice_after", C.c_int32),
+                ("index", C.c_uint8 * 256), ("data", (C.c_float * 5) * SPLICE_MAX_LEN)]
+
+
+class Params(C.Structure):
+    _fields_ = [("dna_submat", (C.c_int32 * 24) * 24), ("protein_submat", (C.c_int32 * 24) * 24),
+                ("submat_index", C.c_uint8 * 256), ("nt2d", C.c_uint8 * 256),
+                ("trans", C.c_uint8 * 4096), ("aa", C.c_uint8 * 40),
+                ("gap_open", C.c_int32), ("gap_extend", C.c_int32),
+                ("codon_gap_open", C.c_int32), ("codon_gap_extend", C.c_int32),
+                ("min_intron", C.c_int32), ("max_intron", C.c_int32),
+                ("intron_open_penalty", C.c_int32), ("frameshift_penalty", C.c_int32),
+                ("splice", SpliceModel * 4)]
+
+
+class Region(C.Structure):
+    _fields_ = [("query_start", C.c_int32), ("target_start", C.c_int32),
+                ("query_length", C.c_int32), ("target_length", C.c_int32)]
+
+    def astuple(self):
+        return (self.query_start, self.target_start, self.query_length, self.target_length)
+
+
+class Pair(C.Structure):
+    _fields_ = [("query", C.c_char_p), ("query_len", C.c_int32),
+                ("target", C.c_char_p), ("target_len", C.c_int32)]
+
+
+class Alignment(C.Structure):
+    _fields_ = [("score", C.c_int32), ("region", Region), ("n_ops", C.c_int32),
+                ("op_transition", C.POINTER(C.c_int32)), ("op_length", C.POINTER(C.c_int32)),
+                ("valid", C.c_int32)]
+
+
+class Continuation(C.Structure):
+    _fields_ = [("first_state", C.c_int32), ("final_state", C.c_int32),
+                ("first_cell", C.c_int32 * CELL_MAX)]
+
+
+class ViterbiJob(C.Structure):
+    _fields_ = [("pair", C.c_int32), ("region", Region), ("use_continuation", C.c_int32),
+                ("continuation", Continuation), ("checkpoint_count", C.c_int32)]
+
+
+class ViterbiResult(C.Structure):
+    _fields_ = [("score", C.c_int32), ("query_start", C.c_int32), ("target_start", C.c_int32),
+                ("query_end", C.c_int32), ("target_end", C.c_int32),
+                ("final_cell", C.c_int32 * CELL_MAX), ("last_srp", C.c_int32),
+                ("n_ops", C.c_int32), ("ops", C.POINTER(C.c_int32)),
+                ("checkpoints", C.POINTER(C.c_int32))]
+
+
+# (name, restype, argtypes) for every symbol include/*.h declares
+PROTOTYPES = [
+    ("c4gpu_abi_version", C.c_int, []),
+    ("c4gpu_last_error", C.c_char_p, []),
+    ("c4gpu_ctx_create", C.c_void_p, [C.c_int]),
+    ("c4gpu_ctx_destroy", None, [C.c_void_p]),
+    ("c4gpu_ctx_set_stream", None, [C.c_void_p, C.c_void_p]),
+    ("c4gpu_ctx_device_info", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int64)]),
+    ("c4gpu_params_default", None, [C.POINTER(Params)]),
+    ("c4gpu_model_get", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(Params), C.POINTER(Model)]),
+    ("c4gpu_model_make_continuation", None, [C.POINTER(Model), C.POINTER(Model)]),
+    ("c4gpu_model_plugin_name", C.c_int, [C.POINTER(Model), C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    ("c4gpu_model_is_accelerated", C.c_int, [C.POINTER(Model)]),
+    ("c4gpu_use_reduced_space", C.c_int, [C.POINTER(Model), C.POINTER(Region), C.c_int]),
+    ("c4gpu_checkpoint_rows", C.c_int, [C.POINTER(Model), C.POINTER(Region), C.c_int]),
+    ("c4gpu_splice_predict", C.c_int, [C.c_void_p, C.POINTER(Params), C.c_char_p, C.c_int32,
+                                       C.POINTER(C.POINTER(C.c_int32))]),
+    ("c4gpu_viterbi_batch", C.c_int, [C.c_void_p, C.POINTER(Model), C.POINTER(Params), C.c_int,
+                                      C.POINTER(Pair), C.c_int32, C.POINTER(ViterbiJob), C.c_int32,
+                                      C.POINTER(ViterbiResult)]),
+    ("c4gpu_viterbi_result_clear", None, [C.POINTER(ViterbiResult)]),
+    ("c4gpu_optimal_find_score_batch", C.c_int, [C.c_void_p, C.POINTER(Model), C.POINTER(Params),
+                                                 C.POINTER(Pair), C.c_int32, C.POINTER(C.c_int32)]),
+    ("c4gpu_optimal_find_path_batch", C.c_int, [C.c_void_p, C.POINTER(Model), C.POINTER(Params),
+                                                C.POINTER(Pair), C.c_int32, C.c_int, C.c_int32,
+                                                C.POINTER(Alignment)]),
+    ("c4gpu_alignment_clear", None, [C.POINTER(Alignment)]),
+    ("c4gpu_batch_create", C.c_void_p, [C.c_void_p, C.POINTER(Model), C.POINTER(Params),
+                                        C.POINTER(Pair), C.c_int32]),
+    ("c4gpu_batch_destroy", None, [C.c_void_p]),
+    ("c4gpu_batch_run", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int32]),
+    ("c4gpu_batch_scores", C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(Region)]),
+    ("c4gpu_batch_alignment", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Alignment)]),
+    ("c4gpu_batch_kernel_stats", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double),
+                                           C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("c4gpu_alignment_format", C.c_int, [C.POINTER(Model), C.POINTER(Alignment), C.c_int,
+                                         C.c_char_p, C.c_int32, C.c_char, C.c_char_p, C.c_int32, C.c_char,
+                                         C.c_int, C.c_char_p, C.c_size_t]),
+    ("c4gpu_splice_max_score", C.c_float, [C.POINTER(SpliceModel)]),
+    # c4m.h
+    ("c4m_model_create", C.c_void_p, [C.c_char_p]),
+    ("c4m_model_destroy", None, [C.c_void_p]),
+    ("c4m_model_rename", None, [C.c_void_p, C.c_char_p]),
+    ("c4m_model_open", None, [C.c_void_p]),
+    ("c4m_model_close", C.c_int, [C.c_void_p]),
+    ("c4m_model_is_open", C.c_int, [C.c_void_p]),
+    ("c4m_model_set_alphabets", None, [C.c_void_p, C.c_int, C.c_int]),
+    ("c4m_add_state", C.c_int, [C.c_void_p, C.c_char_p]),
+    ("c4m_add_calc", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("c4m_add_transition", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int]),
+    ("c4m_add_shadow", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int]),
+    ("c4m_shadow_add_src_state", None, [C.c_void_p, C.c_int, C.c_int]),
+    ("c4m_shadow_add_dst_transition", None, [C.c_void_p, C.c_int, C.c_int]),
+    ("c4m_configure_start_state", None, [C.c_void_p, C.c_int]),
+    ("c4m_configure_end_state", None, [C.c_void_p, C.c_int]),
+    ("c4m_make_stereo", None, [C.c_void_p, C.c_char_p, C.c_char_p]),
+    ("c4m_insert", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    ("c4m_select_single_transition", C.c_int, [C.c_void_p, C.c_int]),
+    ("c4m_select_transitions", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]),
+    ("c4m_transition_input", C.c_int, [C.c_void_p, C.c_int]),
+    ("c4m_transition_output", C.c_int, [C.c_void_p, C.c_int]),
+    ("c4m_transition_id", C.c_int, [C.c_void_p, C.c_int]),
+    ("c4m_flatten", C.c_int, [C.c_void_p, C.POINTER(Model)]),
+    ("c4m_ungapped_create", C.c_void_p, [C.c_int, C.c_int, C.POINTER(Params)]),
+    ("c4m_affine_create", C.c_void_p, [C.c_int, C.c_int, C.c_int, C.POINTER(Params)]),
+    ("c4m_intron_create", C.c_void_p, [C.c_char_p, C.c_int, C.POINTER(Params)]),
+    ("c4m_est2genome_create", C.c_void_p, [C.POINTER(Params)]),
+    ("c4m_protein2dna_create", C.c_void_p, [C.c_int, C.POINTER(Params)]),
+]
+
+_lib = None
+
+
+def load(path=None):
+    """dlopen libc4gpu.so and attach prototypes.  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("C4GPU_LIB", LIB_PATH)
+    if not os.path.exists(p):
+        raise RuntimeError(
+            "libc4gpu.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
+            "there is no Python/CPU fallback for the C4 engine" % p)
+    lib = C.CDLL(p)
+    for name, res, args in PROTOTYPES:
+        fn = getattr(lib, name)          # AttributeError if the ABI header and the library diverge
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib

@@ -1,0 +1,273 @@
+/* c4gpu.h — C ABI of the MI355X-native C4 dynamic-programming engine.
+ *
+ * This is the drop-in boundary.  Everything here is plain C: POD structs, pointers and
+ * sizes; no torch / HIP / GLib types appear in any signature.  Each entry point cites the reference
+ * interface (file:line under the exonerate tree) it replaces; INTEGRATION.md shows the binding a
+ * maintainer adds on the exonerate side (a `Viterbi_DP_Func` shim + a batching `JobQueue`).
+ *
+ * Layering (mirrors the reference):
+ *   c4gpu_model / c4m_*      <->  C4_Model builder API               src/c4/c4.h:198-356, c4.c:1669
+ *   c4gpu_model_get          <->  Model_Type_get_model               src/model/modeltype.c
+ *   c4gpu_viterbi_batch      <->  Viterbi_DP_Func / Viterbi_calculate src/c4/viterbi.h:95-98, viterbi.c:846
+ *   c4gpu_optimal_*_batch    <->  Optimal_find_score / _find_path    src/c4/optimal.c:123,368
+ *   c4gpu_splice_predict     <->  SplicePredictor_predict_array_int  src/sequence/splice.c:383
+ *   c4gpu_alignment_format   <->  Alignment_print_{sugar,cigar,vulgar}_block  src/c4/alignment.c:1622-1779
+ */
+#ifndef INCLUDED_C4GPU_H
+#define INCLUDED_C4GPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C4GPU_ABI_VERSION 1
+
+/* src/c4/c4.h:28-30 */
+typedef int32_t c4gpu_score;
+#define C4GPU_IMPOSSIBLY_LOW_SCORE  (-987654321)
+#define C4GPU_IMPOSSIBLY_HIGH_SCORE (987654321)
+
+#define C4GPU_MAX_STATES       16
+#define C4GPU_MAX_TRANSITIONS  32
+#define C4GPU_MAX_CALCS        16
+#define C4GPU_MAX_SHADOWS       4
+#define C4GPU_NAME_LEN         48
+#define C4GPU_SUBMAT_SIZE      24   /* SUBMAT_ALPHABETSIZE, src/sequence/submat.h:32 */
+#define C4GPU_SPLICE_MAX_LEN   32
+
+/* C4_Scope, src/c4/c4.h:91-97 (same numeric values) */
+enum { C4GPU_SCOPE_ANYWHERE = 0, C4GPU_SCOPE_EDGE, C4GPU_SCOPE_QUERY, C4GPU_SCOPE_TARGET, C4GPU_SCOPE_CORNER };
+/* C4_Label, src/c4/c4.h:114-124 (same numeric values) */
+enum { C4GPU_LABEL_NONE = 0, C4GPU_LABEL_MATCH, C4GPU_LABEL_GAP, C4GPU_LABEL_NER, C4GPU_LABEL_5SS,
+       C4GPU_LABEL_3SS, C4GPU_LABEL_INTRON, C4GPU_LABEL_SPLIT_CODON, C4GPU_LABEL_FRAMESHIFT };
+/* C4_Protect, src/c4/c4.h:69-73 */
+enum { C4GPU_PROTECT_NONE = 0, C4GPU_PROTECT_OVERFLOW = 1, C4GPU_PROTECT_UNDERFLOW = 2 };
+/* Viterbi_Mode, src/c4/viterbi.h:104-109 */
+enum { C4GPU_MODE_FIND_SCORE = 0, C4GPU_MODE_FIND_PATH, C4GPU_MODE_FIND_REGION, C4GPU_MODE_FIND_CHECKPOINTS };
+/* Alphabet_Type, src/sequence/alphabet.h:40-44 */
+enum { C4GPU_ALPHABET_DNA = 0, C4GPU_ALPHABET_PROTEIN = 1 };
+/* SpliceType order used for the per-target splice arrays */
+enum { C4GPU_SS5_FORWARD = 0, C4GPU_SS3_FORWARD = 1, C4GPU_SS3_REVERSE = 2, C4GPU_SS5_REVERSE = 3 };
+
+/* What a C4_Calc's calc_func computes, recognised from the calc (src/c4/c4.h:75-86).  A model whose
+ * calcs are all one of these kinds can run on the device; anything else is "not accelerated". */
+enum {
+    C4GPU_CALC_CONST = 0,        /* returns `value` (gap open/extend affine.c:88-124, frameshift.c:49-59)   */
+    C4GPU_CALC_MATCH_DNA,        /* Match_1_1_dna_score_func      match.c:271  dna submat[q][t]              */
+    C4GPU_CALC_MATCH_PROTEIN,    /* Match_1_1_protein_score_func  match.c:287  protein submat[q][t]          */
+    C4GPU_CALC_MATCH_P2D,        /* Match_1_3_score_func          match.c:347  protein submat[q][aa(t..t+2)] */
+    C4GPU_CALC_SPLICE_PRE,       /* Intron_calc_* with is_pre     intron.c:138-161: value + ss[param][tpos]  */
+    C4GPU_CALC_SPLICE_POST,      /* Intron_calc_* post: length check against shadow, then ss[param][tpos]    */
+    C4GPU_CALC_PHASE_PRE,        /* phase.c split-codon calcs (protein2genome)                               */
+    C4GPU_CALC_PHASE_POST
+};
+
+/* C4_Calc, src/c4/c4.h:75-86 */
+typedef struct {
+    char    name[C4GPU_NAME_LEN];
+    int32_t kind;       /* C4GPU_CALC_* */
+    int32_t value;      /* CONST: the score; SPLICE_PRE: intron open penalty */
+    int32_t param;      /* SPLICE_*: which splice array (C4GPU_SS*); PHASE_*: phase (1|2) */
+    int32_t max_score;  /* C4_Calc.max_score */
+    int32_t protect;    /* C4GPU_PROTECT_* bit set */
+} c4gpu_calc;
+
+/* C4_Transition, src/c4/c4.h:126-137; `id` is the index in c4gpu_model.transitions, which is the closed
+ * model's evaluation / tie-break order (C4_Model_topological_sort, c4.c:1418). */
+typedef struct {
+    char    name[C4GPU_NAME_LEN];
+    int32_t input, output;                  /* state ids */
+    int32_t advance_query, advance_target;
+    int32_t calc;                           /* index into calcs, -1 for a NULL calc (scores 0) */
+    int32_t label;                          /* C4GPU_LABEL_* */
+    uint32_t dst_shadow_mask;               /* shadows whose end_func runs on this transition */
+} c4gpu_transition;
+
+/* C4_Shadow, src/c4/c4.h:139-149.  In-scope shadows carry a sequence position (intron.c:454-493). */
+typedef struct {
+    char    name[C4GPU_NAME_LEN];
+    int32_t designation;                    /* cell slot = designation + 1 */
+    int32_t on_target;                      /* 1: start_func returns target_pos; 0: query_pos */
+    uint32_t src_state_mask;                /* states the shadow starts from */
+    uint32_t dst_transition_mask;           /* transitions it ends on */
+} c4gpu_shadow;
+
+/* A *closed* C4_Model flattened to a POD (src/c4/c4.h:172-194). */
+typedef struct {
+    char    name[C4GPU_NAME_LEN];
+    int32_t n_states, n_transitions, n_calcs, n_shadows;
+    int32_t start_state, end_state;         /* C4_StartState/C4_EndState .state ids */
+    int32_t start_scope, end_scope;         /* C4GPU_SCOPE_* */
+    int32_t max_query_advance, max_target_advance;
+    int32_t total_shadow_designations;
+    int32_t query_alphabet, target_alphabet; /* C4GPU_ALPHABET_* (what the match calcs expect) */
+    char             state_names[C4GPU_MAX_STATES][C4GPU_NAME_LEN];
+    c4gpu_calc       calcs[C4GPU_MAX_CALCS];
+    c4gpu_transition transitions[C4GPU_MAX_TRANSITIONS];
+    c4gpu_shadow     shadows[C4GPU_MAX_SHADOWS];
+} c4gpu_model;
+
+/* One splice-site PSSM after SplicePredictor_create (splice.c:242-295): log-odds floats. */
+typedef struct {
+    int32_t model_length, splice_after;
+    uint8_t index[256];                     /* residue -> column 0..4 */
+    float   data[C4GPU_SPLICE_MAX_LEN][5];
+} c4gpu_splice_model;
+
+/* The scoring data the per-cell calcs read: what `user_data` + the static ArgumentSets hold in the
+ * reference (match.c:39, affine.c:21, intron.c:21, frameshift.c, submat.c, translate.c). */
+typedef struct {
+    int32_t dna_submat[C4GPU_SUBMAT_SIZE][C4GPU_SUBMAT_SIZE];
+    int32_t protein_submat[C4GPU_SUBMAT_SIZE][C4GPU_SUBMAT_SIZE];
+    uint8_t submat_index[256];              /* residue -> row (24 = not in alphabet: rejected) */
+    uint8_t nt2d[256];                      /* translate.h:40-50 */
+    uint8_t trans[4096];
+    uint8_t aa[40];
+    int32_t gap_open, gap_extend, codon_gap_open, codon_gap_extend;   /* affine.c:24-35 */
+    int32_t min_intron, max_intron, intron_open_penalty;              /* intron.c:24-32 */
+    int32_t frameshift_penalty;
+    c4gpu_splice_model splice[4];           /* indexed by C4GPU_SS* */
+} c4gpu_params;
+
+/* Region, src/c4/region.h:26-32 */
+typedef struct { int32_t query_start, target_start, query_length, target_length; } c4gpu_region;
+
+/* One query x target pair handed over at the boundary: residues already flattened to bytes
+ * (Sequence_strncpy, sequence.c:588).  Pointers are HOST pointers for the *_batch calls below. */
+typedef struct {
+    const uint8_t *query;  int32_t query_len;
+    const uint8_t *target; int32_t target_len;
+} c4gpu_pair;
+
+/* AlignmentOperation list, src/c4/alignment.h; ops are (transition id, run length). */
+typedef struct {
+    c4gpu_score  score;
+    c4gpu_region region;                    /* in sequence coordinates */
+    int32_t      n_ops;
+    int32_t     *op_transition;             /* malloc'd by the library, freed by c4gpu_alignment_clear */
+    int32_t     *op_length;
+    int32_t      valid;                     /* 0: no alignment (score below threshold) */
+} c4gpu_alignment;
+
+/* ---- one Viterbi call (Viterbi_DP_Func level) -------------------------------------------------- */
+
+/* Viterbi_Continuation, src/c4/viterbi.h:56-61 */
+typedef struct {
+    int32_t first_state, final_state;
+    c4gpu_score first_cell[1 + C4GPU_MAX_SHADOWS + 3];
+} c4gpu_continuation;
+
+typedef struct {
+    int32_t      pair;                      /* index into the pair array */
+    c4gpu_region region;
+    int32_t      use_continuation;          /* model is run with CORNER/CORNER scopes (viterbi.c:68-76) */
+    c4gpu_continuation continuation;
+    int32_t      checkpoint_count;          /* FIND_CHECKPOINTS: Viterbi_checkpoint_rows (viterbi.c:207) */
+} c4gpu_viterbi_job;
+
+typedef struct {
+    c4gpu_score score;
+    int32_t query_start, target_start, query_end, target_end;  /* vd->curr_* (viterbi.c:464-478), region-relative */
+    c4gpu_score final_cell[1 + C4GPU_MAX_SHADOWS + 3];          /* continuation->final_cell (viterbi.c:828-832) */
+    int32_t last_srp;                                           /* vd->checkpoint->last_srp (viterbi.c:813) */
+    int32_t n_ops;                                              /* FIND_PATH: raw transition path, start->end */
+    int32_t *ops;                                               /* malloc'd transition ids (one per step) */
+    c4gpu_score *checkpoints;                                   /* FIND_CHECKPOINTS: [cp][row][i][state][cell] */
+} c4gpu_viterbi_result;
+
+/* ---- library ----------------------------------------------------------------------------------- */
+
+typedef struct c4gpu_ctx c4gpu_ctx;
+
+int         c4gpu_abi_version(void);
+const char *c4gpu_last_error(void);
+
+/* Opens HIP device `device_ordinal`.  Returns NULL (and sets last_error) when no gfx950 device or the
+ * HIP runtime is unavailable: there is NO CPU fallback in this library. */
+c4gpu_ctx  *c4gpu_ctx_create(int device_ordinal);
+void        c4gpu_ctx_destroy(c4gpu_ctx *ctx);
+/* Use an externally owned HIP stream (e.g. torch's current stream) for all launches; NULL = default. */
+void        c4gpu_ctx_set_stream(c4gpu_ctx *ctx, void *hip_stream);
+int         c4gpu_ctx_device_info(c4gpu_ctx *ctx, char *name, size_t name_len, int *n_cu, int64_t *mem_bytes);
+
+/* Defaults of the reference's ArgumentSets: nucleic / blosum62 matrices, standard genetic code,
+ * primate splice PSSMs, -12/-4, -18/-8, intron 30..200000/-30, frameshift -28. */
+void        c4gpu_params_default(c4gpu_params *out);
+
+/* Model_Type_get_model (modeltype.c): "affine:local", "affine:global", "affine:bestfit",
+ * "affine:overlap", "ungapped", "est2genome", "protein2dna", "protein2dna:bestfit", "protein2genome",
+ * "protein2genome:bestfit".  Returns 0 on success. */
+int         c4gpu_model_get(const char *model_type, int query_alphabet, int target_alphabet,
+                            const c4gpu_params *params, c4gpu_model *out);
+/* Viterbi_create's continuation copy: same tables, CORNER/CORNER scopes (viterbi.c:68-76). */
+void        c4gpu_model_make_continuation(const c4gpu_model *model, c4gpu_model *out);
+/* Codegen_clean_path_component("optimal:<name> find <what>") — the Bootstrapper_lookup key
+ * (codegen.c:39-55, optimal.c:31-67).  Returns length written. */
+int         c4gpu_model_plugin_name(const c4gpu_model *model, int mode, int use_continuation,
+                                    char *buf, size_t buf_len);
+/* 1 when every calc kind / shadow of `model` is implemented by the device engine. */
+int         c4gpu_model_is_accelerated(const c4gpu_model *model);
+
+/* Viterbi_use_reduced_space (viterbi.c:128-150) and Viterbi_checkpoint_rows (viterbi.c:207-218):
+ * identical decisions to the reference for a given --dpmemory (Mb). */
+int         c4gpu_use_reduced_space(const c4gpu_model *model, const c4gpu_region *region, int dpmemory_mb);
+int         c4gpu_checkpoint_rows(const c4gpu_model *model, const c4gpu_region *region, int dpmemory_mb);
+
+/* SplicePredictor_predict_array_int (splice.c:383-397) for the 4 splice types over whole targets, on
+ * the device.  out[k] (k = C4GPU_SS*) receives target_len int32 each. */
+int         c4gpu_splice_predict(c4gpu_ctx *ctx, const c4gpu_params *params,
+                                 const uint8_t *target, int32_t target_len, int32_t *out[4]);
+
+/* Viterbi_DP_Func (viterbi.h:95-98) for a batch of independent jobs in one mode.
+ * soi (SubOpt_Index) must be NULL on the reference side: sub-optimal blocking is not accelerated. */
+int         c4gpu_viterbi_batch(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params,
+                                int mode, const c4gpu_pair *pairs, int32_t n_pairs,
+                                const c4gpu_viterbi_job *jobs, int32_t n_jobs,
+                                c4gpu_viterbi_result *results);
+void        c4gpu_viterbi_result_clear(c4gpu_viterbi_result *r);
+
+/* Optimal_find_score (optimal.c:123) over full pair rectangles. */
+int         c4gpu_optimal_find_score_batch(c4gpu_ctx *ctx, const c4gpu_model *model,
+                                           const c4gpu_params *params,
+                                           const c4gpu_pair *pairs, int32_t n_pairs,
+                                           c4gpu_score *scores);
+/* Optimal_find_path (optimal.c:368): region -> checkpoints -> sub-alignments, same orchestration and
+ * the same memory decisions as the reference at `dpmemory_mb`; alignments[i].valid = 0 when the score
+ * is below `threshold`. */
+int         c4gpu_optimal_find_path_batch(c4gpu_ctx *ctx, const c4gpu_model *model,
+                                          const c4gpu_params *params,
+                                          const c4gpu_pair *pairs, int32_t n_pairs,
+                                          int dpmemory_mb, c4gpu_score threshold,
+                                          c4gpu_alignment *alignments);
+void        c4gpu_alignment_clear(c4gpu_alignment *a);
+
+/* Device-resident batches (bench / shim hot loop): upload once, run many times. */
+typedef struct c4gpu_batch c4gpu_batch;
+c4gpu_batch *c4gpu_batch_create(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params,
+                                const c4gpu_pair *pairs, int32_t n_pairs);
+void         c4gpu_batch_destroy(c4gpu_batch *b);
+/* One pass of the hot path over the resident batch. `what`: 0 = score pass only (FIND_SCORE),
+ * 1 = region pass only, 2 = full Optimal_find_path.  Results stay on the object. */
+int          c4gpu_batch_run(c4gpu_batch *b, int what, int dpmemory_mb, c4gpu_score threshold);
+int          c4gpu_batch_scores(c4gpu_batch *b, c4gpu_score *scores, c4gpu_region *regions);
+int          c4gpu_batch_alignment(c4gpu_batch *b, int32_t i, c4gpu_alignment *out);
+/* Accumulated device time (ms) and launches of the dominant Viterbi kernel since the last reset,
+ * measured with HIP events on the launch stream. */
+int          c4gpu_batch_kernel_stats(c4gpu_batch *b, int reset, double *ms, int64_t *launches, int64_t *cells);
+
+/* Alignment_print_{sugar,cigar,vulgar}_block (alignment.c:1622-1779); coordinates are region
+ * coordinates on the given strands ('+', '-', '.'), flipped to the forward strand when
+ * forward_coords != 0 as --forwardcoordinates does (alignment.c:177-205).  `what`: 0 sugar, 1 cigar,
+ * 2 vulgar.  Returns length written (excluding NUL) or -1. */
+int         c4gpu_alignment_format(const c4gpu_model *model, const c4gpu_alignment *a, int what,
+                                   const char *query_id, int32_t query_len, char query_strand,
+                                   const char *target_id, int32_t target_len, char target_strand,
+                                   int forward_coords, char *buf, size_t buf_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INCLUDED_C4GPU_H */

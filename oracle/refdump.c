@@ -1,0 +1,380 @@
+/* refdump — golden-vector and table dumper that links against the *reference's own objects*.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Built by oracle/Makefile into oracle/_ref/refdump from the reference
+ * sources where they lie under /root/reference (nothing of the reference is copied into this repo;
+ * this file only *calls* the reference's public API).  It is used
+ *   (a) to dump the closed C4 model tables (transition id order, shadows, scopes) that
+ *       exonerate_amd/csrc/c4_models.c must reproduce           -> tests/golden/tables_*.json
+ *   (b) to dump the scoring data tables (submat, translate, splice PSSM)  -> tests/golden/data.json
+ *   (c) to produce golden score / region / operation-list / vulgar / cigar vectors for seeded inputs
+ *       through the reference's Optimal_find_score (src/c4/optimal.c:123) and Optimal_find_path
+ *       (src/c4/optimal.c:368) with the *interpreted* Viterbi (src/c4/viterbi.c:655)
+ *                                                              -> tests/golden/*.golden.jsonl
+ * main() comes from the reference's general/argument.c:319; we supply Argument_main().
+ */
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+
+#include "argument.h"
+#include "c4.h"
+#include "optimal.h"
+#include "alignment.h"
+#include "modeltype.h"
+#include "match.h"
+#include "affine.h"
+#include "intron.h"
+#include "frameshift.h"
+#include "splice.h"
+#include "translate.h"
+#include "submat.h"
+#include "viterbi.h"
+#include "codegen.h"
+#include "sequence.h"
+#include "alphabet.h"
+#include "est2genome.h"
+#include "phase.h"
+#include "heuristic.h"
+#include "sar.h"
+#include "gam.h"
+
+static gint state_index(C4_Model *m, C4_State *s){
+    register guint i;
+    for(i = 0; i < m->state_list->len; i++)
+        if(m->state_list->pdata[i] == s)
+            return i;
+    return -1;
+    }
+
+static gint calc_index(C4_Model *m, C4_Calc *c){
+    register guint i;
+    if(!c) return -1;
+    for(i = 0; i < m->calc_list->len; i++)
+        if(m->calc_list->pdata[i] == c)
+            return i;
+    return -2;
+    }
+
+static void dump_model(C4_Model *m, const char *key){
+    register guint i, j;
+    printf("{\"key\":\"%s\",\"name\":\"%s\",\"start_scope\":%d,\"end_scope\":%d,"
+           "\"max_query_advance\":%d,\"max_target_advance\":%d,\"shadow_designations\":%d,\n",
+           key, m->name, m->start_state->scope, m->end_state->scope,
+           m->max_query_advance, m->max_target_advance, m->total_shadow_designations);
+    printf(" \"start_state\":%d,\"end_state\":%d,\n", state_index(m, m->start_state->state),
+           state_index(m, m->end_state->state));
+    printf(" \"states\":[");
+    for(i = 0; i < m->state_list->len; i++){
+        C4_State *s = m->state_list->pdata[i];
+        printf("%s\"%s\"", i?",":"", s->name);
+        }
+    printf("],\n \"calcs\":[");
+    for(i = 0; i < m->calc_list->len; i++){
+        C4_Calc *c = m->calc_list->pdata[i];
+        printf("%s{\"name\":\"%s\",\"max_score\":%d,\"protect\":%d,\"has_func\":%d}",
+               i?",":"", c->name, c->max_score, c->protect, c->calc_func?1:0);
+        }
+    printf("],\n \"transitions\":[\n");
+    for(i = 0; i < m->transition_list->len; i++){
+        C4_Transition *t = m->transition_list->pdata[i];
+        printf("  %s{\"id\":%d,\"name\":\"%s\",\"in\":%d,\"out\":%d,\"aq\":%d,\"at\":%d,"
+               "\"calc\":%d,\"label\":%d,\"dst_shadows\":[",
+               i?",":"", t->id, t->name, state_index(m, t->input), state_index(m, t->output),
+               t->advance_query, t->advance_target, calc_index(m, t->calc), t->label);
+        for(j = 0; j < t->dst_shadow_list->len; j++){
+            C4_Shadow *sh = t->dst_shadow_list->pdata[j];
+            printf("%s%d", j?",":"", sh->id);
+            }
+        printf("]}\n");
+        }
+    printf(" ],\n \"shadows\":[");
+    for(i = 0; i < m->shadow_list->len; i++){
+        C4_Shadow *sh = m->shadow_list->pdata[i];
+        printf("%s{\"name\":\"%s\",\"designation\":%d,\"src_states\":[", i?",":"",
+               sh->name, sh->designation);
+        for(j = 0; j < sh->src_state_list->len; j++)
+            printf("%s%d", j?",":"", state_index(m, sh->src_state_list->pdata[j]));
+        printf("],\"dst_transitions\":[");
+        for(j = 0; j < sh->dst_transition_list->len; j++){
+            C4_Transition *t = sh->dst_transition_list->pdata[j];
+            printf("%s%d", j?",":"", t->id);
+            }
+        printf("]}");
+        }
+    printf("],\n \"spans\":[");
+    for(i = 0; i < m->span_list->len; i++){
+        C4_Span *sp = m->span_list->pdata[i];
+        printf("%s{\"state\":%d,\"min_q\":%d,\"max_q\":%d,\"min_t\":%d,\"max_t\":%d}", i?",":"",
+               state_index(m, sp->span_state), sp->min_query, sp->max_query,
+               sp->min_target, sp->max_target);
+        }
+    printf("],\n \"portals\":[");
+    for(i = 0; i < m->portal_list->len; i++){
+        C4_Portal *p = m->portal_list->pdata[i];
+        printf("%s{\"name\":\"%s\",\"aq\":%d,\"at\":%d,\"calc\":%d}", i?",":"",
+               p->name, p->advance_query, p->advance_target, calc_index(m, p->calc));
+        }
+    printf("]}\n");
+    }
+
+static void dump_tables(void){
+    struct { const char *key; Model_Type type; Alphabet_Type q, t; } list[] = {
+        {"affine:global:protein", Model_Type_AFFINE_GLOBAL, Alphabet_Type_PROTEIN, Alphabet_Type_PROTEIN},
+        {"affine:bestfit:protein", Model_Type_AFFINE_BESTFIT, Alphabet_Type_PROTEIN, Alphabet_Type_PROTEIN},
+        {"affine:local:protein", Model_Type_AFFINE_LOCAL, Alphabet_Type_PROTEIN, Alphabet_Type_PROTEIN},
+        {"affine:overlap:protein", Model_Type_AFFINE_OVERLAP, Alphabet_Type_PROTEIN, Alphabet_Type_PROTEIN},
+        {"affine:global:dna", Model_Type_AFFINE_GLOBAL, Alphabet_Type_DNA, Alphabet_Type_DNA},
+        {"affine:bestfit:dna", Model_Type_AFFINE_BESTFIT, Alphabet_Type_DNA, Alphabet_Type_DNA},
+        {"affine:local:dna", Model_Type_AFFINE_LOCAL, Alphabet_Type_DNA, Alphabet_Type_DNA},
+        {"affine:overlap:dna", Model_Type_AFFINE_OVERLAP, Alphabet_Type_DNA, Alphabet_Type_DNA},
+        {"ungapped:dna", Model_Type_UNGAPPED, Alphabet_Type_DNA, Alphabet_Type_DNA},
+        {"ungapped:protein", Model_Type_UNGAPPED, Alphabet_Type_PROTEIN, Alphabet_Type_PROTEIN},
+        {"est2genome", Model_Type_EST2GENOME, Alphabet_Type_DNA, Alphabet_Type_DNA},
+        {"protein2dna", Model_Type_PROTEIN2DNA, Alphabet_Type_PROTEIN, Alphabet_Type_DNA},
+        {"protein2dna:bestfit", Model_Type_PROTEIN2DNA_BESTFIT, Alphabet_Type_PROTEIN, Alphabet_Type_DNA},
+        {"protein2genome", Model_Type_PROTEIN2GENOME, Alphabet_Type_PROTEIN, Alphabet_Type_DNA},
+        {"protein2genome:bestfit", Model_Type_PROTEIN2GENOME_BESTFIT, Alphabet_Type_PROTEIN, Alphabet_Type_DNA},
+        };
+    register guint i;
+    printf("[\n");
+    for(i = 0; i < sizeof(list)/sizeof(list[0]); i++){
+        C4_Model *m = Model_Type_get_model(list[i].type, list[i].q, list[i].t);
+        if(i) printf(",\n");
+        dump_model(m, list[i].key);
+        C4_Model_destroy(m);
+        }
+    printf("]\n");
+    }
+
+static void dump_submat(const char *name, Submat *s, gboolean last){
+    register gint i, j;
+    printf(" \"%s\":[", name);
+    for(i = 0; i < SUBMAT_ALPHABETSIZE; i++){
+        printf("%s[", i?",":"");
+        for(j = 0; j < SUBMAT_ALPHABETSIZE; j++)
+            printf("%s%d", j?",":"", s->matrix[i][j]);
+        printf("]");
+        }
+    printf("]%s\n", last?"":",");
+    }
+
+static void dump_splice(const char *name, SplicePredictor *sp){
+    register gint i, j;
+    union { gfloat f; guint32 u; } cv;
+    printf(" \"%s\":{\"model_length\":%d,\"splice_after\":%d,\"max_score_bits\":", name,
+           sp->model_length, sp->model_splice_after);
+    cv.f = SplicePredictor_get_max_score(sp);
+    printf("%u,\"index_ACGTN\":[%d,%d,%d,%d,%d],\"data_bits\":[", cv.u,
+           sp->index['A'], sp->index['C'], sp->index['G'], sp->index['T'], sp->index['N']);
+    for(i = 0; i < sp->model_length; i++){
+        printf("%s[", i?",":"");
+        for(j = 0; j < 5; j++){
+            cv.f = sp->model_data[i][j];
+            printf("%s%u", j?",":"", cv.u);
+            }
+        printf("]");
+        }
+    printf("]},\n");
+    }
+
+static void dump_data(void){
+    register Match_ArgumentSet *mas = Match_ArgumentSet_create(NULL);
+    register Intron_ArgumentSet *ias = Intron_ArgumentSet_create(NULL);
+    register Affine_ArgumentSet *aas = Affine_ArgumentSet_create(NULL);
+    register Frameshift_ArgumentSet *fas = Frameshift_ArgumentSet_create(NULL);
+    register gint i;
+    printf("{\n \"submat_index\":[");
+    for(i = 0; i < 256; i++)
+        printf("%s%d", i?",":"", mas->dna_submat->index[i]);
+    printf("],\n");
+    dump_submat("nucleic", mas->dna_submat, FALSE);
+    dump_submat("blosum62", mas->protein_submat, FALSE);
+    printf(" \"translate_nt2d\":[");
+    for(i = 0; i < 256; i++)
+        printf("%s%d", i?",":"", mas->translate->nt2d[i]);
+    printf("],\n \"translate_trans\":[");
+    for(i = 0; i < Translate_TRANSLATION_SIZE; i++)
+        printf("%s%d", i?",":"", mas->translate->trans[i]);
+    printf("],\n \"translate_aa\":\"");
+    for(i = 0; i < Translate_AA_SET_SIZE && mas->translate->aa[i]; i++)
+        printf("%c", mas->translate->aa[i]);
+    printf("\",\n");
+    dump_splice("ss5_forward", ias->sps->ss5_forward);
+    dump_splice("ss5_reverse", ias->sps->ss5_reverse);
+    dump_splice("ss3_forward", ias->sps->ss3_forward);
+    dump_splice("ss3_reverse", ias->sps->ss3_reverse);
+    printf(" \"gap_open\":%d,\"gap_extend\":%d,\"codon_gap_open\":%d,\"codon_gap_extend\":%d,\n",
+           aas->gap_open, aas->gap_extend, aas->codon_gap_open, aas->codon_gap_extend);
+    printf(" \"min_intron\":%d,\"max_intron\":%d,\"intron_open_penalty\":%d,\"frameshift_penalty\":%d\n}\n",
+           ias->min_intron, ias->max_intron, ias->intron_open_penalty, fas->frameshift_penalty);
+    }
+
+/**/
+
+static gchar *capture_display(Alignment *alignment, Sequence *query, Sequence *target,
+                              void (*func)(Alignment*, Sequence*, Sequence*, FILE*)){
+    char *buf = NULL;
+    size_t len = 0;
+    FILE *fp = open_memstream(&buf, &len);
+    register gchar *result;
+    func(alignment, query, target, fp);
+    fclose(fp);
+    while(len && (buf[len-1] == '\n'))
+        buf[--len] = '\0';
+    result = g_strdup(buf);
+    free(buf);
+    return result;
+    }
+
+static void dump_splice_array(const char *name, SplicePredictor *sp, Sequence *s){
+    register gint *pred = g_new(gint, s->len);
+    register gchar *seq = Sequence_get_str(s);
+    register guint i;
+    SplicePredictor_predict_array_int(sp, seq, s->len, 0, s->len, pred);
+    printf(",\"%s\":[", name);
+    for(i = 0; i < s->len; i++)
+        printf("%s%d", i?",":"", pred[i]);
+    printf("]");
+    g_free(seq);
+    g_free(pred);
+    }
+
+static void run_golden(gchar *model_name, gchar *input_path, gboolean with_splice,
+                       gboolean revcomp_target){
+    register Model_Type type = Model_Type_from_string(model_name);
+    register FILE *fp = fopen(input_path, "r");
+    register Alphabet *dna = Alphabet_create(Alphabet_Type_DNA, FALSE),
+                      *protein = Alphabet_create(Alphabet_Type_PROTEIN, FALSE);
+    register Alphabet *qa, *ta;
+    register C4_Model *model;
+    register Optimal *optimal;
+    register gboolean query_is_protein = FALSE, target_is_protein = FALSE;
+    register size_t cap = 1<<26;
+    register gchar *line = g_malloc(cap);
+    if(!fp)
+        g_error("cannot open [%s]", input_path);
+    switch(type){
+        case Model_Type_PROTEIN2DNA: case Model_Type_PROTEIN2DNA_BESTFIT:
+        case Model_Type_PROTEIN2GENOME: case Model_Type_PROTEIN2GENOME_BESTFIT:
+            query_is_protein = TRUE;
+            break;
+        default:
+            break;
+        }
+    if(strstr(model_name, ":protein")){ /* affine:local:protein etc (refdump-only suffix) */
+        query_is_protein = target_is_protein = TRUE;
+        model_name[strlen(model_name)-strlen(":protein")] = '\0';
+        type = Model_Type_from_string(model_name);
+        }
+    qa = query_is_protein?protein:dna;
+    ta = target_is_protein?protein:dna;
+    model = Model_Type_get_model(type, qa->type, ta->type);
+    optimal = Optimal_create(model, NULL,
+                  Optimal_Type_SCORE|Optimal_Type_PATH|Optimal_Type_REDUCED_SPACE, FALSE);
+    while(fgets(line, cap, fp)){
+        gchar **f;
+        Sequence *query, *target, *tfwd;
+        gpointer user_data;
+        Region region;
+        C4_Score score;
+        Alignment *alignment;
+        g_strchomp(line);
+        if((!line[0]) || (line[0] == '#'))
+            continue;
+        f = g_strsplit(line, "\t", 3);
+        g_assert(f[0] && f[1] && f[2]);
+        query = Sequence_create(f[0], NULL, f[1], 0, Sequence_Strand_FORWARD, qa);
+        tfwd = Sequence_create("tg", NULL, f[2], 0, Sequence_Strand_FORWARD, ta);
+        if(revcomp_target){
+            target = Sequence_revcomp(tfwd);
+        } else {
+            target = Sequence_share(tfwd);
+            }
+        user_data = Model_Type_create_data(type, query, target);
+        Region_init_static(&region, 0, 0, query->len, target->len);
+        score = Optimal_find_score(optimal, &region, user_data, NULL);
+        printf("{\"id\":\"%s\",\"model\":\"%s\",\"qlen\":%d,\"tlen\":%d,\"score\":%d",
+               f[0], model->name, query->len, target->len, score);
+        alignment = Optimal_find_path(optimal, &region, user_data,
+                                      C4_IMPOSSIBLY_LOW_SCORE, NULL);
+        if(alignment){
+            register guint i;
+            gchar *s;
+            printf(",\"path_score\":%d,\"region\":[%d,%d,%d,%d],\"ops\":[",
+                   alignment->score, alignment->region->query_start,
+                   alignment->region->target_start, alignment->region->query_length,
+                   alignment->region->target_length);
+            for(i = 0; i < alignment->operation_list->len; i++){
+                AlignmentOperation *ao = alignment->operation_list->pdata[i];
+                printf("%s[%d,%d]", i?",":"", ao->transition->id, ao->length);
+                }
+            printf("]");
+            s = capture_display(alignment, query, target, Alignment_display_sugar);
+            printf(",\"sugar\":\"%s\"", s); g_free(s);
+            s = capture_display(alignment, query, target, Alignment_display_cigar);
+            printf(",\"cigar\":\"%s\"", s); g_free(s);
+            s = capture_display(alignment, query, target, Alignment_display_vulgar);
+            printf(",\"vulgar\":\"%s\"", s); g_free(s);
+            Alignment_destroy(alignment);
+            }
+        if(with_splice){
+            register Intron_ArgumentSet *ias = Intron_ArgumentSet_create(NULL);
+            dump_splice_array("ss5_forward", ias->sps->ss5_forward, target);
+            dump_splice_array("ss3_forward", ias->sps->ss3_forward, target);
+            dump_splice_array("ss5_reverse", ias->sps->ss5_reverse, target);
+            dump_splice_array("ss3_reverse", ias->sps->ss3_reverse, target);
+            }
+        printf("}\n");
+        fflush(stdout);
+        Model_Type_destroy_data(type, user_data);
+        Sequence_destroy(query);
+        Sequence_destroy(target);
+        Sequence_destroy(tfwd);
+        g_strfreev(f);
+        }
+    fclose(fp);
+    g_free(line);
+    Optimal_destroy(optimal);
+    C4_Model_destroy(model);
+    Alphabet_destroy(dna);
+    Alphabet_destroy(protein);
+    return;
+    }
+
+int Argument_main(Argument *arg){
+    register ArgumentSet *as = ArgumentSet_create("refdump options");
+    gchar *cmd, *model_name, *input_path;
+    gboolean with_splice, revcomp_target;
+    ArgumentSet_add_option(as, '\0', "cmd", "name", "tables|data|golden", "tables",
+                           Argument_parse_string, &cmd);
+    ArgumentSet_add_option(as, 'm', "model", "name", "model name", "affine:local",
+                           Argument_parse_string, &model_name);
+    ArgumentSet_add_option(as, '\0', "input", "path", "tsv of id,query,target", "none",
+                           Argument_parse_string, &input_path);
+    ArgumentSet_add_option(as, '\0', "withsplice", NULL, "dump splice arrays", "FALSE",
+                           Argument_parse_boolean, &with_splice);
+    ArgumentSet_add_option(as, '\0', "revcomptarget", NULL, "align to revcomp of target", "FALSE",
+                           Argument_parse_boolean, &revcomp_target);
+    Argument_absorb_ArgumentSet(arg, as);
+    Translate_ArgumentSet_create(arg);
+    Viterbi_ArgumentSet_create(arg);
+    Codegen_ArgumentSet_create(arg);
+    Sequence_ArgumentSet_create(arg);
+    Match_ArgumentSet_create(arg);
+    Affine_ArgumentSet_create(arg);
+    Intron_ArgumentSet_create(arg);
+    Frameshift_ArgumentSet_create(arg);
+    Alphabet_ArgumentSet_create(arg);
+    Alignment_ArgumentSet_create(arg);
+    Splice_ArgumentSet_create(arg);
+    Argument_process(arg, "refdump", "reference table/golden dumper", "");
+    if(!strcmp(cmd, "tables"))
+        dump_tables();
+    else if(!strcmp(cmd, "data"))
+        dump_data();
+    else if(!strcmp(cmd, "golden"))
+        run_golden(g_strdup(model_name), input_path, with_splice, revcomp_target);
+    else
+        g_error("unknown cmd [%s]", cmd);
+    return 0;
+    }
