@@ -1,0 +1,72 @@
+/* c4_oracle.h — CPU restatement of the reference's C4 Viterbi path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Nothing in the product (exonerate_amd/, libc4gpu.so) may include, link or call this.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker / reported baseline.
+ * It shares nothing with the product but the POD types of include/c4gpu.h.
+ *
+ * Pinned against the reference itself: tests/test_oracle_golden.py replays committed vectors generated
+ * by oracle/_ref/refdump (the reference's own Optimal_find_score / Optimal_find_path), including the
+ * reference's model known-answer tests (src/model/{affine,est2genome,protein2dna}.test.c).
+ */
+#ifndef INCLUDED_C4_ORACLE_H
+#define INCLUDED_C4_ORACLE_H
+
+#include "c4gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* SplicePredictor_predict_array_int, src/sequence/splice.c:383-397 over a whole sequence */
+void oracle_splice_predict(const c4gpu_splice_model *sp, const uint8_t *seq, int32_t len, int32_t *pred);
+
+/* Optimal_find_score, src/c4/optimal.c:123 over the full rectangle of one pair */
+c4gpu_score oracle_find_score(const c4gpu_model *model, const c4gpu_params *params,
+                              const uint8_t *query, int32_t qlen, const uint8_t *target, int32_t tlen);
+
+/* Optimal_find_path, src/c4/optimal.c:368 (region -> checkpoints -> sub-alignments), with the reference's
+ * own memory decisions at `dpmemory_mb`.  Returns 1 and fills `out` (caller frees with
+ * oracle_alignment_clear) or 0 when the score is below threshold. */
+int  oracle_find_path(const c4gpu_model *model, const c4gpu_params *params,
+                      const uint8_t *query, int32_t qlen, const uint8_t *target, int32_t tlen,
+                      int dpmemory_mb, c4gpu_score threshold, c4gpu_alignment *out);
+void oracle_alignment_clear(c4gpu_alignment *a);
+
+/* one raw Viterbi call in any mode (Viterbi_interpreted, src/c4/viterbi.c:655-837); used by the parity
+ * tests of c4gpu_viterbi_batch.  checkpoints (may be NULL) receives
+ * [cp][row < max_target_advance][i <= Q][state][cell_size] ints; ops receives the raw transition path. */
+typedef struct {
+    c4gpu_score score;
+    int32_t query_start, target_start, query_end, target_end;
+    c4gpu_score final_cell[1 + C4GPU_MAX_SHADOWS + 3];
+    int32_t last_srp;
+    int32_t n_ops;
+    int32_t *ops;            /* malloc'd */
+    int32_t *checkpoints;    /* malloc'd */
+    int32_t cell_size;
+} oracle_viterbi_out;
+
+int  oracle_viterbi(const c4gpu_model *model, const c4gpu_params *params, int mode,
+                    const uint8_t *query, int32_t qlen, const uint8_t *target, int32_t tlen,
+                    const c4gpu_region *region, const c4gpu_continuation *continuation,
+                    int checkpoint_count, oracle_viterbi_out *out);
+void oracle_viterbi_out_clear(oracle_viterbi_out *out);
+
+/* Viterbi_use_reduced_space (viterbi.c:128) / Viterbi_checkpoint_rows (viterbi.c:207) */
+int  oracle_use_reduced_space(const c4gpu_model *model, const c4gpu_region *region, int dpmemory_mb);
+int  oracle_checkpoint_rows(const c4gpu_model *model, const c4gpu_region *region, int dpmemory_mb);
+
+/* Alignment_display_{sugar,cigar,vulgar}, src/c4/alignment.c:2671-2706 (the --showsugar/--showcigar/
+ * --showvulgar lines, built from the *_block printers alignment.c:1622-1779).  what: 0 sugar 1 cigar 2 vulgar */
+int  oracle_alignment_format(const c4gpu_model *model, const c4gpu_alignment *a, int what,
+                             const char *qid, int32_t qlen, char qstrand,
+                             const char *tid, int32_t tlen, char tstrand,
+                             int forward_coords, char *buf, size_t buf_len);
+
+/* cells visited by the last oracle_find_path / oracle_find_score on this thread (all passes) */
+int64_t oracle_cells_visited(int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -12,6 +12,8 @@
  *                                                              -> tests/golden/*.golden.jsonl
  * main() comes from the reference's general/argument.c:319; we supply Argument_main().
  */
+#undef _XOPEN_SOURCE
+#define _GNU_SOURCE 1   /* open_memstream */
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
@@ -241,7 +243,7 @@ static void dump_splice_array(const char *name, SplicePredictor *sp, Sequence *s
 
 static void run_golden(gchar *model_name, gchar *input_path, gboolean with_splice,
                        gboolean revcomp_target){
-    register Model_Type type = Model_Type_from_string(model_name);
+    register Model_Type type;
     register FILE *fp = fopen(input_path, "r");
     register Alphabet *dna = Alphabet_create(Alphabet_Type_DNA, FALSE),
                       *protein = Alphabet_create(Alphabet_Type_PROTEIN, FALSE);
@@ -253,6 +255,11 @@ static void run_golden(gchar *model_name, gchar *input_path, gboolean with_splic
     register gchar *line = g_malloc(cap);
     if(!fp)
         g_error("cannot open [%s]", input_path);
+    if(strstr(model_name, ":protein")){ /* affine:local:protein etc (refdump-only suffix) */
+        query_is_protein = target_is_protein = TRUE;
+        model_name[strlen(model_name)-strlen(":protein")] = '\0';
+        }
+    type = Model_Type_from_string(model_name);
     switch(type){
         case Model_Type_PROTEIN2DNA: case Model_Type_PROTEIN2DNA_BESTFIT:
         case Model_Type_PROTEIN2GENOME: case Model_Type_PROTEIN2GENOME_BESTFIT:
@@ -260,11 +267,6 @@ static void run_golden(gchar *model_name, gchar *input_path, gboolean with_splic
             break;
         default:
             break;
-        }
-    if(strstr(model_name, ":protein")){ /* affine:local:protein etc (refdump-only suffix) */
-        query_is_protein = target_is_protein = TRUE;
-        model_name[strlen(model_name)-strlen(":protein")] = '\0';
-        type = Model_Type_from_string(model_name);
         }
     qa = query_is_protein?protein:dna;
     ta = target_is_protein?protein:dna;
@@ -275,7 +277,7 @@ static void run_golden(gchar *model_name, gchar *input_path, gboolean with_splic
         gchar **f;
         Sequence *query, *target, *tfwd;
         gpointer user_data;
-        Region region;
+        Region *region;
         C4_Score score;
         Alignment *alignment;
         g_strchomp(line);
@@ -291,11 +293,11 @@ static void run_golden(gchar *model_name, gchar *input_path, gboolean with_splic
             target = Sequence_share(tfwd);
             }
         user_data = Model_Type_create_data(type, query, target);
-        Region_init_static(&region, 0, 0, query->len, target->len);
-        score = Optimal_find_score(optimal, &region, user_data, NULL);
+        region = Region_create(0, 0, query->len, target->len);
+        score = Optimal_find_score(optimal, region, user_data, NULL);
         printf("{\"id\":\"%s\",\"model\":\"%s\",\"qlen\":%d,\"tlen\":%d,\"score\":%d",
                f[0], model->name, query->len, target->len, score);
-        alignment = Optimal_find_path(optimal, &region, user_data,
+        alignment = Optimal_find_path(optimal, region, user_data,
                                       C4_IMPOSSIBLY_LOW_SCORE, NULL);
         if(alignment){
             register guint i;
@@ -327,6 +329,7 @@ static void run_golden(gchar *model_name, gchar *input_path, gboolean with_splic
         printf("}\n");
         fflush(stdout);
         Model_Type_destroy_data(type, user_data);
+        Region_destroy(region);
         Sequence_destroy(query);
         Sequence_destroy(target);
         Sequence_destroy(tfwd);

@@ -1,0 +1,35 @@
+"""Helpers shared by the golden-vector tests (data only; no reference code)."""
+import json, os
+from exonerate_amd import _abi
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# golden file -> (model type, query alphabet, target alphabet)
+SETS = {
+    "affine_local_dna": ("affine:local", 0, 0), "affine_global_dna": ("affine:global", 0, 0),
+    "affine_bestfit_dna": ("affine:bestfit", 0, 0), "affine_overlap_dna": ("affine:overlap", 0, 0),
+    "affine_local_protein": ("affine:local", 1, 1), "affine_global_protein": ("affine:global", 1, 1),
+    "affine_bestfit_protein": ("affine:bestfit", 1, 1), "affine_overlap_protein": ("affine:overlap", 1, 1),
+    "est2genome": ("est2genome", 0, 0), "protein2dna": ("protein2dna", 1, 0),
+    "affine_local_dna_D0": ("affine:local", 0, 0), "affine_global_dna_D0": ("affine:global", 0, 0),
+    "est2genome_D0": ("est2genome", 0, 0), "protein2dna_D0": ("protein2dna", 1, 0),
+    "est2genome_big": ("est2genome", 0, 0),
+}
+
+
+def load_set(name):
+    with open(os.path.join(GOLDEN_DIR, name + ".jsonl")) as f:
+        return [json.loads(l) for l in f if l.strip()]
+
+
+def get_model(lib, params, name):
+    mt, qa, ta = SETS[name]
+    m = _abi.Model()
+    assert lib.c4gpu_model_get(mt.encode(), qa, ta, params, m) == 0
+    return m
+
+
+def expected(rec):
+    """What the reference printed for this record, in the shape oracle_lib.alignment_to_dict gives."""
+    return {"score": rec["path_score"], "region": rec["region"], "ops": rec["ops"],
+            "sugar": rec["sugar"], "cigar": rec["cigar"], "vulgar": rec["vulgar"]}

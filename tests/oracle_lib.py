@@ -1,0 +1,82 @@
+"""ctypes binding of oracle/libc4oracle.so — the CPU restatement used as the CHECKER in tests.
+
+Test infrastructure only (see oracle/c4_oracle.h).  Never imported by exonerate_amd/.
+"""
+import ctypes as C
+import os, subprocess
+from exonerate_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "oracle", "libc4oracle.so")
+
+
+class ViterbiOut(C.Structure):
+    _fields_ = [("score", C.c_int32), ("query_start", C.c_int32), ("target_start", C.c_int32),
+                ("query_end", C.c_int32), ("target_end", C.c_int32),
+                ("final_cell", C.c_int32 * _abi.CELL_MAX), ("last_srp", C.c_int32),
+                ("n_ops", C.c_int32), ("ops", C.POINTER(C.c_int32)),
+                ("checkpoints", C.POINTER(C.c_int32)), ("cell_size", C.c_int32)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        src = os.path.join(ROOT, "oracle", "c4_oracle.c")
+        if (not os.path.exists(SO)) or os.path.getmtime(SO) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "port"],
+                                  stdout=subprocess.DEVNULL)
+        lib = C.CDLL(SO)
+        lib.oracle_splice_predict.argtypes = [C.POINTER(_abi.SpliceModel), C.c_char_p, C.c_int32,
+                                              C.POINTER(C.c_int32)]
+        lib.oracle_find_score.restype = C.c_int32
+        lib.oracle_find_score.argtypes = [C.POINTER(_abi.Model), C.POINTER(_abi.Params), C.c_char_p,
+                                          C.c_int32, C.c_char_p, C.c_int32]
+        lib.oracle_find_path.restype = C.c_int
+        lib.oracle_find_path.argtypes = [C.POINTER(_abi.Model), C.POINTER(_abi.Params), C.c_char_p,
+                                         C.c_int32, C.c_char_p, C.c_int32, C.c_int, C.c_int32,
+                                         C.POINTER(_abi.Alignment)]
+        lib.oracle_alignment_clear.argtypes = [C.POINTER(_abi.Alignment)]
+        lib.oracle_viterbi.argtypes = [C.POINTER(_abi.Model), C.POINTER(_abi.Params), C.c_int,
+                                       C.c_char_p, C.c_int32, C.c_char_p, C.c_int32,
+                                       C.POINTER(_abi.Region), C.POINTER(_abi.Continuation), C.c_int,
+                                       C.POINTER(ViterbiOut)]
+        lib.oracle_viterbi_out_clear.argtypes = [C.POINTER(ViterbiOut)]
+        lib.oracle_use_reduced_space.argtypes = [C.POINTER(_abi.Model), C.POINTER(_abi.Region), C.c_int]
+        lib.oracle_checkpoint_rows.argtypes = [C.POINTER(_abi.Model), C.POINTER(_abi.Region), C.c_int]
+        lib.oracle_alignment_format.argtypes = [C.POINTER(_abi.Model), C.POINTER(_abi.Alignment), C.c_int,
+                                                C.c_char_p, C.c_int32, C.c_char, C.c_char_p, C.c_int32,
+                                                C.c_char, C.c_int, C.c_char_p, C.c_size_t]
+        lib.oracle_cells_visited.restype = C.c_int64
+        lib.oracle_cells_visited.argtypes = [C.c_int]
+        _lib = lib
+    return _lib
+
+
+def alignment_to_dict(model, a, fmt, qid="qy", qlen=0, tlen=0, qstrand=b"+", tstrand=b"+"):
+    """fmt(model, alignment, what, ...) is either the oracle's or the product's formatter."""
+    out = {"score": a.score, "region": list(a.region.astuple()),
+           "ops": [[a.op_transition[i], a.op_length[i]] for i in range(a.n_ops)]}
+    buf = C.create_string_buffer(1 << 16)
+    for what, key in ((0, "sugar"), (1, "cigar"), (2, "vulgar")):
+        n = fmt(model, a, what, qid.encode(), qlen, qstrand, b"tg", tlen, tstrand, 1, buf, len(buf))
+        assert n >= 0
+        out[key] = buf.value.decode()
+    return out
+
+
+def find_path(model, params, q, t, dpmemory=32, threshold=_abi.IMPOSSIBLY_LOW_SCORE, qid="qy"):
+    lib = load()
+    a = _abi.Alignment()
+    ok = lib.oracle_find_path(model, params, q, len(q), t, len(t), dpmemory, threshold, a)
+    if not ok:
+        return None
+    d = alignment_to_dict(model, a, lib.oracle_alignment_format, qid, len(q), len(t))
+    lib.oracle_alignment_clear(a)
+    return d
+
+
+def find_score(model, params, q, t):
+    return load().oracle_find_score(model, params, q, len(q), t, len(t))

@@ -1,0 +1,65 @@
+"""Pin the oracle (oracle/c4_oracle.c) against outputs of the REFERENCE ITSELF.
+
+tests/golden/*.jsonl were produced by tools/make_golden.py running oracle/_ref/refdump, i.e. the
+reference's own Optimal_find_score / Optimal_find_path (interpreted Viterbi) on seeded inputs and on the
+inputs of the reference's model known-answer tests.  Integer work: every comparison is bit-exact.
+"""
+import pytest
+from exonerate_amd import _abi
+import oracle_lib
+from golden_util import SETS, load_set, get_model, expected
+
+
+@pytest.mark.parametrize("name", sorted(SETS))
+def test_oracle_matches_reference_vectors(lib, params, name):
+    model = get_model(lib, params, name)
+    recs = load_set(name)
+    assert recs
+    for rec in recs:
+        q, t = rec["query"].encode(), rec["target"].encode()
+        assert oracle_lib.find_score(model, params, q, t) == rec["score"], rec["id"]
+        got = oracle_lib.find_path(model, params, q, t, dpmemory=rec["dpmemory"], qid=rec["id"])
+        if "path_score" not in rec:
+            assert got is None
+            continue
+        assert got == expected(rec), rec["id"]
+
+
+def test_reference_known_answer_tests(lib, params):
+    """src/model/affine.test.c:107-110 (-151/18/32/18) and est2genome.test.c:63 (157)."""
+    kat = {"affine_global_protein": -151, "affine_bestfit_protein": 18, "affine_local_protein": 32,
+           "affine_overlap_protein": 18}
+    for name, score in kat.items():
+        rec = [r for r in load_set(name) if r["id"] == "kat_affine"][0]
+        assert rec["score"] == score
+        model = get_model(lib, params, name)
+        assert oracle_lib.find_score(model, params, rec["query"].encode(), rec["target"].encode()) == score
+    rec = [r for r in load_set("est2genome") if r["id"] == "kat_est2genome"][0]
+    assert rec["score"] == 157
+    # vulgar printed by affine.test.c for the local model
+    rec = [r for r in load_set("affine_local_protein") if r["id"] == "kat_affine"][0]
+    assert rec["vulgar"].endswith("32 M 8 8 G 1 0 M 4 4") and rec["region"] == [11, 33, 13, 12]
+
+
+def test_oracle_splice_arrays_match_reference(lib, params):
+    """SplicePredictor_predict_array_int (splice.c:383) per target, all four site types."""
+    import ctypes as C
+    olib = oracle_lib.load()
+    keys = {"ss5_forward": _abi.SS5_FORWARD, "ss3_forward": _abi.SS3_FORWARD,
+            "ss3_reverse": _abi.SS3_REVERSE, "ss5_reverse": _abi.SS5_REVERSE}
+    for rec in load_set("est2genome"):
+        t = rec["target"].encode()
+        for key, k in keys.items():
+            out = (C.c_int32 * len(t))()
+            olib.oracle_splice_predict(params.splice[k], t, len(t), out)
+            assert list(out) == rec[key], (rec["id"], key)
+
+
+def test_memory_decisions(lib, params):
+    """Viterbi_use_reduced_space at the default -D 32: 1 kb x 1 kb affine already exceeds it
+    (SURVEY.md section 9), a 300 x 300 rectangle does not."""
+    olib = oracle_lib.load()
+    model = get_model(lib, params, "affine_local_dna")
+    assert olib.oracle_use_reduced_space(model, _abi.Region(0, 0, 1000, 1000), 32) == 1
+    assert olib.oracle_use_reduced_space(model, _abi.Region(0, 0, 300, 300), 32) == 0
+    assert olib.oracle_use_reduced_space(model, _abi.Region(0, 0, 6, 1000), 0) == 0   # <= 6 x max advance

@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE ITSELF (oracle/_ref/refdump,
+built from /root/reference by `make -C oracle ref`).  Runs only in the build container; the vectors it
+writes are small, committed, and are what pins the oracle (oracle/c4_oracle.c) and the HIP engine.
+
+Inputs are seeded synthetic sequences (generator below, no reference code) plus the hard-coded inputs of
+the reference's own model known-answer tests (src/model/affine.test.c:33-38, est2genome.test.c:24-37,
+protein2dna.test.c) so those KAT scores (-151/18/32/18, 157, 134) are part of the vectors.
+"""
+import json, os, random, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFDUMP = os.path.join(ROOT, "oracle", "_ref", "refdump")
+OUT = os.path.join(ROOT, "tests", "golden")
+AA = "ARNDCQEGHILKMFPSTWYV"
+CODON = {}
+_ncbi = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"
+for i, a in enumerate("TCAG"):
+    for j, b in enumerate("TCAG"):
+        for k, c in enumerate("TCAG"):
+            CODON.setdefault(_ncbi[i * 16 + j * 4 + k], []).append(a + b + c)
+
+
+def rand_dna(rng, n, alphabet="ACGT"):
+    return "".join(rng.choice(alphabet) for _ in range(n))
+
+
+def mutate(rng, s, rate, alphabet):
+    out = []
+    for ch in s:
+        r = rng.random()
+        if r < rate / 3:
+            out.append(rng.choice(alphabet))
+        elif r < 2 * rate / 3:
+            out.append(ch)
+            out.append(rng.choice(alphabet))
+        elif r < rate:
+            pass
+        else:
+            out.append(ch)
+    return "".join(out)
+
+
+def dna_pairs(rng, n):
+    cases = []
+    for k in range(n):
+        ql = rng.choice([0, 1, 2, 5, 13, 40, 77, 150, 300])
+        q = rand_dna(rng, ql, "ACGT" if k % 4 else "ACGTN")
+        mode = k % 5
+        if mode == 0:
+            t = rand_dna(rng, rng.choice([0, 1, 3, 30, 200]))
+        elif mode == 1:
+            t = rand_dna(rng, rng.randint(0, 40)) + mutate(rng, q, 0.1, "ACGT") + rand_dna(rng, rng.randint(0, 40))
+        elif mode == 2:
+            t = q
+        elif mode == 3:
+            t = "N" * rng.randint(1, 60)
+        else:
+            t = mutate(rng, q, 0.3, "ACGT")
+        cases.append(("dna%03d" % k, q, t))
+    return cases
+
+
+def protein_pairs(rng, n):
+    cases = []
+    for k in range(n):
+        ql = rng.choice([1, 2, 7, 30, 90, 200])
+        q = rand_dna(rng, ql, AA)
+        t = rand_dna(rng, rng.randint(0, 30), AA) + mutate(rng, q, 0.15, AA) + rand_dna(rng, rng.randint(0, 30), AA)
+        if k % 6 == 5:
+            t = rand_dna(rng, rng.randint(1, 50), AA)
+        cases.append(("prot%03d" % k, q, t))
+    return cases
+
+
+def est_pairs(rng, n):
+    """cDNA vs genomic with GT..AG introns (some on the reverse gene strand: CT..AC)."""
+    cases = []
+    for k in range(n):
+        ql = rng.choice([30, 60, 120, 200, 320])
+        q = rand_dna(rng, ql)
+        nint = rng.choice([0, 1, 1, 2, 3])
+        cuts = sorted(rng.sample(range(5, max(6, ql - 5)), min(nint, max(0, ql - 11)))) if ql > 12 else []
+        rev = (k % 3 == 2)
+        pieces, last = [], 0
+        for c in cuts + [ql]:
+            pieces.append(q[last:c])
+            last = c
+        t = rand_dna(rng, rng.randint(0, 50))
+        for i, ex in enumerate(pieces):
+            t += mutate(rng, ex, 0.03, "ACGT")
+            if i + 1 < len(pieces):
+                ilen = rng.choice([20, 35, 60, 150, 400])
+                body = rand_dna(rng, max(0, ilen - 4))
+                t += ("CT" + body + "AC") if rev else ("GT" + body + "AG")
+        t += rand_dna(rng, rng.randint(0, 50))
+        if k % 7 == 6:
+            t = t.replace("A", "N", 3)
+        cases.append(("est%03d" % k, q, t))
+    return cases
+
+
+def p2d_pairs(rng, n):
+    cases = []
+    for k in range(n):
+        ql = rng.choice([3, 10, 40, 90, 160])
+        q = rand_dna(rng, ql, AA)
+        coding = "".join(rng.choice(CODON[a]) for a in mutate(rng, q, 0.08, AA))
+        if k % 3 == 1 and len(coding) > 20:      # frameshift
+            p = rng.randint(5, len(coding) - 5)
+            coding = coding[:p] + rng.choice("ACGT") + coding[p:]
+        if k % 3 == 2 and len(coding) > 20:
+            p = rng.randint(5, len(coding) - 5)
+            coding = coding[:p] + coding[p + 2:]
+        t = rand_dna(rng, rng.randint(0, 60)) + coding + rand_dna(rng, rng.randint(0, 60))
+        if k % 8 == 7:
+            t = rand_dna(rng, rng.randint(0, 5))
+        cases.append(("p2d%03d" % k, q, t))
+    return cases
+
+
+KAT_AFFINE = ("kat_affine", "MEEPQSDPSVEPPLSQETFSDLWKLL",
+              "PENNVLSPLPSQAMDDLMLSPDDIEQWFTEDPGPEHSCETFDIWKWCPIECDFLNVISEPNEPIPSQ")
+KAT_E2G = ("kat_est2genome", "CGATCGATCGNATCGATCGATC" "CATCTATCTAGCGAGCGATCTA",
+           "CGATCGATCGATCGATCGATC" "GT" + "N" * 20 + "N" * 47 * 3 + "N" * 27 + "AG" + "CATCTATCTANNNGCGAGCGATCTA")
+
+
+def run(model, cases, dpmemory, extra=()):
+    with tempfile.NamedTemporaryFile("w", suffix=".tsv", delete=False) as f:
+        for cid, q, t in cases:
+            f.write("%s\t%s\t%s\n" % (cid, q, t))
+        path = f.name
+    cmd = [REFDUMP, "--cmd", "golden", "--model", model, "--input", path, "-D", str(dpmemory)] + list(extra)
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout.decode()
+    os.unlink(path)
+    recs = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+    assert len(recs) == len(cases), (model, len(recs), len(cases))
+    for r, (cid, q, t) in zip(recs, cases):
+        assert r["id"] == cid
+        r["query"], r["target"], r["dpmemory"] = q, t, dpmemory
+    return recs
+
+
+def main():
+    rng = random.Random(20260928)
+    sets = []
+    dna = dna_pairs(rng, 30)
+    prot = protein_pairs(rng, 18) + [KAT_AFFINE]
+    est = est_pairs(rng, 28) + [KAT_E2G]
+    p2d = p2d_pairs(rng, 24)
+    for scope in ("local", "global", "bestfit", "overlap"):
+        # empty sequences are rejected by the reference's Sequence_create for non-local global DP
+        d = [c for c in dna if len(c[1]) > 0 and len(c[2]) > 0]
+        sets.append(("affine_%s_dna" % scope, "affine:%s" % scope, d, 32, ()))
+        sets.append(("affine_%s_protein" % scope, "affine:%s:protein" % scope,
+                     [c for c in prot if len(c[2]) > 0], 32, ()))
+    sets.append(("est2genome", "est2genome", est, 32, ("--withsplice", "yes")))
+    sets.append(("protein2dna", "protein2dna", [c for c in p2d if len(c[2]) > 0], 32, ()))
+    # the same inputs with a tiny traceback budget force the reduced-space route (region ->
+    # checkpoints -> recursion -> continuation sub-alignments) on small inputs: -D 0 => every
+    # region larger than 6x the max advance goes through checkpoints.
+    big = [c for c in dna if len(c[1]) >= 13 and len(c[2]) >= 13]
+    sets.append(("affine_local_dna_D0", "affine:local", big, 0, ()))
+    sets.append(("affine_global_dna_D0", "affine:global", big, 0, ()))
+    sets.append(("est2genome_D0", "est2genome", est, 0, ()))
+    sets.append(("protein2dna_D0", "protein2dna", [c for c in p2d if len(c[2]) > 30], 0, ()))
+    # a larger est2genome case that takes the reduced-space route at the DEFAULT -D 32
+    rng2 = random.Random(7)
+    q = rand_dna(rng2, 700)
+    t = rand_dna(rng2, 300) + q[:250] + "GT" + rand_dna(rng2, 700) + "AG" + q[250:520] + "GT" + \
+        rand_dna(rng2, 1500) + "AG" + q[520:] + rand_dna(rng2, 400)
+    sets.append(("est2genome_big", "est2genome", [("estbig0", q, t)], 32, ()))
+    os.makedirs(OUT, exist_ok=True)
+    for name, model, cases, dpm, extra in sets:
+        recs = run(model, cases, dpm, extra)
+        with open(os.path.join(OUT, name + ".jsonl"), "w") as f:
+            for r in recs:
+                f.write(json.dumps(r, separators=(",", ":")) + "\n")
+        print(name, len(recs), "scores", [r["score"] for r in recs[:6]])
+
+
+if __name__ == "__main__":
+    main()
