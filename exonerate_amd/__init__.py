@@ -1,0 +1,238 @@
+"""exonerate_amd — thin Python plumbing over libc4gpu.so (the MI355X-native C4 Viterbi engine).
+
+The product is the C-ABI shared library built from exonerate_amd/csrc (HIP kernels for gfx950 + host
+orchestration).  This package only marshals arguments: it never computes an alignment itself and it
+raises when the library or the GPU is missing — there is no Python / CPU fallback.
+
+Names follow the reference (exonerate src/c4/optimal.h:47-66, src/model/modeltype.h):
+    model = Model("est2genome")                   Model_Type_get_model
+    eng   = Engine()                              one HIP device
+    eng.find_score(model, pairs)                  Optimal_find_score   per pair
+    eng.find_path(model, pairs, dpmemory=32)      Optimal_find_path    per pair -> Alignment
+    aln.vulgar(...), aln.cigar(...), aln.sugar(...)  Alignment_display_{vulgar,cigar,sugar}
+"""
+import ctypes as C
+
+from . import _abi
+from ._abi import (ALPHABET_DNA, ALPHABET_PROTEIN, IMPOSSIBLY_LOW_SCORE, MODE_FIND_SCORE, MODE_FIND_PATH,
+                   MODE_FIND_REGION, MODE_FIND_CHECKPOINTS)
+
+__all__ = ["Model", "Engine", "Alignment", "default_params", "C4GpuError"]
+
+
+class C4GpuError(RuntimeError):
+    pass
+
+
+def _lib():
+    return _abi.load()
+
+
+def _err(prefix):
+    return C4GpuError("%s: %s" % (prefix, (_lib().c4gpu_last_error() or b"").decode()))
+
+
+def default_params():
+    p = _abi.Params()
+    _lib().c4gpu_params_default(p)
+    return p
+
+
+class Model:
+    """A closed C4 model flattened to tables (c4gpu_model)."""
+    _ALPHABETS = {"est2genome": (0, 0), "protein2dna": (1, 0), "protein2dna:bestfit": (1, 0),
+                  "protein2genome": (1, 0), "protein2genome:bestfit": (1, 0)}
+
+    def __init__(self, model_type, query_alphabet=None, target_alphabet=None, params=None):
+        self.params = params if params is not None else default_params()
+        qa, ta = self._ALPHABETS.get(model_type, (ALPHABET_DNA, ALPHABET_DNA))
+        qa = qa if query_alphabet is None else query_alphabet
+        ta = ta if target_alphabet is None else target_alphabet
+        self.c = _abi.Model()
+        if _lib().c4gpu_model_get(model_type.encode(), qa, ta, self.params, self.c) != 0:
+            raise C4GpuError("unknown or unsupported model type %r" % model_type)
+        self.model_type = model_type
+
+    @property
+    def name(self):
+        return self.c.name.decode()
+
+    def plugin_name(self, mode, continuation=False):
+        buf = C.create_string_buffer(256)
+        _lib().c4gpu_model_plugin_name(self.c, mode, int(continuation), buf, 256)
+        return buf.value.decode()
+
+
+class Alignment:
+    def __init__(self, model, c_alignment, qlen, tlen):
+        self.model = model
+        self.score = c_alignment.score
+        self.region = c_alignment.region.astuple()
+        self.ops = [(c_alignment.op_transition[i], c_alignment.op_length[i]) for i in range(c_alignment.n_ops)]
+        self.qlen, self.tlen = qlen, tlen
+
+    def _c(self):
+        a = _abi.Alignment()
+        a.score = self.score
+        a.region = _abi.Region(*self.region)
+        a.n_ops = len(self.ops)
+        self._t = (C.c_int32 * max(1, len(self.ops)))(*[o[0] for o in self.ops])
+        self._l = (C.c_int32 * max(1, len(self.ops)))(*[o[1] for o in self.ops])
+        a.op_transition = C.cast(self._t, C.POINTER(C.c_int32))
+        a.op_length = C.cast(self._l, C.POINTER(C.c_int32))
+        a.valid = 1
+        return a
+
+    def _format(self, what, qid, tid, qstrand, tstrand, forward_coords):
+        buf = C.create_string_buffer(64 + 24 * (len(self.ops) + 4) + len(qid) + len(tid))
+        n = _lib().c4gpu_alignment_format(self.model.c, self._c(), what, qid.encode(), self.qlen,
+                                          qstrand.encode(), tid.encode(), self.tlen, tstrand.encode(),
+                                          int(forward_coords), buf, len(buf))
+        if n < 0:
+            raise C4GpuError("alignment line does not fit its buffer")
+        return buf.value.decode()
+
+    def sugar(self, qid="qy", tid="tg", qstrand="+", tstrand="+", forward_coords=True):
+        return self._format(0, qid, tid, qstrand, tstrand, forward_coords)
+
+    def cigar(self, qid="qy", tid="tg", qstrand="+", tstrand="+", forward_coords=True):
+        return self._format(1, qid, tid, qstrand, tstrand, forward_coords)
+
+    def vulgar(self, qid="qy", tid="tg", qstrand="+", tstrand="+", forward_coords=True):
+        return self._format(2, qid, tid, qstrand, tstrand, forward_coords)
+
+    def as_dict(self, qid="qy"):
+        return {"score": self.score, "region": list(self.region), "ops": [list(o) for o in self.ops],
+                "sugar": self.sugar(qid), "cigar": self.cigar(qid), "vulgar": self.vulgar(qid)}
+
+
+def _pairs(pairs):
+    arr = (_abi.Pair * max(1, len(pairs)))()
+    keep = []
+    for i, (q, t) in enumerate(pairs):
+        q = q if isinstance(q, bytes) else q.encode()
+        t = t if isinstance(t, bytes) else t.encode()
+        keep.append((q, t))
+        arr[i].query, arr[i].query_len, arr[i].target, arr[i].target_len = q, len(q), t, len(t)
+    return arr, keep
+
+
+class Engine:
+    """One HIP device (c4gpu_ctx).  Raises when there is no gfx950 GPU: nothing here runs on the CPU."""
+
+    def __init__(self, device=0, stream=None):
+        self.ctx = _lib().c4gpu_ctx_create(device)
+        if not self.ctx:
+            raise _err("c4gpu_ctx_create")
+        if stream is not None:
+            _lib().c4gpu_ctx_set_stream(self.ctx, C.c_void_p(stream))
+
+    def close(self):
+        if self.ctx:
+            _lib().c4gpu_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        ncu, mem = C.c_int(), C.c_int64()
+        _lib().c4gpu_ctx_device_info(self.ctx, name, 256, ncu, mem)
+        return {"name": name.value.decode(), "compute_units": ncu.value, "memory_bytes": mem.value}
+
+    def find_score(self, model, pairs):
+        arr, keep = _pairs(pairs)
+        out = (C.c_int32 * max(1, len(pairs)))()
+        if _lib().c4gpu_optimal_find_score_batch(self.ctx, model.c, model.params, arr, len(pairs), out) != 0:
+            raise _err("c4gpu_optimal_find_score_batch")
+        return list(out)[:len(pairs)]
+
+    def find_path(self, model, pairs, dpmemory=32, threshold=IMPOSSIBLY_LOW_SCORE):
+        arr, keep = _pairs(pairs)
+        out = (_abi.Alignment * max(1, len(pairs)))()
+        if _lib().c4gpu_optimal_find_path_batch(self.ctx, model.c, model.params, arr, len(pairs), dpmemory,
+                                                threshold, out) != 0:
+            raise _err("c4gpu_optimal_find_path_batch")
+        res = []
+        for i in range(len(pairs)):
+            if out[i].valid:
+                res.append(Alignment(model, out[i], len(keep[i][0]), len(keep[i][1])))
+            else:
+                res.append(None)
+            _lib().c4gpu_alignment_clear(out[i])
+        return res
+
+    def viterbi(self, model, mode, pairs, jobs):
+        """Raw Viterbi_DP_Func level: jobs = list of dict(pair, region, continuation=None, checkpoints=0)."""
+        arr, keep = _pairs(pairs)
+        cj = (_abi.ViterbiJob * max(1, len(jobs)))()
+        for i, j in enumerate(jobs):
+            cj[i].pair = j["pair"]
+            cj[i].region = _abi.Region(*j["region"])
+            cont = j.get("continuation")
+            cj[i].use_continuation = 1 if cont else 0
+            if cont:
+                cj[i].continuation.first_state = cont["first_state"]
+                cj[i].continuation.final_state = cont["final_state"]
+                for l, v in enumerate(cont.get("first_cell", [])):
+                    cj[i].continuation.first_cell[l] = v
+            cj[i].checkpoint_count = j.get("checkpoints", 0)
+        res = (_abi.ViterbiResult * max(1, len(jobs)))()
+        if _lib().c4gpu_viterbi_batch(self.ctx, model.c, model.params, mode, arr, len(pairs), cj, len(jobs),
+                                      res) != 0:
+            raise _err("c4gpu_viterbi_batch")
+        out = []
+        for i in range(len(jobs)):
+            r = res[i]
+            out.append({"score": r.score, "query_start": r.query_start, "target_start": r.target_start,
+                        "query_end": r.query_end, "target_end": r.target_end,
+                        "final_cell": list(r.final_cell), "last_srp": r.last_srp,
+                        "ops": [r.ops[k] for k in range(r.n_ops)]})
+            _lib().c4gpu_viterbi_result_clear(r)
+        return out
+
+    def splice_predict(self, params, target):
+        t = target if isinstance(target, bytes) else target.encode()
+        bufs = [(C.c_int32 * max(1, len(t)))() for _ in range(4)]
+        ptrs = (C.POINTER(C.c_int32) * 4)(*[C.cast(b, C.POINTER(C.c_int32)) for b in bufs])
+        if _lib().c4gpu_splice_predict(self.ctx, params, t, len(t), ptrs) != 0:
+            raise _err("c4gpu_splice_predict")
+        return [list(b)[:len(t)] for b in bufs]
+
+
+class ResidentBatch:
+    """Pairs uploaded once (c4gpu_batch): what bench.py times."""
+
+    def __init__(self, engine, model, pairs):
+        self.engine, self.model = engine, model
+        arr, self._keep = _pairs(pairs)
+        self.n = len(pairs)
+        self.h = _lib().c4gpu_batch_create(engine.ctx, model.c, model.params, arr, len(pairs))
+        if not self.h:
+            raise _err("c4gpu_batch_create")
+
+    def run(self, what=2, dpmemory=32, threshold=IMPOSSIBLY_LOW_SCORE):
+        if _lib().c4gpu_batch_run(self.h, what, dpmemory, threshold) != 0:
+            raise _err("c4gpu_batch_run")
+
+    def scores(self):
+        s = (C.c_int32 * max(1, self.n))()
+        r = (_abi.Region * max(1, self.n))()
+        _lib().c4gpu_batch_scores(self.h, s, r)
+        return list(s)[:self.n], [x.astuple() for x in r][:self.n]
+
+    def alignment(self, i):
+        a = _abi.Alignment()
+        if _lib().c4gpu_batch_alignment(self.h, i, a) != 0:
+            raise _err("c4gpu_batch_alignment")
+        out = Alignment(self.model, a, len(self._keep[i][0]), len(self._keep[i][1])) if a.valid else None
+        _lib().c4gpu_alignment_clear(a)
+        return out
+
+    def kernel_stats(self, reset=False):
+        ms, n, cells = C.c_double(), C.c_int64(), C.c_int64()
+        _lib().c4gpu_batch_kernel_stats(self.h, int(reset), ms, n, cells)
+        return {"ms": ms.value, "launches": n.value, "cells": cells.value}
+
+    def close(self):
+        if self.h:
+            _lib().c4gpu_batch_destroy(self.h)
+            self.h = None

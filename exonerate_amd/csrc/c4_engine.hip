@@ -1,0 +1,802 @@
+// c4_engine.hip — host engine of libc4gpu.so: device context, sequence preparation kernels, batched job
+// launches and the Optimal_* orchestration (exonerate src/c4/optimal.c) over batches of independent pairs.
+//
+// There is NO CPU fallback here: every entry point that computes needs a HIP device and fails loudly
+// (c4gpu_last_error) without one.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "c4gpu.h"
+#include "c4_internal.h"
+#include "c4_launch.h"
+
+using namespace c4k;
+
+namespace c4h {
+static thread_local std::string g_error;
+void set_error(const std::string &msg) { g_error = msg; }
+}  // namespace c4h
+
+#define HIP_OK(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            c4h::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+            return -1;                                                                         \
+        }                                                                                      \
+    } while (0)
+
+struct c4gpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // accumulated statistics of the Viterbi kernel launches (HIP events on the launch stream)
+    double kernel_ms = 0;
+    int64_t kernel_launches = 0, kernel_cells = 0;
+    bool timing = false;
+};
+
+namespace {
+
+// ---- small RAII device buffer ------------------------------------------------------------------------------
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    int alloc(size_t count) {
+        if (count <= n && p) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        if (!count) count = 1;
+        HIP_OK(hipMalloc((void **)&p, count * sizeof(T)));
+        n = count;
+        return 0;
+    }
+    int upload(const T *src, size_t count, hipStream_t s) {
+        if (alloc(count)) return -1;
+        if (count) HIP_OK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+        return 0;
+    }
+    int download(T *dst, size_t count, hipStream_t s) const {
+        if (count) HIP_OK(hipMemcpyAsync(dst, p, count * sizeof(T), hipMemcpyDeviceToHost, s));
+        return 0;
+    }
+};
+
+// ---- which compiled family does a flattened model belong to? ----------------------------------------------
+template <class M>
+bool model_matches(const c4gpu_model &m) {
+    if (m.n_states != M::NS || m.n_transitions != M::NT || m.n_calcs != M::NC || m.n_shadows != M::NSH) return false;
+    if (m.start_state != M::START || m.end_state != M::END || m.total_shadow_designations != M::NDES) return false;
+    for (int k = 0; k < M::NT; k++) {
+        const c4gpu_transition &t = m.transitions[k];
+        const TrDesc &d = M::tr[k];
+        if (t.input != d.in || t.output != d.out || t.advance_query != d.aq || t.advance_target != d.at ||
+            t.calc != d.calc || t.label != d.label || t.dst_shadow_mask != d.dst_shadow_mask) return false;
+    }
+    for (int c = 0; c < M::NC; c++) {
+        const int kind = m.calcs[c].kind, dk = M::calc[c].kind;
+        const bool both_11 = (kind == C4GPU_CALC_MATCH_DNA || kind == C4GPU_CALC_MATCH_PROTEIN) &&
+                             (dk == C4GPU_CALC_MATCH_DNA || dk == C4GPU_CALC_MATCH_PROTEIN);
+        if (!both_11 && kind != dk) return false;
+        if (kind >= C4GPU_CALC_SPLICE_PRE && m.calcs[c].param != M::calc[c].param) return false;
+        if (m.calcs[c].protect != M::calc[c].protect) return false;
+    }
+    for (int s = 0; s < M::NSH; s++) {
+        if (m.shadows[s].designation != M::sh[s].designation || m.shadows[s].on_target != M::sh[s].on_target ||
+            m.shadows[s].src_state_mask != M::sh[s].src_state_mask ||
+            m.shadows[s].dst_transition_mask != M::sh[s].dst_transition_mask) return false;
+    }
+    return true;
+}
+
+int model_family(const c4gpu_model &m) {
+    if (model_matches<UngappedDesc>(m)) return FAM_UNGAPPED;
+    if (model_matches<AffineDesc>(m)) return FAM_AFFINE;
+    if (model_matches<Est2GenomeDesc>(m)) return FAM_EST2GENOME;
+    if (model_matches<UngappedP2DDesc>(m)) return FAM_UNGAPPED_P2D;
+    if (model_matches<Protein2DnaDesc>(m)) return FAM_PROTEIN2DNA;
+    return -1;
+}
+
+bool family_is_p2d(int fam) { return fam == FAM_UNGAPPED_P2D || fam == FAM_PROTEIN2DNA; }
+bool family_has_splice(int fam) { return fam == FAM_EST2GENOME; }
+
+// ---- sequence preparation kernels -------------------------------------------------------------------------
+struct PrepTables {
+    uint8_t submat_index[256];
+    uint8_t nt2d[256];
+    uint8_t trans[4096];
+    uint8_t aa[40];
+};
+
+// residue bytes -> substitution matrix row (Submat_lookup's index step, submat.h:54-56)
+__global__ void encode_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, long long n,
+                              const PrepTables *__restrict__ tab, int *bad) {
+    for (long long x = blockIdx.x * (long long)blockDim.x + threadIdx.x; x < n; x += (long long)gridDim.x * blockDim.x) {
+        const uint8_t c = tab->submat_index[in[x]];
+        if (c >= 24) atomicExch(bad, 1);
+        out[x] = c >= 24 ? 0 : c;
+    }
+}
+
+// protein2dna target: row of the residue encoded by the codon starting at each position
+// (Translate_base, translate.h:73-76, then the submat index)
+__global__ void codon_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const long long *off,
+                             const int *len, const PrepTables *__restrict__ tab, int *bad) {
+    const int pair = blockIdx.y;
+    const uint8_t *s = in + off[pair];
+    uint8_t *o = out + off[pair];
+    const int n = len[pair];
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
+        uint8_t code = 0;
+        if (x + 2 < n) {
+            const uint8_t aa = tab->aa[tab->trans[tab->nt2d[s[x]] | (tab->nt2d[s[x + 1]] << 4) | (tab->nt2d[s[x + 2]] << 8)]];
+            code = tab->submat_index[aa];
+            if (code >= 24) { atomicExch(bad, 2); code = 0; }
+        }
+        o[x] = code;
+    }
+}
+
+// SplicePredictor_predict_array_int (splice.c:383-397): float accumulation left to right over the PSSM
+// window clipped to the sequence (Splice_predict_position, splice.c:320-344), rounded half away from
+// zero in double (SplicePredictor_round, splice.c:379-381).  Plain adds only: no contraction possible.
+__global__ void splice_kernel(const uint8_t *__restrict__ seq, const long long *off, const int *len,
+                              const c4gpu_splice_model *__restrict__ models, int *__restrict__ out,
+                              long long stride) {
+    const int pair = blockIdx.y, type = blockIdx.z;
+    const c4gpu_splice_model *sp = &models[type];
+    const uint8_t *s = seq + off[pair];
+    const int n = len[pair];
+    int *o = out + (long long)type * stride + off[pair];
+    for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += gridDim.x * blockDim.x) {
+        int seq_start = pos - sp->splice_after, model_start = 0, calc_length = sp->model_length;
+        if (seq_start < 0) { model_start = -seq_start; seq_start = 0; calc_length -= model_start; }
+        if (seq_start + calc_length > n) calc_length = n - seq_start;
+        float score = 0.0f;
+        for (int i = 0; i < calc_length; i++) score = score + sp->data[model_start + i][sp->index[s[seq_start + i]]];
+        const double r = score < 0 ? (double)score - 0.5 : (double)score + 0.5;
+        o[pos] = (int)r;
+    }
+}
+
+// ---- resident sequences of a batch --------------------------------------------------------------------------
+struct ResidentSeqs {
+    int n_pairs = 0;
+    std::vector<long long> qoff, toff;
+    std::vector<int> qlen, tlen;
+    long long total_q = 0, total_t = 0;
+    DevBuf<uint8_t> qraw, traw, qcode, tcode;
+    DevBuf<long long> d_qoff, d_toff;
+    DevBuf<int> d_qlen, d_tlen, ss;
+    DevBuf<PrepTables> tables;
+    DevBuf<c4gpu_splice_model> splice_models;
+    DevBuf<int> bad;
+    DevSeqs dev;
+
+    int build(c4gpu_ctx *ctx, int family, const c4gpu_params *params, const c4gpu_pair *pairs, int n) {
+        n_pairs = n;
+        qoff.resize(n); toff.resize(n); qlen.resize(n); tlen.resize(n);
+        total_q = total_t = 0;
+        for (int i = 0; i < n; i++) {
+            qoff[i] = total_q; toff[i] = total_t;
+            qlen[i] = pairs[i].query_len; tlen[i] = pairs[i].target_len;
+            total_q += (pairs[i].query_len + 3) & ~3LL;
+            total_t += (pairs[i].target_len + 3) & ~3LL;
+        }
+        std::vector<uint8_t> hq(total_q ? total_q : 1, 'A'), ht(total_t ? total_t : 1, 'A');
+        for (int i = 0; i < n; i++) {
+            if (qlen[i]) memcpy(&hq[qoff[i]], pairs[i].query, qlen[i]);
+            if (tlen[i]) memcpy(&ht[toff[i]], pairs[i].target, tlen[i]);
+        }
+        PrepTables pt;
+        memcpy(pt.submat_index, params->submat_index, 256);
+        memcpy(pt.nt2d, params->nt2d, 256);
+        memcpy(pt.trans, params->trans, 4096);
+        memcpy(pt.aa, params->aa, 40);
+        hipStream_t s = ctx->stream;
+        if (tables.upload(&pt, 1, s) || qraw.upload(hq.data(), hq.size(), s) || traw.upload(ht.data(), ht.size(), s) ||
+            qcode.alloc(hq.size()) || tcode.alloc(ht.size()) || d_qoff.upload(qoff.data(), n, s) ||
+            d_toff.upload(toff.data(), n, s) || d_qlen.upload(qlen.data(), n, s) || d_tlen.upload(tlen.data(), n, s))
+            return -1;
+        int zero = 0;
+        if (bad.upload(&zero, 1, s)) return -1;
+        const int blocks = 1024;
+        hipLaunchKernelGGL(encode_kernel, dim3(blocks), dim3(256), 0, s, qraw.p, qcode.p, (long long)hq.size(), tables.p, bad.p);
+        int max_t = 1;
+        for (int i = 0; i < n; i++) max_t = std::max(max_t, tlen[i]);
+        const int xb = std::min(256, (max_t + 255) / 256);
+        if (family_is_p2d(family)) {
+            hipLaunchKernelGGL(codon_kernel, dim3(xb, n), dim3(256), 0, s, traw.p, tcode.p, d_toff.p, d_tlen.p, tables.p, bad.p);
+        } else {
+            hipLaunchKernelGGL(encode_kernel, dim3(blocks), dim3(256), 0, s, traw.p, tcode.p, (long long)ht.size(), tables.p, bad.p);
+        }
+        dev.ss = nullptr;
+        dev.ss_stride = 0;
+        if (family_has_splice(family)) {
+            if (splice_models.upload(params->splice, 4, s) || ss.alloc((size_t)4 * ht.size())) return -1;
+            hipLaunchKernelGGL(splice_kernel, dim3(xb, n, 4), dim3(256), 0, s, traw.p, d_toff.p, d_tlen.p,
+                               splice_models.p, ss.p, (long long)ht.size());
+            dev.ss = ss.p;
+            dev.ss_stride = (long long)ht.size();
+        }
+        HIP_OK(hipGetLastError());
+        int hbad = 0;
+        if (bad.download(&hbad, 1, s)) return -1;
+        HIP_OK(hipStreamSynchronize(s));
+        if (hbad) {
+            c4h::set_error(hbad == 2 ? "a target codon translates outside the substitution matrix alphabet (non-IUPAC base?)"
+                                     : "a residue is outside the 24-letter substitution matrix alphabet "
+                                       "(exonerate's Submat index would read out of bounds, submat.c:27-61)");
+            return -1;
+        }
+        dev.qcode = qcode.p; dev.tcode = tcode.p; dev.qoff = d_qoff.p; dev.toff = d_toff.p;
+        return 0;
+    }
+};
+
+// ---- launching a list of jobs ---------------------------------------------------------------------------------
+struct JobSpec {                  // host description of one Viterbi call
+    int pair;
+    c4gpu_region region;
+    int first_state = 0, final_state = 1, cp_count = 0;
+    int first_cell[CELL_MAX] = {0};
+    bool dump_checkpoints = false;
+};
+struct JobOut {
+    DevResult res;
+    std::vector<uint8_t> ops;     // PATH: transition ids START -> END
+    std::vector<DevVsa> vsa;      // CKPT: sub-alignments, last section first
+    std::vector<int> checkpoints; // CKPT + dump_checkpoints
+};
+
+struct Engine {
+    c4gpu_ctx *ctx;
+    const c4gpu_model *model;
+    int family;
+    bool local;
+    DevBuf<KParams> kparams;
+    // reusable device buffers
+    DevBuf<DevJob> d_jobs;
+    DevBuf<DevResult> d_results;
+    DevBuf<DevVsa> d_vsa;
+    DevBuf<uint8_t> d_ops;
+    DevBuf<int> d_bnd, d_ckpt, d_ckpt_dump, d_queue;
+    DevBuf<uint32_t> d_tb;
+
+    int init(c4gpu_ctx *c, const c4gpu_model *m, const c4gpu_params *params) {
+        ctx = c; model = m;
+        family = model_family(*m);
+        if (family < 0) {
+            c4h::set_error(std::string("model [") + m->name + "] is not one of the device-accelerated families");
+            return -1;
+        }
+        local = m->start_scope == C4GPU_SCOPE_ANYWHERE && m->end_scope == C4GPU_SCOPE_ANYWHERE;
+        KParams kp;
+        memset(&kp, 0, sizeof kp);
+        for (int i = 0; i < m->n_calcs; i++) kp.calc_value[i] = m->calcs[i].value;
+        kp.min_intron = params->min_intron; kp.max_intron = params->max_intron;
+        kp.start_scope = m->start_scope; kp.end_scope = m->end_scope;
+        bool protein = false;
+        for (int i = 0; i < m->n_calcs; i++)
+            if (m->calcs[i].kind == C4GPU_CALC_MATCH_PROTEIN || m->calcs[i].kind == C4GPU_CALC_MATCH_P2D) protein = true;
+        memcpy(kp.submat, protein ? &params->protein_submat[0][0] : &params->dna_submat[0][0], sizeof kp.submat);
+        return kparams.upload(&kp, 1, ctx->stream);
+    }
+
+    // Runs `specs` in `mode`; out[i] corresponds to specs[i].
+    int run(const ResidentSeqs &seqs, int mode, bool cont, const std::vector<JobSpec> &specs, std::vector<JobOut> &out) {
+        const int n = (int)specs.size();
+        out.assign(n, JobOut());
+        if (!n) return 0;
+        const bool use_local = local && !cont && (mode == MODE_SCORE || mode == MODE_REGION);
+        const KernelInfo *ki = get_kernel(family, mode, cont, use_local);
+        if (!ki) { c4h::set_error("no compiled kernel for this model/mode"); return -1; }
+        // longest first (persistent waves pull from the queue head)
+        std::vector<int> order(n);
+        std::iota(order.begin(), order.end(), 0);
+        auto cells = [&](int i) { return (long long)(specs[i].region.query_length + 1) * (specs[i].region.target_length + 1); };
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cells(a) > cells(b); });
+        std::vector<DevJob> jobs(n);
+        long long ops_total = 0, vsa_total = 0, dump_total = 0, max_T = 0, max_tb = 0, max_ckpt = 0, total_cells = 0;
+        for (int x = 0; x < n; x++) {
+            const JobSpec &s = specs[order[x]];
+            DevJob &j = jobs[x];
+            memset(&j, 0, sizeof j);
+            j.pair = s.pair; j.q0 = s.region.query_start; j.t0 = s.region.target_start;
+            j.Q = s.region.query_length; j.T = s.region.target_length;
+            j.first_state = s.first_state; j.final_state = s.final_state; j.cp_count = s.cp_count;
+            memcpy(j.first_cell, s.first_cell, sizeof j.first_cell);
+            j.ops_off = ops_total; j.ops_cap = 0; j.vsa_off = (int)vsa_total; j.ckpt_off = -1;
+            total_cells += cells(order[x]);
+            max_T = std::max<long long>(max_T, j.T);
+            const long long strips = (j.Q + 1 + 64 * ki->R - 1) / (64 * ki->R);
+            if (mode == MODE_PATH) {
+                j.ops_cap = 3 * (j.Q + j.T) + 16;
+                ops_total += j.ops_cap;
+                max_tb = std::max(max_tb, strips * (long long)(j.T + 64) * 64 * ki->R);
+            }
+            if (mode == MODE_CKPT) {
+                const long long ck = (long long)j.cp_count * ki->max_at * (j.Q + 1) * ki->n_states * ki->cs;
+                max_ckpt = std::max(max_ckpt, ck);
+                vsa_total += j.cp_count + 1;
+                if (s.dump_checkpoints) { j.ckpt_off = dump_total; dump_total += ck; }
+            }
+        }
+        // persistent grid: as many waves as the device keeps resident, bounded by the scratch it implies
+        int blocks_per_cu = 0;
+        HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, ki->func, 64, 0));
+        if (blocks_per_cu < 1) blocks_per_cu = 1;
+        long long grid = std::min<long long>(n, (long long)blocks_per_cu * ctx->prop.multiProcessorCount);
+        const long long bnd_per_wave = 2 * (max_T + 1) * (long long)std::max(ki->bnd, 1);
+        const long long bytes_per_wave = bnd_per_wave * 4 + max_tb * 4 + max_ckpt * 4;
+        const long long budget = (long long)(ctx->prop.totalGlobalMem / 4);
+        if (bytes_per_wave * grid > budget) grid = std::max<long long>(1, budget / std::max<long long>(1, bytes_per_wave));
+        hipStream_t s = ctx->stream;
+        int zero = 0;
+        if (d_jobs.upload(jobs.data(), n, s) || d_results.alloc(n) || d_queue.upload(&zero, 1, s) ||
+            d_bnd.alloc(bnd_per_wave * grid) || d_ops.alloc(ops_total) || d_vsa.alloc(vsa_total) ||
+            d_tb.alloc(max_tb * grid) || d_ckpt.alloc(max_ckpt * grid) || d_ckpt_dump.alloc(dump_total))
+            return -1;
+        LaunchArgs a;
+        a.kp = kparams.p; a.seqs = seqs.dev; a.jobs = d_jobs.p; a.n_jobs = n; a.results = d_results.p;
+        a.vsas = d_vsa.p; a.ops = d_ops.p; a.queue = d_queue.p; a.grid = (int)grid; a.stream = s;
+        a.scratch.bnd = d_bnd.p; a.scratch.bnd_stride = bnd_per_wave;
+        a.scratch.tb = max_tb ? d_tb.p : nullptr; a.scratch.tb_stride = max_tb;
+        a.scratch.ckpt = max_ckpt ? d_ckpt.p : nullptr; a.scratch.ckpt_stride = max_ckpt;
+        a.scratch.ckpt_dump = d_ckpt_dump.p;
+        if (ctx->timing) HIP_OK(hipEventRecord(ctx->ev0, s));
+        HIP_OK(ki->launch(a));
+        if (ctx->timing) HIP_OK(hipEventRecord(ctx->ev1, s));
+        std::vector<DevResult> res(n);
+        std::vector<uint8_t> ops(ops_total);
+        std::vector<DevVsa> vsa(vsa_total);
+        std::vector<int> dump(dump_total);
+        if (d_results.download(res.data(), n, s) || d_ops.download(ops.data(), ops_total, s) ||
+            d_vsa.download(vsa.data(), vsa_total, s) || d_ckpt_dump.download(dump.data(), dump_total, s))
+            return -1;
+        HIP_OK(hipStreamSynchronize(s));
+        if (ctx->timing) {
+            float ms = 0;
+            HIP_OK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            ctx->kernel_ms += ms; ctx->kernel_launches++; ctx->kernel_cells += total_cells;
+        }
+        for (int x = 0; x < n; x++) {
+            JobOut &o = out[order[x]];
+            o.res = res[x];
+            if (res[x].flags & FLAG_OPS_OVERFLOW) { c4h::set_error("traceback path longer than its buffer"); return -1; }
+            if (mode == MODE_PATH) {        // the walk wrote END -> START
+                o.ops.assign(ops.begin() + jobs[x].ops_off, ops.begin() + jobs[x].ops_off + res[x].n_ops);
+                std::reverse(o.ops.begin(), o.ops.end());
+            }
+            if (mode == MODE_CKPT) {
+                o.vsa.assign(vsa.begin() + jobs[x].vsa_off, vsa.begin() + jobs[x].vsa_off + res[x].n_vsa);
+                if (jobs[x].ckpt_off >= 0) {
+                    const long long ck = (long long)jobs[x].cp_count * ki->max_at * (jobs[x].Q + 1) * ki->n_states * ki->cs;
+                    o.checkpoints.assign(dump.begin() + jobs[x].ckpt_off, dump.begin() + jobs[x].ckpt_off + ck);
+                }
+            }
+        }
+        return 0;
+    }
+};
+
+// ---- Optimal_find_path over a batch (optimal.c:368-413) ---------------------------------------------------------
+struct Segment {                 // one Viterbi_SubAlignment (viterbi.c:482-496) in path order
+    c4gpu_region region;
+    int first_state;
+    int final_cell[CELL_MAX];
+    bool needs_checkpoints;      // Viterbi_use_reduced_space(vsa->region): recurse (optimal.c:203)
+};
+
+struct PairPlan {
+    bool active = false, reduced = false;
+    c4gpu_score region_score = 0;
+    c4gpu_region ar;
+    std::vector<Segment> segs;   // reduced-space: the flattened vsa_list
+};
+
+bool model_is_global(const c4gpu_model *m) {     // C4_Model_is_global, c4.c:1959
+    return m->start_scope == C4GPU_SCOPE_CORNER && m->end_scope == C4GPU_SCOPE_CORNER;
+}
+
+int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gpu_score threshold,
+                    c4gpu_alignment *alignments) {
+    const c4gpu_model *m = eng.model;
+    const int n = seqs.n_pairs;
+    std::vector<PairPlan> plan(n);
+    std::vector<JobSpec> specs;
+    std::vector<JobOut> outs;
+    std::vector<int> owner;
+    for (int i = 0; i < n; i++) memset(&alignments[i], 0, sizeof(c4gpu_alignment));
+    // -- step 1: where the whole rectangle is too large for a traceback, find the region first
+    std::vector<int> region_pairs;
+    for (int i = 0; i < n; i++) {
+        plan[i].ar = c4gpu_region{0, 0, seqs.qlen[i], seqs.tlen[i]};
+        plan[i].active = true;
+        if (c4h::use_reduced_space(m, &plan[i].ar, dpmemory_mb)) {
+            plan[i].reduced = true;
+            if (!model_is_global(m)) region_pairs.push_back(i);        // Optimal_find_region, optimal.c:135
+        }
+    }
+    specs.clear();
+    for (int i : region_pairs) { JobSpec s; s.pair = i; s.region = plan[i].ar; specs.push_back(s); }
+    if (eng.run(seqs, MODE_REGION, false, specs, outs)) return -1;
+    for (size_t x = 0; x < region_pairs.size(); x++) {
+        PairPlan &p = plan[region_pairs[x]];
+        const DevResult &r = outs[x].res;
+        if (r.score < threshold) { p.active = false; continue; }
+        p.region_score = r.score;
+        // Viterbi_Data_finalise, viterbi.c:633-653
+        if (m->start_scope != C4GPU_SCOPE_QUERY) p.ar.query_start = r.qs;
+        if (m->start_scope != C4GPU_SCOPE_TARGET) p.ar.target_start = r.ts;
+        p.ar.query_length = r.qe - (m->start_scope != C4GPU_SCOPE_QUERY ? r.qs : 0);
+        p.ar.target_length = r.te - (m->start_scope != C4GPU_SCOPE_TARGET ? r.ts : 0);
+    }
+    // -- step 2: quadratic-space path wherever the (alignment) region fits (optimal.c:349-364, 382-390)
+    specs.clear(); owner.clear();
+    for (int i = 0; i < n; i++) {
+        PairPlan &p = plan[i];
+        if (!p.active) continue;
+        if (p.reduced && c4h::use_reduced_space(m, &p.ar, dpmemory_mb)) continue;
+        p.reduced = false;
+        JobSpec s; s.pair = i; s.region = p.ar;
+        specs.push_back(s); owner.push_back(i);
+    }
+    if (eng.run(seqs, MODE_PATH, false, specs, outs)) return -1;
+    for (size_t x = 0; x < owner.size(); x++) {
+        const int i = owner[x];
+        const DevResult &r = outs[x].res;
+        c4gpu_alignment &a = alignments[i];
+        a.score = r.score;
+        // Viterbi_Data_create_Alignment, viterbi.c:380-383
+        a.region.query_start = plan[i].ar.query_start + r.qs;
+        a.region.target_start = plan[i].ar.target_start + r.ts;
+        a.region.query_length = r.qe - r.qs;
+        a.region.target_length = r.te - r.ts;
+        int cap = 0;
+        for (uint8_t t : outs[x].ops) c4h::alignment_add(&a, &cap, t, 1);
+        a.valid = 1;
+    }
+    // -- step 3: reduced space: checkpoint passes, recursively (optimal.c:160-230,315-345)
+    std::vector<int> red;
+    for (int i = 0; i < n; i++)
+        if (plan[i].active && plan[i].reduced) {
+            Segment s;
+            memset(&s, 0, sizeof s);
+            s.region = plan[i].ar; s.first_state = m->start_state; s.needs_checkpoints = true;
+            plan[i].segs.assign(1, s);
+            red.push_back(i);
+        }
+    std::vector<c4gpu_score> red_score(n, 0);
+    bool first_round = true;
+    for (;;) {
+        struct Ref { int pair, seg; };
+        std::vector<Ref> refs;
+        specs.clear();
+        for (int i : red) {
+            std::vector<Segment> &sg = plan[i].segs;
+            for (size_t k = 0; k < sg.size(); k++) {
+                if (!sg[k].needs_checkpoints) continue;
+                JobSpec s; s.pair = i; s.region = sg[k].region;
+                s.first_state = sg[k].first_state;
+                // optimal.c:204-213: first cell = final cell of the previous sub-alignment (or the zero cell),
+                // final state = first state of the next one (or END)
+                if (k > 0) memcpy(s.first_cell, sg[k - 1].final_cell, sizeof s.first_cell);
+                s.final_state = (k + 1 < sg.size()) ? sg[k + 1].first_state : m->end_state;
+                s.cp_count = c4h::checkpoint_rows(m, &s.region, dpmemory_mb);
+                specs.push_back(s);
+                refs.push_back(Ref{i, (int)k});
+            }
+        }
+        if (specs.empty()) break;
+        if (eng.run(seqs, MODE_CKPT, true, specs, outs)) return -1;
+        // expand from the back so that segment indices stay valid
+        for (int x = (int)refs.size() - 1; x >= 0; x--) {
+            std::vector<Segment> &sg = plan[refs[x].pair].segs;
+            const int k = refs[x].seg;
+            if (first_round) red_score[refs[x].pair] = outs[x].res.score;
+            std::vector<Segment> children;
+            for (int v = (int)outs[x].vsa.size() - 1; v >= 0; v--) {     // path order = reverse of the list
+                const DevVsa &dv = outs[x].vsa[v];
+                Segment c;
+                c.region = c4gpu_region{dv.qs, dv.ts, dv.ql, dv.tl};
+                c.first_state = dv.first_state;
+                memcpy(c.final_cell, dv.final_cell, sizeof c.final_cell);
+                c.needs_checkpoints = c4h::use_reduced_space(m, &c.region, dpmemory_mb);
+                children.push_back(c);
+            }
+            sg.erase(sg.begin() + k);
+            sg.insert(sg.begin() + k, children.begin(), children.end());
+        }
+        first_round = false;
+    }
+    // -- step 4: the sub-alignments themselves (Optimal_compute_subalignments, optimal.c:266-313)
+    specs.clear();
+    struct Ref2 { int pair, seg; };
+    std::vector<Ref2> refs2;
+    for (int i : red) {
+        std::vector<Segment> &sg = plan[i].segs;
+        for (size_t k = 0; k < sg.size(); k++) {
+            JobSpec s; s.pair = i; s.region = sg[k].region;
+            s.first_state = sg[k].first_state;
+            if (k > 0) memcpy(s.first_cell, sg[k - 1].final_cell, sizeof s.first_cell);
+            s.final_state = (k + 1 < sg.size()) ? sg[k + 1].first_state : m->end_state;
+            specs.push_back(s);
+            refs2.push_back(Ref2{i, (int)k});
+        }
+    }
+    if (eng.run(seqs, MODE_PATH, true, specs, outs)) return -1;
+    {
+        std::vector<int> cap(n, 0);
+        const int path_cs = 1 + m->total_shadow_designations;
+        for (size_t x = 0; x < refs2.size(); x++) {
+            const int i = refs2[x].pair;
+            c4gpu_alignment &a = alignments[i];
+            std::vector<Segment> &sg = plan[i].segs;
+            if (refs2[x].seg == 0) {
+                a.score = red_score[i];
+                a.region = plan[i].ar;
+                a.valid = 1;
+            }
+            // The reference threads the final cell of each sub-DP into the next one (optimal.c:283,301);
+            // we predicted it from the checkpoint rows to run all sub-DPs in one launch: verify.
+            if (memcmp(outs[x].res.final_cell, sg[refs2[x].seg].final_cell, sizeof(int) * path_cs) != 0) {
+                c4h::set_error("internal: continuation cell mismatch between checkpoint pass and sub-alignment");
+                return -1;
+            }
+            for (uint8_t t : outs[x].ops) c4h::alignment_add(&a, &cap[i], t, 1);
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        c4gpu_alignment &a = alignments[i];
+        if (a.valid && a.score < threshold) c4gpu_alignment_clear(&a);     // optimal.c:408-411
+    }
+    return 0;
+}
+
+}  // namespace
+
+// ---- the C ABI --------------------------------------------------------------------------------------------------
+struct c4gpu_batch {
+    c4gpu_ctx *ctx;
+    c4gpu_model model;
+    c4gpu_params params;
+    Engine eng;
+    ResidentSeqs seqs;
+    std::vector<c4gpu_score> scores;
+    std::vector<c4gpu_region> regions;
+    std::vector<c4gpu_alignment> alignments;
+};
+
+extern "C" {
+
+int c4gpu_abi_version(void) { return C4GPU_ABI_VERSION; }
+const char *c4gpu_last_error(void) { return c4h::g_error.c_str(); }
+
+c4gpu_ctx *c4gpu_ctx_create(int device_ordinal) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        c4h::set_error(std::string("no HIP device available (") + hipGetErrorString(e) +
+                       "): libc4gpu has no CPU fallback");
+        return nullptr;
+    }
+    if (device_ordinal < 0 || device_ordinal >= count) { c4h::set_error("bad device ordinal"); return nullptr; }
+    c4gpu_ctx *ctx = new c4gpu_ctx;
+    ctx->device = device_ordinal;
+    if (hipSetDevice(device_ordinal) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device_ordinal) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        c4h::set_error("cannot initialise the HIP device");
+        delete ctx;
+        return nullptr;
+    }
+    if (!strstr(ctx->prop.gcnArchName, "gfx950")) {
+        c4h::set_error(std::string("device is ") + ctx->prop.gcnArchName + ", kernels are built for gfx950 only");
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+void c4gpu_ctx_destroy(c4gpu_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+void c4gpu_ctx_set_stream(c4gpu_ctx *ctx, void *hip_stream) { ctx->stream = (hipStream_t)hip_stream; }
+
+int c4gpu_ctx_device_info(c4gpu_ctx *ctx, char *name, size_t name_len, int *n_cu, int64_t *mem_bytes) {
+    if (name && name_len) snprintf(name, name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    if (n_cu) *n_cu = ctx->prop.multiProcessorCount;
+    if (mem_bytes) *mem_bytes = (int64_t)ctx->prop.totalGlobalMem;
+    return 0;
+}
+
+int c4gpu_splice_predict(c4gpu_ctx *ctx, const c4gpu_params *params, const uint8_t *target, int32_t target_len,
+                         int32_t *out[4]) {
+    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+    c4gpu_pair pair{(const uint8_t *)"A", 1, target, target_len};
+    ResidentSeqs seqs;
+    if (seqs.build(ctx, FAM_EST2GENOME, params, &pair, 1)) return -1;
+    for (int k = 0; k < 4; k++) {
+        HIP_OK(hipMemcpyAsync(out[k], seqs.ss.p + (long long)k * seqs.dev.ss_stride, sizeof(int) * (size_t)target_len,
+                              hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int c4gpu_viterbi_batch(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params, int mode,
+                        const c4gpu_pair *pairs, int32_t n_pairs, const c4gpu_viterbi_job *jobs, int32_t n_jobs,
+                        c4gpu_viterbi_result *results) {
+    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+    Engine eng;
+    ResidentSeqs seqs;
+    if (eng.init(ctx, model, params) || seqs.build(ctx, eng.family, params, pairs, n_pairs)) return -1;
+    // jobs with and without continuation run different kernels (the model copy with CORNER scopes)
+    for (int cont = 0; cont < 2; cont++) {
+        std::vector<JobSpec> specs;
+        std::vector<int> idx;
+        for (int i = 0; i < n_jobs; i++) {
+            if ((jobs[i].use_continuation != 0) != (cont != 0)) continue;
+            JobSpec s;
+            s.pair = jobs[i].pair; s.region = jobs[i].region;
+            s.first_state = jobs[i].continuation.first_state; s.final_state = jobs[i].continuation.final_state;
+            for (int l = 0; l < CELL_MAX; l++) s.first_cell[l] = jobs[i].continuation.first_cell[l];
+            s.cp_count = jobs[i].checkpoint_count;
+            s.dump_checkpoints = (mode == C4GPU_MODE_FIND_CHECKPOINTS);
+            specs.push_back(s); idx.push_back(i);
+        }
+        if ((mode == C4GPU_MODE_FIND_CHECKPOINTS || mode == C4GPU_MODE_FIND_REGION) && !specs.empty() &&
+            ((mode == C4GPU_MODE_FIND_CHECKPOINTS) != (cont != 0))) {
+            c4h::set_error("FIND_CHECKPOINTS runs with a continuation, FIND_REGION without (optimal.c:47-68)");
+            return -1;
+        }
+        std::vector<JobOut> outs;
+        if (eng.run(seqs, mode, cont != 0, specs, outs)) return -1;
+        for (size_t x = 0; x < idx.size(); x++) {
+            c4gpu_viterbi_result &r = results[idx[x]];
+            const DevResult &d = outs[x].res;
+            memset(&r, 0, sizeof r);
+            r.score = d.score; r.query_start = d.qs; r.target_start = d.ts; r.query_end = d.qe; r.target_end = d.te;
+            for (int l = 0; l < CELL_MAX; l++) r.final_cell[l] = d.final_cell[l];
+            r.last_srp = d.last_srp;
+            r.n_ops = (int)outs[x].ops.size();
+            if (r.n_ops) {
+                r.ops = (int32_t *)malloc(sizeof(int32_t) * r.n_ops);
+                for (int k = 0; k < r.n_ops; k++) r.ops[k] = outs[x].ops[k];
+            }
+            if (!outs[x].checkpoints.empty()) {
+                r.checkpoints = (c4gpu_score *)malloc(sizeof(int) * outs[x].checkpoints.size());
+                memcpy(r.checkpoints, outs[x].checkpoints.data(), sizeof(int) * outs[x].checkpoints.size());
+            }
+        }
+    }
+    return 0;
+}
+
+void c4gpu_viterbi_result_clear(c4gpu_viterbi_result *r) {
+    free(r->ops);
+    free(r->checkpoints);
+    r->ops = nullptr; r->checkpoints = nullptr;
+}
+
+static int score_pass(Engine &eng, const ResidentSeqs &seqs, int mode, std::vector<JobOut> &outs) {
+    std::vector<JobSpec> specs(seqs.n_pairs);
+    for (int i = 0; i < seqs.n_pairs; i++) {
+        specs[i].pair = i;
+        specs[i].region = c4gpu_region{0, 0, seqs.qlen[i], seqs.tlen[i]};
+    }
+    return eng.run(seqs, mode, false, specs, outs);
+}
+
+int c4gpu_optimal_find_score_batch(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params,
+                                   const c4gpu_pair *pairs, int32_t n_pairs, c4gpu_score *scores) {
+    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+    Engine eng;
+    ResidentSeqs seqs;
+    std::vector<JobOut> outs;
+    if (eng.init(ctx, model, params) || seqs.build(ctx, eng.family, params, pairs, n_pairs) ||
+        score_pass(eng, seqs, MODE_SCORE, outs)) return -1;
+    for (int i = 0; i < n_pairs; i++) scores[i] = outs[i].res.score;
+    return 0;
+}
+
+int c4gpu_optimal_find_path_batch(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params,
+                                  const c4gpu_pair *pairs, int32_t n_pairs, int dpmemory_mb, c4gpu_score threshold,
+                                  c4gpu_alignment *alignments) {
+    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+    Engine eng;
+    ResidentSeqs seqs;
+    if (eng.init(ctx, model, params) || seqs.build(ctx, eng.family, params, pairs, n_pairs)) return -1;
+    return find_path_batch(eng, seqs, dpmemory_mb, threshold, alignments);
+}
+
+c4gpu_batch *c4gpu_batch_create(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params,
+                                const c4gpu_pair *pairs, int32_t n_pairs) {
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    c4gpu_batch *b = new c4gpu_batch;
+    b->ctx = ctx; b->model = *model; b->params = *params;
+    if (b->eng.init(ctx, &b->model, &b->params) || b->seqs.build(ctx, b->eng.family, &b->params, pairs, n_pairs)) {
+        delete b;
+        return nullptr;
+    }
+    return b;
+}
+
+void c4gpu_batch_destroy(c4gpu_batch *b) {
+    if (!b) return;
+    for (auto &a : b->alignments) c4gpu_alignment_clear(&a);
+    delete b;
+}
+
+int c4gpu_batch_run(c4gpu_batch *b, int what, int dpmemory_mb, c4gpu_score threshold) {
+    if (hipSetDevice(b->ctx->device) != hipSuccess) return -1;
+    const int n = b->seqs.n_pairs;
+    if (what == 0 || what == 1) {
+        std::vector<JobOut> outs;
+        if (score_pass(b->eng, b->seqs, what == 0 ? MODE_SCORE : MODE_REGION, outs)) return -1;
+        b->scores.resize(n); b->regions.resize(n);
+        for (int i = 0; i < n; i++) {
+            const DevResult &r = outs[i].res;
+            b->scores[i] = r.score;
+            b->regions[i] = c4gpu_region{r.qs, r.ts, r.qe - r.qs, r.te - r.ts};
+        }
+        return 0;
+    }
+    for (auto &a : b->alignments) c4gpu_alignment_clear(&a);
+    b->alignments.assign(n, c4gpu_alignment{});
+    if (find_path_batch(b->eng, b->seqs, dpmemory_mb, threshold, b->alignments.data())) return -1;
+    b->scores.resize(n); b->regions.resize(n);
+    for (int i = 0; i < n; i++) { b->scores[i] = b->alignments[i].score; b->regions[i] = b->alignments[i].region; }
+    return 0;
+}
+
+int c4gpu_batch_scores(c4gpu_batch *b, c4gpu_score *scores, c4gpu_region *regions) {
+    for (size_t i = 0; i < b->scores.size(); i++) {
+        if (scores) scores[i] = b->scores[i];
+        if (regions) regions[i] = b->regions[i];
+    }
+    return (int)b->scores.size();
+}
+
+int c4gpu_batch_alignment(c4gpu_batch *b, int32_t i, c4gpu_alignment *out) {
+    if (i < 0 || i >= (int)b->alignments.size()) return -1;
+    const c4gpu_alignment &a = b->alignments[i];
+    *out = a;
+    out->op_transition = out->op_length = nullptr;
+    if (a.n_ops) {
+        out->op_transition = (int32_t *)malloc(sizeof(int32_t) * a.n_ops);
+        out->op_length = (int32_t *)malloc(sizeof(int32_t) * a.n_ops);
+        memcpy(out->op_transition, a.op_transition, sizeof(int32_t) * a.n_ops);
+        memcpy(out->op_length, a.op_length, sizeof(int32_t) * a.n_ops);
+    }
+    return 0;
+}
+
+int c4gpu_batch_kernel_stats(c4gpu_batch *b, int reset, double *ms, int64_t *launches, int64_t *cells) {
+    c4gpu_ctx *ctx = b->ctx;
+    if (ms) *ms = ctx->kernel_ms;
+    if (launches) *launches = ctx->kernel_launches;
+    if (cells) *cells = ctx->kernel_cells;
+    if (reset) { ctx->kernel_ms = 0; ctx->kernel_launches = 0; ctx->kernel_cells = 0; }
+    ctx->timing = true;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,173 @@
+// c4_host.cc — host-side pieces of the C ABI that need no device: the reference's memory decisions
+// (which decide WHICH Viterbi passes run, hence results) and the sugar/cigar/vulgar printers.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "c4gpu.h"
+#include "c4_internal.h"
+
+namespace c4h {
+
+// Matrix3d_size / Matrix4d_size (exonerate src/struct/matrix.c:74-100,137-171): index blocks + data with
+// the "+= size % sizeof(pointer)" padding rule and the floating-point overflow probe.
+static size_t matrix3d_bytes(int a, int b, int c, size_t cell) {
+    const size_t P = sizeof(void *);
+    unsigned long block = b * P + (unsigned long)b * (c * cell);
+    double dblock = (double)(b * P) + (double)b * (double)(c * cell);
+    block += block % P;
+    dblock += (double)(block % P);
+    unsigned long total = a * P + (unsigned long)a * block;
+    double dtotal = (double)(a * P) + (double)a * dblock;
+    return (dtotal - (double)total) > 1 ? 0 : total;
+}
+
+static size_t matrix4d_bytes(int a, int b, int c, int d, size_t cell) {
+    const size_t P = sizeof(void *);
+    unsigned long block = c * P + (unsigned long)c * (d * cell);
+    double dblock = (double)(c * P) + (double)c * (double)(d * cell);
+    block += block % P;
+    dblock += (double)(block % P);
+    unsigned long sheet = b * P + (unsigned long)b * block;
+    double dsheet = (double)(b * P) + (double)b * dblock;
+    sheet += sheet % P;
+    dsheet += (double)(sheet % P);
+    unsigned long total = a * P + (unsigned long)a * sheet;
+    double dtotal = (double)(a * P) + (double)a * dsheet;
+    return (dtotal - (double)total) > 1 ? 0 : total;
+}
+
+// Viterbi_get_row_size (viterbi.c:108-118): the matrix size passes through a gint
+static size_t viterbi_row_bytes(const c4gpu_model *m, const c4gpu_region *r, int cell_size) {
+    const int mat = (int)matrix4d_bytes(m->max_target_advance + 1, r->query_length + 1, m->n_states, cell_size,
+                                        sizeof(c4gpu_score));
+    if (!mat) return 0;
+    return (size_t)24 /* sizeof(Viterbi_Row) */ + (size_t)mat;
+}
+
+bool use_reduced_space(const c4gpu_model *m, const c4gpu_region *r, int dpmemory_mb) {
+    if (r->query_length <= m->max_query_advance * 6) return false;
+    if (r->target_length <= m->max_target_advance * 6) return false;
+    const size_t rows = viterbi_row_bytes(m, r, 1 + m->total_shadow_designations);
+    const size_t traceback = matrix3d_bytes(r->query_length + 1, r->target_length + 1, m->n_states, sizeof(void *));
+    const size_t limit = (size_t)(dpmemory_mb << 20);
+    if (!rows || !traceback) return true;
+    return rows + traceback > limit;
+}
+
+int checkpoint_rows(const c4gpu_model *m, const c4gpu_region *r, int dpmemory_mb) {
+    const size_t rows = viterbi_row_bytes(m, r, 1 + m->total_shadow_designations + 1);
+    const int avail = (int)(((size_t)(dpmemory_mb << 20)) / rows - 1);
+    const int max_rows = r->target_length / (m->max_target_advance << 1) - 2;
+    if (avail < 1) return 1;
+    return avail < max_rows ? avail : max_rows;
+}
+
+// Alignment_add (alignment.c:75-102): run-length merge of equal consecutive transitions
+void alignment_add(c4gpu_alignment *a, int *cap, int transition, int length) {
+    if (a->n_ops && a->op_transition[a->n_ops - 1] == transition) {
+        a->op_length[a->n_ops - 1] += length;
+        if (a->op_length[a->n_ops - 1] == 0) a->n_ops--;
+        return;
+    }
+    if (a->n_ops == *cap) {
+        *cap = *cap ? *cap * 2 : 32;
+        a->op_transition = (int32_t *)realloc(a->op_transition, sizeof(int32_t) * *cap);
+        a->op_length = (int32_t *)realloc(a->op_length, sizeof(int32_t) * *cap);
+    }
+    a->op_transition[a->n_ops] = transition;
+    a->op_length[a->n_ops++] = length;
+}
+
+}  // namespace c4h
+
+extern "C" {
+
+int c4gpu_use_reduced_space(const c4gpu_model *model, const c4gpu_region *region, int dpmemory_mb) {
+    return c4h::use_reduced_space(model, region, dpmemory_mb) ? 1 : 0;
+}
+int c4gpu_checkpoint_rows(const c4gpu_model *model, const c4gpu_region *region, int dpmemory_mb) {
+    return c4h::checkpoint_rows(model, region, dpmemory_mb);
+}
+
+void c4gpu_alignment_clear(c4gpu_alignment *a) {
+    free(a->op_transition);
+    free(a->op_length);
+    memset(a, 0, sizeof(*a));
+}
+
+// Alignment_display_{sugar,cigar,vulgar} (alignment.c:2671-2706) on top of the *_block printers
+// (alignment.c:1622-1779).
+int c4gpu_alignment_format(const c4gpu_model *m, const c4gpu_alignment *a, int what, const char *qid,
+                           int32_t qlen, char qstrand, const char *tid, int32_t tlen, char tstrand,
+                           int forward_coords, char *buf, size_t buf_len) {
+    if (what < 0 || what > 2 || !buf_len) return -1;
+    auto coord = [&](bool on_query, bool start) {      // Alignment_get_coordinate, alignment.c:177-205
+        int pos = on_query ? (start ? a->region.query_start : a->region.query_start + a->region.query_length)
+                           : (start ? a->region.target_start : a->region.target_start + a->region.target_length);
+        if (forward_coords && (on_query ? qstrand : tstrand) == '-') pos = (on_query ? qlen : tlen) - pos;
+        return pos;
+    };
+    static const char *prefix[] = {"sugar: ", "cigar: ", "vulgar: "};
+    std::string out = prefix[what];
+    char tmp[128];
+    out += qid;
+    snprintf(tmp, sizeof tmp, " %d %d %c ", coord(true, true), coord(true, false), qstrand);
+    out += tmp;
+    out += tid;
+    snprintf(tmp, sizeof tmp, " %d %d %c %d", coord(false, true), coord(false, false), tstrand, a->score);
+    out += tmp;
+    if (what == 1 && a->n_ops > 0) {
+        out += " ";
+        const char *gap = "";
+        char type = 0;
+        int move = 0;
+        for (int i = 0; i < a->n_ops; i++) {
+            const c4gpu_transition &t = m->transitions[a->op_transition[i]];
+            char ntype;
+            int nmove;
+            if (!t.advance_query) { ntype = 'D'; nmove = t.advance_target * a->op_length[i]; }
+            else if (!t.advance_target) { ntype = 'I'; nmove = t.advance_query * a->op_length[i]; }
+            else { ntype = 'M'; nmove = (t.advance_query > t.advance_target ? t.advance_query : t.advance_target) * a->op_length[i]; }
+            if (i == 0) { type = ntype; move = nmove; continue; }
+            if (ntype == type) { move += nmove; continue; }
+            if (move) { snprintf(tmp, sizeof tmp, "%s%c %d", gap, type, move); out += tmp; }
+            move = nmove; type = ntype; gap = " ";
+        }
+        if (move) { snprintf(tmp, sizeof tmp, "%s%c %d", gap, type, move); out += tmp; }
+    } else if (what == 2 && a->n_ops > 0) {
+        out += " ";
+        static const char label_char[] = {0, 'M', 'G', 'N', '5', '3', 'I', 'S', 'F'};
+        const char *gap = "";
+        const c4gpu_transition *t = &m->transitions[a->op_transition[0]];
+        int label = t->label, aq = t->advance_query * a->op_length[0], at = t->advance_target * a->op_length[0];
+        bool codon = false;
+        for (int i = 1; i < a->n_ops; i++) {
+            t = &m->transitions[a->op_transition[i]];
+            const bool tcodon = t->advance_query == 3 && t->advance_target == 3;
+            if (t->label == label && (aq || !t->advance_query) && (at || !t->advance_target) && codon == tcodon) {
+                aq += t->advance_query * a->op_length[i];
+                at += t->advance_target * a->op_length[i];
+                continue;
+            }
+            if (label != C4GPU_LABEL_NONE) {
+                char c = (label == C4GPU_LABEL_MATCH && codon) ? 'C' : label_char[label];
+                snprintf(tmp, sizeof tmp, "%s%c %d %d", gap, c, aq, at);
+                out += tmp;
+                gap = " ";
+            }
+            label = t->label; codon = tcodon;
+            aq = t->advance_query * a->op_length[i];
+            at = t->advance_target * a->op_length[i];
+        }
+        // the run still pending here is never printed (alignment.c:1697-1777 has no epilogue)
+    } else if (what != 0) {
+        out += " ";
+    }
+    if (out.size() + 1 > buf_len) return -1;
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return (int)out.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,57 @@
+// c4_launch.h — host-visible table of the compiled Viterbi kernels (the device-side counterpart of the
+// reference's name-keyed Bootstrapper_lookup table, src/model/bootstrapper.c:85-90).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "c4_viterbi_kernel.h"
+
+namespace c4k {
+
+enum Family { FAM_UNGAPPED = 0, FAM_AFFINE, FAM_EST2GENOME, FAM_UNGAPPED_P2D, FAM_PROTEIN2DNA, FAM_COUNT };
+
+struct LaunchArgs {
+    const KParams *kp;
+    DevSeqs seqs;
+    const DevJob *jobs;
+    int n_jobs;
+    DevResult *results;
+    DevVsa *vsas;
+    uint8_t *ops;
+    DevScratch scratch;
+    int *queue;
+    int grid;
+    hipStream_t stream;
+};
+
+struct KernelInfo {
+    hipError_t (*launch)(const LaunchArgs &);
+    const void *func;         // for occupancy queries
+    const char *name;
+    int R;                    // query rows per lane
+    int cs;                   // ints per state cell (1 + extra slots)
+    int bnd;                  // ints per column of the strip carry row
+    int n_states, max_at;
+};
+
+// family x mode x continuation x local-scope specialisation; NULL launch = not compiled
+const KernelInfo *get_kernel(int family, int mode, bool cont, bool local);
+
+#define C4K_DEFINE_KERNEL(SYMBOL, M, RVAL, MODE, CONT, LOCAL)                                              \
+    static hipError_t SYMBOL##_launch(const LaunchArgs &a) {                                               \
+        hipLaunchKernelGGL((viterbi_kernel<M, RVAL, MODE, CONT, LOCAL>), dim3(a.grid), dim3(64), 0,        \
+                           a.stream, a.kp, a.seqs, a.jobs, a.n_jobs, a.results, a.vsas, a.ops, a.scratch,  \
+                           a.queue);                                                                       \
+        return hipGetLastError();                                                                          \
+    }                                                                                                      \
+    const KernelInfo *SYMBOL() {                                                                           \
+        static const KernelInfo ki = {SYMBOL##_launch,                                                     \
+                                      (const void *)viterbi_kernel<M, RVAL, MODE, CONT, LOCAL>,            \
+                                      #SYMBOL,                                                             \
+                                      RVAL,                                                                \
+                                      WaveDP<M, RVAL, MODE, CONT, LOCAL>::CS,                              \
+                                      WaveDP<M, RVAL, MODE, CONT, LOCAL>::BND,                             \
+                                      M::NS,                                                               \
+                                      M::MAXAT};                                                           \
+        return &ki;                                                                                        \
+    }
+
+}  // namespace c4k

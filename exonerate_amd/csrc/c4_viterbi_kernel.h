@@ -1,0 +1,698 @@
+// c4_viterbi_kernel.h — the C4 Viterbi recurrence + traceback as a hand-written CDNA4 (gfx950) kernel.
+//
+// What it computes: exactly the cell recurrence of Viterbi_interpreted (exonerate src/c4/viterbi.c:655-837)
+// in all four modes (viterbi.h:104-109) and with/without continuation (viterbi.c:68-76,705-714), for a
+// model family whose closed transition table is a compile-time descriptor (c4_device_models.inc): the
+// same transition id order, "first valid transition assigns unconditionally, later ones replace on
+// strict <" (viterbi.c:766-775), shadow end / start / transport (viterbi.c:396-462), row-major-first end
+// cell (viterbi.c:778-791), checkpoint rows + SRP slot (viterbi.c:605-631) and the traceback walk of
+// Viterbi_Data_create_Alignment (viterbi.c:342-392) / Viterbi_Checkpoint_traceback (viterbi.c:537-601).
+//
+// How it maps to CDNA4:
+//   * one 64-lane wavefront per (query x target) job; persistent waves pull jobs from an atomic queue
+//     (jobs are pre-sorted longest first), so a launch of N >> 256*k jobs keeps every SIMD busy;
+//   * lanes tile the QUERY axis: lane l owns R consecutive query rows of a 64*R-row strip and walks the
+//     target axis; at wave step s lane l is at column j = s - l (anti-diagonal wavefront).  All live DP
+//     state of the anti-diagonal (columns j-1 .. j-max_target_advance of R rows) lives in VGPRs;
+//   * the (i-1, .) dependency crosses lanes once per step through DPP `wave_shr:1` register shifts (no LDS
+//     round trip); strip-to-strip carry rows go through an L2-resident scratch row, read back 64 columns
+//     at a time (coalesced) and broadcast with v_readlane;
+//   * the substitution matrix lives in LDS (one ds_read per cell); residues and splice-site score arrays
+//     are read coalesced (adjacent lanes = adjacent columns);
+//   * integer max-plus only: no MFMA.  The algorithmic HBM traffic is a few bytes per COLUMN, so the
+//     kernel is VALU-bound by construction (roofline section).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <utility>
+
+namespace c4k {
+
+struct TrDesc { int in, out, aq, at, calc, label; unsigned dst_shadow_mask; };
+struct CalcDesc { int kind, param, protect; };
+struct ShDesc { int designation, on_target; unsigned src_state_mask, dst_transition_mask; };
+
+#include "c4_device_models.inc"
+
+constexpr int LOW = -987654321;
+constexpr int HIGH = 987654321;
+constexpr int CELL_MAX = 8;
+enum { MODE_SCORE = 0, MODE_PATH = 1, MODE_REGION = 2, MODE_CKPT = 3 };
+enum { SCOPE_ANYWHERE = 0, SCOPE_EDGE, SCOPE_QUERY, SCOPE_TARGET, SCOPE_CORNER };
+enum { CALC_CONST = 0, CALC_MATCH_DNA, CALC_MATCH_PROTEIN, CALC_MATCH_P2D, CALC_SPLICE_PRE, CALC_SPLICE_POST };
+enum { FLAG_OPS_OVERFLOW = 1, FLAG_NO_END = 2 };
+
+struct KParams {                 // uniform per launch (device memory, staged to LDS)
+    int calc_value[16];
+    int min_intron, max_intron;
+    int start_scope, end_scope;
+    int submat[24 * 24];
+};
+struct DevSeqs {
+    const uint8_t *qcode, *tcode;        // residue -> submat row codes (tcode: codon codes for 1:3 match)
+    const long long *qoff, *toff;        // per pair offsets into the concatenated arrays
+    const int *ss;                       // [4][ss_stride] splice-site scores, same offsets as tcode
+    long long ss_stride;
+};
+struct DevJob {
+    int pair, q0, t0, Q, T;
+    int first_state, final_state, cp_count;
+    int first_cell[CELL_MAX];
+    long long ops_off;                   // into the ops byte array (PATH)
+    int ops_cap, vsa_off;                // vsa_off: into the DevVsa array (CKPT)
+    long long ckpt_off;                  // >= 0: also dump checkpoint cells there (tests); -1: wave slab only
+};
+struct DevResult {
+    int score, qs, ts, qe, te, end_set, last_srp, n_ops, flags, n_vsa, cell_size, pad;
+    int final_cell[CELL_MAX];
+};
+struct DevVsa { int qs, ts, ql, tl, first_state, pad[3]; int final_cell[CELL_MAX]; };
+struct DevScratch {                      // per persistent wave slabs
+    int *bnd;       long long bnd_stride;
+    uint32_t *tb;   long long tb_stride;
+    int *ckpt;      long long ckpt_stride;
+    int *ckpt_dump;
+};
+
+// compile-time index object: the conversion is always-inlined so that every array index is a literal
+// before the first SROA run (a std::integral_constant conversion is an ordinary call at that point and
+// leaves the per-lane DP state in scratch memory)
+template <int V>
+struct IC {
+    static constexpr int value = V;
+    __device__ __forceinline__ constexpr operator int() const { return V; }
+};
+template <int N, class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(IC<I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
+
+// ---- compile-time facts about a model descriptor ---------------------------------------------------------
+template <class M>
+struct Facts {
+    static constexpr int fanin(int s) { int n = 0; for (int k = 0; k < M::NT; k++) n += (M::tr[k].out == s); return n; }
+    static constexpr int bits(int s) { int f = fanin(s) + 1, b = 0; while ((1 << b) < f) b++; return b; }
+    static constexpr int shift(int s) { int n = 0; for (int x = 0; x < s; x++) n += bits(x); return n; }
+    static constexpr int code(int k) { int n = 1; for (int x = 0; x < k; x++) n += (M::tr[x].out == M::tr[k].out); return n; }
+    static constexpr int total_bits = shift(M::NS);
+    // does state s have an outgoing transition with advance_query > 0 (its value crosses lanes)?
+    static constexpr bool exported(int s) { for (int k = 0; k < M::NT; k++) if (M::tr[k].in == s && M::tr[k].aq > 0) return true; return false; }
+    static constexpr int n_exported() { int n = 0; for (int s = 0; s < M::NS; s++) n += exported(s); return n; }
+    static constexpr bool owns_shadow(int s, int d) { for (int h = 0; h < M::NSH; h++) if (M::sh[h].designation == d && (M::sh[h].src_state_mask >> s & 1)) return true; return false; }
+    static constexpr int consumed_designation(int k) { for (int h = 0; h < M::NSH; h++) if (M::tr[k].dst_shadow_mask >> h & 1) return M::sh[h].designation; return -1; }
+    static constexpr int match_at() { for (int k = 0; k < M::NT; k++) if (M::tr[k].calc >= 0 && M::calc[M::tr[k].calc].kind >= CALC_MATCH_DNA && M::calc[M::tr[k].calc].kind <= CALC_MATCH_P2D) return M::tr[k].at; return 1; }
+    static constexpr bool has_splice() { for (int c = 0; c < M::NC; c++) if (M::calc[c].kind == CALC_SPLICE_PRE || M::calc[c].kind == CALC_SPLICE_POST) return true; return false; }
+    static_assert(M::MAXAQ == 1, "lanes exchange exactly one query row per step");
+    static_assert(total_bits <= 32, "traceback word");
+};
+
+template <class M, int X>
+struct Cell {
+    int sc[M::NS];
+    int ex[M::NS][X > 0 ? X : 1];
+};
+
+__device__ __forceinline__ int dpp_shr1(int old, int v) {      // lane l <- lane l-1 ; lane 0 keeps `old`
+    return __builtin_amdgcn_update_dpp(old, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ bool scope_ok(int scope, bool at_q, bool at_t) {
+    switch (scope) {
+        case SCOPE_ANYWHERE: return true;
+        case SCOPE_EDGE: return at_q || at_t;
+        case SCOPE_QUERY: return at_q;
+        case SCOPE_TARGET: return at_t;
+        default: return at_q && at_t;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// One DP job on one wavefront.
+// -------------------------------------------------------------------------------------------------------------
+template <class M, int R, int MODE, bool CONT, bool LOCAL>
+struct WaveDP {
+    using F = Facts<M>;
+    static constexpr int NDES = M::NDES;
+    static constexpr int X = NDES + (MODE == MODE_REGION ? 2 : 0) + (MODE == MODE_CKPT ? 1 : 0);
+    static constexpr int XS = X > 0 ? X : 1;
+    static constexpr int RSQ = NDES, RST = NDES + 1, SRP = NDES;
+    static constexpr int CS = 1 + X;                    // ints per (state) cell, reference layout
+    static constexpr int W = 64 * R;                    // query rows per strip
+    static constexpr int NEXP = F::n_exported();
+    static constexpr int BND = NEXP * CS;               // ints per column in the strip carry row
+    using C = Cell<M, X>;
+
+    // job / launch constants
+    const KParams *kp;      // in LDS
+    const uint8_t *qc, *tc;
+    const int *ss0, *ss1, *ss2, *ss3;
+    int Q, T, q0, t0, lane;
+    int first_state, final_state, min_intron, max_intron;
+    const int *first_cell;
+    int start_scope, end_scope;
+
+    // per-lane DP state
+    C cur[R], prev[M::MAXAT][R], up, ud[M::MAXAT], expo;
+    int qcode[R];
+    int best, best_i, best_j, best_qs, best_ts;
+    bool best_set;
+
+    __device__ __forceinline__ int splice(int k, int tpos) const {
+        const int *p = k == 0 ? ss0 : k == 1 ? ss1 : k == 2 ? ss2 : ss3;
+        return p[tpos];
+    }
+
+    // ---- one cell -----------------------------------------------------------------------------------------
+    // RR: row inside the lane (compile time).  JINT: every lane is at max_at <= j <= T (main loop).
+    template <int RR, bool JINT>
+    __device__ __forceinline__ void eval_cell(int i, int j, bool active, int mscore, const int (&pre)[4],
+                                              uint32_t &tbword) {
+        C &c = cur[RR];
+        bool set[M::NS];
+        static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+            set[S] = false;
+            c.sc[S] = LOW;
+        });
+        if constexpr (X > 0) {
+            // the START cell's slots are zero unless seeded by a continuation (calloc'd, never written)
+            static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; c.ex[M::START][E] = 0; });
+        }
+        // NOTE on style: every select below works on scalars that were loaded first and uses the
+        // non-short-circuit operators (& |): a `cond ? x : mem[..]` arm is a load under control flow, which
+        // InstCombine (run BEFORE the always-inliner) turns into a load of a selected address and that
+        // keeps the whole per-lane state in scratch memory instead of VGPRs.
+        const bool i_ok = (RR > 0) | (i > 0);
+        uint32_t tbw = 0;
+        static_for<M::NT>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
+            constexpr int k = K;
+            constexpr TrDesc t = M::tr[k];
+            // Layout_transition_is_valid (layout.c:122-154)
+            bool valid = true;
+            if constexpr (t.aq > 0) valid = valid & i_ok;
+            if constexpr (t.at > 0 && !JINT) valid = valid & (j >= t.at);
+            if constexpr (t.in == M::START && !LOCAL)
+                valid = valid & scope_ok(start_scope, i - t.aq == 0, j - t.at == 0);
+            if constexpr (t.out == M::END && !LOCAL)
+                valid = valid & scope_ok(end_scope, i == Q, j == T);
+            // continuation seeding (viterbi.c:705-714): first cell into the first state, at the corner only
+            if constexpr (CONT && t.in == M::START) {
+                static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                    const bool seed = valid & (first_state == S);
+                    const int old_sc = c.sc[S], fc0 = first_cell[0];
+                    c.sc[S] = seed ? fc0 : old_sc;
+                    static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
+                        if constexpr (X > 0) {
+                            const int old_ex = c.ex[S][E], fce = first_cell[1 + E];
+                            c.ex[S][E] = seed ? fce : old_ex;
+                        }
+                    });
+                    set[S] = set[S] | seed;
+                });
+            }
+            // source cell
+            const C &src = (t.aq == 0 && t.at == 0) ? c
+                         : (t.aq == 1 && t.at == 0) ? (RR > 0 ? cur[RR > 0 ? RR - 1 : 0] : up)
+                         : (t.aq == 0)              ? prev[t.at > 0 ? t.at - 1 : 0][RR]
+                                                    : (RR > 0 ? prev[t.at > 0 ? t.at - 1 : 0][RR > 0 ? RR - 1 : 0]
+                                                              : ud[t.at > 0 ? t.at - 1 : 0]);
+            int tscore;
+            if constexpr (t.in == M::START) tscore = CONT ? src.sc[M::START] : 0;
+            else tscore = src.sc[t.in];
+            // calc (C4_Calc_score, c4.c:1700)
+            if constexpr (t.calc >= 0) {
+                constexpr CalcDesc cd = M::calc[t.calc];
+                if constexpr (cd.kind == CALC_CONST) {
+                    tscore += kp->calc_value[t.calc];
+                } else if constexpr (cd.kind >= CALC_MATCH_DNA && cd.kind <= CALC_MATCH_P2D) {
+                    tscore += mscore;
+                } else if constexpr (cd.kind == CALC_SPLICE_PRE) {
+                    tscore += pre[cd.param];             // open penalty + ss[param][tpos], hoisted per column
+                } else if constexpr (cd.kind == CALC_SPLICE_POST) {
+                    // Intron_calc_*: the shadow end func has just loaded curr_intron_start (intron.c:468)
+                    constexpr int des = F::consumed_designation(k);
+                    static_assert(des >= 0, "post-splice calc without a shadow");
+                    const int intron_length = (t0 + j - t.at) - src.ex[t.in][des] + 2;
+                    const bool bad = (intron_length < min_intron) | (intron_length > max_intron);
+                    const int ssv = pre[cd.param];
+                    tscore += bad ? LOW : ssv;
+                }
+                if constexpr (cd.protect & 2) tscore = tscore < LOW ? LOW : tscore;
+                if constexpr (cd.protect & 1) tscore = tscore > HIGH ? HIGH : tscore;
+            }
+            const bool was_set = set[t.out];
+            const int old_sc = c.sc[t.out];
+            const bool win = valid & (!was_set | (old_sc < tscore));
+            // Viterbi_Data_assign (viterbi.c:445-462)
+            c.sc[t.out] = win ? tscore : old_sc;
+            if constexpr (X > 0) {
+                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
+                    constexpr int e = E;
+                    int v = src.ex[t.in][e];
+                    if constexpr (e < NDES) {
+                        if constexpr (F::owns_shadow(t.in, e)) v = t0 + j - t.at;      // intron.c:454-458
+                    } else if constexpr (MODE == MODE_REGION && t.in == M::START) {
+                        v = (e == RSQ) ? (i - t.aq) : (j - t.at);                        // viterbi.c:403-412
+                    }
+                    const int old_ex = c.ex[t.out][e];
+                    c.ex[t.out][e] = win ? v : old_ex;
+                });
+            }
+            if constexpr (MODE == MODE_PATH) {
+                constexpr uint32_t mask = ((1u << F::bits(t.out)) - 1u) << F::shift(t.out);
+                constexpr uint32_t code = (uint32_t)F::code(k) << F::shift(t.out);
+                tbw = win ? ((tbw & ~mask) | code) : tbw;
+            }
+            set[t.out] = was_set | valid;
+        });
+        tbword = tbw;
+        // end cell (viterbi.c:778-791).  In continuation mode the score is read off the corner cell later.
+        if constexpr (!CONT) {
+            const int tsc = c.sc[M::END];
+            const bool end_set = set[M::END], b_set = best_set;
+            const int b = best, bi = best_i, bj = best_j;
+            const bool upd = active & end_set & (!b_set | (b < tsc));
+            best = upd ? tsc : b;
+            best_i = upd ? i : bi;
+            best_j = upd ? j : bj;
+            if constexpr (MODE == MODE_REGION) {
+                const int nqs = c.ex[M::END][RSQ], nts = c.ex[M::END][RST], oqs = best_qs, ots = best_ts;
+                best_qs = upd ? nqs : oqs;
+                best_ts = upd ? nts : ots;
+            }
+            best_set = b_set | upd;
+        }
+    }
+
+    // ---- cross-lane / cross-strip exchange ----------------------------------------------------------------
+    // pack / unpack the exported states of a cell (those with advance_query > 0 successors)
+    template <class Fn>
+    __device__ __forceinline__ static void for_exported(Fn &&fn) {
+        int slot = 0;
+        static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+            if constexpr (F::exported(S)) {
+                fn(S_, slot);
+                slot += CS;
+            }
+        });
+    }
+
+    // ---- one wave step: every lane evaluates its R rows of column j = s - lane ---------------------------
+    template <bool JINT>
+    __device__ __forceinline__ void step(int s, int i0, bool first_strip, bool last_strip, const int *bnd_in,
+                                         int *bnd_out, uint32_t *tb_slab, long long tb_base, int *ckpt,
+                                         int section_length, int cp_count) {
+        const int j = s - lane;
+        const bool jact = JINT || (j >= 0 && j <= T);
+        // (1) row i0-1 of this column: from lane-1 (DPP) or, for lane 0, from the previous strip's carry row
+        {
+            C nb;
+            for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
+                int sc0 = LOW, ex0[XS];
+                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; ex0[E] = 0; });
+                if (!first_strip && lane == 0 && jact) {
+                    const int *p = bnd_in + (long long)j * BND + slot;
+                    sc0 = p[0];
+                    static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; if constexpr (X > 0) ex0[E] = p[1 + E]; });
+                }
+                nb.sc[S] = dpp_shr1(sc0, expo.sc[S]);
+                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; if constexpr (X > 0) nb.ex[S][E] = dpp_shr1(ex0[E], expo.ex[S][E]); });
+            });
+            // shift the (i0-1, j-d) history, then install the new (i0-1, j)
+            static_for<M::MAXAT>([&](auto D_) __attribute__((always_inline)) { constexpr int D = D_;
+                constexpr int d = M::MAXAT - 1 - D;
+                for_exported([&](auto S_, int) __attribute__((always_inline)) { constexpr int S = S_;
+                    ud[d].sc[S] = (d == 0) ? up.sc[S] : ud[d > 0 ? d - 1 : 0].sc[S];
+                    static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
+                        if constexpr (X > 0) ud[d].ex[S][E] = (d == 0) ? up.ex[S][E] : ud[d > 0 ? d - 1 : 0].ex[S][E];
+                    });
+                });
+            });
+            for_exported([&](auto S_, int) __attribute__((always_inline)) { constexpr int S = S_;
+                up.sc[S] = nb.sc[S];
+                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; if constexpr (X > 0) up.ex[S][E] = nb.ex[S][E]; });
+            });
+        }
+        // (2) per-column scoring data (coalesced: adjacent lanes read adjacent columns)
+        int tcode = 0;
+        int sp[4] = {0, 0, 0, 0};
+        {
+            constexpr int mat = F::match_at();
+            const int jj = j - mat;
+            if (jact && jj >= 0) tcode = tc[t0 + jj];
+            if constexpr (F::has_splice()) {
+                const int tpos = t0 + j - 2;
+                if (jact && j >= 2) {
+                    static_for<M::NC>([&](auto CI_) __attribute__((always_inline)) { constexpr int CI = CI_;
+                        constexpr CalcDesc cd = M::calc[CI];
+                        if constexpr (cd.kind == CALC_SPLICE_PRE) sp[cd.param] = kp->calc_value[CI] + splice(cd.param, tpos);
+                        if constexpr (cd.kind == CALC_SPLICE_POST) sp[cd.param] = splice(cd.param, tpos);
+                    });
+                }
+            }
+        }
+        // (3) the R cells of this lane, top to bottom
+        uint32_t tbw[R];
+        static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+            constexpr int r = RR;
+            const int i = i0 + r;
+            const int ms = kp->submat[qcode[r] * 24 + tcode];
+            eval_cell<r, JINT>(i, j, jact && i <= Q, ms, sp, tbw[r]);
+        });
+        // (4) traceback words, step-major (fully coalesced)
+        if constexpr (MODE == MODE_PATH) {
+            uint32_t *p = tb_slab + tb_base + ((long long)s * 64 + lane) * R;
+            if (jact) static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_; p[RR] = tbw[RR]; });
+        }
+        // (5) export the bottom row BEFORE any checkpoint edit (the next lane still needs column j as it was)
+        for_exported([&](auto S_, int) __attribute__((always_inline)) { constexpr int S = S_;
+            expo.sc[S] = cur[R - 1].sc[S];
+            static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; if constexpr (X > 0) expo.ex[S][E] = cur[R - 1].ex[S][E]; });
+        });
+        if (!last_strip && lane == 63 && jact) {
+            for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
+                int *p = bnd_out + (long long)j * BND + slot;
+                p[0] = expo.sc[S];
+                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; if constexpr (X > 0) p[1 + E] = expo.ex[S][E]; });
+            });
+        }
+        // (6) the corner cell (Q, T): final cell of a continuation / last SRP (viterbi.c:813-832)
+        if constexpr (CONT) {
+            if (jact && j == T) {
+                static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                    if (i0 + RR == Q) {
+                        static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                            if (final_state == S) {
+                                corner[0] = cur[RR].sc[S];
+                                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; if constexpr (X > 0) corner[1 + E] = cur[RR].ex[S][E]; });
+                                corner_set = true;
+                            }
+                        });
+                    }
+                });
+            }
+        }
+        // (7) checkpoint rows (Viterbi_Checkpoint_process, viterbi.c:605-631)
+        if constexpr (MODE == MODE_CKPT) {
+            const bool at_cp = jact && j > 0 && (j % section_length == 0) && (j / section_length - 1 < cp_count);
+            if (at_cp) {
+                const int cpi = j / section_length - 1;
+                static_for<M::MAXAT>([&](auto ROW_) __attribute__((always_inline)) { constexpr int ROW = ROW_;
+                    constexpr int row = ROW;
+                    static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                        const int i = i0 + RR;
+                        C &cell = (row == 0) ? cur[RR] : prev[row > 0 ? row - 1 : 0][RR];
+                        if (i <= Q) {
+                            int *p = ckpt + ((((long long)cpi * M::MAXAT + row) * (Q + 1) + i) * M::NS) * CS;
+                            static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                                p[S * CS] = cell.sc[S];
+                                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; p[S * CS + 1 + E] = cell.ex[S][E]; });
+                            });
+                        }
+                        static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                            cell.ex[S][SRP] = ((i * M::NS) + S) * M::MAXAT + row;     // viterbi.c:515-522
+                        });
+                    });
+                    // our copies of row i0-1 at columns j (up) and j-1.. (ud) get the same edit
+                    C &nbc = (row == 0) ? up : ud[row > 0 ? row - 1 : 0];
+                    static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_; nbc.ex[S][SRP] = (((i0 - 1) * M::NS) + S) * M::MAXAT + row; });
+                });
+            }
+        }
+        // (8) rotate columns
+        static_for<M::MAXAT>([&](auto D_) __attribute__((always_inline)) { constexpr int D = D_;
+            constexpr int d = M::MAXAT - 1 - D;
+            static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                    prev[d][RR].sc[S] = (d == 0) ? cur[RR].sc[S] : prev[d > 0 ? d - 1 : 0][RR].sc[S];
+                    static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
+                        if constexpr (X > 0)
+                            prev[d][RR].ex[S][E] = (d == 0) ? cur[RR].ex[S][E] : prev[d > 0 ? d - 1 : 0][RR].ex[S][E];
+                    });
+                });
+            });
+        });
+    }
+
+    int corner[CELL_MAX];
+    bool corner_set;
+
+    // ---- the whole rectangle ------------------------------------------------------------------------------
+    __device__ __forceinline__ void run(const DevJob &job, const DevSeqs &seqs, int *bnd, uint32_t *tb, int *ckpt) {
+        Q = job.Q; T = job.T; q0 = job.q0; t0 = job.t0;
+        first_state = job.first_state; final_state = CONT ? job.final_state : M::END;
+        first_cell = job.first_cell;
+        min_intron = kp->min_intron; max_intron = kp->max_intron;
+        start_scope = CONT ? SCOPE_CORNER : kp->start_scope;
+        end_scope = CONT ? SCOPE_CORNER : kp->end_scope;
+        qc = seqs.qcode + seqs.qoff[job.pair];
+        tc = seqs.tcode + seqs.toff[job.pair];
+        if constexpr (F::has_splice()) {
+            const int *base = seqs.ss + seqs.toff[job.pair];
+            ss0 = base; ss1 = base + seqs.ss_stride; ss2 = base + 2 * seqs.ss_stride; ss3 = base + 3 * seqs.ss_stride;
+        }
+        best = LOW; best_i = best_j = best_qs = best_ts = 0; best_set = false;
+        corner_set = false;
+        const int section_length = (MODE == MODE_CKPT) ? T / (job.cp_count + 1) : 1;
+        const int nstrips = (Q + 1 + W - 1) / W;
+        const long long strip_tb = (long long)(T + 64) * 64 * R;
+        for (int b = 0; b < nstrips; b++) {
+            const int i0 = b * W + lane * R;
+            static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                const int qpos = q0 + i0 + RR - 1;            // residue consumed by an advance_query=1 move into row i
+                qcode[RR] = (i0 + RR >= 1 && i0 + RR <= Q) ? qc[qpos] : 0;
+            });
+            // neighbour registers start empty (row -1 does not exist; validity masks keep it unread)
+            static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                up.sc[S] = LOW; expo.sc[S] = LOW;
+                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; up.ex[S][E] = 0; expo.ex[S][E] = 0; });
+                static_for<M::MAXAT>([&](auto D_) __attribute__((always_inline)) { constexpr int D = D_;
+                    ud[D].sc[S] = LOW;
+                    static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; ud[D].ex[S][E] = 0; });
+                    static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                        prev[D][RR].sc[S] = LOW;
+                        static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; prev[D][RR].ex[S][E] = 0; });
+                    });
+                });
+            });
+            if constexpr (!CONT) strip_begin();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int *bnd_in = bnd + (long long)((b + 1) & 1) * (T + 1) * BND;
+            int *bnd_out = bnd + (long long)(b & 1) * (T + 1) * BND;
+            const bool first = (b == 0), last = (b == nstrips - 1);
+            const int nsteps = T + 64;
+            const int main_lo = 63 + M::MAXAT, main_hi = T;          // steps where every lane is interior in j
+            int s = 0;
+            for (; s < nsteps && s < main_lo; s++)
+                step<false>(s, i0, first, last, bnd_in, bnd_out, tb, b * strip_tb, ckpt, section_length, job.cp_count);
+            for (; s <= main_hi; s++)
+                step<true>(s, i0, first, last, bnd_in, bnd_out, tb, b * strip_tb, ckpt, section_length, job.cp_count);
+            for (; s < nsteps; s++)
+                step<false>(s, i0, first, last, bnd_in, bnd_out, tb, b * strip_tb, ckpt, section_length, job.cp_count);
+            if constexpr (!CONT) strip_end();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // carry row / traceback visible to the next strip
+        }
+    }
+
+    // ---- epilogue: wave-wide end cell, traceback walk, checkpoint traceback -----------------------------
+    // Row-major-first maximum (viterbi.c:778-791): highest score, then smallest j, then smallest i.
+    __device__ __forceinline__ void reduce_best() {
+        for (int off = 32; off > 0; off >>= 1) {
+            const int o_best = __shfl_xor(best, off), o_i = __shfl_xor(best_i, off), o_j = __shfl_xor(best_j, off);
+            const int o_qs = __shfl_xor(best_qs, off), o_ts = __shfl_xor(best_ts, off);
+            const bool o_set = __shfl_xor((int)best_set, off) != 0;
+            const int b = best, bi = best_i, bj = best_j, bqs = best_qs, bts = best_ts;
+            const bool bs = best_set;
+            const bool take = o_set & (!bs | (o_best > b) | ((o_best == b) & ((o_j < bj) | ((o_j == bj) & (o_i < bi)))));
+            best = take ? o_best : b;  best_i = take ? o_i : bi;  best_j = take ? o_j : bj;
+            best_qs = take ? o_qs : bqs;  best_ts = take ? o_ts : bts;
+            best_set = bs | o_set;
+        }
+    }
+
+    // strict-greater per strip is row-major-first only inside a strip: merge strips with the full order
+    int sbest, sbest_i, sbest_j, sbest_qs, sbest_ts;
+    bool sbest_set;
+    __device__ __forceinline__ void strip_begin() {
+        sbest = best; sbest_i = best_i; sbest_j = best_j; sbest_qs = best_qs; sbest_ts = best_ts; sbest_set = best_set;
+        best_set = false; best = LOW;
+    }
+    __device__ __forceinline__ void strip_end() {
+        const int b = best, bi = best_i, bj = best_j, bqs = best_qs, bts = best_ts;
+        const int ob = sbest, oi = sbest_i, oj = sbest_j, oqs = sbest_qs, ots = sbest_ts;
+        const bool bs = best_set, os = sbest_set;
+        const bool keep_old = os & (!bs | (ob > b) | ((ob == b) & ((oj < bj) | ((oj == bj) & (oi < bi)))));
+        best = keep_old ? ob : b;  best_i = keep_old ? oi : bi;  best_j = keep_old ? oj : bj;
+        best_qs = keep_old ? oqs : bqs;  best_ts = keep_old ? ots : bts;
+        best_set = bs | os;
+    }
+
+    // traceback word of cell (i, j) in the step-major slab
+    __device__ static uint32_t tb_at(const uint32_t *tb, int i, int j, int T) {
+        const int b = i / W, l = (i - b * W) / R, r = (i - b * W) - l * R;
+        const long long strip_tb = (long long)(T + 64) * 64 * R;
+        return tb[b * strip_tb + ((long long)(j + l) * 64 + l) * R + r];
+    }
+    __device__ __forceinline__ static int tb_transition(uint32_t word, int state) {      // -1: never assigned (NULL)
+        int code = 0;
+        static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+            if constexpr (F::bits(S) > 0)
+                if (state == S) code = (word >> F::shift(S)) & ((1u << F::bits(S)) - 1u);
+        });
+        int tr = -1;
+        static_for<M::NT>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; if (M::tr[K].out == state && F::code(K) == code) tr = K; });
+        return tr;
+    }
+    __device__ __forceinline__ static void tr_info(int k, int &in, int &out, int &aq, int &at) {
+        in = out = aq = at = 0;
+        static_for<M::NT>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; if (k == K) { in = M::tr[K].in; out = M::tr[K].out; aq = M::tr[K].aq; at = M::tr[K].at; } });
+    }
+
+    // Viterbi_Data_create_Alignment's walk (viterbi.c:342-379), by lane 0; path is written END -> START.
+    __device__ __noinline__ static void walk(const uint32_t *tb, int T, int first_state, int final_state, int qe,
+                                             int te, uint8_t *ops, int cap, DevResult &res) {
+        int i = qe, j = te, n = 0, in, out, aq, at;
+        int tr = tb_transition(tb_at(tb, i, j, T), final_state);
+        bool overflow = false;
+        while (tr >= 0) {
+            if (n < cap) ops[n] = (uint8_t)tr; else overflow = true;
+            n++;
+            tr_info(tr, in, out, aq, at);
+            i -= aq; j -= at;
+            tr = tb_transition(tb_at(tb, i, j, T), in);
+            if (tr < 0) break;
+            tr_info(tr, in, out, aq, at);
+            if (in == M::START) {
+                if (n < cap) ops[n] = (uint8_t)tr; else overflow = true;
+                n++;
+                i -= aq; j -= at;
+                break;
+            }
+            if (CONT && !(i | j) && out == first_state) break;
+        }
+        res.qs = i; res.ts = j; res.n_ops = n;
+        if (overflow) res.flags |= FLAG_OPS_OVERFLOW;
+    }
+
+    // Viterbi_Checkpoint_traceback (viterbi.c:537-601), by lane 0; list is written last section first.
+    __device__ __noinline__ static void checkpoint_traceback(const int *ckpt, const DevJob &job, DevVsa *vsa,
+                                                             DevResult &res) {
+        const int Q = job.Q, T = job.T, q0 = job.q0, t0 = job.t0;
+        const int cpn = job.cp_count, section_length = T / (cpn + 1);
+        auto decode = [&](int srp, int &state, int &row, int &pos) {
+            row = srp % M::MAXAT;
+            const int rem = srp / M::MAXAT;
+            state = rem % M::NS;
+            pos = rem / M::NS;
+        };
+        auto cell_at = [&](int cp, int row, int qpos, int state) {
+            return ckpt + ((((long long)cp * M::MAXAT + row) * (Q + 1) + qpos) * M::NS + state) * CS;
+        };
+        int state, row, pos, n = 0;
+        decode(res.last_srp, state, row, pos);
+        int query_start = q0 + pos, target_start = t0 + section_length * cpn - row;
+        DevVsa v;
+        v.qs = query_start; v.ts = target_start;
+        v.ql = (q0 + Q) - query_start; v.tl = (t0 + T) - target_start;
+        v.first_state = state;
+        for (int l = 0; l < CELL_MAX; l++) v.final_cell[l] = l < CS ? res.final_cell[l] : 0;
+        vsa[n++] = v;
+        for (int c = cpn - 1; c >= 1; c--) {
+            const DevVsa p = v;
+            const int prev_row = row;
+            const int *cell = cell_at(c, prev_row, p.qs - q0, p.first_state);
+            decode(cell[CS - 1], state, row, pos);
+            query_start = q0 + pos;
+            target_start = p.ts - section_length - row + prev_row;
+            v.qs = query_start; v.ts = target_start; v.ql = p.qs - query_start; v.tl = p.ts - target_start;
+            v.first_state = state;
+            for (int l = 0; l < CELL_MAX; l++) v.final_cell[l] = l < CS ? cell[l] : 0;
+            vsa[n++] = v;
+        }
+        {
+            const DevVsa p = v;
+            const int *cell = cell_at(0, row, p.qs - q0, p.first_state);
+            v.qs = q0; v.ts = t0; v.ql = query_start - q0; v.tl = target_start - t0;
+            v.first_state = job.first_state;
+            for (int l = 0; l < CELL_MAX; l++) v.final_cell[l] = l < CS ? cell[l] : 0;
+            vsa[n++] = v;
+        }
+        res.n_vsa = n;
+    }
+};
+
+
+// -------------------------------------------------------------------------------------------------------------
+// Kernel: persistent waves, one job at a time per wave.
+// -------------------------------------------------------------------------------------------------------------
+template <class M, int R, int MODE, bool CONT, bool LOCAL>
+__global__ __launch_bounds__(64) void viterbi_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs,
+                                                     int n_jobs, DevResult *results, DevVsa *vsas, uint8_t *ops,
+                                                     DevScratch scratch, int *queue) {
+    using DP = WaveDP<M, R, MODE, CONT, LOCAL>;
+    __shared__ KParams kp_lds;
+    __shared__ int next_job;
+    {
+        const int *src = reinterpret_cast<const int *>(kparams);
+        int *dst = reinterpret_cast<int *>(&kp_lds);
+        for (int x = threadIdx.x; x < (int)(sizeof(KParams) / sizeof(int)); x += 64) dst[x] = src[x];
+    }
+    __syncthreads();
+    const int wave = blockIdx.x;
+    int *bnd = scratch.bnd + (long long)wave * scratch.bnd_stride;
+    uint32_t *tb = scratch.tb ? scratch.tb + (long long)wave * scratch.tb_stride : nullptr;
+    int *ckpt_slab = scratch.ckpt ? scratch.ckpt + (long long)wave * scratch.ckpt_stride : nullptr;
+    for (;;) {
+        if (threadIdx.x == 0) next_job = atomicAdd(queue, 1);
+        __syncthreads();
+        const int jid = next_job;
+        __syncthreads();
+        if (jid >= n_jobs) break;
+        const DevJob &job = jobs[jid];
+        DP dp;
+        dp.kp = &kp_lds;
+        dp.lane = threadIdx.x;
+        int *ckpt = ckpt_slab;
+        if constexpr (MODE == MODE_CKPT)
+            if (job.ckpt_off >= 0) ckpt = scratch.ckpt_dump + job.ckpt_off;
+        dp.run(job, seqs, bnd, tb, ckpt);
+        DevResult res;
+        res.flags = 0; res.n_ops = 0; res.n_vsa = 0; res.last_srp = 0; res.qs = res.ts = 0; res.pad = 0;
+        res.cell_size = DP::CS;
+        for (int l = 0; l < CELL_MAX; l++) res.final_cell[l] = 0;
+        if constexpr (CONT) {
+            // the lane that owns (Q, T) holds the corner cell of the final state
+            const unsigned long long owners = __ballot(dp.corner_set);
+            const int owner = owners ? __ffsll((long long)owners) - 1 : 0;
+            for (int l = 0; l < DP::CS; l++) res.final_cell[l] = __shfl(dp.corner[l], owner);
+            res.end_set = owners != 0;
+            res.score = res.final_cell[0];
+            res.qe = job.Q; res.te = job.T;
+            if constexpr (MODE == MODE_CKPT) res.last_srp = res.final_cell[DP::CS - 1];
+        } else {
+            dp.reduce_best();
+            res.score = dp.best; res.end_set = dp.best_set;
+            res.qe = dp.best_i; res.te = dp.best_j;
+            if constexpr (MODE == MODE_REGION) { res.qs = dp.best_qs; res.ts = dp.best_ts; }
+        }
+        if (!res.end_set) res.flags |= FLAG_NO_END;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if constexpr (MODE == MODE_PATH) {
+                if (res.end_set) DP::walk(tb, job.T, job.first_state, CONT ? job.final_state : M::END, res.qe, res.te,
+                                          ops + job.ops_off, job.ops_cap, res);
+            }
+            if constexpr (MODE == MODE_CKPT) {
+                if (res.end_set) DP::checkpoint_traceback(ckpt, job, vsas + job.vsa_off, res);
+            }
+            results[jid] = res;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace c4k

@@ -1,0 +1,175 @@
+"""Parity of the HIP engine (through the C ABI of libc4gpu.so) with the reference.
+
+Golden vectors = outputs of the reference itself (tests/golden/*.jsonl, tools/make_golden.py); the oracle
+(oracle/c4_oracle.c, pinned to the same vectors in test_oracle_golden.py) is the checker for seeded inputs
+that have no golden record.  Integer work: every comparison is bit-exact.
+"""
+import random
+import pytest
+
+import exonerate_amd as ex
+from exonerate_amd import _abi
+import oracle_lib
+from golden_util import SETS, load_set, expected
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = ex.Engine(0)
+    yield e
+    e.close()
+
+
+def _model(name):
+    mt, qa, ta = SETS[name]
+    return ex.Model(mt, qa, ta)
+
+
+@pytest.mark.parametrize("name", sorted(SETS))
+def test_find_score_and_path_match_reference_vectors(eng, name):
+    model = _model(name)
+    recs = load_set(name)
+    pairs = [(r["query"], r["target"]) for r in recs]
+    scores = eng.find_score(model, pairs)
+    assert scores == [r["score"] for r in recs]
+    alns = eng.find_path(model, pairs, dpmemory=recs[0]["dpmemory"])
+    for rec, aln in zip(recs, alns):
+        if "path_score" not in rec:
+            assert aln is None, rec["id"]
+            continue
+        assert aln is not None, rec["id"]
+        assert aln.as_dict(rec["id"]) == expected(rec), rec["id"]
+
+
+def test_reference_known_answer_tests_on_gpu(eng):
+    """src/model/affine.test.c:107-110, est2genome.test.c:63, with the printed local vulgar."""
+    for name, score in (("affine_global_protein", -151), ("affine_bestfit_protein", 18),
+                        ("affine_local_protein", 32), ("affine_overlap_protein", 18)):
+        rec = [r for r in load_set(name) if r["id"] == "kat_affine"][0]
+        assert eng.find_score(_model(name), [(rec["query"], rec["target"])]) == [score]
+    rec = [r for r in load_set("est2genome") if r["id"] == "kat_est2genome"][0]
+    assert eng.find_score(_model("est2genome"), [(rec["query"], rec["target"])]) == [157]
+    rec = [r for r in load_set("affine_local_protein") if r["id"] == "kat_affine"][0]
+    aln = eng.find_path(_model("affine_local_protein"), [(rec["query"], rec["target"])])[0]
+    assert aln.vulgar("kat_affine").endswith("32 M 8 8 G 1 0 M 4 4") and aln.region == (11, 33, 13, 12)
+
+
+def test_splice_arrays_match_reference(eng):
+    model = _model("est2genome")
+    keys = ["ss5_forward", "ss3_forward", "ss3_reverse", "ss5_reverse"]       # C4GPU_SS* order
+    for rec in load_set("est2genome")[:10]:
+        got = eng.splice_predict(model.params, rec["target"])
+        for k, key in enumerate(keys):
+            assert got[k] == rec[key], (rec["id"], key)
+
+
+def _rand(rng, n, alpha="ACGT"):
+    return "".join(rng.choice(alpha) for _ in range(n))
+
+
+def _mutate(rng, s, rate, alpha="ACGT"):
+    out = []
+    for ch in s:
+        r = rng.random()
+        if r < rate / 3:
+            out.append(rng.choice(alpha))
+        elif r < 2 * rate / 3:
+            out.append(ch + rng.choice(alpha))
+        elif r >= rate:
+            out.append(ch)
+    return "".join(out)
+
+
+@pytest.mark.parametrize("model_type,qlen,tlen,dpm", [
+    ("affine:local", 300, 330, 32), ("affine:local", 700, 900, 32), ("affine:global", 520, 500, 32),
+    ("affine:bestfit", 130, 900, 32), ("affine:overlap", 260, 300, 1),
+    ("est2genome", 257, 3000, 32), ("est2genome", 600, 9000, 32), ("est2genome", 300, 2500, 0),
+])
+def test_seeded_pairs_match_oracle(eng, model_type, qlen, tlen, dpm):
+    """Sizes that cross the 64*R strip boundary and take the region -> checkpoint -> sub-alignment route."""
+    rng = random.Random(hash((model_type, qlen, tlen)) & 0xffff)
+    model = ex.Model(model_type)
+    pairs = []
+    for k in range(6):
+        q = _rand(rng, qlen + k)
+        if model_type == "est2genome":
+            cut = sorted(rng.sample(range(20, qlen - 20), 2))
+            t = (_rand(rng, 100) + _mutate(rng, q[:cut[0]], 0.03) + "GT" + _rand(rng, tlen // 4) + "AG" +
+                 _mutate(rng, q[cut[0]:cut[1]], 0.03) + "GT" + _rand(rng, tlen // 3) + "AG" +
+                 _mutate(rng, q[cut[1]:], 0.03) + _rand(rng, 150))
+        else:
+            t = _rand(rng, 40) + _mutate(rng, q, 0.1) + _rand(rng, max(0, tlen - qlen))
+        pairs.append((q, t))
+    scores = eng.find_score(model, pairs)
+    alns = eng.find_path(model, pairs, dpmemory=dpm)
+    for (q, t), s, a in zip(pairs, scores, alns):
+        assert s == oracle_lib.find_score(model.c, model.params, q.encode(), t.encode())
+        exp = oracle_lib.find_path(model.c, model.params, q.encode(), t.encode(), dpmemory=dpm)
+        assert a.as_dict() == exp
+
+
+def test_raw_viterbi_modes_match_oracle(eng):
+    """Viterbi_DP_Func level: region + checkpoint (continuation) passes against oracle_viterbi."""
+    import ctypes as C
+    olib = oracle_lib.load()
+    model = ex.Model("est2genome")
+    rng = random.Random(5)
+    q = _rand(rng, 150)
+    t = _rand(rng, 60) + q[:70] + "GT" + _rand(rng, 300) + "AG" + q[70:] + _rand(rng, 80)
+    region = (0, 0, len(q), len(t))
+    got = eng.viterbi(model, ex.MODE_FIND_REGION, [(q, t)], [{"pair": 0, "region": region}])[0]
+    vo = oracle_lib.ViterbiOut()
+    olib.oracle_viterbi(model.c, model.params, ex.MODE_FIND_REGION, q.encode(), len(q), t.encode(), len(t),
+                        _abi.Region(*region), None, 0, vo)
+    assert (got["score"], got["query_start"], got["target_start"], got["query_end"], got["target_end"]) == \
+           (vo.score, vo.query_start, vo.target_start, vo.query_end, vo.target_end)
+    olib.oracle_viterbi_out_clear(vo)
+    # checkpoint pass over the aligned region, from START to END
+    ar = (got["query_start"], got["target_start"], got["query_end"] - got["query_start"],
+          got["target_end"] - got["target_start"])
+    cont = _abi.Continuation()
+    cont.first_state, cont.final_state = model.c.start_state, model.c.end_state
+    vo = oracle_lib.ViterbiOut()
+    olib.oracle_viterbi(model.c, model.params, ex.MODE_FIND_CHECKPOINTS, q.encode(), len(q), t.encode(), len(t),
+                        _abi.Region(*ar), cont, 5, vo)
+    got = eng.viterbi(model, ex.MODE_FIND_CHECKPOINTS, [(q, t)],
+                      [{"pair": 0, "region": ar, "checkpoints": 5,
+                        "continuation": {"first_state": model.c.start_state, "final_state": model.c.end_state}}])[0]
+    assert got["score"] == vo.score and got["last_srp"] == vo.last_srp
+    assert got["final_cell"][:vo.cell_size] == list(vo.final_cell)[:vo.cell_size]
+    olib.oracle_viterbi_out_clear(vo)
+
+
+def test_residue_outside_alphabet_is_rejected(eng):
+    model = ex.Model("affine:local")
+    with pytest.raises(ex.C4GpuError):
+        eng.find_score(model, [("ACGT", "AC#T")])
+
+
+def test_full_size_properties(eng):
+    """BASELINE-size pair (1 kb x 100 kb est2genome): size-independent properties.
+    (a) the alignment of a cDNA to genomic with planted introns recovers every exon block;
+    (b) score of (q, t) is unchanged by appending unrelated flank to the target (local model);
+    (c) region pass and score pass agree on the score."""
+    rng = random.Random(11)
+    model = ex.Model("est2genome")
+    q = _rand(rng, 1000)
+    cuts = [0, 230, 520, 790, 1000]
+    t = _rand(rng, 30000)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        t += q[a:b]
+        if b != 1000:
+            t += "GT" + _rand(rng, 4000) + "AG"
+    core = t
+    t = core + _rand(rng, 100000 - len(core))
+    s_full, s_core = eng.find_score(model, [(q, t), (q, core)])
+    assert s_full == s_core
+    aln = eng.find_path(model, [(q, t)])[0]
+    assert aln.score == s_full
+    v = aln.vulgar().split()[9:]
+    m_blocks = [int(v[i + 1]) for i in range(0, len(v), 3) if v[i] == "M"]
+    assert m_blocks == [230, 290, 270, 210]
+    introns = [int(v[i + 2]) for i in range(0, len(v), 3) if v[i] == "I"]
+    assert introns == [4000, 4000, 4000]
