@@ -17,7 +17,7 @@ from . import _abi
 from ._abi import (ALPHABET_DNA, ALPHABET_PROTEIN, IMPOSSIBLY_LOW_SCORE, MODE_FIND_SCORE, MODE_FIND_PATH,
                    MODE_FIND_REGION, MODE_FIND_CHECKPOINTS)
 
-__all__ = ["Model", "Engine", "Alignment", "default_params", "C4GpuError"]
+__all__ = ["Model", "Engine", "Alignment", "ResidentBatch", "default_params", "C4GpuError"]
 
 
 class C4GpuError(RuntimeError):
@@ -227,9 +227,9 @@ class ResidentBatch:
         _lib().c4gpu_alignment_clear(a)
         return out
 
-    def kernel_stats(self, reset=False):
+    def kernel_stats(self, mode, reset=False):
         ms, n, cells = C.c_double(), C.c_int64(), C.c_int64()
-        _lib().c4gpu_batch_kernel_stats(self.h, int(reset), ms, n, cells)
+        _lib().c4gpu_batch_kernel_stats(self.h, mode, int(reset), ms, n, cells)
         return {"ms": ms.value, "launches": n.value, "cells": cells.value}
 
     def close(self):

@@ -141,7 +141,7 @@ PROTOTYPES = [
     ("c4gpu_batch_run", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int32]),
     ("c4gpu_batch_scores", C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(Region)]),
     ("c4gpu_batch_alignment", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Alignment)]),
-    ("c4gpu_batch_kernel_stats", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double),
+    ("c4gpu_batch_kernel_stats", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double),
                                            C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("c4gpu_alignment_format", C.c_int, [C.POINTER(Model), C.POINTER(Alignment), C.c_int,
                                          C.c_char_p, C.c_int32, C.c_char, C.c_char_p, C.c_int32, C.c_char,

@@ -39,8 +39,8 @@ struct c4gpu_ctx {
     hipDeviceProp_t prop;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // accumulated statistics of the Viterbi kernel launches (HIP events on the launch stream)
-    double kernel_ms = 0;
-    int64_t kernel_launches = 0, kernel_cells = 0;
+    double kernel_ms[4] = {0, 0, 0, 0};            // indexed by Viterbi mode
+    int64_t kernel_launches[4] = {0, 0, 0, 0}, kernel_cells[4] = {0, 0, 0, 0};
     bool timing = false;
 };
 
@@ -371,7 +371,7 @@ struct Engine {
         if (ctx->timing) {
             float ms = 0;
             HIP_OK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-            ctx->kernel_ms += ms; ctx->kernel_launches++; ctx->kernel_cells += total_cells;
+            ctx->kernel_ms[mode] += ms; ctx->kernel_launches[mode]++; ctx->kernel_cells[mode] += total_cells;
         }
         for (int x = 0; x < n; x++) {
             JobOut &o = out[order[x]];
@@ -789,12 +789,13 @@ int c4gpu_batch_alignment(c4gpu_batch *b, int32_t i, c4gpu_alignment *out) {
     return 0;
 }
 
-int c4gpu_batch_kernel_stats(c4gpu_batch *b, int reset, double *ms, int64_t *launches, int64_t *cells) {
+int c4gpu_batch_kernel_stats(c4gpu_batch *b, int mode, int reset, double *ms, int64_t *launches, int64_t *cells) {
     c4gpu_ctx *ctx = b->ctx;
-    if (ms) *ms = ctx->kernel_ms;
-    if (launches) *launches = ctx->kernel_launches;
-    if (cells) *cells = ctx->kernel_cells;
-    if (reset) { ctx->kernel_ms = 0; ctx->kernel_launches = 0; ctx->kernel_cells = 0; }
+    if (mode < 0 || mode > 3) return -1;
+    if (ms) *ms = ctx->kernel_ms[mode];
+    if (launches) *launches = ctx->kernel_launches[mode];
+    if (cells) *cells = ctx->kernel_cells[mode];
+    if (reset) { ctx->kernel_ms[mode] = 0; ctx->kernel_launches[mode] = 0; ctx->kernel_cells[mode] = 0; }
     ctx->timing = true;
     return 0;
 }

@@ -254,9 +254,11 @@ void         c4gpu_batch_destroy(c4gpu_batch *b);
 int          c4gpu_batch_run(c4gpu_batch *b, int what, int dpmemory_mb, c4gpu_score threshold);
 int          c4gpu_batch_scores(c4gpu_batch *b, c4gpu_score *scores, c4gpu_region *regions);
 int          c4gpu_batch_alignment(c4gpu_batch *b, int32_t i, c4gpu_alignment *out);
-/* Accumulated device time (ms) and launches of the dominant Viterbi kernel since the last reset,
- * measured with HIP events on the launch stream. */
-int          c4gpu_batch_kernel_stats(c4gpu_batch *b, int reset, double *ms, int64_t *launches, int64_t *cells);
+/* Accumulated device time (ms), launches and lattice cells of the Viterbi kernel of one mode
+ * (C4GPU_MODE_*) since the last reset, measured with HIP events on the launch stream.  The first call
+ * switches the measurement on. */
+int          c4gpu_batch_kernel_stats(c4gpu_batch *b, int mode, int reset, double *ms, int64_t *launches,
+                                      int64_t *cells);
 
 /* Alignment_print_{sugar,cigar,vulgar}_block (alignment.c:1622-1779); coordinates are region
  * coordinates on the given strands ('+', '-', '.'), flipped to the forward strand when

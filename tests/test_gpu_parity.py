@@ -168,7 +168,7 @@ def test_full_size_properties(eng):
     assert s_full == s_core
     aln = eng.find_path(model, [(q, t)])[0]
     assert aln.score == s_full
-    v = aln.vulgar().split()[9:]
+    v = aln.vulgar().split()[10:]
     m_blocks = [int(v[i + 1]) for i in range(0, len(v), 3) if v[i] == "M"]
     assert m_blocks == [230, 290, 270, 210]
     introns = [int(v[i + 2]) for i in range(0, len(v), 3) if v[i] == "I"]
