@@ -302,7 +302,12 @@ struct Engine {
         out.assign(n, JobOut());
         if (!n) return 0;
         const bool use_local = local && !cont && (mode == MODE_SCORE || mode == MODE_REGION);
-        const KernelInfo *ki = get_kernel(family, mode, cont, use_local);
+        // packed region-start slot: (query_start << tshift) | target_start must fit 31 bits for every job
+        auto nbits = [](int v) { int b = 0; while ((1LL << b) <= v) b++; return b; };
+        bool pack = (mode == MODE_REGION);
+        for (int i = 0; i < n && pack; i++)
+            pack = nbits(specs[i].region.query_length) + nbits(specs[i].region.target_length) <= 31;
+        const KernelInfo *ki = get_kernel(family, mode, cont, use_local, pack);
         if (!ki) { c4h::set_error("no compiled kernel for this model/mode"); return -1; }
         // longest first (persistent waves pull from the queue head)
         std::vector<int> order(n);
@@ -318,6 +323,7 @@ struct Engine {
             j.pair = s.pair; j.q0 = s.region.query_start; j.t0 = s.region.target_start;
             j.Q = s.region.query_length; j.T = s.region.target_length;
             j.first_state = s.first_state; j.final_state = s.final_state; j.cp_count = s.cp_count;
+            j.tshift = nbits(j.T);
             memcpy(j.first_cell, s.first_cell, sizeof j.first_cell);
             j.ops_off = ops_total; j.ops_cap = 0; j.vsa_off = (int)vsa_total; j.ckpt_off = -1;
             total_cells += cells(order[x]);

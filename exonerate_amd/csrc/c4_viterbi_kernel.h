@@ -57,6 +57,7 @@ struct DevSeqs {
 struct DevJob {
     int pair, q0, t0, Q, T;
     int first_state, final_state, cp_count;
+    int tshift, pad0;                    // packed region start: (query_start << tshift) | target_start
     int first_cell[CELL_MAX];
     long long ops_off;                   // into the ops byte array (PATH)
     int ops_cap, vsa_off;                // vsa_off: into the DevVsa array (CKPT)
@@ -133,45 +134,93 @@ __device__ __forceinline__ bool scope_ok(int scope, bool at_q, bool at_t) {
 // -------------------------------------------------------------------------------------------------------------
 // One DP job on one wavefront.
 // -------------------------------------------------------------------------------------------------------------
-template <class M, int R, int MODE, bool CONT, bool LOCAL>
+// PACK (FIND_REGION only): the two region-start slots (viterbi.c:403-412) share one int,
+// (query_start << tshift) | target_start; the host picks PACK when bits(Q) + bits(T) <= 31.
+template <class M, int R, int MODE, bool CONT, bool LOCAL, bool PACK = false>
 struct WaveDP {
     using F = Facts<M>;
     static constexpr int NDES = M::NDES;
-    static constexpr int X = NDES + (MODE == MODE_REGION ? 2 : 0) + (MODE == MODE_CKPT ? 1 : 0);
+    static constexpr int NRS = (MODE == MODE_REGION) ? (PACK ? 1 : 2) : 0;
+    static constexpr int X = NDES + NRS + (MODE == MODE_CKPT ? 1 : 0);      // register slots per state
     static constexpr int XS = X > 0 ? X : 1;
     static constexpr int RSQ = NDES, RST = NDES + 1, SRP = NDES;
-    static constexpr int CS = 1 + X;                    // ints per (state) cell, reference layout
+    // reference cell layout (viterbi.c:154-173): score, designations, [region q, region t], [checkpoint]
+    static constexpr int CS = 1 + NDES + (MODE == MODE_REGION ? 2 : 0) + (MODE == MODE_CKPT ? 1 : 0);
     static constexpr int W = 64 * R;                    // query rows per strip
+    static constexpr int NCOL = M::MAXAT + 1;           // live columns, kept as a ring (no register rotation)
     static constexpr int NEXP = F::n_exported();
-    static constexpr int BND = NEXP * CS;               // ints per column in the strip carry row
+    static constexpr int BND = NEXP * (1 + XS);         // ints per column in the strip carry row
     using C = Cell<M, X>;
+
+    // Is slot e of state s ever read?  A designation slot only matters while a path to a consuming
+    // transition exists that does not pass through a state that re-starts the shadow (e.g. est2genome:
+    // only the two intron states).  Dead slots are neither stored nor transported; cells leaving the
+    // kernel carry 0 there.
+    static constexpr bool slot_live(int s, int e) {
+        if (e >= NDES) return true;
+        bool live[M::NS] = {};
+        for (int it = 0; it < M::NS; it++)
+            for (int k = 0; k < M::NT; k++) {
+                const int in = M::tr[k].in, out = M::tr[k].out;
+                if (F::consumed_designation(k) == e) live[in] = true;
+                else if (!F::owns_shadow(in, e) && live[out]) live[in] = true;
+            }
+        return live[s];
+    }
 
     // job / launch constants
     const KParams *kp;      // in LDS
     const uint8_t *qc, *tc;
     const int *ss0, *ss1, *ss2, *ss3;
-    int Q, T, q0, t0, lane;
+    int Q, T, q0, t0, lane, tshift;
     int first_state, final_state, min_intron, max_intron;
     const int *first_cell;
     int start_scope, end_scope;
 
-    // per-lane DP state
-    C cur[R], prev[M::MAXAT][R], up, ud[M::MAXAT], expo;
+    // per-lane DP state: col[p] = the R cells evaluated at the step with phase p = s % NCOL,
+    // nbr[p] = the cell above them (row i0-1 of that column), expo = our bottom row for the lane below
+    C col[NCOL][R], nbr[NCOL], expo;
     int qcode[R];
     int best, best_i, best_j, best_qs, best_ts;
     bool best_set;
+    int corner[CELL_MAX];
+    bool corner_set;
 
     __device__ __forceinline__ int splice(int k, int tpos) const {
         const int *p = k == 0 ? ss0 : k == 1 ? ss1 : k == 2 ? ss2 : ss3;
         return p[tpos];
     }
 
+    // cell slots in the reference layout (for cells that leave the kernel)
+    template <int S>
+    __device__ __forceinline__ void export_cell(const C &c, int *out) const {
+        out[0] = c.sc[S];
+        static_for<NDES>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
+            out[1 + E] = slot_live(S, E) ? c.ex[S][E] : 0;
+        });
+        if constexpr (MODE == MODE_REGION) {
+            if constexpr (PACK) {
+                out[1 + NDES] = c.ex[S][RSQ] >> tshift;
+                out[2 + NDES] = c.ex[S][RSQ] & ((1 << tshift) - 1);
+            } else {
+                out[1 + NDES] = c.ex[S][RSQ];
+                out[2 + NDES] = c.ex[S][RST];
+            }
+        }
+        if constexpr (MODE == MODE_CKPT) out[1 + NDES] = c.ex[S][SRP];
+    }
+
     // ---- one cell -----------------------------------------------------------------------------------------
-    // RR: row inside the lane (compile time).  JINT: every lane is at max_at <= j <= T (main loop).
-    template <int RR, bool JINT>
+    // RR: row inside the lane, PH: ring phase of this step (both compile time).
+    // JINT: every lane is at max_at <= j <= T (main loop).
+    // NOTE on style: every select works on scalars that were loaded first and uses the non-short-circuit
+    // operators (& |): a `cond ? x : mem[..]` arm is a load under control flow, which InstCombine (run
+    // BEFORE the always-inliner) turns into a load of a selected address, and that keeps the whole per-lane
+    // state in scratch memory instead of VGPRs.
+    template <int RR, int PH, bool JINT>
     __device__ __forceinline__ void eval_cell(int i, int j, bool active, int mscore, const int (&pre)[4],
                                               uint32_t &tbword) {
-        C &c = cur[RR];
+        C &c = col[PH][RR];
         bool set[M::NS];
         static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
             set[S] = false;
@@ -181,10 +230,6 @@ struct WaveDP {
             // the START cell's slots are zero unless seeded by a continuation (calloc'd, never written)
             static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; c.ex[M::START][E] = 0; });
         }
-        // NOTE on style: every select below works on scalars that were loaded first and uses the
-        // non-short-circuit operators (& |): a `cond ? x : mem[..]` arm is a load under control flow, which
-        // InstCombine (run BEFORE the always-inliner) turns into a load of a selected address and that
-        // keeps the whole per-lane state in scratch memory instead of VGPRs.
         const bool i_ok = (RR > 0) | (i > 0);
         uint32_t tbw = 0;
         static_for<M::NT>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
@@ -206,19 +251,18 @@ struct WaveDP {
                     c.sc[S] = seed ? fc0 : old_sc;
                     static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
                         if constexpr (X > 0) {
-                            const int old_ex = c.ex[S][E], fce = first_cell[1 + E];
-                            c.ex[S][E] = seed ? fce : old_ex;
+                            if constexpr (slot_live(S, E)) {
+                                const int old_ex = c.ex[S][E], fce = first_cell[1 + E];
+                                c.ex[S][E] = seed ? fce : old_ex;
+                            }
                         }
                     });
                     set[S] = set[S] | seed;
                 });
             }
-            // source cell
-            const C &src = (t.aq == 0 && t.at == 0) ? c
-                         : (t.aq == 1 && t.at == 0) ? (RR > 0 ? cur[RR > 0 ? RR - 1 : 0] : up)
-                         : (t.aq == 0)              ? prev[t.at > 0 ? t.at - 1 : 0][RR]
-                                                    : (RR > 0 ? prev[t.at > 0 ? t.at - 1 : 0][RR > 0 ? RR - 1 : 0]
-                                                              : ud[t.at > 0 ? t.at - 1 : 0]);
+            // source cell: same cell (silent), row above (lane-local or the neighbour's), earlier columns
+            constexpr int PD = (PH - t.at + NCOL) % NCOL;
+            const C &src = (t.aq == 0) ? col[PD][RR] : (RR > 0 ? col[PD][RR > 0 ? RR - 1 : 0] : nbr[PD]);
             int tscore;
             if constexpr (t.in == M::START) tscore = CONT ? src.sc[M::START] : 0;
             else tscore = src.sc[t.in];
@@ -235,6 +279,7 @@ struct WaveDP {
                     // Intron_calc_*: the shadow end func has just loaded curr_intron_start (intron.c:468)
                     constexpr int des = F::consumed_designation(k);
                     static_assert(des >= 0, "post-splice calc without a shadow");
+                    static_assert(slot_live(t.in, des), "consumed slot must be live");
                     const int intron_length = (t0 + j - t.at) - src.ex[t.in][des] + 2;
                     const bool bad = (intron_length < min_intron) | (intron_length > max_intron);
                     const int ssv = pre[cd.param];
@@ -251,14 +296,20 @@ struct WaveDP {
             if constexpr (X > 0) {
                 static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
                     constexpr int e = E;
-                    int v = src.ex[t.in][e];
-                    if constexpr (e < NDES) {
-                        if constexpr (F::owns_shadow(t.in, e)) v = t0 + j - t.at;      // intron.c:454-458
-                    } else if constexpr (MODE == MODE_REGION && t.in == M::START) {
-                        v = (e == RSQ) ? (i - t.aq) : (j - t.at);                        // viterbi.c:403-412
+                    if constexpr (slot_live(t.out, e)) {
+                        int v = 0;
+                        if constexpr (e < NDES) {
+                            if constexpr (F::owns_shadow(t.in, e)) v = t0 + j - t.at;      // intron.c:454-458
+                            else if constexpr (slot_live(t.in, e)) v = src.ex[t.in][e];
+                        } else if constexpr (MODE == MODE_REGION && t.in == M::START) {     // viterbi.c:403-412
+                            if constexpr (PACK) v = ((i - t.aq) << tshift) | (j - t.at);
+                            else v = (e == RSQ) ? (i - t.aq) : (j - t.at);
+                        } else {
+                            v = src.ex[t.in][e];
+                        }
+                        const int old_ex = c.ex[t.out][e];
+                        c.ex[t.out][e] = win ? v : old_ex;
                     }
-                    const int old_ex = c.ex[t.out][e];
-                    c.ex[t.out][e] = win ? v : old_ex;
                 });
             }
             if constexpr (MODE == MODE_PATH) {
@@ -270,97 +321,116 @@ struct WaveDP {
         });
         tbword = tbw;
         // end cell (viterbi.c:778-791).  In continuation mode the score is read off the corner cell later.
+        // A new maximum is rare (it only grows along the alignment), so the bookkeeping sits behind a
+        // wave-uniform branch.
         if constexpr (!CONT) {
             const int tsc = c.sc[M::END];
             const bool end_set = set[M::END], b_set = best_set;
-            const int b = best, bi = best_i, bj = best_j;
+            const int b = best;
             const bool upd = active & end_set & (!b_set | (b < tsc));
-            best = upd ? tsc : b;
-            best_i = upd ? i : bi;
-            best_j = upd ? j : bj;
-            if constexpr (MODE == MODE_REGION) {
-                const int nqs = c.ex[M::END][RSQ], nts = c.ex[M::END][RST], oqs = best_qs, ots = best_ts;
-                best_qs = upd ? nqs : oqs;
-                best_ts = upd ? nts : ots;
+            if (__builtin_amdgcn_ballot_w64(upd)) {
+                const int bi = best_i, bj = best_j;
+                best = upd ? tsc : b;
+                best_i = upd ? i : bi;
+                best_j = upd ? j : bj;
+                if constexpr (MODE == MODE_REGION) {
+                    const int nqs = c.ex[M::END][RSQ], oqs = best_qs;
+                    best_qs = upd ? nqs : oqs;
+                    if constexpr (!PACK) {
+                        const int nts = c.ex[M::END][RST], ots = best_ts;
+                        best_ts = upd ? nts : ots;
+                    }
+                }
+                best_set = b_set | upd;
             }
-            best_set = b_set | upd;
         }
     }
 
     // ---- cross-lane / cross-strip exchange ----------------------------------------------------------------
-    // pack / unpack the exported states of a cell (those with advance_query > 0 successors)
     template <class Fn>
     __device__ __forceinline__ static void for_exported(Fn &&fn) {
         int slot = 0;
         static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
             if constexpr (F::exported(S)) {
                 fn(S_, slot);
-                slot += CS;
+                slot += 1 + XS;
             }
         });
     }
 
+    // lane 0's neighbour row comes from the carry row the previous strip wrote (column j)
+    C nx_carry;
+    __device__ __forceinline__ void prefetch_carry(int j, bool first_strip, const int *bnd_in) {
+        const bool take = !first_strip & (lane == 0) & (j >= 0) & (j <= T);
+        for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
+            int sc0 = LOW, ex0[XS];
+            static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; ex0[E] = 0; });
+            if (take) {
+                const int *p = bnd_in + (long long)j * BND + slot;
+                sc0 = p[0];
+                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
+                    if constexpr (X > 0) if constexpr (slot_live(S, E)) ex0[E] = p[1 + E];
+                });
+            }
+            nx_carry.sc[S] = sc0;
+            static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
+                if constexpr (X > 0) if constexpr (slot_live(S, E)) nx_carry.ex[S][E] = ex0[E];
+            });
+        });
+    }
+
+    // per-column inputs of column j: target residue code for the match transitions and, for spliced
+    // models, open penalty + splice-site scores at the column the (0,2) transitions leave from
+    int nx_tcode, nx_sp[4];
+    __device__ __forceinline__ void prefetch_column(int j) {
+        const bool jact = (j >= 0) & (j <= T);
+        constexpr int mat = F::match_at();
+        const int jj = j - mat;
+        int tcv = 0;
+        if (jact && jj >= 0) tcv = tc[t0 + jj];
+        nx_tcode = tcv;
+        static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; nx_sp[K] = 0; });
+        if constexpr (F::has_splice()) {
+            const int tpos = t0 + j - 2;
+            if (jact && j >= 2) {
+                static_for<M::NC>([&](auto CI_) __attribute__((always_inline)) { constexpr int CI = CI_;
+                    constexpr CalcDesc cd = M::calc[CI];
+                    if constexpr (cd.kind == CALC_SPLICE_PRE) nx_sp[cd.param] = kp->calc_value[CI] + splice(cd.param, tpos);
+                    if constexpr (cd.kind == CALC_SPLICE_POST) nx_sp[cd.param] = splice(cd.param, tpos);
+                });
+            }
+        }
+    }
+
     // ---- one wave step: every lane evaluates its R rows of column j = s - lane ---------------------------
-    template <bool JINT>
+    template <bool JINT, int PH>
     __device__ __forceinline__ void step(int s, int i0, bool first_strip, bool last_strip, const int *bnd_in,
                                          int *bnd_out, uint32_t *tb_slab, long long tb_base, int *ckpt,
                                          int section_length, int cp_count) {
         const int j = s - lane;
         const bool jact = JINT || (j >= 0 && j <= T);
         // (1) row i0-1 of this column: from lane-1 (DPP) or, for lane 0, from the previous strip's carry row
-        {
-            C nb;
-            for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
-                int sc0 = LOW, ex0[XS];
-                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; ex0[E] = 0; });
-                if (!first_strip && lane == 0 && jact) {
-                    const int *p = bnd_in + (long long)j * BND + slot;
-                    sc0 = p[0];
-                    static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; if constexpr (X > 0) ex0[E] = p[1 + E]; });
-                }
-                nb.sc[S] = dpp_shr1(sc0, expo.sc[S]);
-                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; if constexpr (X > 0) nb.ex[S][E] = dpp_shr1(ex0[E], expo.ex[S][E]); });
+        // (requested one step ago, like the column data below)
+        for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
+            nbr[PH].sc[S] = dpp_shr1(nx_carry.sc[S], expo.sc[S]);
+            static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
+                if constexpr (X > 0) if constexpr (slot_live(S, E)) nbr[PH].ex[S][E] = dpp_shr1(nx_carry.ex[S][E], expo.ex[S][E]);
             });
-            // shift the (i0-1, j-d) history, then install the new (i0-1, j)
-            static_for<M::MAXAT>([&](auto D_) __attribute__((always_inline)) { constexpr int D = D_;
-                constexpr int d = M::MAXAT - 1 - D;
-                for_exported([&](auto S_, int) __attribute__((always_inline)) { constexpr int S = S_;
-                    ud[d].sc[S] = (d == 0) ? up.sc[S] : ud[d > 0 ? d - 1 : 0].sc[S];
-                    static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
-                        if constexpr (X > 0) ud[d].ex[S][E] = (d == 0) ? up.ex[S][E] : ud[d > 0 ? d - 1 : 0].ex[S][E];
-                    });
-                });
-            });
-            for_exported([&](auto S_, int) __attribute__((always_inline)) { constexpr int S = S_;
-                up.sc[S] = nb.sc[S];
-                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; if constexpr (X > 0) up.ex[S][E] = nb.ex[S][E]; });
-            });
-        }
-        // (2) per-column scoring data (coalesced: adjacent lanes read adjacent columns)
-        int tcode = 0;
-        int sp[4] = {0, 0, 0, 0};
-        {
-            constexpr int mat = F::match_at();
-            const int jj = j - mat;
-            if (jact && jj >= 0) tcode = tc[t0 + jj];
-            if constexpr (F::has_splice()) {
-                const int tpos = t0 + j - 2;
-                if (jact && j >= 2) {
-                    static_for<M::NC>([&](auto CI_) __attribute__((always_inline)) { constexpr int CI = CI_;
-                        constexpr CalcDesc cd = M::calc[CI];
-                        if constexpr (cd.kind == CALC_SPLICE_PRE) sp[cd.param] = kp->calc_value[CI] + splice(cd.param, tpos);
-                        if constexpr (cd.kind == CALC_SPLICE_POST) sp[cd.param] = splice(cd.param, tpos);
-                    });
-                }
-            }
-        }
+        });
+        prefetch_carry(j + 1, first_strip, bnd_in);
+        // (2) per-column scoring data (coalesced: adjacent lanes read adjacent columns).  The values for
+        // THIS step were requested one step ago (nx_*); the loads for the next column are issued now so
+        // their latency overlaps this step's arithmetic.
+        const int tcode = nx_tcode;
+        int sp[4];
+        static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; sp[K] = nx_sp[K]; });
+        prefetch_column(j + 1);
         // (3) the R cells of this lane, top to bottom
         uint32_t tbw[R];
         static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
-            constexpr int r = RR;
-            const int i = i0 + r;
-            const int ms = kp->submat[qcode[r] * 24 + tcode];
-            eval_cell<r, JINT>(i, j, jact && i <= Q, ms, sp, tbw[r]);
+            const int i = i0 + RR;
+            const int ms = kp->submat[qcode[RR] * 24 + tcode];
+            eval_cell<RR, PH, JINT>(i, j, jact && i <= Q, ms, sp, tbw[RR]);
         });
         // (4) traceback words, step-major (fully coalesced)
         if constexpr (MODE == MODE_PATH) {
@@ -369,14 +439,18 @@ struct WaveDP {
         }
         // (5) export the bottom row BEFORE any checkpoint edit (the next lane still needs column j as it was)
         for_exported([&](auto S_, int) __attribute__((always_inline)) { constexpr int S = S_;
-            expo.sc[S] = cur[R - 1].sc[S];
-            static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; if constexpr (X > 0) expo.ex[S][E] = cur[R - 1].ex[S][E]; });
+            expo.sc[S] = col[PH][R - 1].sc[S];
+            static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
+                if constexpr (X > 0) if constexpr (slot_live(S, E)) expo.ex[S][E] = col[PH][R - 1].ex[S][E];
+            });
         });
         if (!last_strip && lane == 63 && jact) {
             for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
                 int *p = bnd_out + (long long)j * BND + slot;
                 p[0] = expo.sc[S];
-                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; if constexpr (X > 0) p[1 + E] = expo.ex[S][E]; });
+                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
+                    if constexpr (X > 0) if constexpr (slot_live(S, E)) p[1 + E] = expo.ex[S][E];
+                });
             });
         }
         // (6) the corner cell (Q, T): final cell of a continuation / last SRP (viterbi.c:813-832)
@@ -386,8 +460,7 @@ struct WaveDP {
                     if (i0 + RR == Q) {
                         static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
                             if (final_state == S) {
-                                corner[0] = cur[RR].sc[S];
-                                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; if constexpr (X > 0) corner[1 + E] = cur[RR].ex[S][E]; });
+                                export_cell<S>(col[PH][RR], corner);
                                 corner_set = true;
                             }
                         });
@@ -401,48 +474,33 @@ struct WaveDP {
             if (at_cp) {
                 const int cpi = j / section_length - 1;
                 static_for<M::MAXAT>([&](auto ROW_) __attribute__((always_inline)) { constexpr int ROW = ROW_;
-                    constexpr int row = ROW;
+                    constexpr int PR = (PH - ROW + NCOL) % NCOL;
                     static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
                         const int i = i0 + RR;
-                        C &cell = (row == 0) ? cur[RR] : prev[row > 0 ? row - 1 : 0][RR];
+                        C &cell = col[PR][RR];
                         if (i <= Q) {
-                            int *p = ckpt + ((((long long)cpi * M::MAXAT + row) * (Q + 1) + i) * M::NS) * CS;
+                            int *p = ckpt + ((((long long)cpi * M::MAXAT + ROW) * (Q + 1) + i) * M::NS) * CS;
                             static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
-                                p[S * CS] = cell.sc[S];
-                                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; p[S * CS + 1 + E] = cell.ex[S][E]; });
+                                export_cell<S>(cell, p + S * CS);
                             });
                         }
                         static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
-                            cell.ex[S][SRP] = ((i * M::NS) + S) * M::MAXAT + row;     // viterbi.c:515-522
+                            cell.ex[S][SRP] = ((i * M::NS) + S) * M::MAXAT + ROW;     // viterbi.c:515-522
                         });
                     });
-                    // our copies of row i0-1 at columns j (up) and j-1.. (ud) get the same edit
-                    C &nbc = (row == 0) ? up : ud[row > 0 ? row - 1 : 0];
-                    static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_; nbc.ex[S][SRP] = (((i0 - 1) * M::NS) + S) * M::MAXAT + row; });
+                    // our copies of row i0-1 at these columns get the same edit
+                    static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                        nbr[PR].ex[S][SRP] = (((i0 - 1) * M::NS) + S) * M::MAXAT + ROW;
+                    });
                 });
             }
         }
-        // (8) rotate columns
-        static_for<M::MAXAT>([&](auto D_) __attribute__((always_inline)) { constexpr int D = D_;
-            constexpr int d = M::MAXAT - 1 - D;
-            static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
-                static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
-                    prev[d][RR].sc[S] = (d == 0) ? cur[RR].sc[S] : prev[d > 0 ? d - 1 : 0][RR].sc[S];
-                    static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
-                        if constexpr (X > 0)
-                            prev[d][RR].ex[S][E] = (d == 0) ? cur[RR].ex[S][E] : prev[d > 0 ? d - 1 : 0][RR].ex[S][E];
-                    });
-                });
-            });
-        });
     }
-
-    int corner[CELL_MAX];
-    bool corner_set;
 
     // ---- the whole rectangle ------------------------------------------------------------------------------
     __device__ __forceinline__ void run(const DevJob &job, const DevSeqs &seqs, int *bnd, uint32_t *tb, int *ckpt) {
         Q = job.Q; T = job.T; q0 = job.q0; t0 = job.t0;
+        tshift = job.tshift;
         first_state = job.first_state; final_state = CONT ? job.final_state : M::END;
         first_cell = job.first_cell;
         min_intron = kp->min_intron; max_intron = kp->max_intron;
@@ -465,16 +523,16 @@ struct WaveDP {
                 const int qpos = q0 + i0 + RR - 1;            // residue consumed by an advance_query=1 move into row i
                 qcode[RR] = (i0 + RR >= 1 && i0 + RR <= Q) ? qc[qpos] : 0;
             });
-            // neighbour registers start empty (row -1 does not exist; validity masks keep it unread)
+            // registers start empty (row -1 does not exist; validity masks keep it unread)
             static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
-                up.sc[S] = LOW; expo.sc[S] = LOW;
-                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; up.ex[S][E] = 0; expo.ex[S][E] = 0; });
-                static_for<M::MAXAT>([&](auto D_) __attribute__((always_inline)) { constexpr int D = D_;
-                    ud[D].sc[S] = LOW;
-                    static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; ud[D].ex[S][E] = 0; });
+                expo.sc[S] = LOW;
+                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; expo.ex[S][E] = 0; });
+                static_for<NCOL>([&](auto D_) __attribute__((always_inline)) { constexpr int D = D_;
+                    nbr[D].sc[S] = LOW;
+                    static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; nbr[D].ex[S][E] = 0; });
                     static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
-                        prev[D][RR].sc[S] = LOW;
-                        static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; prev[D][RR].ex[S][E] = 0; });
+                        col[D][RR].sc[S] = LOW;
+                        static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; col[D][RR].ex[S][E] = 0; });
                     });
                 });
             });
@@ -485,13 +543,23 @@ struct WaveDP {
             const bool first = (b == 0), last = (b == nstrips - 1);
             const int nsteps = T + 64;
             const int main_lo = 63 + M::MAXAT, main_hi = T;          // steps where every lane is interior in j
+            // steps run in groups of NCOL with compile-time ring phases (s % NCOL); the padding steps past
+            // nsteps have every lane outside the rectangle and do nothing
+            const int nsteps_r = (nsteps + NCOL - 1) / NCOL * NCOL;
+            const int main_lo_r = (main_lo + NCOL - 1) / NCOL * NCOL;
+            auto group = [&](auto JI_, int s0) __attribute__((always_inline)) {
+                constexpr bool JI = decltype(JI_)::value != 0;
+                static_for<NCOL>([&](auto P_) __attribute__((always_inline)) { constexpr int P = P_;
+                    step<JI, P>(s0 + P, i0, first, last, bnd_in, bnd_out, tb, b * strip_tb, ckpt, section_length,
+                                job.cp_count);
+                });
+            };
+            prefetch_column(0 - lane);
+            prefetch_carry(0 - lane, first, bnd_in);
             int s = 0;
-            for (; s < nsteps && s < main_lo; s++)
-                step<false>(s, i0, first, last, bnd_in, bnd_out, tb, b * strip_tb, ckpt, section_length, job.cp_count);
-            for (; s <= main_hi; s++)
-                step<true>(s, i0, first, last, bnd_in, bnd_out, tb, b * strip_tb, ckpt, section_length, job.cp_count);
-            for (; s < nsteps; s++)
-                step<false>(s, i0, first, last, bnd_in, bnd_out, tb, b * strip_tb, ckpt, section_length, job.cp_count);
+            for (; s < main_lo_r && s < nsteps_r; s += NCOL) group(IC<0>{}, s);
+            for (; s + NCOL - 1 <= main_hi; s += NCOL) group(IC<1>{}, s);
+            for (; s < nsteps_r; s += NCOL) group(IC<0>{}, s);
             if constexpr (!CONT) strip_end();
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // carry row / traceback visible to the next strip
         }
@@ -628,11 +696,11 @@ struct WaveDP {
 // -------------------------------------------------------------------------------------------------------------
 // Kernel: persistent waves, one job at a time per wave.
 // -------------------------------------------------------------------------------------------------------------
-template <class M, int R, int MODE, bool CONT, bool LOCAL>
+template <class M, int R, int MODE, bool CONT, bool LOCAL, bool PACK>
 __global__ __launch_bounds__(64) void viterbi_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs,
                                                      int n_jobs, DevResult *results, DevVsa *vsas, uint8_t *ops,
                                                      DevScratch scratch, int *queue) {
-    using DP = WaveDP<M, R, MODE, CONT, LOCAL>;
+    using DP = WaveDP<M, R, MODE, CONT, LOCAL, PACK>;
     __shared__ KParams kp_lds;
     __shared__ int next_job;
     {
@@ -676,7 +744,10 @@ __global__ __launch_bounds__(64) void viterbi_kernel(const KParams *kparams, Dev
             dp.reduce_best();
             res.score = dp.best; res.end_set = dp.best_set;
             res.qe = dp.best_i; res.te = dp.best_j;
-            if constexpr (MODE == MODE_REGION) { res.qs = dp.best_qs; res.ts = dp.best_ts; }
+            if constexpr (MODE == MODE_REGION) {
+                if constexpr (PACK) { res.qs = dp.best_qs >> job.tshift; res.ts = dp.best_qs & ((1 << job.tshift) - 1); }
+                else { res.qs = dp.best_qs; res.ts = dp.best_ts; }
+            }
         }
         if (!res.end_set) res.flags |= FLAG_NO_END;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
