@@ -196,7 +196,7 @@ struct ResidentSeqs {
             total_q += (pairs[i].query_len + 3) & ~3LL;
             total_t += (pairs[i].target_len + 3) & ~3LL;
         }
-        std::vector<uint8_t> hq(total_q ? total_q : 1, 'A'), ht(total_t ? total_t : 1, 'A');
+        std::vector<uint8_t> hq(total_q + 64, 'A'), ht(total_t + 64, 'A');
         for (int i = 0; i < n; i++) {
             if (qlen[i]) memcpy(&hq[qoff[i]], pairs[i].query, qlen[i]);
             if (tlen[i]) memcpy(&ht[toff[i]], pairs[i].target, tlen[i]);
@@ -242,7 +242,7 @@ struct ResidentSeqs {
                                        "(exonerate's Submat index would read out of bounds, submat.c:27-61)");
             return -1;
         }
-        dev.qcode = qcode.p; dev.tcode = tcode.p; dev.qoff = d_qoff.p; dev.toff = d_toff.p;
+        dev.qcode = qcode.p; dev.tcode = tcode.p; dev.qoff = d_qoff.p; dev.toff = d_toff.p; dev.tlen = d_tlen.p;
         return 0;
     }
 };
@@ -307,7 +307,8 @@ struct Engine {
         bool pack = (mode == MODE_REGION);
         for (int i = 0; i < n && pack; i++)
             pack = nbits(specs[i].region.query_length) + nbits(specs[i].region.target_length) <= 31;
-        const KernelInfo *ki = get_kernel(family, mode, cont, use_local, pack);
+        static const int wpe_env = getenv("C4GPU_WPE") ? atoi(getenv("C4GPU_WPE")) : 0;
+        const KernelInfo *ki = get_kernel(family, mode, cont, use_local, pack, wpe_env);
         if (!ki) { c4h::set_error("no compiled kernel for this model/mode"); return -1; }
         // longest first (persistent waves pull from the queue head)
         std::vector<int> order(n);

@@ -33,18 +33,18 @@ struct KernelInfo {
 };
 
 // family x mode x continuation x local-scope specialisation; NULL launch = not compiled
-const KernelInfo *get_kernel(int family, int mode, bool cont, bool local, bool pack);
+const KernelInfo *get_kernel(int family, int mode, bool cont, bool local, bool pack, int wpe = 0);
 
-#define C4K_DEFINE_KERNEL(SYMBOL, M, RVAL, MODE, CONT, LOCAL, PACK)                                            \
+#define C4K_DEFINE_KERNEL(SYMBOL, M, RVAL, MODE, CONT, LOCAL, PACK, WPE)                                            \
     static hipError_t SYMBOL##_launch(const LaunchArgs &a) {                                               \
-        hipLaunchKernelGGL((viterbi_kernel<M, RVAL, MODE, CONT, LOCAL, PACK>), dim3(a.grid), dim3(64), 0,        \
+        hipLaunchKernelGGL((viterbi_kernel<M, RVAL, MODE, CONT, LOCAL, PACK, WPE>), dim3(a.grid), dim3(64), 0,        \
                            a.stream, a.kp, a.seqs, a.jobs, a.n_jobs, a.results, a.vsas, a.ops, a.scratch,  \
                            a.queue);                                                                       \
         return hipGetLastError();                                                                          \
     }                                                                                                      \
     const KernelInfo *SYMBOL() {                                                                           \
         static const KernelInfo ki = {SYMBOL##_launch,                                                     \
-                                      (const void *)viterbi_kernel<M, RVAL, MODE, CONT, LOCAL, PACK>,            \
+                                      (const void *)viterbi_kernel<M, RVAL, MODE, CONT, LOCAL, PACK, WPE>,            \
                                       #SYMBOL,                                                             \
                                       RVAL,                                                                \
                                       WaveDP<M, RVAL, MODE, CONT, LOCAL, PACK>::CS,                              \

@@ -51,6 +51,7 @@ struct KParams {                 // uniform per launch (device memory, staged to
 struct DevSeqs {
     const uint8_t *qcode, *tcode;        // residue -> submat row codes (tcode: codon codes for 1:3 match)
     const long long *qoff, *toff;        // per pair offsets into the concatenated arrays
+    const int *tlen;                     // per pair target length (prefetch clamps)
     const int *ss;                       // [4][ss_stride] splice-site scores, same offsets as tcode
     long long ss_stride;
 };
@@ -358,47 +359,35 @@ struct WaveDP {
         });
     }
 
-    // lane 0's neighbour row comes from the carry row the previous strip wrote (column j)
+    // lane 0's neighbour row comes from the carry row the previous strip wrote.  Lane 0 is at column
+    // j = s, so every lane requests the same (clamped) column one step ahead: an unconditional, uniform
+    // load with no dependent ALU op, so nothing waits for it until the next step's DPP exchange.
     C nx_carry;
-    __device__ __forceinline__ void prefetch_carry(int j, bool first_strip, const int *bnd_in) {
-        const bool take = !first_strip & (lane == 0) & (j >= 0) & (j <= T);
+    __device__ __forceinline__ void prefetch_carry(int s_next, const int *bnd_in) {
+        const int jc = s_next < 0 ? 0 : (s_next > T ? T : s_next);
         for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
-            int sc0 = LOW, ex0[XS];
-            static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; ex0[E] = 0; });
-            if (take) {
-                const int *p = bnd_in + (long long)j * BND + slot;
-                sc0 = p[0];
-                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
-                    if constexpr (X > 0) if constexpr (slot_live(S, E)) ex0[E] = p[1 + E];
-                });
-            }
-            nx_carry.sc[S] = sc0;
+            const int *p = bnd_in + (long long)jc * BND + slot;
+            nx_carry.sc[S] = p[0];
             static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
-                if constexpr (X > 0) if constexpr (slot_live(S, E)) nx_carry.ex[S][E] = ex0[E];
+                if constexpr (X > 0) if constexpr (slot_live(S, E)) nx_carry.ex[S][E] = p[1 + E];
             });
         });
     }
 
     // per-column inputs of column j: target residue code for the match transitions and, for spliced
-    // models, open penalty + splice-site scores at the column the (0,2) transitions leave from
-    int nx_tcode, nx_sp[4];
+    // models, the splice-site scores at the column the (0,2) transitions leave from.  Requested one step
+    // ahead from clamped (always valid) addresses; a lane outside the rectangle gets values it never
+    // uses, because every transition that would read them is masked invalid.
+    int nx_tcode, nx_sp[4], tlast;
     __device__ __forceinline__ void prefetch_column(int j) {
-        const bool jact = (j >= 0) & (j <= T);
         constexpr int mat = F::match_at();
-        const int jj = j - mat;
-        int tcv = 0;
-        if (jact && jj >= 0) tcv = tc[t0 + jj];
-        nx_tcode = tcv;
-        static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; nx_sp[K] = 0; });
+        int ti = t0 + j - mat;
+        ti = ti < 0 ? 0 : (ti > tlast ? tlast : ti);
+        nx_tcode = tc[ti];
         if constexpr (F::has_splice()) {
-            const int tpos = t0 + j - 2;
-            if (jact && j >= 2) {
-                static_for<M::NC>([&](auto CI_) __attribute__((always_inline)) { constexpr int CI = CI_;
-                    constexpr CalcDesc cd = M::calc[CI];
-                    if constexpr (cd.kind == CALC_SPLICE_PRE) nx_sp[cd.param] = kp->calc_value[CI] + splice(cd.param, tpos);
-                    if constexpr (cd.kind == CALC_SPLICE_POST) nx_sp[cd.param] = splice(cd.param, tpos);
-                });
-            }
+            int tp = t0 + j - 2;
+            tp = tp < 0 ? 0 : (tp > tlast ? tlast : tp);
+            static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; nx_sp[K] = splice(K, tp); });
         }
     }
 
@@ -409,28 +398,41 @@ struct WaveDP {
                                          int section_length, int cp_count) {
         const int j = s - lane;
         const bool jact = JINT || (j >= 0 && j <= T);
+        // (0) substitution scores of this column for our R query rows: LDS reads issued first so that
+        // their latency overlaps the lane exchange below
+        const int tcode = nx_tcode;
+        int ms[R];
+        static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+            ms[RR] = kp->submat[qcode[RR] * 24 + tcode];
+        });
+        int sp[4] = {0, 0, 0, 0};
+        if constexpr (F::has_splice()) {
+            static_for<M::NC>([&](auto CI_) __attribute__((always_inline)) { constexpr int CI = CI_;
+                constexpr CalcDesc cd = M::calc[CI];
+                if constexpr (cd.kind == CALC_SPLICE_PRE) sp[cd.param] = kp->calc_value[CI] + nx_sp[cd.param];
+                if constexpr (cd.kind == CALC_SPLICE_POST) sp[cd.param] = nx_sp[cd.param];
+            });
+        }
         // (1) row i0-1 of this column: from lane-1 (DPP) or, for lane 0, from the previous strip's carry row
-        // (requested one step ago, like the column data below)
+        // (requested one step ago)
         for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
-            nbr[PH].sc[S] = dpp_shr1(nx_carry.sc[S], expo.sc[S]);
+            const int c_sc = nx_carry.sc[S];
+            nbr[PH].sc[S] = dpp_shr1(first_strip ? LOW : c_sc, expo.sc[S]);
             static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
-                if constexpr (X > 0) if constexpr (slot_live(S, E)) nbr[PH].ex[S][E] = dpp_shr1(nx_carry.ex[S][E], expo.ex[S][E]);
+                if constexpr (X > 0) if constexpr (slot_live(S, E)) {
+                    const int c_ex = nx_carry.ex[S][E];
+                    nbr[PH].ex[S][E] = dpp_shr1(first_strip ? 0 : c_ex, expo.ex[S][E]);
+                }
             });
         });
-        prefetch_carry(j + 1, first_strip, bnd_in);
-        // (2) per-column scoring data (coalesced: adjacent lanes read adjacent columns).  The values for
-        // THIS step were requested one step ago (nx_*); the loads for the next column are issued now so
-        // their latency overlaps this step's arithmetic.
-        const int tcode = nx_tcode;
-        int sp[4];
-        static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; sp[K] = nx_sp[K]; });
+        // (2) request the next step's inputs
+        prefetch_carry(s + 1, bnd_in);
         prefetch_column(j + 1);
         // (3) the R cells of this lane, top to bottom
         uint32_t tbw[R];
         static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
             const int i = i0 + RR;
-            const int ms = kp->submat[qcode[RR] * 24 + tcode];
-            eval_cell<RR, PH, JINT>(i, j, jact && i <= Q, ms, sp, tbw[RR]);
+            eval_cell<RR, PH, JINT>(i, j, jact && i <= Q, ms[RR], sp, tbw[RR]);
         });
         // (4) traceback words, step-major (fully coalesced)
         if constexpr (MODE == MODE_PATH) {
@@ -501,6 +503,7 @@ struct WaveDP {
     __device__ __forceinline__ void run(const DevJob &job, const DevSeqs &seqs, int *bnd, uint32_t *tb, int *ckpt) {
         Q = job.Q; T = job.T; q0 = job.q0; t0 = job.t0;
         tshift = job.tshift;
+        tlast = seqs.tlen[job.pair] > 0 ? seqs.tlen[job.pair] - 1 : 0;
         first_state = job.first_state; final_state = CONT ? job.final_state : M::END;
         first_cell = job.first_cell;
         min_intron = kp->min_intron; max_intron = kp->max_intron;
@@ -555,7 +558,7 @@ struct WaveDP {
                 });
             };
             prefetch_column(0 - lane);
-            prefetch_carry(0 - lane, first, bnd_in);
+            prefetch_carry(0, bnd_in);
             int s = 0;
             for (; s < main_lo_r && s < nsteps_r; s += NCOL) group(IC<0>{}, s);
             for (; s + NCOL - 1 <= main_hi; s += NCOL) group(IC<1>{}, s);
@@ -696,8 +699,9 @@ struct WaveDP {
 // -------------------------------------------------------------------------------------------------------------
 // Kernel: persistent waves, one job at a time per wave.
 // -------------------------------------------------------------------------------------------------------------
-template <class M, int R, int MODE, bool CONT, bool LOCAL, bool PACK>
-__global__ __launch_bounds__(64) void viterbi_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs,
+// WPE: waves per SIMD the register allocator must leave room for (1 = no cap: 512 unified registers)
+template <class M, int R, int MODE, bool CONT, bool LOCAL, bool PACK, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void viterbi_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs,
                                                      int n_jobs, DevResult *results, DevVsa *vsas, uint8_t *ops,
                                                      DevScratch scratch, int *queue) {
     using DP = WaveDP<M, R, MODE, CONT, LOCAL, PACK>;
