@@ -257,7 +257,7 @@ struct JobSpec {                  // host description of one Viterbi call
 };
 struct JobOut {
     DevResult res;
-    std::vector<uint8_t> ops;     // PATH: transition ids START -> END
+    std::vector<uint32_t> runs;   // PATH: (transition << 24 | length) runs, START -> END
     std::vector<DevVsa> vsa;      // CKPT: sub-alignments, last section first
     std::vector<int> checkpoints; // CKPT + dump_checkpoints
 };
@@ -272,6 +272,8 @@ struct Engine {
     DevBuf<DevJob> d_jobs;
     DevBuf<DevResult> d_results;
     DevBuf<DevVsa> d_vsa;
+    DevBuf<uint32_t> d_runs, d_runs_out;
+    DevBuf<unsigned long long> d_runs_used;
     DevBuf<uint8_t> d_ops;
     DevBuf<int> d_bnd, d_ckpt, d_ckpt_dump, d_queue;
     DevBuf<uint32_t> d_tb;
@@ -317,6 +319,7 @@ struct Engine {
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cells(a) > cells(b); });
         std::vector<DevJob> jobs(n);
         long long ops_total = 0, vsa_total = 0, dump_total = 0, max_T = 0, max_tb = 0, max_ckpt = 0, total_cells = 0;
+        long long max_runs = 0;
         for (int x = 0; x < n; x++) {
             const JobSpec &s = specs[order[x]];
             DevJob &j = jobs[x];
@@ -332,6 +335,7 @@ struct Engine {
             const long long strips = (j.Q + 1 + 64 * ki->R - 1) / (64 * ki->R);
             if (mode == MODE_PATH) {
                 j.ops_cap = 3 * (j.Q + j.T) + 16;
+                max_runs = std::max<long long>(max_runs, j.ops_cap);
                 ops_total += j.ops_cap;
                 max_tb = std::max(max_tb, strips * (long long)(j.T + 64) * 64 * ki->R);
             }
@@ -348,45 +352,65 @@ struct Engine {
         if (blocks_per_cu < 1) blocks_per_cu = 1;
         long long grid = std::min<long long>(n, (long long)blocks_per_cu * ctx->prop.multiProcessorCount);
         const long long bnd_per_wave = 2 * (max_T + 1) * (long long)std::max(ki->bnd, 1);
-        const long long bytes_per_wave = bnd_per_wave * 4 + max_tb * 4 + max_ckpt * 4;
+        const long long bytes_per_wave = bnd_per_wave * 4 + max_tb * 4 + max_ckpt * 4 + max_runs * 4;
+        // compact run array: paths are mostly long runs, so a fraction of the worst case is plenty; a
+        // launch that overflows it is repeated with the worst case
+        long long runs_capacity = std::min<long long>(ops_total, std::max<long long>(1 << 20, (long long)n * 256));
         const long long budget = (long long)(ctx->prop.totalGlobalMem / 4);
         if (bytes_per_wave * grid > budget) grid = std::max<long long>(1, budget / std::max<long long>(1, bytes_per_wave));
         hipStream_t s = ctx->stream;
-        int zero = 0;
-        if (d_jobs.upload(jobs.data(), n, s) || d_results.alloc(n) || d_queue.upload(&zero, 1, s) ||
-            d_bnd.alloc(bnd_per_wave * grid) || d_ops.alloc(ops_total) || d_vsa.alloc(vsa_total) ||
-            d_tb.alloc(max_tb * grid) || d_ckpt.alloc(max_ckpt * grid) || d_ckpt_dump.alloc(dump_total))
-            return -1;
-        LaunchArgs a;
-        a.kp = kparams.p; a.seqs = seqs.dev; a.jobs = d_jobs.p; a.n_jobs = n; a.results = d_results.p;
-        a.vsas = d_vsa.p; a.ops = d_ops.p; a.queue = d_queue.p; a.grid = (int)grid; a.stream = s;
-        a.scratch.bnd = d_bnd.p; a.scratch.bnd_stride = bnd_per_wave;
-        a.scratch.tb = max_tb ? d_tb.p : nullptr; a.scratch.tb_stride = max_tb;
-        a.scratch.ckpt = max_ckpt ? d_ckpt.p : nullptr; a.scratch.ckpt_stride = max_ckpt;
-        a.scratch.ckpt_dump = d_ckpt_dump.p;
-        if (ctx->timing) HIP_OK(hipEventRecord(ctx->ev0, s));
-        HIP_OK(ki->launch(a));
-        if (ctx->timing) HIP_OK(hipEventRecord(ctx->ev1, s));
         std::vector<DevResult> res(n);
-        std::vector<uint8_t> ops(ops_total);
+        std::vector<uint32_t> runs;
         std::vector<DevVsa> vsa(vsa_total);
         std::vector<int> dump(dump_total);
-        if (d_results.download(res.data(), n, s) || d_ops.download(ops.data(), ops_total, s) ||
-            d_vsa.download(vsa.data(), vsa_total, s) || d_ckpt_dump.download(dump.data(), dump_total, s))
-            return -1;
-        HIP_OK(hipStreamSynchronize(s));
-        if (ctx->timing) {
-            float ms = 0;
-            HIP_OK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-            ctx->kernel_ms[mode] += ms; ctx->kernel_launches[mode]++; ctx->kernel_cells[mode] += total_cells;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            int zero = 0;
+            unsigned long long zero64 = 0;
+            if (d_jobs.upload(jobs.data(), n, s) || d_results.alloc(n) || d_queue.upload(&zero, 1, s) ||
+                d_runs_used.upload(&zero64, 1, s) || d_bnd.alloc(bnd_per_wave * grid) || d_vsa.alloc(vsa_total) ||
+                d_runs.alloc(max_runs * grid) || d_runs_out.alloc(runs_capacity) ||
+                d_tb.alloc(max_tb * grid) || d_ckpt.alloc(max_ckpt * grid) || d_ckpt_dump.alloc(dump_total))
+                return -1;
+            LaunchArgs a;
+            a.kp = kparams.p; a.seqs = seqs.dev; a.jobs = d_jobs.p; a.n_jobs = n; a.results = d_results.p;
+            a.vsas = d_vsa.p; a.ops = nullptr; a.queue = d_queue.p; a.grid = (int)grid; a.stream = s;
+            a.scratch.bnd = d_bnd.p; a.scratch.bnd_stride = bnd_per_wave;
+            a.scratch.tb = max_tb ? d_tb.p : nullptr; a.scratch.tb_stride = max_tb;
+            a.scratch.ckpt = max_ckpt ? d_ckpt.p : nullptr; a.scratch.ckpt_stride = max_ckpt;
+            a.scratch.ckpt_dump = d_ckpt_dump.p;
+            a.scratch.runs = d_runs.p; a.scratch.runs_stride = max_runs;
+            a.scratch.runs_out = d_runs_out.p; a.scratch.runs_capacity = runs_capacity;
+            a.scratch.runs_used = d_runs_used.p;
+            if (ctx->timing) HIP_OK(hipEventRecord(ctx->ev0, s));
+            HIP_OK(ki->launch(a));
+            if (ctx->timing) HIP_OK(hipEventRecord(ctx->ev1, s));
+            unsigned long long used = 0;
+            if (d_results.download(res.data(), n, s) || d_runs_used.download(&used, 1, s) ||
+                d_vsa.download(vsa.data(), vsa_total, s) || d_ckpt_dump.download(dump.data(), dump_total, s))
+                return -1;
+            HIP_OK(hipStreamSynchronize(s));
+            if (ctx->timing) {
+                float ms = 0;
+                HIP_OK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+                ctx->kernel_ms[mode] += ms; ctx->kernel_launches[mode]++; ctx->kernel_cells[mode] += total_cells;
+            }
+            if ((long long)used > runs_capacity) {          // rare: paths with very short runs
+                if (attempt == 1) { c4h::set_error("traceback runs exceed their worst-case buffer"); return -1; }
+                runs_capacity = ops_total;
+                continue;
+            }
+            runs.resize(used);
+            if (d_runs_out.download(runs.data(), used, s)) return -1;
+            HIP_OK(hipStreamSynchronize(s));
+            break;
         }
         for (int x = 0; x < n; x++) {
             JobOut &o = out[order[x]];
             o.res = res[x];
             if (res[x].flags & FLAG_OPS_OVERFLOW) { c4h::set_error("traceback path longer than its buffer"); return -1; }
             if (mode == MODE_PATH) {        // the walk wrote END -> START
-                o.ops.assign(ops.begin() + jobs[x].ops_off, ops.begin() + jobs[x].ops_off + res[x].n_ops);
-                std::reverse(o.ops.begin(), o.ops.end());
+                o.runs.assign(runs.begin() + res[x].ops_off, runs.begin() + res[x].ops_off + res[x].n_ops);
+                std::reverse(o.runs.begin(), o.runs.end());
             }
             if (mode == MODE_CKPT) {
                 o.vsa.assign(vsa.begin() + jobs[x].vsa_off, vsa.begin() + jobs[x].vsa_off + res[x].n_vsa);
@@ -474,7 +498,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
         a.region.query_length = r.qe - r.qs;
         a.region.target_length = r.te - r.ts;
         int cap = 0;
-        for (uint8_t t : outs[x].ops) c4h::alignment_add(&a, &cap, t, 1);
+        for (uint32_t r : outs[x].runs) c4h::alignment_add(&a, &cap, (int)(r >> 24), (int)(r & 0xffffff));
         a.valid = 1;
     }
     // -- step 3: reduced space: checkpoint passes, recursively (optimal.c:160-230,315-345)
@@ -564,7 +588,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
                 c4h::set_error("internal: continuation cell mismatch between checkpoint pass and sub-alignment");
                 return -1;
             }
-            for (uint8_t t : outs[x].ops) c4h::alignment_add(&a, &cap[i], t, 1);
+            for (uint32_t r : outs[x].runs) c4h::alignment_add(&a, &cap[i], (int)(r >> 24), (int)(r & 0xffffff));
         }
     }
     for (int i = 0; i < n; i++) {
@@ -683,10 +707,13 @@ int c4gpu_viterbi_batch(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_pa
             r.score = d.score; r.query_start = d.qs; r.target_start = d.ts; r.query_end = d.qe; r.target_end = d.te;
             for (int l = 0; l < CELL_MAX; l++) r.final_cell[l] = d.final_cell[l];
             r.last_srp = d.last_srp;
-            r.n_ops = (int)outs[x].ops.size();
+            r.n_ops = 0;
+            for (uint32_t run : outs[x].runs) r.n_ops += (int)(run & 0xffffff);
             if (r.n_ops) {
                 r.ops = (int32_t *)malloc(sizeof(int32_t) * r.n_ops);
-                for (int k = 0; k < r.n_ops; k++) r.ops[k] = outs[x].ops[k];
+                int k = 0;
+                for (uint32_t run : outs[x].runs)
+                    for (uint32_t c = 0; c < (run & 0xffffff); c++) r.ops[k++] = (int)(run >> 24);
             }
             if (!outs[x].checkpoints.empty()) {
                 r.checkpoints = (c4gpu_score *)malloc(sizeof(int) * outs[x].checkpoints.size());

@@ -66,6 +66,7 @@ struct DevJob {
 };
 struct DevResult {
     int score, qs, ts, qe, te, end_set, last_srp, n_ops, flags, n_vsa, cell_size, pad;
+    long long ops_off;                   // PATH: first run of this job in the compact run array
     int final_cell[CELL_MAX];
 };
 struct DevVsa { int qs, ts, ql, tl, first_state, pad[3]; int final_cell[CELL_MAX]; };
@@ -74,6 +75,9 @@ struct DevScratch {                      // per persistent wave slabs
     uint32_t *tb;   long long tb_stride;
     int *ckpt;      long long ckpt_stride;
     int *ckpt_dump;
+    uint32_t *runs; long long runs_stride;        // per wave: run-length encoded path being walked
+    uint32_t *runs_out; long long runs_capacity;  // all jobs: compacted (transition << 24 | length) runs
+    unsigned long long *runs_used;
 };
 
 // compile-time index object: the conversion is always-inlined so that every array index is a literal
@@ -622,28 +626,34 @@ struct WaveDP {
         static_for<M::NT>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; if (k == K) { in = M::tr[K].in; out = M::tr[K].out; aq = M::tr[K].aq; at = M::tr[K].at; } });
     }
 
-    // Viterbi_Data_create_Alignment's walk (viterbi.c:342-379), by lane 0; path is written END -> START.
+    // Viterbi_Data_create_Alignment's walk (viterbi.c:342-379), by lane 0.  The path is emitted END -> START
+    // as runs (transition << 24 | length): the run-length merge of Alignment_add (alignment.c:75-102).
     __device__ __noinline__ static void walk(const uint32_t *tb, int T, int first_state, int final_state, int qe,
-                                             int te, uint8_t *ops, int cap, DevResult &res) {
+                                             int te, uint32_t *runs, int cap, DevResult &res) {
         int i = qe, j = te, n = 0, in, out, aq, at;
         int tr = tb_transition(tb_at(tb, i, j, T), final_state);
         bool overflow = false;
+        int run_tr = -1, run_len = 0;
+        auto emit = [&](int t) {
+            if (t == run_tr && run_len < 0xffffff) { run_len++; return; }
+            if (run_tr >= 0) { if (n < cap) runs[n] = ((uint32_t)run_tr << 24) | (uint32_t)run_len; else overflow = true; n++; }
+            run_tr = t; run_len = 1;
+        };
         while (tr >= 0) {
-            if (n < cap) ops[n] = (uint8_t)tr; else overflow = true;
-            n++;
+            emit(tr);
             tr_info(tr, in, out, aq, at);
             i -= aq; j -= at;
             tr = tb_transition(tb_at(tb, i, j, T), in);
             if (tr < 0) break;
             tr_info(tr, in, out, aq, at);
             if (in == M::START) {
-                if (n < cap) ops[n] = (uint8_t)tr; else overflow = true;
-                n++;
+                emit(tr);
                 i -= aq; j -= at;
                 break;
             }
             if (CONT && !(i | j) && out == first_state) break;
         }
+        if (run_tr >= 0) { if (n < cap) runs[n] = ((uint32_t)run_tr << 24) | (uint32_t)run_len; else overflow = true; n++; }
         res.qs = i; res.ts = j; res.n_ops = n;
         if (overflow) res.flags |= FLAG_OPS_OVERFLOW;
     }
@@ -707,6 +717,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
     using DP = WaveDP<M, R, MODE, CONT, LOCAL, PACK>;
     __shared__ KParams kp_lds;
     __shared__ int next_job;
+    __shared__ long long run_off;
+    __shared__ int run_n;
     {
         const int *src = reinterpret_cast<const int *>(kparams);
         int *dst = reinterpret_cast<int *>(&kp_lds);
@@ -758,8 +770,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
         __syncthreads();
         if (threadIdx.x == 0) {
             if constexpr (MODE == MODE_PATH) {
+                uint32_t *runs = scratch.runs + (long long)wave * scratch.runs_stride;
+                res.ops_off = 0;
                 if (res.end_set) DP::walk(tb, job.T, job.first_state, CONT ? job.final_state : M::END, res.qe, res.te,
-                                          ops + job.ops_off, job.ops_cap, res);
+                                          runs, (int)scratch.runs_stride, res);
+                res.ops_off = (long long)atomicAdd(scratch.runs_used, (unsigned long long)res.n_ops);
+                if (res.ops_off + res.n_ops > scratch.runs_capacity) { res.flags |= FLAG_OPS_OVERFLOW; res.n_ops = 0; }
+                run_off = res.ops_off; run_n = res.n_ops;
             }
             if constexpr (MODE == MODE_CKPT) {
                 if (res.end_set) DP::checkpoint_traceback(ckpt, job, vsas + job.vsa_off, res);
@@ -767,6 +784,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
             results[jid] = res;
         }
         __syncthreads();
+        if constexpr (MODE == MODE_PATH) {          // all lanes copy the runs to their compact place
+            const uint32_t *runs = scratch.runs + (long long)wave * scratch.runs_stride;
+            for (int x = threadIdx.x; x < run_n; x += 64) scratch.runs_out[run_off + x] = runs[x];
+            __syncthreads();
+        }
     }
 }
 
