@@ -25,6 +25,55 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def cpu_baseline(args, rank, model, pairs, batch, eng):
+    """The CPU path timed on this host, 1 core, on a bounded sample of the same workload.
+
+    Preferred: the REFERENCE ITSELF with its own compiled (code-generated) Viterbi, oracle/_ref/exonerate-compiled
+    (built in the build container by `make -C oracle compiled`; travels with the repo snapshot), on pair 0 —
+    which also checks the GPU's vulgar line against the reference's at full size.  Otherwise the oracle
+    (oracle/c4_oracle.c, an interpreted-style restatement, ~2x slower than the reference's compiled path)."""
+    import subprocess, tempfile
+    import exonerate_amd as ex
+    from exonerate_amd import workloads
+    q, t = pairs[0]
+    cells = (len(q) + 1) * (len(t) + 1)
+    exe = os.path.join(ROOT, "oracle", "_ref", "exonerate-compiled")
+    if os.path.exists(exe) and cells <= 3e8:
+        try:
+            with tempfile.TemporaryDirectory() as d:
+                open(os.path.join(d, "q.fa"), "w").write(">qy\n%s\n" % q.decode())
+                open(os.path.join(d, "t.fa"), "w").write(">tg\n%s\n" % t.decode())
+                c0 = time.perf_counter()
+                r = subprocess.run([exe, "-m", "est2genome", "-E", "yes", "-S", "no", "--revcomp", "no",
+                                    "--showalignment", "no", "--showvulgar", "yes", "-V", "0",
+                                    os.path.join(d, "q.fa"), os.path.join(d, "t.fa")],
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                cpu_s = time.perf_counter() - c0
+            ref_lines = [l for l in r.stdout.decode().splitlines() if l.startswith("vulgar:")]
+            got = batch.alignment(0)
+            if r.returncode == 0 and ref_lines:
+                same = got is not None and got.vulgar("qy", "tg") == ref_lines[0].strip()
+                assert same, "GPU vulgar differs from the reference: %r vs %r" % (got and got.vulgar(), ref_lines[0])
+                return {"value": cells / cpu_s, "unit": "cells/s", "cores": 1, "kind": "reference",
+                        "sample": "pair 0 of the batch (%d x %d) through the reference's own exonerate (compiled "
+                                  "Viterbi, -m est2genome -E yes -S no --revcomp no), %.1f s wall incl. all passes"
+                                  % (len(q), len(t), cpu_s),
+                        "vulgar_identical_to_gpu": True}
+        except (OSError, subprocess.SubprocessError):
+            pass
+    import oracle_lib
+    q, t = workloads.est2genome_pairs(1, args.qlen, min(args.tlen, 20000), first=rank * args.pairs)[0]
+    c0 = time.perf_counter()
+    exp = oracle_lib.find_path(model.c, model.params, q, t)
+    cpu_s = time.perf_counter() - c0
+    got = eng.find_path(model, [(q, t)])[0]
+    assert got is not None and got.as_dict() == exp, "GPU alignment differs from the oracle"
+    return {"value": (len(q) + 1) * (len(t) + 1) / cpu_s, "unit": "cells/s", "cores": 1, "kind": "port",
+            "sample": "1 pair from the same generator (%d x %d), oracle/c4_oracle.c -O3, %.1f s, all passes of "
+                      "Optimal_find_path" % (len(q), len(t), cpu_s),
+            "checked_bit_exact_vs_gpu": True}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,6 +139,15 @@ def main():
         algo_bytes = sum(len(q) + len(t) + 16 * len(t) + 32 for q, t in pairs)
         avg_ms = reg["ms"] / max(1, reg["launches"])
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM bytes per launch of the same kernel from the PMC passes committed under profiles/ (bench.py
+        # itself cannot read PMCs); only quoted when the run has the configuration that was profiled
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+            if tj["config"] == {"pairs_per_gpu": args.pairs, "query_len": args.qlen, "target_len": args.tlen}:
+                traffic = tj["bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "DP cells/s (first-pass lattice cells / end-to-end time), est2genome 1kb x 100kb batch, "
                       "bit-exact vulgar vs reference",
@@ -103,7 +161,7 @@ def main():
                        "pairs_per_gpu": args.pairs, "query_len": args.qlen, "target_len": args.tlen,
                        "aligned_in_sample": n_aligned},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": algo_bytes,
                          "kernel": "viterbi_kernel<Est2GenomeDesc, MODE_REGION>",
                          "avg_launch_ms": avg_ms, "launches": reg["launches"],
                          "kernel_cells_per_s": reg["cells"] / (reg["ms"] * 1e-3) if reg["ms"] else 0.0,
@@ -113,19 +171,7 @@ def main():
             "kernel_ms": {"region": stats[2]["ms"], "checkpoint": stats[3]["ms"], "path": stats[1]["ms"]},
         }
         if not args.no_cpu_baseline:
-            import oracle_lib
-            # bounded sample: one pair from the same generator with a 20 kb window (~10 s of CPU work)
-            q, t = workloads.est2genome_pairs(1, args.qlen, min(args.tlen, 20000), first=rank * args.pairs)[0]
-            c0 = time.perf_counter()
-            exp = oracle_lib.find_path(model.c, model.params, q, t)
-            cpu_s = time.perf_counter() - c0
-            got = eng.find_path(model, [(q, t)])[0]
-            assert got is not None and got.as_dict() == exp, "GPU alignment differs from the oracle"
-            out["cpu_baseline"] = {"value": (len(q) + 1) * (len(t) + 1) / cpu_s, "unit": "cells/s", "cores": 1,
-                                   "kind": "port",
-                                   "sample": "1 pair from the same generator (%d x %d), oracle/c4_oracle.c -O3, %.1f s, "
-                                             "all passes of Optimal_find_path" % (len(q), len(t), cpu_s),
-                                   "checked_bit_exact_vs_gpu": True}
+            out["cpu_baseline"] = cpu_baseline(args, rank, model, pairs, batch, eng)
             out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["value"] / world
         print(json.dumps(out))
     batch.close()
