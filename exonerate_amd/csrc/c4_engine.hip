@@ -312,6 +312,17 @@ struct Engine {
         static const int wpe_env = getenv("C4GPU_WPE") ? atoi(getenv("C4GPU_WPE")) : 0;
         const KernelInfo *ki = get_kernel(family, mode, cont, use_local, pack, wpe_env);
         if (!ki) { c4h::set_error("no compiled kernel for this model/mode"); return -1; }
+        // whole-rectangle passes whose query spans several 64*R-row strips run on 4 cooperating waves per
+        // job (strip carry rows stay in LDS instead of HBM); C4GPU_MW=0 forces the one-wave kernels
+        static const int mw_env = getenv("C4GPU_MW") ? atoi(getenv("C4GPU_MW")) : 1;
+        if (mw_env && !cont && (mode == MODE_SCORE || mode == MODE_REGION)) {
+            const KernelInfo *kmw = get_kernel_mw(family, mode, use_local, pack);
+            if (kmw) {
+                long long strips = 0;
+                for (int i = 0; i < n; i++) strips += (specs[i].region.query_length + 1 + 64 * kmw->R - 1) / (64 * kmw->R);
+                if (strips >= 3LL * n) ki = kmw;
+            }
+        }
         // longest first (persistent waves pull from the queue head)
         std::vector<int> order(n);
         std::iota(order.begin(), order.end(), 0);
@@ -348,7 +359,7 @@ struct Engine {
         }
         // persistent grid: as many waves as the device keeps resident, bounded by the scratch it implies
         int blocks_per_cu = 0;
-        HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, ki->func, 64, 0));
+        HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, ki->func, 64 * ki->waves, 0));
         if (blocks_per_cu < 1) blocks_per_cu = 1;
         long long grid = std::min<long long>(n, (long long)blocks_per_cu * ctx->prop.multiProcessorCount);
         const long long bnd_per_wave = 2 * (max_T + 1) * (long long)std::max(ki->bnd, 1);

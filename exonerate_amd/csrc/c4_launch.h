@@ -30,10 +30,13 @@ struct KernelInfo {
     int cs;                   // ints per state cell (1 + extra slots)
     int bnd;                  // ints per column of the strip carry row
     int n_states, max_at;
+    int waves;                // waves per job (workgroup = 64 * waves threads)
 };
 
 // family x mode x continuation x local-scope specialisation; NULL launch = not compiled
 const KernelInfo *get_kernel(int family, int mode, bool cont, bool local, bool pack, int wpe = 0);
+// multi-wave kernels (4 cooperating waves per job) for FIND_SCORE / FIND_REGION without continuation
+const KernelInfo *get_kernel_mw(int family, int mode, bool local, bool pack);
 
 #define C4K_DEFINE_KERNEL(SYMBOL, M, RVAL, MODE, CONT, LOCAL, PACK, WPE)                                            \
     static hipError_t SYMBOL##_launch(const LaunchArgs &a) {                                               \
@@ -50,7 +53,28 @@ const KernelInfo *get_kernel(int family, int mode, bool cont, bool local, bool p
                                       WaveDP<M, RVAL, MODE, CONT, LOCAL, PACK>::CS,                              \
                                       WaveDP<M, RVAL, MODE, CONT, LOCAL, PACK>::BND,                             \
                                       M::NS,                                                               \
-                                      M::MAXAT};                                                           \
+                                      M::MAXAT,                                                            \
+                                      1};                                                           \
+        return &ki;                                                                                        \
+    }
+
+#define C4K_DEFINE_KERNEL_MW(SYMBOL, M, RVAL, MODE, LOCAL, PACK, NWV, WPE)                                   \
+    static hipError_t SYMBOL##_launch(const LaunchArgs &a) {                                               \
+        hipLaunchKernelGGL((viterbi_kernel_mw<M, RVAL, MODE, LOCAL, PACK, NWV, WPE>), dim3(a.grid),          \
+                           dim3(64 * NWV), 0, a.stream, a.kp, a.seqs, a.jobs, a.n_jobs, a.results,          \
+                           a.scratch, a.queue);                                                            \
+        return hipGetLastError();                                                                          \
+    }                                                                                                      \
+    const KernelInfo *SYMBOL() {                                                                           \
+        static const KernelInfo ki = {SYMBOL##_launch,                                                     \
+                                      (const void *)viterbi_kernel_mw<M, RVAL, MODE, LOCAL, PACK, NWV, WPE>, \
+                                      #SYMBOL,                                                             \
+                                      RVAL,                                                                \
+                                      WaveDP<M, RVAL, MODE, false, LOCAL, PACK>::CS,                       \
+                                      WaveDP<M, RVAL, MODE, false, LOCAL, PACK>::BND,                      \
+                                      M::NS,                                                               \
+                                      M::MAXAT,                                                            \
+                                      NWV};                                                                \
         return &ki;                                                                                        \
     }
 

@@ -367,15 +367,30 @@ struct WaveDP {
     // j = s, so every lane requests the same (clamped) column one step ahead: an unconditional, uniform
     // load with no dependent ALU op, so nothing waits for it until the next step's DPP exchange.
     C nx_carry;
+    static constexpr int RING = 256;                    // columns of an LDS carry ring (multi-wave kernels)
+    typedef __attribute__((address_space(3))) int lds_int;
+    lds_int *ring_in, *ring_out;
+    bool use_ring_in, use_ring_out;                     // the row above / below lives in LDS (LDS offset 0 is a
+                                                        // valid address, so a null test cannot tell)
     __device__ __forceinline__ void prefetch_carry(int s_next, const int *bnd_in) {
         const int jc = s_next < 0 ? 0 : (s_next > T ? T : s_next);
-        for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
-            const int *p = bnd_in + (long long)jc * BND + slot;
-            nx_carry.sc[S] = p[0];
-            static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
-                if constexpr (X > 0) if constexpr (slot_live(S, E)) nx_carry.ex[S][E] = p[1 + E];
+        if (use_ring_in) {
+            for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
+                const lds_int *p = ring_in + (jc & (RING - 1)) * BND + slot;
+                nx_carry.sc[S] = p[0];
+                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
+                    if constexpr (X > 0) if constexpr (slot_live(S, E)) nx_carry.ex[S][E] = p[1 + E];
+                });
             });
-        });
+        } else {
+            for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
+                const int *p = bnd_in + (long long)jc * BND + slot;
+                nx_carry.sc[S] = p[0];
+                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
+                    if constexpr (X > 0) if constexpr (slot_live(S, E)) nx_carry.ex[S][E] = p[1 + E];
+                });
+            });
+        }
     }
 
     // per-column inputs of column j: target residue code for the match transitions and, for spliced
@@ -451,13 +466,23 @@ struct WaveDP {
             });
         });
         if (!last_strip && lane == 63 && jact) {
-            for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
-                int *p = bnd_out + (long long)j * BND + slot;
-                p[0] = expo.sc[S];
-                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
-                    if constexpr (X > 0) if constexpr (slot_live(S, E)) p[1 + E] = expo.ex[S][E];
+            if (use_ring_out) {
+                for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
+                    lds_int *p = ring_out + (j & (RING - 1)) * BND + slot;
+                    p[0] = expo.sc[S];
+                    static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
+                        if constexpr (X > 0) if constexpr (slot_live(S, E)) p[1 + E] = expo.ex[S][E];
+                    });
                 });
-            });
+            } else {
+                for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
+                    int *p = bnd_out + (long long)j * BND + slot;
+                    p[0] = expo.sc[S];
+                    static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
+                        if constexpr (X > 0) if constexpr (slot_live(S, E)) p[1 + E] = expo.ex[S][E];
+                    });
+                });
+            }
         }
         // (6) the corner cell (Q, T): final cell of a continuation / last SRP (viterbi.c:813-832)
         if constexpr (CONT) {
@@ -521,6 +546,7 @@ struct WaveDP {
         }
         best = LOW; best_i = best_j = best_qs = best_ts = 0; best_set = false;
         corner_set = false;
+        ring_in = nullptr; ring_out = nullptr; use_ring_in = false; use_ring_out = false;
         const int section_length = (MODE == MODE_CKPT) ? T / (job.cp_count + 1) : 1;
         const int nstrips = (Q + 1 + W - 1) / W;
         const long long strip_tb = (long long)(T + 64) * 64 * R;
@@ -569,6 +595,101 @@ struct WaveDP {
             for (; s < nsteps_r; s += NCOL) group(IC<0>{}, s);
             if constexpr (!CONT) strip_end();
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // carry row / traceback visible to the next strip
+        }
+    }
+
+    // ---- the whole rectangle on NW cooperating waves (FIND_SCORE / FIND_REGION) ----------------------------
+    // Wave w of the workgroup owns strip w of each "super-strip" of NW*64*R query rows and runs 2 chunks
+    // of CH steps behind wave w-1; bottom rows go from wave to wave through LDS rings (no HBM carry row
+    // unless Q+1 exceeds one super-strip), all waves meet at a barrier after every chunk.
+    // Wave w at chunk c' reads columns [CH*c', CH*c'+CH] of the row above; wave w-1 has then finished
+    // chunk c'+1, i.e. columns up to CH*(c'+2)-64: enough for CH >= 64.  Ring span <= 3*CH-64 < RING.
+    static constexpr int CH = (64 + NCOL - 1) / NCOL * NCOL;
+    template <int NW>
+    __device__ __forceinline__ void run_mw(const DevJob &job, const DevSeqs &seqs, int *bnd, lds_int *rings,
+                                           int wid) {
+        static_assert(!CONT && (MODE == MODE_SCORE || MODE == MODE_REGION), "multi-wave: full-rectangle passes");
+        Q = job.Q; T = job.T; q0 = job.q0; t0 = job.t0;
+        tshift = job.tshift;
+        tlast = seqs.tlen[job.pair] > 0 ? seqs.tlen[job.pair] - 1 : 0;
+        first_state = job.first_state; final_state = M::END;
+        first_cell = job.first_cell;
+        min_intron = kp->min_intron; max_intron = kp->max_intron;
+        start_scope = kp->start_scope; end_scope = kp->end_scope;
+        qc = seqs.qcode + seqs.qoff[job.pair];
+        tc = seqs.tcode + seqs.toff[job.pair];
+        if constexpr (F::has_splice()) {
+            const int *base = seqs.ss + seqs.toff[job.pair];
+            ss0 = base; ss1 = base + seqs.ss_stride; ss2 = base + 2 * seqs.ss_stride; ss3 = base + 3 * seqs.ss_stride;
+        }
+        best = LOW; best_i = best_j = best_qs = best_ts = 0; best_set = false;
+        corner_set = false;
+        const int nstrips = (Q + 1 + W - 1) / W;
+        const int nsuper = (nstrips + NW - 1) / NW;
+        const int nsteps = T + 64;
+        const int nchunks = (nsteps + CH - 1) / CH;
+        const int main_lo = 63 + M::MAXAT, main_hi = T;
+        for (int sb = 0; sb < nsuper; sb++) {
+            const int b = sb * NW + wid;
+            const int i0 = b * W + lane * R;
+            static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                const int qpos = q0 + i0 + RR - 1;
+                qcode[RR] = (i0 + RR >= 1 && i0 + RR <= Q) ? qc[qpos] : 0;
+            });
+            static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                expo.sc[S] = LOW;
+                static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; expo.ex[S][E] = 0; });
+                static_for<NCOL>([&](auto D_) __attribute__((always_inline)) { constexpr int D = D_;
+                    nbr[D].sc[S] = LOW;
+                    static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; nbr[D].ex[S][E] = 0; });
+                    static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                        col[D][RR].sc[S] = LOW;
+                        static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; col[D][RR].ex[S][E] = 0; });
+                    });
+                });
+            });
+            strip_begin();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int *bnd_in = bnd + (long long)((sb + 1) & 1) * (T + 1) * BND;
+            int *bnd_out = bnd + (long long)(sb & 1) * (T + 1) * BND;
+            use_ring_in = wid > 0;  use_ring_out = wid < NW - 1;
+            ring_in = rings + (wid > 0 ? wid - 1 : 0) * RING * BND;
+            ring_out = rings + (wid < NW - 1 ? wid : 0) * RING * BND;
+            const bool first = (b == 0);                       // no row above at all
+            const bool last = (b >= nstrips - 1);              // nobody below needs our bottom row
+            const bool idle = (b >= nstrips);                  // strip entirely below the rectangle
+            auto group = [&](auto JI_, int s0) __attribute__((always_inline)) {
+                constexpr bool JI = decltype(JI_)::value != 0;
+                static_for<NCOL>([&](auto P_) __attribute__((always_inline)) { constexpr int P = P_;
+                    step<JI, P>(s0 + P, i0, first, last, bnd_in, bnd_out, nullptr, 0, nullptr, 1, 0);
+                });
+            };
+            // every wave executes exactly nticks barriers: 2*wid before its first chunk, one after each
+            // of its nchunks chunks, 2*(NW-1-wid) after its last
+            for (int t = 0; t < 2 * wid; t++) __syncthreads();
+            if (idle) {
+                for (int k = 0; k < nchunks; k++) __syncthreads();
+            } else {
+                prefetch_column(0 - lane);
+                prefetch_carry(0, bnd_in);
+                int k = 0;
+                for (; k < nchunks && k * CH < main_lo; k++) {
+                    for (int s = k * CH; s < k * CH + CH; s += NCOL) group(IC<0>{}, s);
+                    __syncthreads();
+                }
+                for (; k < nchunks && k * CH + CH - 1 <= main_hi; k++) {
+                    for (int s = k * CH; s < k * CH + CH; s += NCOL) group(IC<1>{}, s);
+                    __syncthreads();
+                }
+                for (; k < nchunks; k++) {
+                    for (int s = k * CH; s < k * CH + CH; s += NCOL) group(IC<0>{}, s);
+                    __syncthreads();
+                }
+            }
+            for (int t = 0; t < 2 * (NW - 1 - wid); t++) __syncthreads();
+            strip_end();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
         }
     }
 
@@ -789,6 +910,67 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
             for (int x = threadIdx.x; x < run_n; x += 64) scratch.runs_out[run_off + x] = runs[x];
             __syncthreads();
         }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// Kernel: NW cooperating waves per job (FIND_SCORE / FIND_REGION over whole rectangles).
+// -------------------------------------------------------------------------------------------------------------
+template <class M, int R, int MODE, bool LOCAL, bool PACK, int NW, int WPE>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
+void viterbi_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, int n_jobs, DevResult *results,
+                       DevScratch scratch, int *queue) {
+    using DP = WaveDP<M, R, MODE, false, LOCAL, PACK>;
+    __shared__ KParams kp_lds;
+    __shared__ int next_job;
+    __shared__ int rings[(NW > 1 ? NW - 1 : 1) * DP::RING * DP::BND];
+    __shared__ int wave_best[NW][8];
+    {
+        const int *src = reinterpret_cast<const int *>(kparams);
+        int *dst = reinterpret_cast<int *>(&kp_lds);
+        for (int x = threadIdx.x; x < (int)(sizeof(KParams) / sizeof(int)); x += 64 * NW) dst[x] = src[x];
+    }
+    __syncthreads();
+    const int wid = threadIdx.x >> 6;
+    int *bnd = scratch.bnd + (long long)blockIdx.x * scratch.bnd_stride;
+    for (;;) {
+        if (threadIdx.x == 0) next_job = atomicAdd(queue, 1);
+        __syncthreads();
+        const int jid = next_job;
+        __syncthreads();
+        if (jid >= n_jobs) break;
+        const DevJob &job = jobs[jid];
+        DP dp;
+        dp.kp = &kp_lds;
+        dp.lane = threadIdx.x & 63;
+        dp.template run_mw<NW>(job, seqs, bnd, (typename DP::lds_int *)rings, wid);
+        dp.reduce_best();
+        if (dp.lane == 0) {
+            wave_best[wid][0] = dp.best; wave_best[wid][1] = dp.best_i; wave_best[wid][2] = dp.best_j;
+            wave_best[wid][3] = dp.best_qs; wave_best[wid][4] = dp.best_ts; wave_best[wid][5] = dp.best_set;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int b = LOW, bi = 0, bj = 0, bqs = 0, bts = 0; bool bs = false;
+            for (int w = 0; w < NW; w++) {           // row-major-first merge (viterbi.c:778-791)
+                const int ob = wave_best[w][0], oi = wave_best[w][1], oj = wave_best[w][2];
+                const bool os = wave_best[w][5] != 0;
+                const bool take = os && (!bs || ob > b || (ob == b && (oj < bj || (oj == bj && oi < bi))));
+                if (take) { b = ob; bi = oi; bj = oj; bqs = wave_best[w][3]; bts = wave_best[w][4]; }
+                bs = bs || os;
+            }
+            DevResult res;
+            res.flags = bs ? 0 : FLAG_NO_END; res.n_ops = 0; res.n_vsa = 0; res.last_srp = 0; res.pad = 0;
+            res.cell_size = DP::CS; res.ops_off = 0;
+            for (int l = 0; l < CELL_MAX; l++) res.final_cell[l] = 0;
+            res.score = b; res.end_set = bs; res.qe = bi; res.te = bj; res.qs = 0; res.ts = 0;
+            if constexpr (MODE == MODE_REGION) {
+                if constexpr (PACK) { res.qs = bqs >> job.tshift; res.ts = bqs & ((1 << job.tshift) - 1); }
+                else { res.qs = bqs; res.ts = bts; }
+            }
+            results[jid] = res;
+        }
+        __syncthreads();
     }
 }
 
