@@ -90,9 +90,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("C4_BENCH_FORCE_DIST") == "1"     # the latter: exercise RCCL on 1 GPU
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
 
@@ -107,12 +111,23 @@ def main():
     first_pass_cells = sum((len(q) + 1) * (len(t) + 1) for q, t in pairs)
     batch.kernel_stats(ex.MODE_FIND_REGION, reset=True)  # switches HIP-event timing of the kernels on
 
+    def flush_c_stdio():
+        # RCCL prints a version banner through C stdio; push it out now so that the JSON line is the last
+        # thing on stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
+    barrier()
+    flush_c_stdio()
     for _ in range(args.warmup):
         batch.run(2)
     for m in range(4):
@@ -123,11 +138,12 @@ def main():
         batch.run(2)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    out = None
     stats = {m: batch.kernel_stats(m) for m in range(4)}
     n_aligned = sum(1 for i in range(min(args.pairs, 64)) if batch.alignment(i) is not None)
     if rank == 0:
@@ -173,11 +189,13 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, rank, model, pairs, batch, eng)
             out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["value"] / world
-        print(json.dumps(out))
     batch.close()
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    flush_c_stdio()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

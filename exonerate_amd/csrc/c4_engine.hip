@@ -454,6 +454,70 @@ bool model_is_global(const c4gpu_model *m) {     // C4_Model_is_global, c4.c:195
     return m->start_scope == C4GPU_SCOPE_CORNER && m->end_scope == C4GPU_SCOPE_CORNER;
 }
 
+// Optimal_find_path_reduced_space for ONE pair exactly as the reference sequences it (optimal.c:160-345):
+// every Viterbi call is its own launch and each sub-DP receives the final cell the previous one actually
+// produced.  Slow path: only used when the batched prediction of those cells fails its verification.
+struct SeqVsa { c4gpu_region region; int first_state; int final_cell[CELL_MAX]; };
+
+int sequential_recur(Engine &eng, const ResidentSeqs &seqs, int pair, int dpmemory_mb, const c4gpu_region &region,
+                     int first_state, const int *first_cell, int final_state, int *final_cell_out,
+                     c4gpu_score *score_out, std::vector<SeqVsa> &leaves) {
+    const c4gpu_model *m = eng.model;
+    JobSpec js;
+    js.pair = pair; js.region = region; js.first_state = first_state; js.final_state = final_state;
+    memcpy(js.first_cell, first_cell, sizeof js.first_cell);
+    js.cp_count = c4h::checkpoint_rows(m, &region, dpmemory_mb);
+    std::vector<JobOut> outs;
+    if (eng.run(seqs, MODE_CKPT, true, std::vector<JobSpec>(1, js), outs)) return -1;
+    *score_out = outs[0].res.score;
+    memcpy(final_cell_out, outs[0].res.final_cell, sizeof(int) * CELL_MAX);
+    std::vector<SeqVsa> sub;
+    for (int v = (int)outs[0].vsa.size() - 1; v >= 0; v--) {          // path order
+        const DevVsa &dv = outs[0].vsa[v];
+        SeqVsa sv;
+        sv.region = c4gpu_region{dv.qs, dv.ts, dv.ql, dv.tl};
+        sv.first_state = dv.first_state;
+        memcpy(sv.final_cell, dv.final_cell, sizeof sv.final_cell);
+        sub.push_back(sv);
+    }
+    for (size_t k = 0; k < sub.size(); k++) {
+        if (c4h::use_reduced_space(m, &sub[k].region, dpmemory_mb)) {
+            const int *sub_first = k ? sub[k - 1].final_cell : first_cell;
+            const int sub_final_state = (k + 1 < sub.size()) ? sub[k + 1].first_state : final_state;
+            c4gpu_score dummy;
+            if (sequential_recur(eng, seqs, pair, dpmemory_mb, sub[k].region, sub[k].first_state, sub_first,
+                                 sub_final_state, sub[k].final_cell, &dummy, leaves)) return -1;
+        } else {
+            leaves.push_back(sub[k]);
+        }
+    }
+    return 0;
+}
+
+int sequential_reduced_path(Engine &eng, const ResidentSeqs &seqs, int pair, int dpmemory_mb,
+                            const c4gpu_region &ar, c4gpu_alignment *a) {
+    const c4gpu_model *m = eng.model;
+    int zero[CELL_MAX] = {0}, final_cell[CELL_MAX];
+    std::vector<SeqVsa> leaves;
+    c4gpu_score score = 0;
+    if (sequential_recur(eng, seqs, pair, dpmemory_mb, ar, m->start_state, zero, m->end_state, final_cell, &score,
+                         leaves)) return -1;
+    c4gpu_alignment_clear(a);
+    a->score = score; a->region = ar; a->valid = 1;
+    int cap = 0;
+    for (size_t k = 0; k < leaves.size(); k++) {                      // Optimal_compute_subalignments
+        JobSpec js;
+        js.pair = pair; js.region = leaves[k].region; js.first_state = leaves[k].first_state;
+        memcpy(js.first_cell, k ? leaves[k - 1].final_cell : zero, sizeof js.first_cell);
+        js.final_state = (k + 1 < leaves.size()) ? leaves[k + 1].first_state : m->end_state;
+        std::vector<JobOut> outs;
+        if (eng.run(seqs, MODE_PATH, true, std::vector<JobSpec>(1, js), outs)) return -1;
+        memcpy(leaves[k].final_cell, outs[0].res.final_cell, sizeof(int) * CELL_MAX);   // optimal.c:243,301
+        for (uint32_t r : outs[0].runs) c4h::alignment_add(a, &cap, (int)(r >> 24), (int)(r & 0xffffff));
+    }
+    return 0;
+}
+
 int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gpu_score threshold,
                     c4gpu_alignment *alignments) {
     const c4gpu_model *m = eng.model;
@@ -523,6 +587,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
             red.push_back(i);
         }
     std::vector<c4gpu_score> red_score(n, 0);
+    std::vector<char> redo(n, 0);
     bool first_round = true;
     for (;;) {
         struct Ref { int pair, seg; };
@@ -560,6 +625,11 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
                 c.needs_checkpoints = c4h::use_reduced_space(m, &c.region, dpmemory_mb);
                 children.push_back(c);
             }
+            // optimal.c:214-217 passes vsa->final_cell as the buffer the recursive pass overwrites; siblings
+            // scheduled in the same round used the old value: it must not have changed
+            if (!first_round && !children.empty() &&
+                memcmp(children.back().final_cell, sg[k].final_cell, sizeof(int) * (1 + m->total_shadow_designations)) != 0)
+                redo[refs[x].pair] = 1;
             sg.erase(sg.begin() + k);
             sg.insert(sg.begin() + k, children.begin(), children.end());
         }
@@ -584,6 +654,8 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
     {
         std::vector<int> cap(n, 0);
         const int path_cs = 1 + m->total_shadow_designations;
+        static const bool force_seq = getenv("C4GPU_FORCE_SEQUENTIAL") != nullptr;    // test hook
+        if (force_seq) for (int i : red) redo[i] = 1;
         for (size_t x = 0; x < refs2.size(); x++) {
             const int i = refs2[x].pair;
             c4gpu_alignment &a = alignments[i];
@@ -594,14 +666,15 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
                 a.valid = 1;
             }
             // The reference threads the final cell of each sub-DP into the next one (optimal.c:283,301);
-            // we predicted it from the checkpoint rows to run all sub-DPs in one launch: verify.
-            if (memcmp(outs[x].res.final_cell, sg[refs2[x].seg].final_cell, sizeof(int) * path_cs) != 0) {
-                c4h::set_error("internal: continuation cell mismatch between checkpoint pass and sub-alignment");
-                return -1;
-            }
+            // we predicted it from the checkpoint rows to run all sub-DPs in one launch: verify, and redo the
+            // pair strictly sequentially if the prediction was wrong.
+            if (memcmp(outs[x].res.final_cell, sg[refs2[x].seg].final_cell, sizeof(int) * path_cs) != 0)
+                redo[i] = 1;
             for (uint32_t r : outs[x].runs) c4h::alignment_add(&a, &cap[i], (int)(r >> 24), (int)(r & 0xffffff));
         }
     }
+    for (int i : red)
+        if (redo[i] && sequential_reduced_path(eng, seqs, i, dpmemory_mb, plan[i].ar, &alignments[i])) return -1;
     for (int i = 0; i < n; i++) {
         c4gpu_alignment &a = alignments[i];
         if (a.valid && a.score < threshold) c4gpu_alignment_clear(&a);     // optimal.c:408-411

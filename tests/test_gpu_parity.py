@@ -174,3 +174,28 @@ def test_full_size_properties(eng):
     assert m_blocks == [230, 290, 270, 210]
     introns = [int(v[i + 2]) for i in range(0, len(v), 3) if v[i] == "I"]
     assert introns == [4000, 4000, 4000]
+
+
+def test_sequential_fallback_path_is_exact(monkeypatch):
+    """The strictly sequential reduced-space route (used when the batched prediction of continuation cells
+    fails its check) gives the reference's alignments too.  Forced through C4GPU_FORCE_SEQUENTIAL in a
+    fresh process (the switch is read once)."""
+    import subprocess, sys, os, json
+    code = r'''
+import sys, json
+sys.path.insert(0, "tests")
+import exonerate_amd as ex
+from golden_util import load_set, expected
+eng = ex.Engine(0)
+for name, mt in (("est2genome_D0", "est2genome"), ("affine_local_dna_D0", "affine:local")):
+    recs = load_set(name)
+    alns = eng.find_path(ex.Model(mt), [(r["query"], r["target"]) for r in recs], dpmemory=0)
+    for r, a in zip(recs, alns):
+        assert a.as_dict(r["id"]) == expected(r), r["id"]
+print("OK")
+'''
+    env = dict(os.environ, C4GPU_FORCE_SEQUENTIAL="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0 and b"OK" in out.stdout, out.stderr.decode()[-2000:]
