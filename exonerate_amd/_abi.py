@@ -177,6 +177,8 @@ PROTOTYPES = [
     ("c4m_intron_create", C.c_void_p, [C.c_char_p, C.c_int, C.POINTER(Params)]),
     ("c4m_est2genome_create", C.c_void_p, [C.POINTER(Params)]),
     ("c4m_protein2dna_create", C.c_void_p, [C.c_int, C.POINTER(Params)]),
+    ("c4m_phase_create", C.c_void_p, [C.POINTER(Params)]),
+    ("c4m_protein2genome_create", C.c_void_p, [C.c_int, C.POINTER(Params)]),
 ]
 
 _lib = None

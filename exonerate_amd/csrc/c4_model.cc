@@ -540,6 +540,53 @@ c4m_model *c4m_protein2dna_create(int type, const c4gpu_params *p) {
     return m;
 }
 
+// Phase_create(NULL, match = protein2dna, on_query = FALSE, on_target = TRUE), src/model/phase.c:354-548:
+// three target introns (phase 0:0, 1:2, 2:1) around split-codon states; the post-intron transitions score
+// the codon re-assembled across the intron from the shadow (phase.c:188-208).
+c4m_model *c4m_phase_create(const c4gpu_params *p) {
+    const std::string sfx = "phase-T";
+    c4m_model *m = c4m_model_create(sfx.c_str());
+    c4m_model_set_alphabets(m, C4GPU_ALPHABET_PROTEIN, C4GPU_ALPHABET_DNA);
+    c4m_model *i00 = c4m_intron_create(("0:0 " + sfx).c_str(), 1, p);
+    c4m_model *i12 = c4m_intron_create(("1:2 " + sfx).c_str(), 1, p);
+    c4m_model *i21 = c4m_intron_create(("2:1 " + sfx).c_str(), 1, p);
+    const int mx = submat_max(p->protein_submat);               // Match_max_score, match.c:885
+    int c1 = c4m_add_calc(m, ("phase1post to dst " + sfx).c_str(), C4GPU_CALC_PHASE_POST, 0, 1, mx, 0);
+    int c2 = c4m_add_calc(m, ("phase2post to dst " + sfx).c_str(), C4GPU_CALC_PHASE_POST, 0, 2, mx, 0);
+    int pre1 = c4m_add_state(m, ("phase1pre " + sfx).c_str());
+    int post1 = c4m_add_state(m, ("phase1post " + sfx).c_str());
+    int pre2 = c4m_add_state(m, ("phase2pre " + sfx).c_str());
+    int post2 = c4m_add_state(m, ("phase2post " + sfx).c_str());
+    // against a peptide, introns on the target: pre 0/1 and 0/2, post 1/2 and 1/1 (phase.c:400-411)
+    c4m_add_transition(m, ("(START) to phase1pre " + sfx).c_str(), C4M_START, pre1, 0, 1, -1, C4GPU_LABEL_SPLIT_CODON);
+    c4m_add_transition(m, ("(START) to phase2pre " + sfx).c_str(), C4M_START, pre2, 0, 2, -1, C4GPU_LABEL_SPLIT_CODON);
+    int t1 = c4m_add_transition(m, ("phase1post " + sfx + " to (END)").c_str(), post1, C4M_END, 1, 2, c1, C4GPU_LABEL_SPLIT_CODON);
+    int t2 = c4m_add_transition(m, ("phase2post " + sfx + " to (END)").c_str(), post2, C4M_END, 1, 1, c2, C4GPU_LABEL_SPLIT_CODON);
+    c4m_insert(m, i00, C4M_START, C4M_END);
+    c4m_insert(m, i12, pre1, post1);
+    c4m_insert(m, i21, pre2, post2);
+    c4m_shadow_add_dst_transition(m, 1, t1);                    // phase.c:528-532
+    c4m_shadow_add_dst_transition(m, 2, t2);
+    c4m_model_destroy(i00); c4m_model_destroy(i12); c4m_model_destroy(i21);
+    c4m_model_close(m);
+    return m;
+}
+
+// Protein2Genome_create, src/model/protein2genome.c:44-68
+c4m_model *c4m_protein2genome_create(int type, const c4gpu_params *p) {
+    static const char *type_name[] = {"global", "bestfit", "local", "overlap"};
+    c4m_model *m = c4m_protein2dna_create(type, p);
+    if (!m) return nullptr;
+    c4m_model_rename(m, (std::string("protein2genome:") + type_name[type]).c_str());
+    c4m_model_open(m);
+    int match_tr = c4m_select_single_transition(m, C4GPU_LABEL_MATCH);
+    c4m_model *phase = c4m_phase_create(p);
+    c4m_insert(m, phase, m->tr[match_tr].input, m->tr[match_tr].output);
+    c4m_model_destroy(phase);
+    c4m_model_close(m);
+    return m;
+}
+
 // Model_Type_get_model, src/model/modeltype.c
 int c4gpu_model_get(const char *type, int qa, int ta, const c4gpu_params *params, c4gpu_model *out) {
     c4gpu_params defaults;
@@ -554,6 +601,8 @@ int c4gpu_model_get(const char *type, int qa, int ta, const c4gpu_params *params
     else if (t == "est2genome" || t == "e2g") m = c4m_est2genome_create(params);
     else if (t == "protein2dna" || t == "p2d") m = c4m_protein2dna_create(C4M_AFFINE_LOCAL, params);
     else if (t == "protein2dna:bestfit" || t == "p2d:b") m = c4m_protein2dna_create(C4M_AFFINE_BESTFIT, params);
+    else if (t == "protein2genome" || t == "p2g") m = c4m_protein2genome_create(C4M_AFFINE_LOCAL, params);
+    else if (t == "protein2genome:bestfit" || t == "p2g:b") m = c4m_protein2genome_create(C4M_AFFINE_BESTFIT, params);
     if (!m) return -1;
     int rc = c4m_flatten(m, out);
     c4m_model_destroy(m);
@@ -585,7 +634,7 @@ int c4gpu_model_plugin_name(const c4gpu_model *model, int mode, int use_continua
 
 int c4gpu_model_is_accelerated(const c4gpu_model *model) {
     for (int c = 0; c < model->n_calcs; c++)
-        if (model->calcs[c].kind > C4GPU_CALC_SPLICE_POST) return 0;
+        if (model->calcs[c].kind > C4GPU_CALC_PHASE_POST) return 0;
     for (int s = 0; s < model->n_shadows; s++)
         if (!model->shadows[s].on_target) return 0;
     if (model->total_shadow_designations > 1) return 0;

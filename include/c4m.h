@@ -67,6 +67,8 @@ c4m_model *c4m_affine_create(int scope_type, int query_alphabet, int target_alph
 c4m_model *c4m_intron_create(const char *suffix, int is_forward, const c4gpu_params *p);        /* intron.c:588 (target introns) */
 c4m_model *c4m_est2genome_create(const c4gpu_params *p);                                        /* est2genome.c:58 */
 c4m_model *c4m_protein2dna_create(int scope_type, const c4gpu_params *p);                       /* protein2dna.c:56 */
+c4m_model *c4m_phase_create(const c4gpu_params *p);                                             /* phase.c:354 (protein query, target introns) */
+c4m_model *c4m_protein2genome_create(int scope_type, const c4gpu_params *p);                    /* protein2genome.c:44 */
 
 /* Affine_Model_Type, src/model/affine.h */
 enum { C4M_AFFINE_GLOBAL = 0, C4M_AFFINE_BESTFIT, C4M_AFFINE_LOCAL, C4M_AFFINE_OVERLAP };

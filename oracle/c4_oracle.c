@@ -109,6 +109,19 @@ static c4gpu_score calc_score(odata *od, int calc, int32_t qpos, int32_t tpos){
                 return LOW;
             return od->ss[c->param][tpos];
             }
+        case C4GPU_CALC_PHASE_POST: {    /* Phase_{1,2}_PROTEIN2DNA_FALSE_TRUE_calc_func, phase.c:188-213 */
+            const int phase = c->param, cis = od->curr_intron_start;
+            int tp1, tp2, tp3;
+            uint8_t aa;
+            if(cis < phase)                  /* Phase_calc_is_valid, target chain has the intron */
+                return LOW;
+            if(phase == 1){ tp1 = cis - 1; tp2 = tpos; tp3 = tpos + 1; }
+            else { tp1 = cis - 2; tp2 = cis - 1; tp3 = tpos; }
+            aa = p->aa[p->trans[ p->nt2d[od->target[tp1]]
+                              | (p->nt2d[od->target[tp2]] << 4)
+                              | (p->nt2d[od->target[tp3]] << 8)]];
+            return p->protein_submat[p->submat_index[od->query[qpos]]][p->submat_index[aa]];
+            }
         default:
             fprintf(stderr, "oracle: calc kind %d not restated\n", c->kind);
             abort();

@@ -14,6 +14,7 @@ SETS = {
     "affine_local_dna_D0": ("affine:local", 0, 0), "affine_global_dna_D0": ("affine:global", 0, 0),
     "est2genome_D0": ("est2genome", 0, 0), "protein2dna_D0": ("protein2dna", 1, 0),
     "est2genome_big": ("est2genome", 0, 0),
+    "protein2genome": ("protein2genome", 1, 0), "protein2genome_D0": ("protein2genome", 1, 0),
 }
 
 

@@ -18,6 +18,7 @@ IN_SCOPE = {
     "ungapped:dna": ("ungapped", 0, 0), "ungapped:protein": ("ungapped", 1, 1),
     "est2genome": ("est2genome", 0, 0),
     "protein2dna": ("protein2dna", 1, 0), "protein2dna:bestfit": ("protein2dna:bestfit", 1, 0),
+    "protein2genome": ("protein2genome", 1, 0), "protein2genome:bestfit": ("protein2genome:bestfit", 1, 0),
 }
 
 

@@ -119,6 +119,29 @@ def p2d_pairs(rng, n):
     return cases
 
 
+def p2g_pairs(rng, n):
+    """protein vs genomic: coding sequence interrupted by GT..AG introns at codon phase 0, 1 or 2."""
+    cases = []
+    for k in range(n):
+        ql = rng.choice([8, 25, 60, 120])
+        q = rand_dna(rng, ql, AA)
+        coding = "".join(rng.choice(CODON[a]) for a in mutate(rng, q, 0.05, AA))
+        nint = rng.choice([0, 1, 1, 2, 3])
+        cuts = sorted(rng.sample(range(4, max(5, len(coding) - 4)), min(nint, max(0, len(coding) - 9)))) \
+            if len(coding) > 10 else []
+        t = rand_dna(rng, rng.randint(0, 40))
+        last = 0
+        for c in cuts:
+            t += coding[last:c] + "GT" + rand_dna(rng, rng.choice([26, 40, 90, 200])) + "AG"
+            last = c
+        t += coding[last:] + rand_dna(rng, rng.randint(0, 40))
+        if k % 5 == 4 and len(t) > 30:          # frameshift as well
+            p = rng.randint(10, len(t) - 10)
+            t = t[:p] + rng.choice("ACGT") + t[p:]
+        cases.append(("p2g%03d" % k, q, t))
+    return cases
+
+
 KAT_AFFINE = ("kat_affine", "MEEPQSDPSVEPPLSQETFSDLWKLL",
               "PENNVLSPLPSQAMDDLMLSPDDIEQWFTEDPGPEHSCETFDIWKWCPIECDFLNVISEPNEPIPSQ")
 KAT_E2G = ("kat_est2genome", "CGATCGATCGNATCGATCGATC" "CATCTATCTAGCGAGCGATCTA",
@@ -148,6 +171,7 @@ def main():
     prot = protein_pairs(rng, 18) + [KAT_AFFINE]
     est = est_pairs(rng, 28) + [KAT_E2G]
     p2d = p2d_pairs(rng, 24)
+    p2g = p2g_pairs(random.Random(99), 26)
     for scope in ("local", "global", "bestfit", "overlap"):
         # empty sequences are rejected by the reference's Sequence_create for non-local global DP
         d = [c for c in dna if len(c[1]) > 0 and len(c[2]) > 0]
@@ -164,6 +188,8 @@ def main():
     sets.append(("affine_global_dna_D0", "affine:global", big, 0, ()))
     sets.append(("est2genome_D0", "est2genome", est, 0, ()))
     sets.append(("protein2dna_D0", "protein2dna", [c for c in p2d if len(c[2]) > 30], 0, ()))
+    sets.append(("protein2genome", "protein2genome", p2g, 32, ()))
+    sets.append(("protein2genome_D0", "protein2genome", p2g, 0, ()))
     # a larger est2genome case that takes the reduced-space route at the DEFAULT -D 32
     rng2 = random.Random(7)
     q = rand_dna(rng2, 700)
@@ -171,7 +197,10 @@ def main():
         rand_dna(rng2, 1500) + "AG" + q[520:] + rand_dna(rng2, 400)
     sets.append(("est2genome_big", "est2genome", [("estbig0", q, t)], 32, ()))
     os.makedirs(OUT, exist_ok=True)
+    only = set(sys.argv[1:])
     for name, model, cases, dpm, extra in sets:
+        if only and name not in only:
+            continue
         recs = run(model, cases, dpm, extra)
         with open(os.path.join(OUT, name + ".jsonl"), "w") as f:
             for r in recs:
