@@ -107,11 +107,13 @@ int model_family(const c4gpu_model &m) {
     if (model_matches<Est2GenomeDesc>(m)) return FAM_EST2GENOME;
     if (model_matches<UngappedP2DDesc>(m)) return FAM_UNGAPPED_P2D;
     if (model_matches<Protein2DnaDesc>(m)) return FAM_PROTEIN2DNA;
+    if (model_matches<Protein2GenomeDesc>(m)) return FAM_PROTEIN2GENOME;
     return -1;
 }
 
-bool family_is_p2d(int fam) { return fam == FAM_UNGAPPED_P2D || fam == FAM_PROTEIN2DNA; }
-bool family_has_splice(int fam) { return fam == FAM_EST2GENOME; }
+bool family_is_p2d(int fam) { return fam == FAM_UNGAPPED_P2D || fam == FAM_PROTEIN2DNA || fam == FAM_PROTEIN2GENOME; }
+bool family_has_splice(int fam) { return fam == FAM_EST2GENOME || fam == FAM_PROTEIN2GENOME; }
+bool family_has_phase(int fam) { return fam == FAM_PROTEIN2GENOME; }
 
 // ---- sequence preparation kernels -------------------------------------------------------------------------
 struct PrepTables {
@@ -150,6 +152,22 @@ __global__ void codon_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict
     }
 }
 
+// split-codon calcs (phase.c:188-208) re-read bases around an intron: per position the 4-bit base masks
+// (Translate nt2d, translate.h:40-50) of positions p, p-1, p-2, p-3
+__global__ void tn4_kernel(const uint8_t *__restrict__ in, uint16_t *__restrict__ out, const long long *off,
+                           const int *len, const PrepTables *__restrict__ tab) {
+    const int pair = blockIdx.y;
+    const uint8_t *s = in + off[pair];
+    uint16_t *o = out + off[pair];
+    const int n = len[pair];
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
+        unsigned v = 0;
+        for (int d = 0; d < 4; d++)
+            if (x - d >= 0) v |= (unsigned)tab->nt2d[s[x - d]] << (4 * d);
+        o[x] = (uint16_t)v;
+    }
+}
+
 // SplicePredictor_predict_array_int (splice.c:383-397): float accumulation left to right over the PSSM
 // window clipped to the sequence (Splice_predict_position, splice.c:320-344), rounded half away from
 // zero in double (SplicePredictor_round, splice.c:379-381).  Plain adds only: no contraction possible.
@@ -181,6 +199,7 @@ struct ResidentSeqs {
     DevBuf<uint8_t> qraw, traw, qcode, tcode;
     DevBuf<long long> d_qoff, d_toff;
     DevBuf<int> d_qlen, d_tlen, ss;
+    DevBuf<uint16_t> tn4;
     DevBuf<PrepTables> tables;
     DevBuf<c4gpu_splice_model> splice_models;
     DevBuf<int> bad;
@@ -231,6 +250,12 @@ struct ResidentSeqs {
                                splice_models.p, ss.p, (long long)ht.size());
             dev.ss = ss.p;
             dev.ss_stride = (long long)ht.size();
+        }
+        dev.tn4 = nullptr;
+        if (family_has_phase(family)) {
+            if (tn4.alloc(ht.size())) return -1;
+            hipLaunchKernelGGL(tn4_kernel, dim3(xb, n), dim3(256), 0, s, traw.p, tn4.p, d_toff.p, d_tlen.p, tables.p);
+            dev.tn4 = tn4.p;
         }
         HIP_OK(hipGetLastError());
         int hbad = 0;
@@ -295,6 +320,10 @@ struct Engine {
         for (int i = 0; i < m->n_calcs; i++)
             if (m->calcs[i].kind == C4GPU_CALC_MATCH_PROTEIN || m->calcs[i].kind == C4GPU_CALC_MATCH_P2D) protein = true;
         memcpy(kp.submat, protein ? &params->protein_submat[0][0] : &params->dna_submat[0][0], sizeof kp.submat);
+        for (int c = 0; c < 4096; c++) {
+            const uint8_t row = params->submat_index[params->aa[params->trans[c]]];
+            kp.codon_row[c] = row < 24 ? row : 0;        // '-' (empty mask) never scores: such columns are rejected at upload
+        }
         return kparams.upload(&kp, 1, ctx->stream);
     }
 

@@ -6,7 +6,7 @@
 
 namespace c4k {
 
-enum Family { FAM_UNGAPPED = 0, FAM_AFFINE, FAM_EST2GENOME, FAM_UNGAPPED_P2D, FAM_PROTEIN2DNA, FAM_COUNT };
+enum Family { FAM_UNGAPPED = 0, FAM_AFFINE, FAM_EST2GENOME, FAM_UNGAPPED_P2D, FAM_PROTEIN2DNA, FAM_PROTEIN2GENOME, FAM_COUNT };
 
 struct LaunchArgs {
     const KParams *kp;

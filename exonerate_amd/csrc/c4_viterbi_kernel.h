@@ -39,7 +39,8 @@ constexpr int HIGH = 987654321;
 constexpr int CELL_MAX = 8;
 enum { MODE_SCORE = 0, MODE_PATH = 1, MODE_REGION = 2, MODE_CKPT = 3 };
 enum { SCOPE_ANYWHERE = 0, SCOPE_EDGE, SCOPE_QUERY, SCOPE_TARGET, SCOPE_CORNER };
-enum { CALC_CONST = 0, CALC_MATCH_DNA, CALC_MATCH_PROTEIN, CALC_MATCH_P2D, CALC_SPLICE_PRE, CALC_SPLICE_POST };
+enum { CALC_CONST = 0, CALC_MATCH_DNA, CALC_MATCH_PROTEIN, CALC_MATCH_P2D, CALC_SPLICE_PRE, CALC_SPLICE_POST,
+       CALC_PHASE_PRE, CALC_PHASE_POST };
 enum { FLAG_OPS_OVERFLOW = 1, FLAG_NO_END = 2 };
 
 struct KParams {                 // uniform per launch (device memory, staged to LDS)
@@ -47,12 +48,14 @@ struct KParams {                 // uniform per launch (device memory, staged to
     int min_intron, max_intron;
     int start_scope, end_scope;
     int submat[24 * 24];
+    uint8_t codon_row[4096];             // split-codon calcs: 3 x 4-bit base masks -> Submat row of the residue
 };
 struct DevSeqs {
     const uint8_t *qcode, *tcode;        // residue -> submat row codes (tcode: codon codes for 1:3 match)
     const long long *qoff, *toff;        // per pair offsets into the concatenated arrays
     const int *tlen;                     // per pair target length (prefetch clamps)
     const int *ss;                       // [4][ss_stride] splice-site scores, same offsets as tcode
+    const uint16_t *tn4;                 // per target position: 4-bit base masks of positions p, p-1, p-2, p-3
     long long ss_stride;
 };
 struct DevJob {
@@ -111,6 +114,7 @@ struct Facts {
     static constexpr bool owns_shadow(int s, int d) { for (int h = 0; h < M::NSH; h++) if (M::sh[h].designation == d && (M::sh[h].src_state_mask >> s & 1)) return true; return false; }
     static constexpr int consumed_designation(int k) { for (int h = 0; h < M::NSH; h++) if (M::tr[k].dst_shadow_mask >> h & 1) return M::sh[h].designation; return -1; }
     static constexpr int match_at() { for (int k = 0; k < M::NT; k++) if (M::tr[k].calc >= 0 && M::calc[M::tr[k].calc].kind >= CALC_MATCH_DNA && M::calc[M::tr[k].calc].kind <= CALC_MATCH_P2D) return M::tr[k].at; return 1; }
+    static constexpr bool has_phase() { for (int c = 0; c < M::NC; c++) if (M::calc[c].kind == CALC_PHASE_POST) return true; return false; }
     static constexpr bool has_splice() { for (int c = 0; c < M::NC; c++) if (M::calc[c].kind == CALC_SPLICE_PRE || M::calc[c].kind == CALC_SPLICE_POST) return true; return false; }
     static_assert(M::MAXAQ == 1, "lanes exchange exactly one query row per step");
     static_assert(total_bits <= 32, "traceback word");
@@ -146,9 +150,14 @@ struct WaveDP {
     using F = Facts<M>;
     static constexpr int NDES = M::NDES;
     static constexpr int NRS = (MODE == MODE_REGION) ? (PACK ? 1 : 2) : 0;
-    static constexpr int X = NDES + NRS + (MODE == MODE_CKPT ? 1 : 0);      // register slots per state
+    // split-codon models keep, next to the intron-start shadow, the two bases in front of the intron (an
+    // internal slot: the phase calcs of phase.c:188-208 re-read exactly those bases through the shadow)
+    static constexpr int NAUX = F::has_phase() ? 1 : 0;
+    static constexpr int AUX = NDES;
+    static constexpr int X = NDES + NAUX + NRS + (MODE == MODE_CKPT ? 1 : 0);      // register slots per state
     static constexpr int XS = X > 0 ? X : 1;
-    static constexpr int RSQ = NDES, RST = NDES + 1, SRP = NDES;
+    static constexpr int RSQ = NDES + NAUX, RST = NDES + NAUX + 1, SRP = NDES + NAUX;
+    static_assert(NAUX == 0 || NDES == 1, "the base slot rides on designation 0");
     // reference cell layout (viterbi.c:154-173): score, designations, [region q, region t], [checkpoint]
     static constexpr int CS = 1 + NDES + (MODE == MODE_REGION ? 2 : 0) + (MODE == MODE_CKPT ? 1 : 0);
     static constexpr int W = 64 * R;                    // query rows per strip
@@ -162,6 +171,7 @@ struct WaveDP {
     // only the two intron states).  Dead slots are neither stored nor transported; cells leaving the
     // kernel carry 0 there.
     static constexpr bool slot_live(int s, int e) {
+        if (NAUX && e == AUX) e = 0;
         if (e >= NDES) return true;
         bool live[M::NS] = {};
         for (int it = 0; it < M::NS; it++)
@@ -178,7 +188,7 @@ struct WaveDP {
     const uint8_t *qc, *tc;
     const int *ss0, *ss1, *ss2, *ss3;
     int Q, T, q0, t0, lane, tshift;
-    int first_state, final_state, min_intron, max_intron;
+    int first_state, final_state, min_intron, max_intron, seed_aux;
     const int *first_cell;
     int start_scope, end_scope;
 
@@ -224,7 +234,7 @@ struct WaveDP {
     // state in scratch memory instead of VGPRs.
     template <int RR, int PH, bool JINT>
     __device__ __forceinline__ void eval_cell(int i, int j, bool active, int mscore, const int (&pre)[4],
-                                              uint32_t &tbword) {
+                                              int qrow, int tn4col, uint32_t &tbword) {
         C &c = col[PH][RR];
         bool set[M::NS];
         static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
@@ -257,7 +267,9 @@ struct WaveDP {
                     static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
                         if constexpr (X > 0) {
                             if constexpr (slot_live(S, E)) {
-                                const int old_ex = c.ex[S][E], fce = first_cell[1 + E];
+                                // register slot -> reference cell slot (the base slot is re-derived)
+                                const int old_ex = c.ex[S][E];
+                                const int fce = (NAUX && E == AUX) ? seed_aux : first_cell[1 + E - (E > AUX ? NAUX : 0)];
                                 c.ex[S][E] = seed ? fce : old_ex;
                             }
                         }
@@ -289,6 +301,21 @@ struct WaveDP {
                     const bool bad = (intron_length < min_intron) | (intron_length > max_intron);
                     const int ssv = pre[cd.param];
                     tscore += bad ? LOW : ssv;
+                } else if constexpr (cd.kind == CALC_PHASE_POST) {
+                    // Phase_{1,2}_PROTEIN2DNA_FALSE_TRUE_calc_func (phase.c:188-213): the codon split by the
+                    // intron = base(s) kept from in front of the intron + base(s) of this column
+                    constexpr int des = F::consumed_designation(k);
+                    static_assert(des == 0 && NAUX == 1, "phase calc needs the shadow and its base slot");
+                    const int cis = src.ex[t.in][des], aux = src.ex[t.in][AUX];
+                    constexpr int nib = t.at - 1;                 // base at target_pos = t0 + j - at
+                    int codon;
+                    if constexpr (cd.param == 1)
+                        codon = (aux & 15) | (((tn4col >> (4 * nib)) & 15) << 4) | (((tn4col >> (4 * (nib - 1))) & 15) << 8);
+                    else
+                        codon = ((aux >> 4) & 15) | ((aux & 15) << 4) | (((tn4col >> (4 * nib)) & 15) << 8);
+                    const int row = kp->codon_row[codon];
+                    const int psc = kp->submat[qrow * 24 + row];
+                    tscore += (cis < cd.param) ? LOW : psc;
                 }
                 if constexpr (cd.protect & 2) tscore = tscore < LOW ? LOW : tscore;
                 if constexpr (cd.protect & 1) tscore = tscore > HIGH ? HIGH : tscore;
@@ -305,6 +332,10 @@ struct WaveDP {
                         int v = 0;
                         if constexpr (e < NDES) {
                             if constexpr (F::owns_shadow(t.in, e)) v = t0 + j - t.at;      // intron.c:454-458
+                            else if constexpr (slot_live(t.in, e)) v = src.ex[t.in][e];
+                        } else if constexpr (NAUX == 1 && e == AUX) {
+                            // bases at (shadow - 1) and (shadow - 2), shadow = t0 + j - at
+                            if constexpr (F::owns_shadow(t.in, 0)) v = (tn4col >> (4 * t.at)) & 0xff;
                             else if constexpr (slot_live(t.in, e)) v = src.ex[t.in][e];
                         } else if constexpr (MODE == MODE_REGION && t.in == M::START) {     // viterbi.c:403-412
                             if constexpr (PACK) v = ((i - t.aq) << tshift) | (j - t.at);
@@ -397,12 +428,18 @@ struct WaveDP {
     // models, the splice-site scores at the column the (0,2) transitions leave from.  Requested one step
     // ahead from clamped (always valid) addresses; a lane outside the rectangle gets values it never
     // uses, because every transition that would read them is masked invalid.
-    int nx_tcode, nx_sp[4], tlast;
+    int nx_tcode, nx_sp[4], nx_tn4, tlast;
+    const uint16_t *tn4p;
     __device__ __forceinline__ void prefetch_column(int j) {
         constexpr int mat = F::match_at();
         int ti = t0 + j - mat;
         ti = ti < 0 ? 0 : (ti > tlast ? tlast : ti);
         nx_tcode = tc[ti];
+        if constexpr (F::has_phase()) {
+            int tq = t0 + j - 1;
+            tq = tq < 0 ? 0 : (tq > tlast ? tlast : tq);
+            nx_tn4 = tn4p[tq];
+        }
         if constexpr (F::has_splice()) {
             int tp = t0 + j - 2;
             tp = tp < 0 ? 0 : (tp > tlast ? tlast : tp);
@@ -420,6 +457,7 @@ struct WaveDP {
         // (0) substitution scores of this column for our R query rows: LDS reads issued first so that
         // their latency overlaps the lane exchange below
         const int tcode = nx_tcode;
+        const int tn4col = F::has_phase() ? nx_tn4 : 0;
         int ms[R];
         static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
             ms[RR] = kp->submat[qcode[RR] * 24 + tcode];
@@ -451,7 +489,7 @@ struct WaveDP {
         uint32_t tbw[R];
         static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
             const int i = i0 + RR;
-            eval_cell<RR, PH, JINT>(i, j, jact && i <= Q, ms[RR], sp, tbw[RR]);
+            eval_cell<RR, PH, JINT>(i, j, jact && i <= Q, ms[RR], sp, qcode[RR], tn4col, tbw[RR]);
         });
         // (4) traceback words, step-major (fully coalesced)
         if constexpr (MODE == MODE_PATH) {
@@ -533,6 +571,14 @@ struct WaveDP {
         Q = job.Q; T = job.T; q0 = job.q0; t0 = job.t0;
         tshift = job.tshift;
         tlast = seqs.tlen[job.pair] > 0 ? seqs.tlen[job.pair] - 1 : 0;
+        seed_aux = 0;
+        if constexpr (F::has_phase()) {
+            tn4p = seqs.tn4 + seqs.toff[job.pair];
+            if constexpr (CONT) {                     // bases in front of an intron that is open at the seam
+                const int cis = job.first_cell[1];
+                seed_aux = (cis >= 1 && cis - 1 <= tlast) ? (tn4p[cis - 1] & 0xff) : 0;
+            }
+        }
         first_state = job.first_state; final_state = CONT ? job.final_state : M::END;
         first_cell = job.first_cell;
         min_intron = kp->min_intron; max_intron = kp->max_intron;
@@ -612,6 +658,14 @@ struct WaveDP {
         Q = job.Q; T = job.T; q0 = job.q0; t0 = job.t0;
         tshift = job.tshift;
         tlast = seqs.tlen[job.pair] > 0 ? seqs.tlen[job.pair] - 1 : 0;
+        seed_aux = 0;
+        if constexpr (F::has_phase()) {
+            tn4p = seqs.tn4 + seqs.toff[job.pair];
+            if constexpr (CONT) {                     // bases in front of an intron that is open at the seam
+                const int cis = job.first_cell[1];
+                seed_aux = (cis >= 1 && cis - 1 <= tlast) ? (tn4p[cis - 1] & 0xff) : 0;
+            }
+        }
         first_state = job.first_state; final_state = M::END;
         first_cell = job.first_cell;
         min_intron = kp->min_intron; max_intron = kp->max_intron;
