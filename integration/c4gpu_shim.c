@@ -1,0 +1,328 @@
+/* c4gpu_shim.c — the ONE file a maintainer adds to exonerate to run C4 Viterbi calls on libc4gpu.so.
+ *
+ * It provides `Bootstrapper_lookup`, the name-keyed plug-in table Viterbi_create consults
+ * (src/c4/viterbi.c:81-90).  For names of accelerated (model x mode) functions it returns a
+ * Viterbi_DP_Func (src/c4/viterbi.h:95-98) backed by the GPU engine; for everything else, and for calls
+ * with sub-optimal blocking (soi != NULL), it hands over to the reference's own generated CPU function
+ * (`Bootstrapper_lookup_cpu` = the generated lookup of the compiled-model archive, renamed at link time by
+ * integration/Makefile).  Host code, model builders, FASTA I/O, GAM, printers: all untouched reference C.
+ *
+ * Build: integration/Makefile (needs the reference tree; compiled here against its own headers).
+ */
+#include <string.h>
+#include <stdlib.h>
+#include <stdio.h>
+
+#include "viterbi.h"
+#include "ungapped.h"
+#include "affine.h"
+#include "intron.h"
+#include "frameshift.h"
+#include "splice.h"
+#include "translate.h"
+#include "submat.h"
+#include "match.h"
+#include "codegen.h"
+
+#include "c4gpu.h"
+
+extern gpointer Bootstrapper_lookup_cpu(gchar *name);
+
+static c4gpu_ctx *shim_ctx = NULL;
+static gboolean shim_tried = FALSE, shim_verbose = FALSE;
+
+static c4gpu_ctx *shim_get_ctx(void){
+    if(!shim_tried){
+        shim_tried = TRUE;
+        shim_verbose = (g_getenv("C4GPU_VERBOSE") != NULL);
+        if(!g_getenv("C4GPU_DISABLE")){
+            shim_ctx = c4gpu_ctx_create(g_getenv("C4GPU_DEVICE") ? atoi(g_getenv("C4GPU_DEVICE")) : 0);
+            if(!shim_ctx)
+                g_warning("c4gpu: %s -- using the CPU Viterbi", c4gpu_last_error());
+            }
+        }
+    return shim_ctx;
+    }
+
+/* ---- C4_Model (closed) -> c4gpu_model ------------------------------------------------------------- */
+
+static gboolean shim_flatten(C4_Model *m, Ungapped_Data *ud, c4gpu_model *out){
+    register guint i, j;
+    memset(out, 0, sizeof(*out));
+    if((m->state_list->len > C4GPU_MAX_STATES) || (m->transition_list->len > C4GPU_MAX_TRANSITIONS)
+    || (m->calc_list->len > C4GPU_MAX_CALCS) || (m->shadow_list->len > C4GPU_MAX_SHADOWS))
+        return FALSE;
+    g_strlcpy(out->name, m->name, C4GPU_NAME_LEN);
+    out->n_states = m->state_list->len;
+    out->n_transitions = m->transition_list->len;
+    out->n_calcs = m->calc_list->len;
+    out->n_shadows = m->shadow_list->len;
+    out->start_state = m->start_state->state->id;
+    out->end_state = m->end_state->state->id;
+    out->start_scope = m->start_state->scope;       /* C4_Scope values are the C4GPU_SCOPE_* values */
+    out->end_scope = m->end_state->scope;
+    out->max_query_advance = m->max_query_advance;
+    out->max_target_advance = m->max_target_advance;
+    out->total_shadow_designations = m->total_shadow_designations;
+    out->query_alphabet = (ud->query->alphabet->type == Alphabet_Type_PROTEIN);
+    out->target_alphabet = (ud->target->alphabet->type == Alphabet_Type_PROTEIN);
+    if(m->start_state->cell_start_func || m->end_state->cell_end_func)
+        return FALSE;                                /* BSDP span models: not accelerated */
+    for(i = 0; i < m->state_list->len; i++){
+        C4_State *s = m->state_list->pdata[i];
+        g_strlcpy(out->state_names[i], s->name, C4GPU_NAME_LEN);
+        }
+    for(i = 0; i < m->calc_list->len; i++){
+        C4_Calc *c = m->calc_list->pdata[i];
+        c4gpu_calc *o = &out->calcs[i];
+        g_strlcpy(o->name, c->name, C4GPU_NAME_LEN);
+        o->max_score = c->max_score;
+        o->protect = c->protect;
+        /* calc functions are file-static in the reference: recognised by the names the model builders give */
+        if(!strcmp(c->name, "match")){
+            if(out->query_alphabet && !out->target_alphabet) o->kind = C4GPU_CALC_MATCH_P2D;
+            else if(out->query_alphabet && out->target_alphabet) o->kind = C4GPU_CALC_MATCH_PROTEIN;
+            else if(!out->query_alphabet && !out->target_alphabet) o->kind = C4GPU_CALC_MATCH_DNA;
+            else return FALSE;
+            if(ud->query->annotation) return FALSE; /* cds veto, match.c:276-281 */
+        } else if((!strcmp(c->name, "gap open")) || (!strcmp(c->name, "gap extend"))
+               || (!strcmp(c->name, "frameshift"))){
+            o->kind = C4GPU_CALC_CONST;
+            o->value = c->calc_func ? c->calc_func(0, 0, ud) : c->max_score;
+        } else if(!strncmp(c->name, "5'ss forward", 12)){
+            o->kind = C4GPU_CALC_SPLICE_PRE; o->param = C4GPU_SS5_FORWARD;
+            o->value = Intron_ArgumentSet_create(NULL)->intron_open_penalty;
+        } else if(!strncmp(c->name, "3'ss forward", 12)){
+            o->kind = C4GPU_CALC_SPLICE_POST; o->param = C4GPU_SS3_FORWARD;
+        } else if(!strncmp(c->name, "3'ss reverse", 12)){
+            o->kind = C4GPU_CALC_SPLICE_PRE; o->param = C4GPU_SS3_REVERSE;
+            o->value = Intron_ArgumentSet_create(NULL)->intron_open_penalty;
+        } else if(!strncmp(c->name, "5'ss reverse", 12)){
+            o->kind = C4GPU_CALC_SPLICE_POST; o->param = C4GPU_SS5_REVERSE;
+        } else if(!strncmp(c->name, "phase1post to dst", 17)){
+            o->kind = C4GPU_CALC_PHASE_POST; o->param = 1;
+        } else if(!strncmp(c->name, "phase2post to dst", 17)){
+            o->kind = C4GPU_CALC_PHASE_POST; o->param = 2;
+        } else {
+            return FALSE;
+            }
+        }
+    for(i = 0; i < m->transition_list->len; i++){
+        C4_Transition *t = m->transition_list->pdata[i];
+        c4gpu_transition *o = &out->transitions[i];
+        g_strlcpy(o->name, t->name, C4GPU_NAME_LEN);
+        o->input = t->input->id;
+        o->output = t->output->id;
+        o->advance_query = t->advance_query;
+        o->advance_target = t->advance_target;
+        o->calc = t->calc ? t->calc->id : -1;
+        o->label = t->label;
+        for(j = 0; j < t->dst_shadow_list->len; j++)
+            o->dst_shadow_mask |= 1u << ((C4_Shadow*)t->dst_shadow_list->pdata[j])->id;
+        }
+    for(i = 0; i < m->shadow_list->len; i++){
+        C4_Shadow *s = m->shadow_list->pdata[i];
+        c4gpu_shadow *o = &out->shadows[i];
+        g_strlcpy(o->name, s->name, C4GPU_NAME_LEN);
+        o->designation = s->designation;
+        o->on_target = !strncmp(s->name, "target intron", 13);
+        if(!o->on_target)
+            return FALSE;
+        for(j = 0; j < s->src_state_list->len; j++)
+            o->src_state_mask |= 1u << ((C4_State*)s->src_state_list->pdata[j])->id;
+        for(j = 0; j < s->dst_transition_list->len; j++)
+            o->dst_transition_mask |= 1u << ((C4_Transition*)s->dst_transition_list->pdata[j])->id;
+        }
+    return c4gpu_model_is_accelerated(out);
+    }
+
+/* the static ArgumentSets + Match tables -> c4gpu_params */
+static void shim_params(Ungapped_Data *ud, c4gpu_params *p){
+    register Affine_ArgumentSet *aas = Affine_ArgumentSet_create(NULL);
+    register Intron_ArgumentSet *ias = Intron_ArgumentSet_create(NULL);
+    register Frameshift_ArgumentSet *fas = Frameshift_ArgumentSet_create(NULL);
+    register gint i, j, k;
+    SplicePredictor *sp[4];
+    c4gpu_params_default(p);
+    for(i = 0; i < SUBMAT_ALPHABETSIZE; i++)
+        for(j = 0; j < SUBMAT_ALPHABETSIZE; j++){
+            p->dna_submat[i][j] = ud->mas->dna_submat->matrix[i][j];
+            p->protein_submat[i][j] = ud->mas->protein_submat->matrix[i][j];
+            }
+    memcpy(p->submat_index, ud->mas->dna_submat->index, 256);
+    if(ud->mas->translate){
+        memcpy(p->nt2d, ud->mas->translate->nt2d, 256);
+        memcpy(p->trans, ud->mas->translate->trans, 4096);
+        memcpy(p->aa, ud->mas->translate->aa, 40);
+        }
+    p->gap_open = aas->gap_open; p->gap_extend = aas->gap_extend;
+    p->codon_gap_open = aas->codon_gap_open; p->codon_gap_extend = aas->codon_gap_extend;
+    p->min_intron = ias->min_intron; p->max_intron = ias->max_intron;
+    p->intron_open_penalty = ias->intron_open_penalty;
+    p->frameshift_penalty = fas->frameshift_penalty;
+    if(ias->sps){
+        sp[C4GPU_SS5_FORWARD] = ias->sps->ss5_forward; sp[C4GPU_SS3_FORWARD] = ias->sps->ss3_forward;
+        sp[C4GPU_SS3_REVERSE] = ias->sps->ss3_reverse; sp[C4GPU_SS5_REVERSE] = ias->sps->ss5_reverse;
+        for(k = 0; k < 4; k++){
+            if(sp[k]->model_length > C4GPU_SPLICE_MAX_LEN)
+                continue;
+            p->splice[k].model_length = sp[k]->model_length;
+            p->splice[k].splice_after = sp[k]->model_splice_after;
+            memcpy(p->splice[k].index, sp[k]->index, 256);
+            for(i = 0; i < sp[k]->model_length; i++)
+                for(j = 0; j < 5; j++)
+                    p->splice[k].data[i][j] = sp[k]->model_data[i][j];
+            }
+        }
+    }
+
+/* ---- one Viterbi call ----------------------------------------------------------------------------------- */
+
+static gboolean shim_forcegtag(void){
+    return Splice_ArgumentSet_create(NULL)->force_gtag;
+    }
+
+static C4_Score shim_dp(C4_Model *model, Region *region, Viterbi_Data *vd, SubOpt_Index *soi,
+                        gpointer user_data, int mode, Viterbi_DP_Func cpu_func){
+    Ungapped_Data *ud = user_data;
+    c4gpu_model fm;
+    c4gpu_params params;
+    c4gpu_pair pair;
+    c4gpu_viterbi_job job;
+    c4gpu_viterbi_result r;
+    register gchar *qstr, *tstr;
+    register gint i, j, k, l, cs = vd->vr->cell_size;
+    register C4_Score score;
+    if(soi || (!shim_get_ctx()) || shim_forcegtag() || (!shim_flatten(model, ud, &fm))){
+        if(!cpu_func)
+            g_error("c4gpu shim: no CPU implementation to fall back to");
+        return cpu_func(model, region, vd, soi, user_data);
+        }
+    shim_params(ud, &params);
+    qstr = Sequence_get_str(ud->query);
+    tstr = Sequence_get_str(ud->target);
+    pair.query = (const uint8_t*)qstr;  pair.query_len = ud->query->len;
+    pair.target = (const uint8_t*)tstr; pair.target_len = ud->target->len;
+    memset(&job, 0, sizeof(job));
+    job.pair = 0;
+    job.region.query_start = region->query_start;   job.region.target_start = region->target_start;
+    job.region.query_length = region->query_length; job.region.target_length = region->target_length;
+    if(vd->continuation){                            /* viterbi.c:705-714 */
+        job.use_continuation = 1;
+        job.continuation.first_state = vd->continuation->first_state->id;
+        job.continuation.final_state = vd->continuation->final_state->id;
+        for(l = 0; l < cs; l++)
+            job.continuation.first_cell[l] = vd->continuation->first_cell[l];
+        }
+    if(mode == C4GPU_MODE_FIND_CHECKPOINTS)
+        job.checkpoint_count = vd->checkpoint->checkpoint_list->len;
+    if(c4gpu_viterbi_batch(shim_ctx, &fm, &params, mode, &pair, 1, &job, 1, &r) != 0){
+        g_warning("c4gpu: %s -- using the CPU Viterbi for this call", c4gpu_last_error());
+        g_free(qstr); g_free(tstr);
+        return cpu_func(model, region, vd, soi, user_data);
+        }
+    if(shim_verbose)
+        g_message("c4gpu: %s mode %d region %d %d %d %d -> %d", model->name, mode, region->query_start,
+                  region->target_start, region->query_length, region->target_length, r.score);
+    score = r.score;
+    /* out-parameters by mode (viterbi.c:464-478,633-653,813-832) */
+    vd->curr_query_end = r.query_end;
+    vd->curr_target_end = r.target_end;
+    if(mode == C4GPU_MODE_FIND_REGION){
+        if(vd->vr->region_start_query_id != -1)
+            vd->curr_query_start = r.query_start;
+        if(vd->vr->region_start_target_id != -1)
+            vd->curr_target_start = r.target_start;
+        if(vd->alignment_region){                    /* Viterbi_Data_finalise */
+            if(vd->vr->region_start_query_id != -1)
+                vd->alignment_region->query_start = vd->curr_query_start + region->query_start;
+            if(vd->vr->region_start_target_id != -1)
+                vd->alignment_region->target_start = vd->curr_target_start + region->target_start;
+            vd->alignment_region->query_length = vd->curr_query_end - vd->curr_query_start;
+            vd->alignment_region->target_length = vd->curr_target_end - vd->curr_target_start;
+            }
+        }
+    if(mode == C4GPU_MODE_FIND_PATH){
+        /* lay the transition pointers along the path so that Viterbi_Data_create_Alignment
+         * (viterbi.c:342-392) walks exactly it; everything else stays NULL (g_malloc0) */
+        i = r.query_start; j = r.target_start;
+        for(k = 0; k < r.n_ops; k++){
+            C4_Transition *t = model->transition_list->pdata[r.ops[k]];
+            i += t->advance_query; j += t->advance_target;
+            vd->traceback[i][j][t->output->id] = t;
+            }
+        }
+    if(mode == C4GPU_MODE_FIND_CHECKPOINTS){
+        register gint nstates = model->state_list->len, mta = model->max_target_advance,
+                      ql = region->query_length;
+        for(k = 0; k < (gint)vd->checkpoint->checkpoint_list->len; k++){
+            C4_Score ****cp = vd->checkpoint->checkpoint_list->pdata[k];
+            register gint row, s;
+            for(row = 0; row < mta; row++)
+                for(i = 0; i <= ql; i++)
+                    for(s = 0; s < nstates; s++)
+                        for(l = 0; l < cs; l++)
+                            cp[row][i][s][l] = r.checkpoints[(((( (size_t)k * mta + row) * (ql+1) + i)
+                                                               * nstates + s) * cs) + l];
+            }
+        vd->checkpoint->last_srp = r.last_srp;
+        vd->checkpoint->counter = vd->checkpoint->checkpoint_list->len;
+        }
+    if(vd->continuation)
+        for(l = 0; l < cs; l++)
+            vd->continuation->final_cell[l] = r.final_cell[l];
+    c4gpu_viterbi_result_clear(&r);
+    g_free(qstr);
+    g_free(tstr);
+    return score;
+    }
+
+/* ---- the plug-in table --------------------------------------------------------------------------------- */
+/* One Viterbi_DP_Func per looked-up name: each remembers its mode and the CPU function of the same name. */
+
+#define SHIM_SLOTS 64
+static struct { gchar *name; int mode; Viterbi_DP_Func cpu; } shim_slot[SHIM_SLOTS];
+static gint shim_slot_count = 0;
+
+#define SHIM_FUNC(n) \
+    static C4_Score shim_func_##n(C4_Model *model, Region *region, Viterbi_Data *vd, SubOpt_Index *soi, \
+                                  gpointer user_data){ \
+        return shim_dp(model, region, vd, soi, user_data, shim_slot[n].mode, shim_slot[n].cpu); }
+#define S4(a) SHIM_FUNC(a##0) SHIM_FUNC(a##1) SHIM_FUNC(a##2) SHIM_FUNC(a##3)
+SHIM_FUNC(0) SHIM_FUNC(1) SHIM_FUNC(2) SHIM_FUNC(3) SHIM_FUNC(4) SHIM_FUNC(5) SHIM_FUNC(6) SHIM_FUNC(7)
+SHIM_FUNC(8) SHIM_FUNC(9) SHIM_FUNC(10) SHIM_FUNC(11) SHIM_FUNC(12) SHIM_FUNC(13) SHIM_FUNC(14) SHIM_FUNC(15)
+SHIM_FUNC(16) SHIM_FUNC(17) SHIM_FUNC(18) SHIM_FUNC(19) SHIM_FUNC(20) SHIM_FUNC(21) SHIM_FUNC(22) SHIM_FUNC(23)
+SHIM_FUNC(24) SHIM_FUNC(25) SHIM_FUNC(26) SHIM_FUNC(27) SHIM_FUNC(28) SHIM_FUNC(29) SHIM_FUNC(30) SHIM_FUNC(31)
+static Viterbi_DP_Func shim_funcs[] = {
+    shim_func_0, shim_func_1, shim_func_2, shim_func_3, shim_func_4, shim_func_5, shim_func_6, shim_func_7,
+    shim_func_8, shim_func_9, shim_func_10, shim_func_11, shim_func_12, shim_func_13, shim_func_14, shim_func_15,
+    shim_func_16, shim_func_17, shim_func_18, shim_func_19, shim_func_20, shim_func_21, shim_func_22, shim_func_23,
+    shim_func_24, shim_func_25, shim_func_26, shim_func_27, shim_func_28, shim_func_29, shim_func_30, shim_func_31};
+
+/* "…_find_32_score" / "_path" / "_region" / "_checkpoint" / "_path_32_continuation" (optimal.c:31-67) */
+static int shim_mode_of(const gchar *name){
+    if(g_str_has_suffix(name, "_find_32_score")) return C4GPU_MODE_FIND_SCORE;
+    if(g_str_has_suffix(name, "_find_32_path")) return C4GPU_MODE_FIND_PATH;
+    if(g_str_has_suffix(name, "_find_32_path_32_continuation")) return C4GPU_MODE_FIND_PATH;
+    if(g_str_has_suffix(name, "_find_32_region")) return C4GPU_MODE_FIND_REGION;
+    if(g_str_has_suffix(name, "_find_32_checkpoint")) return C4GPU_MODE_FIND_CHECKPOINTS;
+    return -1;
+    }
+
+gpointer Bootstrapper_lookup(gchar *name){
+    register gint i;
+    register int mode = shim_mode_of(name);
+    register Viterbi_DP_Func cpu = (Viterbi_DP_Func)Bootstrapper_lookup_cpu(name);
+    /* only the Optimal (full Viterbi) functions are ours: "optimal_58_<model>_32_find_32_<mode>" */
+    if((mode < 0) || strncmp(name, "optimal_58_", 11) || g_getenv("C4GPU_DISABLE"))
+        return (gpointer)cpu;
+    for(i = 0; i < shim_slot_count; i++)
+        if(!strcmp(shim_slot[i].name, name))
+            return (gpointer)shim_funcs[i];
+    if(shim_slot_count >= 32)
+        return (gpointer)cpu;
+    shim_slot[shim_slot_count].name = g_strdup(name);
+    shim_slot[shim_slot_count].mode = mode;
+    shim_slot[shim_slot_count].cpu = cpu;
+    return (gpointer)shim_funcs[shim_slot_count++];
+    }

@@ -1,0 +1,70 @@
+"""End-to-end drop-in check: the reference's own `exonerate` binary with integration/c4gpu_shim.c linked in
+(integration/_build/exonerate-gpu; every Optimal Viterbi call of accelerated models goes to libc4gpu.so)
+prints byte-identical output to the unmodified reference with its compiled CPU Viterbi
+(oracle/_ref/exonerate-compiled).  Both binaries are built in the build container and travel with the repo."""
+import os, subprocess, random
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GPU_EXE = os.path.join(ROOT, "integration", "_build", "exonerate-gpu")
+CPU_EXE = os.path.join(ROOT, "oracle", "_ref", "exonerate-compiled")
+
+
+def _fasta(path, recs):
+    with open(path, "w") as f:
+        for name, seq in recs:
+            f.write(">%s\n%s\n" % (name, seq))
+
+
+def _run(exe, args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    return r.stdout.decode(), r.stderr.decode()
+
+
+@pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
+                    reason="reference binaries are built in the build container (make -C integration)")
+@pytest.mark.parametrize("model,extra", [
+    ("est2genome", []), ("est2genome", ["-D", "1"]), ("affine:local", []), ("affine:global", []),
+    ("protein2dna", []), ("protein2genome", []),
+])
+def test_exonerate_gpu_output_is_byte_identical(tmp_path, model, extra):
+    rng = random.Random(len(model) * 7 + len(extra))
+    dna = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    aa = lambda n: "".join(rng.choice("ARNDCQEGHILKMFPSTWYV") for _ in range(n))
+    table = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"
+    codon = {}
+    for i, a in enumerate("TCAG"):
+        for j, b in enumerate("TCAG"):
+            for k, c in enumerate("TCAG"):
+                codon.setdefault(table[i * 16 + j * 4 + k], []).append(a + b + c)
+    qs, ts = [], []
+    for n in range(3):
+        if model.startswith("protein"):
+            q = aa(120 + 30 * n)
+            coding = "".join(rng.choice(codon[x]) for x in q)
+            if model == "protein2genome":
+                c1, c2 = 100 + n, 250 + 2 * n
+                coding = coding[:c1] + "GT" + dna(300) + "AG" + coding[c1:c2] + "GT" + dna(500) + "AG" + coding[c2:]
+            t = dna(400) + coding + dna(600)
+        else:
+            q = dna(500 + 100 * n)
+            if model == "est2genome":
+                t = dna(2000) + q[:200] + "GT" + dna(1500) + "AG" + q[200:420] + "GT" + dna(3000) + "AG" + q[420:] + dna(2500)
+            else:
+                t = dna(100) + q[:250] + dna(3) + q[260:] + dna(150)
+        qs.append(("qy%d" % n, q))
+        ts.append(("tg%d" % n, t))
+    qf, tf = str(tmp_path / "q.fa"), str(tmp_path / "t.fa")
+    _fasta(qf, qs)
+    _fasta(tf, ts)
+    args = ["-m", model, "-E", "yes", "-S", "no", "--showalignment", "yes", "--showvulgar", "yes",
+            "--showcigar", "yes", "-V", "0"] + extra + [qf, tf]
+    ref_out, _ = _run(CPU_EXE, args)
+    gpu_out, gpu_err = _run(GPU_EXE, args, {"C4GPU_VERBOSE": "1"})
+    assert "c4gpu:" in gpu_err, "the GPU engine was not used:\n" + gpu_err[-1500:]
+    assert gpu_out == ref_out
+    assert ref_out.count("vulgar:") >= 3
