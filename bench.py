@@ -157,11 +157,11 @@ def main():
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM bytes per launch of the same kernel from the PMC passes committed under profiles/ (bench.py
         # itself cannot read PMCs); only quoted when the run has the configuration that was profiled
-        traffic = None
+        traffic, kname, valu = None, "viterbi_kernel_mw<Est2GenomeDesc, MODE_REGION>", None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
             if tj["config"] == {"pairs_per_gpu": args.pairs, "query_len": args.qlen, "target_len": args.tlen}:
-                traffic = tj["bytes_per_launch"]
+                traffic, kname, valu = tj["bytes_per_launch"], tj["kernel"], tj.get("valu")
         except (OSError, ValueError, KeyError):
             pass
         out = {
@@ -178,12 +178,12 @@ def main():
                        "aligned_in_sample": n_aligned},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": algo_bytes,
-                         "kernel": "viterbi_kernel<Est2GenomeDesc, MODE_REGION>",
+                         "kernel": kname, "valu_pmc": valu,
                          "avg_launch_ms": avg_ms, "launches": reg["launches"],
                          "kernel_cells_per_s": reg["cells"] / (reg["ms"] * 1e-3) if reg["ms"] else 0.0,
                          "note": "integer max-plus with all live DP state in VGPRs: compulsory HBM traffic is "
-                                 "~17 B per target column, so the kernel is VALU-bound by construction "
-                                 "(DESIGN.md section 5)"},
+                                 "~17 B per target column, so the kernel is VALU-bound by construction; "
+                                 "valu_pmc (profiles/) is the SQ-counter view of that bound (DESIGN.md section 5)"},
             "kernel_ms": {"region": stats[2]["ms"], "checkpoint": stats[3]["ms"], "path": stats[1]["ms"]},
         }
         if not args.no_cpu_baseline:
