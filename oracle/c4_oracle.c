@@ -45,6 +45,194 @@ void oracle_splice_predict(const c4gpu_splice_model *sp, const uint8_t *seq, int
         }
     }
 
+/* ---- SubOpt: blocked points of earlier alignments of the same pair (src/c4/subopt.c) ---------------- */
+
+struct oracle_subopt {
+    int32_t query_length, target_length;
+    int32_t n, cap;
+    int32_t *q, *t;                 /* unique points, insertion order, sequence coordinates */
+    int32_t path_count;
+};
+
+oracle_subopt *oracle_subopt_create(int32_t query_length, int32_t target_length){   /* subopt.c:24 */
+    oracle_subopt *so = calloc(1, sizeof(*so));
+    so->query_length = query_length; so->target_length = target_length;
+    return so;
+    }
+
+void oracle_subopt_destroy(oracle_subopt *so){
+    if(!so) return;
+    free(so->q); free(so->t); free(so);
+    }
+
+static int subopt_check_pos(const oracle_subopt *so, int32_t q, int32_t t){          /* subopt.c:58 */
+    int32_t k;
+    for(k = 0; k < so->n; k++)
+        if((so->q[k] == q) && (so->t[k] == t))
+            return 1;
+    return 0;
+    }
+
+static void subopt_add_point(oracle_subopt *so, int32_t q, int32_t t){
+    if(so->n == so->cap){
+        so->cap = so->cap ? so->cap * 2 : 256;
+        so->q = realloc(so->q, sizeof(int32_t) * so->cap);
+        so->t = realloc(so->t, sizeof(int32_t) * so->cap);
+        }
+    so->q[so->n] = q; so->t[so->n] = t; so->n++;
+    }
+
+static int gcd_of(int a, int b){                                                     /* subopt.c:51 */
+    while(b){ int r = a % b; a = b; b = r; }
+    return a;
+    }
+
+/* SubOpt_add_AlignmentOperation, subopt.c:64-128: the cells each step of a match operation LEAVES
+ * from (and the sub-steps of a multi-residue match), then the lead-in positions */
+static void subopt_add_operation(oracle_subopt *so, int aq, int at, int length, int32_t qpos, int32_t tpos){
+    const int g = gcd_of(aq, at), q_move = aq / g, t_move = at / g;
+    int32_t q_limit = qpos, t_limit = tpos, qp, tp;
+    int i;
+    for(i = 0; i < length; i++){
+        qp = q_limit; tp = t_limit;
+        q_limit += aq; t_limit += at;
+        while(qp < q_limit){
+            if(!subopt_check_pos(so, qp, tp))
+                subopt_add_point(so, qp, tp);
+            qp += q_move; tp += t_move;
+            }
+        }
+    qp = qpos - aq + q_move;
+    tp = tpos - at + t_move;
+    while(qp < qpos){
+        if(!subopt_check_pos(so, qp, tp))
+            if((qp >= 0) && (tp >= 0))
+                subopt_add_point(so, qp, tp);
+        qp += q_move; tp += t_move;
+        }
+    }
+
+/* SubOpt_add_alignment, subopt.c:131-148 */
+void oracle_subopt_add_alignment(oracle_subopt *so, const c4gpu_model *model, const c4gpu_alignment *a){
+    int32_t qpos = a->region.query_start, tpos = a->region.target_start;
+    int k;
+    for(k = 0; k < a->n_ops; k++){
+        const c4gpu_transition *tr = &model->transitions[a->op_transition[k]];
+        if(tr->label == C4GPU_LABEL_MATCH)
+            subopt_add_operation(so, tr->advance_query, tr->advance_target, a->op_length[k], qpos, tpos);
+        qpos += tr->advance_query * a->op_length[k];
+        tpos += tr->advance_target * a->op_length[k];
+        }
+    so->path_count++;
+    }
+
+static int point_cmp(const void *a, const void *b){              /* subopt.c:239-248: target, then query */
+    const int32_t *x = a, *y = b;
+    if(x[0] != y[0]) return (x[0] < y[0]) ? -1 : 1;
+    return (x[1] < y[1]) ? -1 : (x[1] > y[1]);
+    }
+
+int32_t oracle_subopt_points(const oracle_subopt *so, int32_t *q, int32_t *t, int32_t max){
+    int32_t k, (*p)[2] = malloc(sizeof(int32_t[2]) * (so->n ? so->n : 1));
+    for(k = 0; k < so->n; k++){ p[k][0] = so->t[k]; p[k][1] = so->q[k]; }
+    qsort(p, so->n, sizeof(int32_t[2]), point_cmp);
+    for(k = 0; (k < so->n) && (k < max); k++){ q[k] = p[k][1]; t[k] = p[k][0]; }
+    free(p);
+    return so->n;
+    }
+
+/* SubOpt_Index, subopt.c:250-392: the points inside one region, as rows (one per target position, in
+ * region coordinates) of ascending query positions ending in the dummy position query_length+1 */
+typedef struct { int32_t target_pos, total, *query_pos; } osoi_row;
+typedef struct {
+    osoi_row *rows;                 /* the last one is the blank row */
+    int32_t n_rows;
+    osoi_row *curr_row;
+    int32_t curr_row_index, curr_query_index;
+} osoi;
+
+static osoi *osoi_create(const oracle_subopt *so, const c4gpu_region *region){
+    int32_t k, n = 0, (*p)[2], r;
+    osoi *x;
+    if(!so) return NULL;
+    p = malloc(sizeof(int32_t[2]) * (so->n ? so->n : 1));
+    /* RangeTree_find with lengths +1 (subopt.c:258-261, rangetree.c:70-79): both ends inclusive */
+    for(k = 0; k < so->n; k++)
+        if((so->q[k] >= region->query_start) && (so->q[k] <= region->query_start + region->query_length)
+        && (so->t[k] >= region->target_start) && (so->t[k] <= region->target_start + region->target_length)){
+            p[n][0] = so->t[k] - region->target_start;
+            p[n][1] = so->q[k] - region->query_start;
+            n++;
+            }
+    if(!n){
+        free(p);
+        return NULL;                /* "Found no points in region" */
+        }
+    qsort(p, n, sizeof(int32_t[2]), point_cmp);
+    x = calloc(1, sizeof(*x));
+    x->rows = calloc(n + 1, sizeof(osoi_row));
+    for(k = 0; k < n; k++){
+        if((!x->n_rows) || (x->rows[x->n_rows-1].target_pos != p[k][0])){
+            x->rows[x->n_rows].target_pos = p[k][0];
+            x->rows[x->n_rows].query_pos = malloc(sizeof(int32_t) * (n + 1));
+            x->n_rows++;
+            }
+        r = x->n_rows - 1;
+        x->rows[r].query_pos[x->rows[r].total++] = p[k][1];
+        }
+    for(r = 0; r < x->n_rows; r++)
+        x->rows[r].query_pos[x->rows[r].total] = so->query_length + 1;
+    x->rows[x->n_rows].target_pos = so->target_length + 1;         /* blank row */
+    x->rows[x->n_rows].total = 1;
+    x->rows[x->n_rows].query_pos = malloc(sizeof(int32_t));
+    x->rows[x->n_rows].query_pos[0] = so->query_length + 1;
+    x->n_rows++;
+    x->curr_row = &x->rows[x->n_rows-1];
+    free(p);
+    return x;
+    }
+
+static void osoi_destroy(osoi *x){
+    int32_t r;
+    if(!x) return;
+    for(r = 0; r < x->n_rows; r++)
+        free(x->rows[r].query_pos);
+    free(x->rows); free(x);
+    }
+
+static void osoi_set_row(osoi *x, int32_t target_pos){                               /* subopt.c:340-375 */
+    osoi_row *row;
+    if(!x) return;
+    row = &x->rows[x->curr_row_index];
+    while(row && (row->target_pos < target_pos)){
+        if(x->curr_row_index < x->n_rows - 1){
+            x->curr_row_index++;
+            row = &x->rows[x->curr_row_index];
+        } else {
+            row = NULL;
+            }
+        }
+    if(row){
+        while(row && (row->target_pos > target_pos)){
+            if(x->curr_row_index > 0){
+                x->curr_row_index--;
+                row = &x->rows[x->curr_row_index];
+            } else {
+                row = NULL;
+                }
+            }
+        x->curr_row = (row && (row->target_pos == target_pos)) ? row : &x->rows[x->n_rows-1];
+        }
+    x->curr_query_index = 0;
+    }
+
+/* SubOpt_Index_is_blocked_fast, subopt.h:77-80: the cursor moves by at most one per call */
+static int osoi_is_blocked_fast(osoi *x, int32_t q_pos){
+    if(x->curr_row->query_pos[x->curr_query_index] < q_pos)
+        return x->curr_row->query_pos[++x->curr_query_index] == q_pos;
+    return x->curr_row->query_pos[x->curr_query_index] == q_pos;
+    }
+
 /* ---- per-pair data (what `user_data` is in the reference) --------------------------------------- */
 
 typedef struct {
@@ -298,7 +486,7 @@ typedef struct {
 
 /* Viterbi_interpreted, src/c4/viterbi.c:655-837 */
 static c4gpu_score viterbi_run(const oviterbi *v, const c4gpu_region *region, ovdata *vd, odata *od,
-                               const c4gpu_continuation *cont){
+                               const c4gpu_continuation *cont, osoi *soi){
     const c4gpu_model *m = v->m;
     const int Q = region->query_length, T = region->target_length, S = m->n_states,
               cs = v->cell_size, mta = m->max_target_advance;
@@ -306,6 +494,7 @@ static c4gpu_score viterbi_run(const oviterbi *v, const c4gpu_region *region, ov
     int i, j, k, l, end_is_set = 0, final_state, state_is_set[C4GPU_MAX_STATES];
     final_state = cont ? cont->final_state : m->end_state;
     for(j = 0; j <= T; j++){
+        osoi_set_row(soi, j);                                       /* viterbi.c:689 */
         for(i = 0; i <= Q; i++){
             for(k = 0; k < S; k++){
                 state_is_set[k] = 0;
@@ -315,6 +504,8 @@ static c4gpu_score viterbi_run(const oviterbi *v, const c4gpu_region *region, ov
                 const c4gpu_transition *tr = &m->transitions[k];
                 if(!transition_valid(m, v->start_scope, v->end_scope, tr, i, j, Q, T))
                     continue;
+                if((tr->label == C4GPU_LABEL_MATCH) && soi && osoi_is_blocked_fast(soi, i))
+                    continue;                                       /* viterbi.c:701-704 */
                 if(cont && (tr->input == m->start_state)){          /* viterbi.c:705-714 */
                     dst = CELL(v, vd->prev_row[0], 0, cont->first_state);
                     for(l = 0; l < cs; l++)
@@ -479,15 +670,26 @@ int oracle_viterbi(const c4gpu_model *model, const c4gpu_params *params, int mod
                    const uint8_t *query, int32_t qlen, const uint8_t *target, int32_t tlen,
                    const c4gpu_region *region, const c4gpu_continuation *continuation,
                    int checkpoint_count, oracle_viterbi_out *out){
+    return oracle_viterbi_subopt(model, params, mode, query, qlen, target, tlen, region, continuation,
+                                 checkpoint_count, NULL, out);
+    }
+
+/* Viterbi_calculate, viterbi.c:846-865: the index is built per call from the pair's SubOpt */
+int oracle_viterbi_subopt(const c4gpu_model *model, const c4gpu_params *params, int mode,
+                   const uint8_t *query, int32_t qlen, const uint8_t *target, int32_t tlen,
+                   const c4gpu_region *region, const c4gpu_continuation *continuation,
+                   int checkpoint_count, const oracle_subopt *subopt, oracle_viterbi_out *out){
     oviterbi v;
     ovdata vd;
     odata od;
+    osoi *soi = osoi_create(subopt, region);
     int l;
     memset(out, 0, sizeof(*out));
     odata_init(&od, model, params, query, qlen, target, tlen);
     oviterbi_init(&v, model, mode, continuation ? 1 : 0);
     ovdata_init(&vd, &v, region, checkpoint_count);
-    out->score = viterbi_run(&v, region, &vd, &od, continuation);
+    out->score = viterbi_run(&v, region, &vd, &od, continuation, soi);
+    osoi_destroy(soi);
     out->cell_size = v.cell_size;
     out->query_start = vd.curr_query_start; out->target_start = vd.curr_target_start;
     out->query_end = vd.curr_query_end; out->target_end = vd.curr_target_end;
@@ -575,6 +777,7 @@ typedef struct {
     const uint8_t *query, *target;
     int32_t qlen, tlen;
     int dpmemory_mb;
+    const oracle_subopt *subopt;
 } octx;
 
 /* Viterbi_Checkpoint_traceback, src/c4/viterbi.c:537-601 */
@@ -635,8 +838,8 @@ static c4gpu_score find_checkpoints_recur(const octx *cx, const c4gpu_region *re
     c4gpu_score score;
     cont.first_state = first_state; cont.final_state = final_state;
     for(l = 0; l < CELL_MAX; l++) cont.first_cell[l] = first_cell[l];
-    oracle_viterbi(cx->model, cx->params, C4GPU_MODE_FIND_CHECKPOINTS, cx->query, cx->qlen,
-                   cx->target, cx->tlen, region, &cont, cp_count, &vo);
+    oracle_viterbi_subopt(cx->model, cx->params, C4GPU_MODE_FIND_CHECKPOINTS, cx->query, cx->qlen,
+                   cx->target, cx->tlen, region, &cont, cp_count, cx->subopt, &vo);
     score = vo.score;
     checkpoint_traceback(cx, &vo, cp_count, region, first_state, &sub);
     oracle_viterbi_out_clear(&vo);
@@ -684,8 +887,8 @@ static void find_path_reduced_space(const octx *cx, const c4gpu_region *region, 
         cont.final_state = (n+1 < vsa_list.n) ? vsa_list.v[n+1].first_state : cx->model->end_state;
         for(l = 0; l < CELL_MAX; l++) cont.first_cell[l] = first_cell[l];
         /* Optimal_find_path_quadratic_space_continuation, optimal.c:232-264 */
-        oracle_viterbi(cx->model, cx->params, C4GPU_MODE_FIND_PATH, cx->query, cx->qlen,
-                       cx->target, cx->tlen, &vsa->region, &cont, 0, &vo);
+        oracle_viterbi_subopt(cx->model, cx->params, C4GPU_MODE_FIND_PATH, cx->query, cx->qlen,
+                       cx->target, cx->tlen, &vsa->region, &cont, 0, cx->subopt, &vo);
         path_to_alignment(out, &cap, vo.ops, vo.n_ops);
         oracle_viterbi_out_clear(&vo);
         }
@@ -696,8 +899,8 @@ static void find_path_reduced_space(const octx *cx, const c4gpu_region *region, 
 static void find_path_quadratic_space(const octx *cx, const c4gpu_region *region, c4gpu_alignment *out){
     oracle_viterbi_out vo;
     int cap = 0;
-    oracle_viterbi(cx->model, cx->params, C4GPU_MODE_FIND_PATH, cx->query, cx->qlen, cx->target, cx->tlen,
-                   region, NULL, 0, &vo);
+    oracle_viterbi_subopt(cx->model, cx->params, C4GPU_MODE_FIND_PATH, cx->query, cx->qlen, cx->target, cx->tlen,
+                   region, NULL, 0, cx->subopt, &vo);
     memset(out, 0, sizeof(*out));
     out->score = vo.score;
     out->region.query_start = region->query_start + vo.query_start;
@@ -717,15 +920,22 @@ static int model_is_global(const c4gpu_model *m){   /* C4_Model_is_global, c4.c:
 int oracle_find_path(const c4gpu_model *model, const c4gpu_params *params,
                      const uint8_t *query, int32_t qlen, const uint8_t *target, int32_t tlen,
                      int dpmemory_mb, c4gpu_score threshold, c4gpu_alignment *out){
-    octx cx = {model, params, query, target, qlen, tlen, dpmemory_mb};
+    return oracle_find_path_subopt(model, params, query, qlen, target, tlen, dpmemory_mb, threshold, NULL, out);
+    }
+
+int oracle_find_path_subopt(const c4gpu_model *model, const c4gpu_params *params,
+                     const uint8_t *query, int32_t qlen, const uint8_t *target, int32_t tlen,
+                     int dpmemory_mb, c4gpu_score threshold, const oracle_subopt *subopt,
+                     c4gpu_alignment *out){
+    octx cx = {model, params, query, target, qlen, tlen, dpmemory_mb, subopt};
     c4gpu_region region = {0, 0, qlen, tlen};
     memset(out, 0, sizeof(*out));
     if(oracle_use_reduced_space(model, &region, dpmemory_mb)){
         c4gpu_region ar = region;
         if(!model_is_global(model)){                         /* Optimal_find_region, optimal.c:135-156 */
             oracle_viterbi_out vo;
-            oracle_viterbi(model, params, C4GPU_MODE_FIND_REGION, query, qlen, target, tlen,
-                           &region, NULL, 0, &vo);
+            oracle_viterbi_subopt(model, params, C4GPU_MODE_FIND_REGION, query, qlen, target, tlen,
+                           &region, NULL, 0, subopt, &vo);
             if(vo.score < threshold){
                 oracle_viterbi_out_clear(&vo);
                 return 0;

@@ -32,6 +32,21 @@ int  oracle_find_path(const c4gpu_model *model, const c4gpu_params *params,
                       int dpmemory_mb, c4gpu_score threshold, c4gpu_alignment *out);
 void oracle_alignment_clear(c4gpu_alignment *a);
 
+/* SubOpt, src/c4/subopt.c: the blocked points of the alignments already reported for a pair (sequence
+ * coordinates).  oracle_subopt_add_alignment = SubOpt_add_alignment (subopt.c:131); the _subopt variants
+ * of find_path / viterbi skip MATCH-labelled transitions at blocked cells (viterbi.c:701-704) exactly as
+ * SubOpt_Index_create / _set_row / _is_blocked_fast (subopt.c:250-392, subopt.h:77-80) make them. */
+typedef struct oracle_subopt oracle_subopt;
+oracle_subopt *oracle_subopt_create(int32_t query_length, int32_t target_length);
+void    oracle_subopt_destroy(oracle_subopt *so);
+void    oracle_subopt_add_alignment(oracle_subopt *so, const c4gpu_model *model, const c4gpu_alignment *a);
+/* points sorted by target then query; returns the total number */
+int32_t oracle_subopt_points(const oracle_subopt *so, int32_t *q, int32_t *t, int32_t max);
+int  oracle_find_path_subopt(const c4gpu_model *model, const c4gpu_params *params,
+                      const uint8_t *query, int32_t qlen, const uint8_t *target, int32_t tlen,
+                      int dpmemory_mb, c4gpu_score threshold, const oracle_subopt *subopt,
+                      c4gpu_alignment *out);
+
 /* one raw Viterbi call in any mode (Viterbi_interpreted, src/c4/viterbi.c:655-837); used by the parity
  * tests of c4gpu_viterbi_batch.  checkpoints (may be NULL) receives
  * [cp][row < max_target_advance][i <= Q][state][cell_size] ints; ops receives the raw transition path. */
@@ -50,6 +65,10 @@ int  oracle_viterbi(const c4gpu_model *model, const c4gpu_params *params, int mo
                     const uint8_t *query, int32_t qlen, const uint8_t *target, int32_t tlen,
                     const c4gpu_region *region, const c4gpu_continuation *continuation,
                     int checkpoint_count, oracle_viterbi_out *out);
+int  oracle_viterbi_subopt(const c4gpu_model *model, const c4gpu_params *params, int mode,
+                    const uint8_t *query, int32_t qlen, const uint8_t *target, int32_t tlen,
+                    const c4gpu_region *region, const c4gpu_continuation *continuation,
+                    int checkpoint_count, const oracle_subopt *subopt, oracle_viterbi_out *out);
 void oracle_viterbi_out_clear(oracle_viterbi_out *out);
 
 /* Viterbi_use_reduced_space (viterbi.c:128) / Viterbi_checkpoint_rows (viterbi.c:207) */

@@ -241,8 +241,81 @@ static void dump_splice_array(const char *name, SplicePredictor *sp, Sequence *s
     g_free(pred);
     }
 
+/* SubOpt points of the whole pair, sorted by target then query (the order SubOpt_Index uses) */
+static gboolean collect_point(gint query_pos, gint target_pos, gint path_id, gpointer user_data){
+    register GArray *a = user_data;
+    gint v[2];
+    v[0] = target_pos; v[1] = query_pos;
+    g_array_append_val(a, v[0]);
+    g_array_append_val(a, v[1]);
+    return FALSE;
+    }
+
+static int compare_point(const void *a, const void *b){
+    const gint *x = a, *y = b;
+    if(x[0] != y[0]) return x[0] - y[0];
+    return x[1] - y[1];
+    }
+
+static void dump_subopt_points(SubOpt *subopt, Sequence *query, Sequence *target){
+    register GArray *a = g_array_new(FALSE, FALSE, sizeof(gint));
+    register guint i;
+    Region all;
+    all.query_start = 0; all.target_start = 0;
+    all.query_length = query->len + 1; all.target_length = target->len + 1;
+    SubOpt_find(subopt, &all, collect_point, a);
+    qsort(a->data, a->len/2, 2*sizeof(gint), compare_point);
+    printf(",\"points\":[");
+    for(i = 0; i < a->len; i += 2)
+        printf("%s[%d,%d]", i?",":"", g_array_index(a, gint, i+1), g_array_index(a, gint, i));
+    printf("]");
+    g_array_free(a, TRUE);
+    return;
+    }
+
+static void dump_alignment_fields(Alignment *alignment, Sequence *query, Sequence *target){
+    register guint i;
+    gchar *s;
+    printf("\"path_score\":%d,\"region\":[%d,%d,%d,%d],\"ops\":[",
+           alignment->score, alignment->region->query_start,
+           alignment->region->target_start, alignment->region->query_length,
+           alignment->region->target_length);
+    for(i = 0; i < alignment->operation_list->len; i++){
+        AlignmentOperation *ao = alignment->operation_list->pdata[i];
+        printf("%s[%d,%d]", i?",":"", ao->transition->id, ao->length);
+        }
+    printf("]");
+    s = capture_display(alignment, query, target, Alignment_display_vulgar);
+    printf(",\"vulgar\":\"%s\"", s); g_free(s);
+    return;
+    }
+
+/* the loop of GAM_Result_exhaustive_create (gam.c:1139-1180): next best path with everything found so
+ * far blocked, until the score drops below the threshold */
+static void run_subopt(Optimal *optimal, Region *region, gpointer user_data,
+                       Sequence *query, Sequence *target, gint subopt_max, gint threshold){
+    register SubOpt *subopt = SubOpt_create(query->len, target->len);
+    register Alignment *alignment;
+    register gint k;
+    printf(",\"threshold\":%d,\"subopt\":[", threshold);
+    for(k = 0; k < subopt_max; k++){
+        alignment = Optimal_find_path(optimal, region, user_data, threshold, subopt);
+        if(!alignment)
+            break;
+        printf("%s{", k?",":"");
+        dump_alignment_fields(alignment, query, target);
+        SubOpt_add_alignment(subopt, alignment);
+        dump_subopt_points(subopt, query, target);
+        printf("}");
+        Alignment_destroy(alignment);
+        }
+    printf("]");
+    SubOpt_destroy(subopt);
+    return;
+    }
+
 static void run_golden(gchar *model_name, gchar *input_path, gboolean with_splice,
-                       gboolean revcomp_target){
+                       gboolean revcomp_target, gint subopt_max, gint subopt_threshold){
     register Model_Type type;
     register FILE *fp = fopen(input_path, "r");
     register Alphabet *dna = Alphabet_create(Alphabet_Type_DNA, FALSE),
@@ -319,6 +392,8 @@ static void run_golden(gchar *model_name, gchar *input_path, gboolean with_splic
             printf(",\"vulgar\":\"%s\"", s); g_free(s);
             Alignment_destroy(alignment);
             }
+        if(subopt_max > 0)
+            run_subopt(optimal, region, user_data, query, target, subopt_max, subopt_threshold);
         if(with_splice){
             register Intron_ArgumentSet *ias = Intron_ArgumentSet_create(NULL);
             dump_splice_array("ss5_forward", ias->sps->ss5_forward, target);
@@ -348,6 +423,7 @@ int Argument_main(Argument *arg){
     register ArgumentSet *as = ArgumentSet_create("refdump options");
     gchar *cmd, *model_name, *input_path;
     gboolean with_splice, revcomp_target;
+    gint subopt_max, subopt_threshold;
     ArgumentSet_add_option(as, '\0', "cmd", "name", "tables|data|golden", "tables",
                            Argument_parse_string, &cmd);
     ArgumentSet_add_option(as, 'm', "model", "name", "model name", "affine:local",
@@ -358,6 +434,10 @@ int Argument_main(Argument *arg){
                            Argument_parse_boolean, &with_splice);
     ArgumentSet_add_option(as, '\0', "revcomptarget", NULL, "align to revcomp of target", "FALSE",
                            Argument_parse_boolean, &revcomp_target);
+    ArgumentSet_add_option(as, '\0', "suboptmax", "n", "also dump up to n successive sub-optimal paths", "0",
+                           Argument_parse_int, &subopt_max);
+    ArgumentSet_add_option(as, '\0', "suboptthreshold", "score", "threshold of the sub-optimal loop", "30",
+                           Argument_parse_int, &subopt_threshold);
     Argument_absorb_ArgumentSet(arg, as);
     Translate_ArgumentSet_create(arg);
     Viterbi_ArgumentSet_create(arg);
@@ -376,7 +456,8 @@ int Argument_main(Argument *arg){
     else if(!strcmp(cmd, "data"))
         dump_data();
     else if(!strcmp(cmd, "golden"))
-        run_golden(g_strdup(model_name), input_path, with_splice, revcomp_target);
+        run_golden(g_strdup(model_name), input_path, with_splice, revcomp_target,
+                   subopt_max, subopt_threshold);
     else
         g_error("unknown cmd [%s]", cmd);
     return 0;

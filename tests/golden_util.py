@@ -18,13 +18,23 @@ SETS = {
 }
 
 
+# sets with the GAM sub-optimal loop (rec["subopt"] = successive alignments, rec["threshold"])
+SUBOPT_SETS = {
+    "affine_local_dna_subopt": ("affine:local", 0, 0), "affine_local_dna_subopt_D0": ("affine:local", 0, 0),
+    "affine_global_dna_subopt": ("affine:global", 0, 0),
+    "est2genome_subopt": ("est2genome", 0, 0), "est2genome_subopt_D0": ("est2genome", 0, 0),
+    "protein2dna_subopt": ("protein2dna", 1, 0), "protein2dna_subopt_D0": ("protein2dna", 1, 0),
+    "protein2genome_subopt": ("protein2genome", 1, 0), "protein2genome_subopt_D0": ("protein2genome", 1, 0),
+}
+
+
 def load_set(name):
     with open(os.path.join(GOLDEN_DIR, name + ".jsonl")) as f:
         return [json.loads(l) for l in f if l.strip()]
 
 
 def get_model(lib, params, name):
-    mt, qa, ta = SETS[name]
+    mt, qa, ta = SETS[name] if name in SETS else SUBOPT_SETS[name]
     m = _abi.Model()
     assert lib.c4gpu_model_get(mt.encode(), qa, ta, params, m) == 0
     return m

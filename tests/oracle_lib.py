@@ -49,6 +49,20 @@ def load():
         lib.oracle_alignment_format.argtypes = [C.POINTER(_abi.Model), C.POINTER(_abi.Alignment), C.c_int,
                                                 C.c_char_p, C.c_int32, C.c_char, C.c_char_p, C.c_int32,
                                                 C.c_char, C.c_int, C.c_char_p, C.c_size_t]
+        lib.oracle_subopt_create.restype = C.c_void_p
+        lib.oracle_subopt_create.argtypes = [C.c_int32, C.c_int32]
+        lib.oracle_subopt_destroy.argtypes = [C.c_void_p]
+        lib.oracle_subopt_add_alignment.argtypes = [C.c_void_p, C.POINTER(_abi.Model), C.POINTER(_abi.Alignment)]
+        lib.oracle_subopt_points.restype = C.c_int32
+        lib.oracle_subopt_points.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32]
+        lib.oracle_find_path_subopt.restype = C.c_int
+        lib.oracle_find_path_subopt.argtypes = [C.POINTER(_abi.Model), C.POINTER(_abi.Params), C.c_char_p,
+                                                C.c_int32, C.c_char_p, C.c_int32, C.c_int, C.c_int32,
+                                                C.c_void_p, C.POINTER(_abi.Alignment)]
+        lib.oracle_viterbi_subopt.argtypes = [C.POINTER(_abi.Model), C.POINTER(_abi.Params), C.c_int,
+                                              C.c_char_p, C.c_int32, C.c_char_p, C.c_int32,
+                                              C.POINTER(_abi.Region), C.POINTER(_abi.Continuation), C.c_int,
+                                              C.c_void_p, C.POINTER(ViterbiOut)]
         lib.oracle_cells_visited.restype = C.c_int64
         lib.oracle_cells_visited.argtypes = [C.c_int]
         _lib = lib
@@ -80,3 +94,31 @@ def find_path(model, params, q, t, dpmemory=32, threshold=_abi.IMPOSSIBLY_LOW_SC
 
 def find_score(model, params, q, t):
     return load().oracle_find_score(model, params, q, len(q), t, len(t))
+
+
+def subopt_points(so):
+    lib = load()
+    n = lib.oracle_subopt_points(so, None, None, 0)
+    q, t = (C.c_int32 * max(1, n))(), (C.c_int32 * max(1, n))()
+    lib.oracle_subopt_points(so, q, t, n)
+    return [[q[i], t[i]] for i in range(n)]
+
+
+def find_paths_subopt(model, params, q, t, dpmemory, threshold, max_paths, qid="qy"):
+    """GAM_Result_exhaustive_create's loop (gam.c:1139-1180): successive best paths, each with the match
+    cells of all earlier ones blocked.  Returns [(alignment dict, blocked points after adding it)]."""
+    lib = load()
+    so = lib.oracle_subopt_create(len(q), len(t))
+    out = []
+    try:
+        for _ in range(max_paths):
+            a = _abi.Alignment()
+            if not lib.oracle_find_path_subopt(model, params, q, len(q), t, len(t), dpmemory, threshold, so, a):
+                break
+            d = alignment_to_dict(model, a, lib.oracle_alignment_format, qid, len(q), len(t))
+            lib.oracle_subopt_add_alignment(so, model, a)
+            lib.oracle_alignment_clear(a)
+            out.append((d, subopt_points(so)))
+    finally:
+        lib.oracle_subopt_destroy(so)
+    return out

@@ -7,7 +7,7 @@ inputs of the reference's model known-answer tests.  Integer work: every compari
 import pytest
 from exonerate_amd import _abi
 import oracle_lib
-from golden_util import SETS, load_set, get_model, expected
+from golden_util import SETS, SUBOPT_SETS, load_set, get_model, expected
 
 
 @pytest.mark.parametrize("name", sorted(SETS))
@@ -23,6 +23,23 @@ def test_oracle_matches_reference_vectors(lib, params, name):
             assert got is None
             continue
         assert got == expected(rec), rec["id"]
+
+
+@pytest.mark.parametrize("name", sorted(SUBOPT_SETS))
+def test_oracle_suboptimal_loop_matches_reference(lib, params, name):
+    """SubOpt blocking (subopt.c, viterbi.c:701-704): the successive alignments of the GAM loop and the
+    blocked point set after each, as the reference produced them."""
+    model = get_model(lib, params, name)
+    for rec in load_set(name):
+        q, t = rec["query"].encode(), rec["target"].encode()
+        got = oracle_lib.find_paths_subopt(model, params, q, t, rec["dpmemory"], rec["threshold"], 6
+                                           if "global" not in name else 3, qid=rec["id"])
+        assert len(got) == len(rec["subopt"]), rec["id"]
+        for (d, pts), exp in zip(got, rec["subopt"]):
+            assert (d["score"], d["region"], d["ops"], d["vulgar"]) == \
+                   (exp["path_score"], exp["region"], exp["ops"], exp["vulgar"]), rec["id"]
+            if "points" in exp:
+                assert pts == exp["points"], rec["id"]
 
 
 def test_reference_known_answer_tests(lib, params):

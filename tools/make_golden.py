@@ -148,6 +148,39 @@ KAT_E2G = ("kat_est2genome", "CGATCGATCGNATCGATCGATC" "CATCTATCTAGCGAGCGATCTA",
            "CGATCGATCGATCGATCGATC" "GT" + "N" * 20 + "N" * 47 * 3 + "N" * 27 + "AG" + "CATCTATCTANNNGCGAGCGATCTA")
 
 
+def repeat_pairs(rng, n, kind):
+    """Targets holding several diverged copies of the query: successive sub-optimal alignments
+    (GAM_Result_exhaustive_create's loop) each find the next copy, or a second path through the same one."""
+    cases = []
+    for k in range(n):
+        if kind == "dna":
+            q = rand_dna(rng, rng.choice([25, 40, 60, 90]))
+            copies = [mutate(rng, q, r, "ACGT") for r in rng.sample([0.0, 0.05, 0.1, 0.2, 0.3], rng.randint(1, 3))]
+            if k % 4 == 3:
+                copies.append(q[len(q) // 3:])          # partial copy
+            t = rand_dna(rng, rng.randint(0, 20))
+            for c in copies:
+                t += c + rand_dna(rng, rng.randint(0, 25))
+            if k % 5 == 4:
+                t = q + q                                # exact tandem repeat: ties everywhere
+        elif kind == "est":
+            base = est_pairs(rng, 2)
+            q = base[0][1]
+            t = base[0][2] + rand_dna(rng, 30) + mutate(rng, base[0][2], 0.05, "ACGT")
+            if k % 3 == 2:
+                t += rand_dna(rng, 10) + q               # an intron-less (processed) copy
+        elif kind == "p2d":
+            base = p2d_pairs(rng, 1)[0]
+            q = base[1]
+            t = base[2] + rand_dna(rng, 21) + mutate(rng, base[2], 0.04, "ACGT")
+        else:
+            base = p2g_pairs(rng, 1)[0]
+            q = base[1]
+            t = base[2] + rand_dna(rng, 21) + mutate(rng, base[2], 0.03, "ACGT")
+        cases.append(("%ssub%03d" % (kind, k), q, t))
+    return cases
+
+
 def run(model, cases, dpmemory, extra=()):
     with tempfile.NamedTemporaryFile("w", suffix=".tsv", delete=False) as f:
         for cid, q, t in cases:
@@ -196,12 +229,31 @@ def main():
     t = rand_dna(rng2, 300) + q[:250] + "GT" + rand_dna(rng2, 700) + "AG" + q[250:520] + "GT" + \
         rand_dna(rng2, 1500) + "AG" + q[520:] + rand_dna(rng2, 400)
     sets.append(("est2genome_big", "est2genome", [("estbig0", q, t)], 32, ()))
+    # sub-optimal alignments (SubOpt blocking, src/c4/subopt.c) through the GAM loop
+    so = ("--suboptmax", "6", "--suboptthreshold", "30")
+    rs = random.Random(4242)
+    sub_dna, sub_est = repeat_pairs(rs, 16, "dna"), repeat_pairs(rs, 10, "est")
+    sub_p2d, sub_p2g = repeat_pairs(rs, 8, "p2d"), repeat_pairs(rs, 8, "p2g")
+    sub_p2d = [c for c in sub_p2d if len(c[2]) > 30]
+    sets.append(("affine_local_dna_subopt", "affine:local", sub_dna, 32, so))
+    sets.append(("affine_local_dna_subopt_D0", "affine:local", sub_dna, 0, so))
+    sets.append(("affine_global_dna_subopt", "affine:global", sub_dna, 32, ("--suboptmax", "3", "--suboptthreshold", "-100000")))
+    sets.append(("est2genome_subopt", "est2genome", sub_est, 32, so))
+    sets.append(("est2genome_subopt_D0", "est2genome", sub_est, 0, so))
+    sets.append(("protein2dna_subopt", "protein2dna", sub_p2d, 32, so))
+    sets.append(("protein2dna_subopt_D0", "protein2dna", sub_p2d, 0, so))
+    sets.append(("protein2genome_subopt", "protein2genome", sub_p2g, 32, so))
+    sets.append(("protein2genome_subopt_D0", "protein2genome", sub_p2g, 0, so))
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])
     for name, model, cases, dpm, extra in sets:
         if only and name not in only:
             continue
         recs = run(model, cases, dpm, extra)
+        if name.endswith("_subopt_D0"):      # the point sets are those of the -D 32 twin: keep the files small
+            for r in recs:
+                for a in r.get("subopt", []):
+                    a.pop("points", None)
         with open(os.path.join(OUT, name + ".jsonl"), "w") as f:
             for r in recs:
                 f.write(json.dumps(r, separators=(",", ":")) + "\n")
