@@ -106,6 +106,34 @@ class Alignment:
                 "sugar": self.sugar(qid), "cigar": self.cigar(qid), "vulgar": self.vulgar(qid)}
 
 
+class SubOpt:
+    """c4gpu_subopt: the cells blocked by the alignments already reported for one pair (SubOpt, subopt.h)."""
+
+    def __init__(self, query_length, target_length):
+        self.h = _lib().c4gpu_subopt_create(query_length, target_length)
+
+    def add_alignment(self, alignment):
+        if _lib().c4gpu_subopt_add_alignment(self.h, alignment.model.c, alignment._c()) != 0:
+            raise _err("c4gpu_subopt_add_alignment")
+
+    def add_point(self, query_pos, target_pos):
+        _lib().c4gpu_subopt_add_point(self.h, query_pos, target_pos)
+
+    def points(self):
+        n = _lib().c4gpu_subopt_points(self.h, None, None, 0)
+        q, t = (C.c_int32 * max(1, n))(), (C.c_int32 * max(1, n))()
+        _lib().c4gpu_subopt_points(self.h, q, t, n)
+        return [[q[i], t[i]] for i in range(n)]
+
+    def close(self):
+        if self.h:
+            _lib().c4gpu_subopt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
 def _pairs(pairs):
     arr = (_abi.Pair * max(1, len(pairs)))()
     keep = []
@@ -160,8 +188,51 @@ class Engine:
             _lib().c4gpu_alignment_clear(out[i])
         return res
 
+    def find_path_subopt(self, model, pairs, subopts, active=None, dpmemory=32, threshold=IMPOSSIBLY_LOW_SCORE):
+        """One round of the sub-optimal loop: subopts[i] is a SubOpt or None."""
+        arr, keep = _pairs(pairs)
+        n = len(pairs)
+        out = (_abi.Alignment * max(1, n))()
+        so = (C.c_void_p * max(1, n))(*[(s.h if s is not None else None) for s in subopts])
+        act = None if active is None else (C.c_uint8 * max(1, n))(*[1 if a else 0 for a in active])
+        if _lib().c4gpu_optimal_find_path_batch_subopt(self.ctx, model.c, model.params, arr, n, dpmemory,
+                                                       threshold, so, act, out) != 0:
+            raise _err("c4gpu_optimal_find_path_batch_subopt")
+        res = []
+        for i in range(n):
+            res.append(Alignment(model, out[i], len(keep[i][0]), len(keep[i][1])) if out[i].valid else None)
+            _lib().c4gpu_alignment_clear(out[i])
+        return res
+
+    def find_all_paths(self, model, pairs, dpmemory=32, threshold=IMPOSSIBLY_LOW_SCORE, max_paths=1 << 30):
+        """GAM_Result_exhaustive_create's loop (gam.c:1139-1180) for every pair at once: successive best
+        paths, each round with the match cells of everything found so far blocked, until a pair's score
+        drops below the threshold.  Returns a list of alignment lists."""
+        n = len(pairs)
+        found = [[] for _ in range(n)]
+        subs = [SubOpt(len(q), len(t)) for q, t in pairs]
+        active = [True] * n
+        try:
+            for _ in range(max_paths):
+                if not any(active):
+                    break
+                res = self.find_path_subopt(model, pairs, subs, active, dpmemory, threshold)
+                for i, a in enumerate(res):
+                    if not active[i]:
+                        continue
+                    if a is None:
+                        active[i] = False
+                    else:
+                        found[i].append(a)
+                        subs[i].add_alignment(a)
+        finally:
+            for s in subs:
+                s.close()
+        return found
+
     def viterbi(self, model, mode, pairs, jobs):
-        """Raw Viterbi_DP_Func level: jobs = list of dict(pair, region, continuation=None, checkpoints=0)."""
+        """Raw Viterbi_DP_Func level: jobs = list of dict(pair, region, continuation=None, checkpoints=0,
+        subopt=None)."""
         arr, keep = _pairs(pairs)
         cj = (_abi.ViterbiJob * max(1, len(jobs)))()
         for i, j in enumerate(jobs):
@@ -175,6 +246,7 @@ class Engine:
                 for l, v in enumerate(cont.get("first_cell", [])):
                     cj[i].continuation.first_cell[l] = v
             cj[i].checkpoint_count = j.get("checkpoints", 0)
+            cj[i].subopt = j["subopt"].h if j.get("subopt") is not None else None
         res = (_abi.ViterbiResult * max(1, len(jobs)))()
         if _lib().c4gpu_viterbi_batch(self.ctx, model.c, model.params, mode, arr, len(pairs), cj, len(jobs),
                                       res) != 0:
@@ -212,6 +284,13 @@ class ResidentBatch:
     def run(self, what=2, dpmemory=32, threshold=IMPOSSIBLY_LOW_SCORE):
         if _lib().c4gpu_batch_run(self.h, what, dpmemory, threshold) != 0:
             raise _err("c4gpu_batch_run")
+
+    def next_paths(self, dpmemory=32, threshold=IMPOSSIBLY_LOW_SCORE):
+        """Next round of the sub-optimal loop (c4gpu_batch_next_paths); returns the number found."""
+        n = _lib().c4gpu_batch_next_paths(self.h, dpmemory, threshold)
+        if n < 0:
+            raise _err("c4gpu_batch_next_paths")
+        return n
 
     def scores(self):
         s = (C.c_int32 * max(1, self.n))()

@@ -96,7 +96,7 @@ class Continuation(C.Structure):
 
 class ViterbiJob(C.Structure):
     _fields_ = [("pair", C.c_int32), ("region", Region), ("use_continuation", C.c_int32),
-                ("continuation", Continuation), ("checkpoint_count", C.c_int32)]
+                ("continuation", Continuation), ("checkpoint_count", C.c_int32), ("subopt", C.c_void_p)]
 
 
 class ViterbiResult(C.Structure):
@@ -134,7 +134,17 @@ PROTOTYPES = [
     ("c4gpu_optimal_find_path_batch", C.c_int, [C.c_void_p, C.POINTER(Model), C.POINTER(Params),
                                                 C.POINTER(Pair), C.c_int32, C.c_int, C.c_int32,
                                                 C.POINTER(Alignment)]),
+    ("c4gpu_optimal_find_path_batch_subopt", C.c_int, [C.c_void_p, C.POINTER(Model), C.POINTER(Params),
+                                                       C.POINTER(Pair), C.c_int32, C.c_int, C.c_int32,
+                                                       C.POINTER(C.c_void_p), C.POINTER(C.c_uint8),
+                                                       C.POINTER(Alignment)]),
     ("c4gpu_alignment_clear", None, [C.POINTER(Alignment)]),
+    ("c4gpu_subopt_create", C.c_void_p, [C.c_int32, C.c_int32]),
+    ("c4gpu_subopt_destroy", None, [C.c_void_p]),
+    ("c4gpu_subopt_add_alignment", C.c_int, [C.c_void_p, C.POINTER(Model), C.POINTER(Alignment)]),
+    ("c4gpu_subopt_add_point", C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    ("c4gpu_subopt_points", C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32]),
+    ("c4gpu_batch_next_paths", C.c_int, [C.c_void_p, C.c_int, C.c_int32]),
     ("c4gpu_batch_create", C.c_void_p, [C.c_void_p, C.POINTER(Model), C.POINTER(Params),
                                         C.POINTER(Pair), C.c_int32]),
     ("c4gpu_batch_destroy", None, [C.c_void_p]),

@@ -191,6 +191,23 @@ __global__ void splice_kernel(const uint8_t *__restrict__ seq, const long long *
 }
 
 // ---- resident sequences of a batch --------------------------------------------------------------------------
+// Column pointers of the blocked-cell lists (the device form of SubOpt_Index's rows, subopt.c:250-333): for
+// every job and every column 0..T+1 the index of the first point at or after that column.
+__global__ void subopt_colptr_kernel(const DevJob *jobs, int n_jobs, const int *pts_t, int *colptr) {
+    for (int x = blockIdx.x; x < n_jobs; x += gridDim.x) {
+        const DevJob &j = jobs[x];
+        const int *pt = pts_t + j.sub_pt_off;
+        for (int c = threadIdx.x; c <= j.T + 1; c += blockDim.x) {
+            int lo = 0, hi = j.sub_pt_n;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (pt[mid] < c) lo = mid + 1; else hi = mid;
+            }
+            colptr[j.sub_off + c] = j.sub_pt_off + lo;
+        }
+    }
+}
+
 struct ResidentSeqs {
     int n_pairs = 0;
     std::vector<long long> qoff, toff;
@@ -279,7 +296,9 @@ struct JobSpec {                  // host description of one Viterbi call
     int first_state = 0, final_state = 1, cp_count = 0;
     int first_cell[CELL_MAX] = {0};
     bool dump_checkpoints = false;
+    const c4gpu_subopt *sub = nullptr;   // sub-optimal blocking for this call (else the engine's per-pair table)
 };
+typedef std::vector<std::pair<int32_t, int32_t>> RegionPoints;   // (target, query) in region coordinates, ascending
 struct JobOut {
     DevResult res;
     std::vector<uint32_t> runs;   // PATH: (transition << 24 | length) runs, START -> END
@@ -302,6 +321,9 @@ struct Engine {
     DevBuf<uint8_t> d_ops;
     DevBuf<int> d_bnd, d_ckpt, d_ckpt_dump, d_queue;
     DevBuf<uint32_t> d_tb;
+    DevBuf<int> d_sub_t, d_sub_q, d_sub_colptr;
+    // per-pair SubOpt of the Optimal_find_path in progress (NULL entries / NULL table: nothing blocked)
+    const std::vector<const c4gpu_subopt *> *pair_sub = nullptr;
 
     int init(c4gpu_ctx *c, const c4gpu_model *m, const c4gpu_params *params) {
         ctx = c; model = m;
@@ -327,8 +349,36 @@ struct Engine {
         return kparams.upload(&kp, 1, ctx->stream);
     }
 
-    // Runs `specs` in `mode`; out[i] corresponds to specs[i].
+    // Runs `specs` in `mode`; out[i] corresponds to specs[i].  Calls whose region holds blocked cells
+    // (SubOpt_Index_create returns an index, subopt.c:250-266) go to the kernels compiled with blocking, the
+    // others (it returns NULL) to the plain ones.
     int run(const ResidentSeqs &seqs, int mode, bool cont, const std::vector<JobSpec> &specs, std::vector<JobOut> &out) {
+        const int n = (int)specs.size();
+        std::vector<int> plain, blocked;
+        std::vector<RegionPoints> pts;
+        for (int i = 0; i < n; i++) {
+            const c4gpu_subopt *so = specs[i].sub ? specs[i].sub : (pair_sub ? (*pair_sub)[specs[i].pair] : nullptr);
+            RegionPoints rp;
+            if (so && !so->points.empty()) c4h::subopt_region_points(so, specs[i].region, rp);
+            if (rp.empty()) plain.push_back(i);
+            else { blocked.push_back(i); pts.push_back(std::move(rp)); }
+        }
+        if (blocked.empty()) return run_impl(seqs, mode, cont, specs, out, nullptr);
+        out.assign(n, JobOut());
+        std::vector<JobSpec> part;
+        std::vector<JobOut> part_out;
+        for (int i : plain) part.push_back(specs[i]);
+        if (run_impl(seqs, mode, cont, part, part_out, nullptr)) return -1;
+        for (size_t x = 0; x < plain.size(); x++) out[plain[x]] = std::move(part_out[x]);
+        part.clear();
+        for (int i : blocked) part.push_back(specs[i]);
+        if (run_impl(seqs, mode, cont, part, part_out, &pts)) return -1;
+        for (size_t x = 0; x < blocked.size(); x++) out[blocked[x]] = std::move(part_out[x]);
+        return 0;
+    }
+
+    int run_impl(const ResidentSeqs &seqs, int mode, bool cont, const std::vector<JobSpec> &specs,
+                 std::vector<JobOut> &out, const std::vector<RegionPoints> *pts) {
         const int n = (int)specs.size();
         out.assign(n, JobOut());
         if (!n) return 0;
@@ -339,12 +389,12 @@ struct Engine {
         for (int i = 0; i < n && pack; i++)
             pack = nbits(specs[i].region.query_length) + nbits(specs[i].region.target_length) <= 31;
         static const int wpe_env = getenv("C4GPU_WPE") ? atoi(getenv("C4GPU_WPE")) : 0;
-        const KernelInfo *ki = get_kernel(family, mode, cont, use_local, pack, wpe_env);
+        const KernelInfo *ki = get_kernel(family, mode, cont, use_local, pack, pts ? 0 : wpe_env, pts != nullptr);
         if (!ki) { c4h::set_error("no compiled kernel for this model/mode"); return -1; }
         // whole-rectangle passes whose query spans several 64*R-row strips run on 4 cooperating waves per
         // job (strip carry rows stay in LDS instead of HBM); C4GPU_MW=0 forces the one-wave kernels
         static const int mw_env = getenv("C4GPU_MW") ? atoi(getenv("C4GPU_MW")) : 1;
-        if (mw_env && !cont && (mode == MODE_SCORE || mode == MODE_REGION)) {
+        if (mw_env && !pts && !cont && (mode == MODE_SCORE || mode == MODE_REGION)) {
             const KernelInfo *kmw = get_kernel_mw(family, mode, use_local, pack);
             if (kmw) {
                 long long strips = 0;
@@ -359,11 +409,18 @@ struct Engine {
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cells(a) > cells(b); });
         std::vector<DevJob> jobs(n);
         long long ops_total = 0, vsa_total = 0, dump_total = 0, max_T = 0, max_tb = 0, max_ckpt = 0, total_cells = 0;
-        long long max_runs = 0;
+        long long max_runs = 0, sub_cols = 0;
+        std::vector<int> sub_t, sub_q;
         for (int x = 0; x < n; x++) {
             const JobSpec &s = specs[order[x]];
             DevJob &j = jobs[x];
             memset(&j, 0, sizeof j);
+            if (pts) {
+                const RegionPoints &rp = (*pts)[order[x]];
+                j.sub_off = sub_cols; j.sub_pt_off = (int)sub_t.size(); j.sub_pt_n = (int)rp.size();
+                sub_cols += s.region.target_length + 2;
+                for (const auto &p : rp) { sub_t.push_back(p.first); sub_q.push_back(p.second); }
+            }
             j.pair = s.pair; j.q0 = s.region.query_start; j.t0 = s.region.target_start;
             j.Q = s.region.query_length; j.T = s.region.target_length;
             j.first_state = s.first_state; j.final_state = s.final_state; j.cp_count = s.cp_count;
@@ -413,6 +470,15 @@ struct Engine {
                 return -1;
             LaunchArgs a;
             a.kp = kparams.p; a.seqs = seqs.dev; a.jobs = d_jobs.p; a.n_jobs = n; a.results = d_results.p;
+            a.seqs.sub_colptr = nullptr; a.seqs.sub_rows = nullptr;
+            if (pts) {
+                if (d_sub_t.upload(sub_t.data(), sub_t.size(), s) || d_sub_q.upload(sub_q.data(), sub_q.size(), s) ||
+                    d_sub_colptr.alloc(sub_cols)) return -1;
+                hipLaunchKernelGGL(subopt_colptr_kernel, dim3(std::min(n, 65535)), dim3(256), 0, s, d_jobs.p, n,
+                                   d_sub_t.p, d_sub_colptr.p);
+                HIP_OK(hipGetLastError());
+                a.seqs.sub_colptr = d_sub_colptr.p; a.seqs.sub_rows = d_sub_q.p;
+            }
             a.vsas = d_vsa.p; a.ops = nullptr; a.queue = d_queue.p; a.grid = (int)grid; a.stream = s;
             a.scratch.bnd = d_bnd.p; a.scratch.bnd_stride = bnd_per_wave;
             a.scratch.tb = max_tb ? d_tb.p : nullptr; a.scratch.tb_stride = max_tb;
@@ -547,10 +613,18 @@ int sequential_reduced_path(Engine &eng, const ResidentSeqs &seqs, int pair, int
     return 0;
 }
 
+// subs (may be NULL): per-pair SubOpt, the `subopt` argument the reference hands to every Viterbi_calculate of
+// the path (optimal.c:368-413); active (may be NULL): pairs to run, the others get no alignment.
 int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gpu_score threshold,
-                    c4gpu_alignment *alignments) {
+                    c4gpu_alignment *alignments, const std::vector<const c4gpu_subopt *> *subs = nullptr,
+                    const uint8_t *active = nullptr) {
     const c4gpu_model *m = eng.model;
     const int n = seqs.n_pairs;
+    struct SubScope {                // every eng.run below sees the pairs' blocked cells
+        Engine &e;
+        SubScope(Engine &e_, const std::vector<const c4gpu_subopt *> *s) : e(e_) { e.pair_sub = s; }
+        ~SubScope() { e.pair_sub = nullptr; }
+    } sub_scope(eng, subs);
     std::vector<PairPlan> plan(n);
     std::vector<JobSpec> specs;
     std::vector<JobOut> outs;
@@ -560,7 +634,8 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
     std::vector<int> region_pairs;
     for (int i = 0; i < n; i++) {
         plan[i].ar = c4gpu_region{0, 0, seqs.qlen[i], seqs.tlen[i]};
-        plan[i].active = true;
+        plan[i].active = !active || active[i];
+        if (!plan[i].active) continue;
         if (c4h::use_reduced_space(m, &plan[i].ar, dpmemory_mb)) {
             plan[i].reduced = true;
             if (!model_is_global(m)) region_pairs.push_back(i);        // Optimal_find_region, optimal.c:135
@@ -723,6 +798,13 @@ struct c4gpu_batch {
     std::vector<c4gpu_score> scores;
     std::vector<c4gpu_region> regions;
     std::vector<c4gpu_alignment> alignments;
+    // the sub-optimal loop (c4gpu_batch_next_paths): one SubOpt per pair, pairs still in the loop
+    std::vector<c4gpu_subopt *> subopts;
+    std::vector<uint8_t> in_loop;
+    void clear_loop() {
+        for (c4gpu_subopt *so : subopts) c4gpu_subopt_destroy(so);
+        subopts.clear(); in_loop.clear();
+    }
 };
 
 extern "C" {
@@ -804,6 +886,7 @@ int c4gpu_viterbi_batch(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_pa
             for (int l = 0; l < CELL_MAX; l++) s.first_cell[l] = jobs[i].continuation.first_cell[l];
             s.cp_count = jobs[i].checkpoint_count;
             s.dump_checkpoints = (mode == C4GPU_MODE_FIND_CHECKPOINTS);
+            s.sub = jobs[i].subopt;
             specs.push_back(s); idx.push_back(i);
         }
         if ((mode == C4GPU_MODE_FIND_CHECKPOINTS || mode == C4GPU_MODE_FIND_REGION) && !specs.empty() &&
@@ -874,6 +957,19 @@ int c4gpu_optimal_find_path_batch(c4gpu_ctx *ctx, const c4gpu_model *model, cons
     return find_path_batch(eng, seqs, dpmemory_mb, threshold, alignments);
 }
 
+int c4gpu_optimal_find_path_batch_subopt(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params,
+                                         const c4gpu_pair *pairs, int32_t n_pairs, int dpmemory_mb,
+                                         c4gpu_score threshold, const c4gpu_subopt *const *subopts,
+                                         const uint8_t *active, c4gpu_alignment *alignments) {
+    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+    Engine eng;
+    ResidentSeqs seqs;
+    if (eng.init(ctx, model, params) || seqs.build(ctx, eng.family, params, pairs, n_pairs)) return -1;
+    std::vector<const c4gpu_subopt *> subs(n_pairs, nullptr);
+    if (subopts) for (int i = 0; i < n_pairs; i++) subs[i] = subopts[i];
+    return find_path_batch(eng, seqs, dpmemory_mb, threshold, alignments, &subs, active);
+}
+
 c4gpu_batch *c4gpu_batch_create(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params,
                                 const c4gpu_pair *pairs, int32_t n_pairs) {
     if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
@@ -888,6 +984,7 @@ c4gpu_batch *c4gpu_batch_create(c4gpu_ctx *ctx, const c4gpu_model *model, const 
 
 void c4gpu_batch_destroy(c4gpu_batch *b) {
     if (!b) return;
+    b->clear_loop();
     for (auto &a : b->alignments) c4gpu_alignment_clear(&a);
     delete b;
 }
@@ -908,10 +1005,44 @@ int c4gpu_batch_run(c4gpu_batch *b, int what, int dpmemory_mb, c4gpu_score thres
     }
     for (auto &a : b->alignments) c4gpu_alignment_clear(&a);
     b->alignments.assign(n, c4gpu_alignment{});
+    b->clear_loop();
     if (find_path_batch(b->eng, b->seqs, dpmemory_mb, threshold, b->alignments.data())) return -1;
     b->scores.resize(n); b->regions.resize(n);
     for (int i = 0; i < n; i++) { b->scores[i] = b->alignments[i].score; b->regions[i] = b->alignments[i].region; }
     return 0;
+}
+
+// GAM_Result_exhaustive_create's do/while (gam.c:1158-1172) for the whole batch: block what the previous
+// round found (GAM_Result_add_alignment -> SubOpt_add_alignment, gam.c:673), then the next best paths.
+int c4gpu_batch_next_paths(c4gpu_batch *b, int dpmemory_mb, c4gpu_score threshold) {
+    if (hipSetDevice(b->ctx->device) != hipSuccess) return -1;
+    const int n = b->seqs.n_pairs;
+    if ((int)b->alignments.size() != n) { c4h::set_error("c4gpu_batch_next_paths needs a c4gpu_batch_run(b, 2, ...) first"); return -1; }
+    if (b->subopts.empty()) {
+        b->subopts.resize(n);
+        for (int i = 0; i < n; i++) b->subopts[i] = c4gpu_subopt_create(b->seqs.qlen[i], b->seqs.tlen[i]);
+        b->in_loop.assign(n, 1);
+    }
+    std::vector<const c4gpu_subopt *> subs(n);
+    int still = 0;
+    for (int i = 0; i < n; i++) {
+        if (b->in_loop[i] && b->alignments[i].valid) {
+            if (c4gpu_subopt_add_alignment(b->subopts[i], &b->model, &b->alignments[i])) return -1;
+            still++;
+        } else {
+            b->in_loop[i] = 0;
+        }
+        subs[i] = b->subopts[i];
+    }
+    for (auto &a : b->alignments) c4gpu_alignment_clear(&a);
+    if (!still) return 0;
+    if (find_path_batch(b->eng, b->seqs, dpmemory_mb, threshold, b->alignments.data(), &subs, b->in_loop.data())) return -1;
+    int found = 0;
+    for (int i = 0; i < n; i++) {
+        found += b->alignments[i].valid ? 1 : 0;
+        b->scores[i] = b->alignments[i].score; b->regions[i] = b->alignments[i].region;
+    }
+    return found;
 }
 
 int c4gpu_batch_scores(c4gpu_batch *b, c4gpu_score *scores, c4gpu_region *regions) {

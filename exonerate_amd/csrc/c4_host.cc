@@ -1,5 +1,7 @@
 // c4_host.cc — host-side pieces of the C ABI that need no device: the reference's memory decisions
 // (which decide WHICH Viterbi passes run, hence results) and the sugar/cigar/vulgar printers.
+#include <climits>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -80,9 +82,76 @@ void alignment_add(c4gpu_alignment *a, int *cap, int transition, int length) {
     a->op_length[a->n_ops++] = length;
 }
 
+void subopt_region_points(const c4gpu_subopt *so, const c4gpu_region &r,
+                          std::vector<std::pair<int32_t, int32_t>> &out) {
+    out.clear();
+    if (!so) return;
+    auto it = so->points.lower_bound(std::make_pair(r.target_start, INT32_MIN));
+    for (; it != so->points.end() && it->first <= r.target_start + r.target_length; ++it)
+        if (it->second >= r.query_start && it->second <= r.query_start + r.query_length)
+            out.emplace_back(it->first - r.target_start, it->second - r.query_start);
+}
+
 }  // namespace c4h
 
 extern "C" {
+
+c4gpu_subopt *c4gpu_subopt_create(int32_t query_length, int32_t target_length) {     // subopt.c:24-33
+    c4gpu_subopt *so = new c4gpu_subopt;
+    so->query_length = query_length; so->target_length = target_length; so->path_count = 0;
+    return so;
+}
+void c4gpu_subopt_destroy(c4gpu_subopt *so) { delete so; }
+
+int c4gpu_subopt_add_point(c4gpu_subopt *so, int32_t query_pos, int32_t target_pos) {
+    if (!so) return -1;
+    so->points.insert(std::make_pair(target_pos, query_pos));
+    return 0;
+}
+
+int32_t c4gpu_subopt_points(const c4gpu_subopt *so, int32_t *query_pos, int32_t *target_pos, int32_t max) {
+    int32_t k = 0;
+    for (const auto &p : so->points) {
+        if (k >= max) break;
+        query_pos[k] = p.second; target_pos[k] = p.first; k++;
+    }
+    return (int32_t)so->points.size();
+}
+
+// SubOpt_add_alignment (subopt.c:131-148) over SubOpt_add_AlignmentOperation (subopt.c:64-128).  A match
+// operation (aq, at) of length n starting at (q, t) blocks, per step, the cell the step leaves from and
+// the intermediate cells of a multi-residue step (stride (aq, at) / gcd); then the lead-in cells in front
+// of its first step, when they are inside the sequences.  The reference tests membership before every
+// insertion; a set needs no such test.
+int c4gpu_subopt_add_alignment(c4gpu_subopt *so, const c4gpu_model *model, const c4gpu_alignment *a) {
+    if (!so || !model || !a) return -1;
+    int32_t q = a->region.query_start, t = a->region.target_start;
+    for (int32_t k = 0; k < a->n_ops; k++) {
+        const int tr = a->op_transition[k];
+        if (tr < 0 || tr >= model->n_transitions) { c4h::set_error("alignment operation outside the model"); return -1; }
+        const c4gpu_transition &x = model->transitions[tr];
+        const int32_t len = a->op_length[k];
+        if (x.label == C4GPU_LABEL_MATCH) {
+            int g = x.advance_query, h = x.advance_target;
+            while (h) { const int r = g % h; g = h; h = r; }
+            if (g > 0) {
+                const int dq = x.advance_query / g, dt = x.advance_target / g;
+                for (int32_t step = 0; step < len; step++)
+                    for (int sub = 0; sub * dq < x.advance_query; sub++)
+                        so->points.insert(std::make_pair(t + step * x.advance_target + sub * dt,
+                                                         q + step * x.advance_query + sub * dq));
+                for (int sub = 1; sub * dq < x.advance_query; sub++) {
+                    const int32_t lq = q - x.advance_query + sub * dq, lt = t - x.advance_target + sub * dt;
+                    if (lq >= 0 && lt >= 0) so->points.insert(std::make_pair(lt, lq));
+                }
+            }
+        }
+        q += x.advance_query * len;
+        t += x.advance_target * len;
+    }
+    so->path_count++;
+    return 0;
+}
 
 int c4gpu_use_reduced_space(const c4gpu_model *model, const c4gpu_region *region, int dpmemory_mb) {
     return c4h::use_reduced_space(model, region, dpmemory_mb) ? 1 : 0;

@@ -34,20 +34,21 @@ struct KernelInfo {
 };
 
 // family x mode x continuation x local-scope specialisation; NULL launch = not compiled
-const KernelInfo *get_kernel(int family, int mode, bool cont, bool local, bool pack, int wpe = 0);
+// sub: the variant with sub-optimal blocking (DevSeqs::sub_colptr / sub_rows must be set)
+const KernelInfo *get_kernel(int family, int mode, bool cont, bool local, bool pack, int wpe = 0, bool sub = false);
 // multi-wave kernels (4 cooperating waves per job) for FIND_SCORE / FIND_REGION without continuation
 const KernelInfo *get_kernel_mw(int family, int mode, bool local, bool pack);
 
-#define C4K_DEFINE_KERNEL(SYMBOL, M, RVAL, MODE, CONT, LOCAL, PACK, WPE)                                            \
+#define C4K_DEFINE_KERNEL(SYMBOL, M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV)                                          \
     static hipError_t SYMBOL##_launch(const LaunchArgs &a) {                                               \
-        hipLaunchKernelGGL((viterbi_kernel<M, RVAL, MODE, CONT, LOCAL, PACK, WPE>), dim3(a.grid), dim3(64), 0,        \
+        hipLaunchKernelGGL((viterbi_kernel<M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV>), dim3(a.grid), dim3(64), 0,        \
                            a.stream, a.kp, a.seqs, a.jobs, a.n_jobs, a.results, a.vsas, a.ops, a.scratch,  \
                            a.queue);                                                                       \
         return hipGetLastError();                                                                          \
     }                                                                                                      \
     const KernelInfo *SYMBOL() {                                                                           \
         static const KernelInfo ki = {SYMBOL##_launch,                                                     \
-                                      (const void *)viterbi_kernel<M, RVAL, MODE, CONT, LOCAL, PACK, WPE>,            \
+                                      (const void *)viterbi_kernel<M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV>,            \
                                       #SYMBOL,                                                             \
                                       RVAL,                                                                \
                                       WaveDP<M, RVAL, MODE, CONT, LOCAL, PACK>::CS,                              \

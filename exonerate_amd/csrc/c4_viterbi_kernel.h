@@ -42,6 +42,7 @@ enum { SCOPE_ANYWHERE = 0, SCOPE_EDGE, SCOPE_QUERY, SCOPE_TARGET, SCOPE_CORNER }
 enum { CALC_CONST = 0, CALC_MATCH_DNA, CALC_MATCH_PROTEIN, CALC_MATCH_P2D, CALC_SPLICE_PRE, CALC_SPLICE_POST,
        CALC_PHASE_PRE, CALC_PHASE_POST };
 enum { FLAG_OPS_OVERFLOW = 1, FLAG_NO_END = 2 };
+enum { LABEL_NONE = 0, LABEL_MATCH = 1 };            // C4_Label, c4.h:78-89
 
 struct KParams {                 // uniform per launch (device memory, staged to LDS)
     int calc_value[16];
@@ -57,6 +58,9 @@ struct DevSeqs {
     const int *ss;                       // [4][ss_stride] splice-site scores, same offsets as tcode
     const uint16_t *tn4;                 // per target position: 4-bit base masks of positions p, p-1, p-2, p-3
     long long ss_stride;
+    // sub-optimal blocking (SUB kernels): per job T+2 column pointers into sub_rows, which holds the blocked
+    // query rows (region coordinates) of each column, ascending
+    const int *sub_colptr, *sub_rows;
 };
 struct DevJob {
     int pair, q0, t0, Q, T;
@@ -66,6 +70,8 @@ struct DevJob {
     long long ops_off;                   // into the ops byte array (PATH)
     int ops_cap, vsa_off;                // vsa_off: into the DevVsa array (CKPT)
     long long ckpt_off;                  // >= 0: also dump checkpoint cells there (tests); -1: wave slab only
+    long long sub_off;                   // SUB kernels: this job's column pointers start at sub_colptr + sub_off
+    int sub_pt_off, sub_pt_n;            // its points in the launch's point arrays (colptr construction)
 };
 struct DevResult {
     int score, qs, ts, qe, te, end_set, last_srp, n_ops, flags, n_vsa, cell_size, pad;
@@ -145,7 +151,9 @@ __device__ __forceinline__ bool scope_ok(int scope, bool at_q, bool at_t) {
 // -------------------------------------------------------------------------------------------------------------
 // PACK (FIND_REGION only): the two region-start slots (viterbi.c:403-412) share one int,
 // (query_start << tshift) | target_start; the host picks PACK when bits(Q) + bits(T) <= 31.
-template <class M, int R, int MODE, bool CONT, bool LOCAL, bool PACK = false>
+// SUB: sub-optimal blocking (SubOpt_Index, src/c4/subopt.c): MATCH transitions skip the blocked cells listed
+// per column in DevSeqs::sub_colptr / sub_rows.
+template <class M, int R, int MODE, bool CONT, bool LOCAL, bool PACK = false, bool SUB = false>
 struct WaveDP {
     using F = Facts<M>;
     static constexpr int NDES = M::NDES;
@@ -234,7 +242,7 @@ struct WaveDP {
     // state in scratch memory instead of VGPRs.
     template <int RR, int PH, bool JINT>
     __device__ __forceinline__ void eval_cell(int i, int j, bool active, int mscore, const int (&pre)[4],
-                                              int qrow, int tn4col, uint32_t &tbword) {
+                                              int qrow, int tn4col, bool blocked, uint32_t &tbword) {
         C &c = col[PH][RR];
         bool set[M::NS];
         static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
@@ -258,6 +266,8 @@ struct WaveDP {
                 valid = valid & scope_ok(start_scope, i - t.aq == 0, j - t.at == 0);
             if constexpr (t.out == M::END && !LOCAL)
                 valid = valid & scope_ok(end_scope, i == Q, j == T);
+            // sub-optimal blocking: MATCH transitions do not enter a blocked cell (viterbi.c:701-704)
+            if constexpr (SUB && t.label == LABEL_MATCH) valid = valid & !blocked;
             // continuation seeding (viterbi.c:705-714): first cell into the first state, at the corner only
             if constexpr (CONT && t.in == M::START) {
                 static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
@@ -430,8 +440,15 @@ struct WaveDP {
     // uses, because every transition that would read them is masked invalid.
     int nx_tcode, nx_sp[4], nx_tn4, tlast;
     const uint16_t *tn4p;
+    const int *sub_cp, *sub_rows;       // SUB: column pointers of this job, blocked rows of the launch
+    int nx_sub_lo, nx_sub_hi;
     __device__ __forceinline__ void prefetch_column(int j) {
         constexpr int mat = F::match_at();
+        if constexpr (SUB) {
+            const int jc = j < 0 ? 0 : (j > T ? T : j);
+            nx_sub_lo = sub_cp[jc];
+            nx_sub_hi = sub_cp[jc + 1];
+        }
         int ti = t0 + j - mat;
         ti = ti < 0 ? 0 : (ti > tlast ? tlast : ti);
         nx_tcode = tc[ti];
@@ -458,6 +475,18 @@ struct WaveDP {
         // their latency overlaps the lane exchange below
         const int tcode = nx_tcode;
         const int tn4col = F::has_phase() ? nx_tn4 : 0;
+        // blocked rows of this column among our R rows: columns that hold any blocked cell are rare, so
+        // the list walk sits behind a wave-uniform branch
+        unsigned blk = 0;
+        if constexpr (SUB) {
+            const int lo = nx_sub_lo, hi = nx_sub_hi;
+            if (__builtin_amdgcn_ballot_w64(hi > lo)) {
+                for (int p = lo; p < hi; p++) {
+                    const int r = sub_rows[p] - i0;
+                    blk |= (r >= 0 && r < R) ? (1u << r) : 0u;
+                }
+            }
+        }
         int ms[R];
         static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
             ms[RR] = kp->submat[qcode[RR] * 24 + tcode];
@@ -489,7 +518,7 @@ struct WaveDP {
         uint32_t tbw[R];
         static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
             const int i = i0 + RR;
-            eval_cell<RR, PH, JINT>(i, j, jact && i <= Q, ms[RR], sp, qcode[RR], tn4col, tbw[RR]);
+            eval_cell<RR, PH, JINT>(i, j, jact && i <= Q, ms[RR], sp, qcode[RR], tn4col, (blk >> RR) & 1u, tbw[RR]);
         });
         // (4) traceback words, step-major (fully coalesced)
         if constexpr (MODE == MODE_PATH) {
@@ -579,6 +608,7 @@ struct WaveDP {
                 seed_aux = (cis >= 1 && cis - 1 <= tlast) ? (tn4p[cis - 1] & 0xff) : 0;
             }
         }
+        if constexpr (SUB) { sub_cp = seqs.sub_colptr + job.sub_off; sub_rows = seqs.sub_rows; }
         first_state = job.first_state; final_state = CONT ? job.final_state : M::END;
         first_cell = job.first_cell;
         min_intron = kp->min_intron; max_intron = kp->max_intron;
@@ -666,6 +696,7 @@ struct WaveDP {
                 seed_aux = (cis >= 1 && cis - 1 <= tlast) ? (tn4p[cis - 1] & 0xff) : 0;
             }
         }
+        if constexpr (SUB) { sub_cp = seqs.sub_colptr + job.sub_off; sub_rows = seqs.sub_rows; }
         first_state = job.first_state; final_state = M::END;
         first_cell = job.first_cell;
         min_intron = kp->min_intron; max_intron = kp->max_intron;
@@ -885,11 +916,11 @@ struct WaveDP {
 // Kernel: persistent waves, one job at a time per wave.
 // -------------------------------------------------------------------------------------------------------------
 // WPE: waves per SIMD the register allocator must leave room for (1 = no cap: 512 unified registers)
-template <class M, int R, int MODE, bool CONT, bool LOCAL, bool PACK, int WPE>
+template <class M, int R, int MODE, bool CONT, bool LOCAL, bool PACK, int WPE, bool SUB = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void viterbi_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs,
                                                      int n_jobs, DevResult *results, DevVsa *vsas, uint8_t *ops,
                                                      DevScratch scratch, int *queue) {
-    using DP = WaveDP<M, R, MODE, CONT, LOCAL, PACK>;
+    using DP = WaveDP<M, R, MODE, CONT, LOCAL, PACK, SUB>;
     __shared__ KParams kp_lds;
     __shared__ int next_job;
     __shared__ long long run_off;

@@ -160,12 +160,18 @@ typedef struct {
     c4gpu_score first_cell[1 + C4GPU_MAX_SHADOWS + 3];
 } c4gpu_continuation;
 
+/* SubOpt, src/c4/subopt.h:33-48: the cells blocked by the alignments already reported for one pair
+ * (sequence coordinates).  Opaque; see c4gpu_subopt_* below. */
+typedef struct c4gpu_subopt c4gpu_subopt;
+
 typedef struct {
     int32_t      pair;                      /* index into the pair array */
     c4gpu_region region;
     int32_t      use_continuation;          /* model is run with CORNER/CORNER scopes (viterbi.c:68-76) */
     c4gpu_continuation continuation;
     int32_t      checkpoint_count;          /* FIND_CHECKPOINTS: Viterbi_checkpoint_rows (viterbi.c:207) */
+    const c4gpu_subopt *subopt;             /* NULL, or what Viterbi_calculate builds its SubOpt_Index from
+                                               (viterbi.c:846-865): MATCH transitions skip blocked cells */
 } c4gpu_viterbi_job;
 
 typedef struct {
@@ -221,8 +227,19 @@ int         c4gpu_checkpoint_rows(const c4gpu_model *model, const c4gpu_region *
 int         c4gpu_splice_predict(c4gpu_ctx *ctx, const c4gpu_params *params,
                                  const uint8_t *target, int32_t target_len, int32_t *out[4]);
 
-/* Viterbi_DP_Func (viterbi.h:95-98) for a batch of independent jobs in one mode.
- * soi (SubOpt_Index) must be NULL on the reference side: sub-optimal blocking is not accelerated. */
+/* SubOpt_create / _destroy / _add_alignment (subopt.c:24-148).  add_alignment blocks the cells every
+ * MATCH-labelled operation of `a` leaves from (and the lead-in cells of multi-residue matches), skipping
+ * cells already present.  add_point is for callers that hold the reference's own SubOpt / SubOpt_Index
+ * and only mirror it.  points() returns the total and writes up to `max` points sorted
+ * by target then query — the order SubOpt_Index_create (subopt.c:250) sorts them in. */
+c4gpu_subopt *c4gpu_subopt_create(int32_t query_length, int32_t target_length);
+void        c4gpu_subopt_destroy(c4gpu_subopt *subopt);
+int         c4gpu_subopt_add_alignment(c4gpu_subopt *subopt, const c4gpu_model *model, const c4gpu_alignment *a);
+int         c4gpu_subopt_add_point(c4gpu_subopt *subopt, int32_t query_pos, int32_t target_pos);
+int32_t     c4gpu_subopt_points(const c4gpu_subopt *subopt, int32_t *query_pos, int32_t *target_pos, int32_t max);
+
+/* Viterbi_DP_Func (viterbi.h:95-98) for a batch of independent jobs in one mode.  A job's `subopt` plays
+ * the part of the soi argument: the device evaluates SubOpt_Index_is_blocked for the job's region. */
 int         c4gpu_viterbi_batch(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params,
                                 int mode, const c4gpu_pair *pairs, int32_t n_pairs,
                                 const c4gpu_viterbi_job *jobs, int32_t n_jobs,
@@ -242,6 +259,15 @@ int         c4gpu_optimal_find_path_batch(c4gpu_ctx *ctx, const c4gpu_model *mod
                                           const c4gpu_pair *pairs, int32_t n_pairs,
                                           int dpmemory_mb, c4gpu_score threshold,
                                           c4gpu_alignment *alignments);
+/* The same with sub-optimal blocking: subopts[i] (may be NULL) is pair i's SubOpt, as the `subopt`
+ * argument of Optimal_find_path (optimal.c:368); active[i] == 0 (active may be NULL = all) skips pair i.
+ * One round of GAM_Result_exhaustive_create's do/while loop (gam.c:1158-1172) for every pair at once. */
+int         c4gpu_optimal_find_path_batch_subopt(c4gpu_ctx *ctx, const c4gpu_model *model,
+                                                 const c4gpu_params *params,
+                                                 const c4gpu_pair *pairs, int32_t n_pairs,
+                                                 int dpmemory_mb, c4gpu_score threshold,
+                                                 const c4gpu_subopt *const *subopts, const uint8_t *active,
+                                                 c4gpu_alignment *alignments);
 void        c4gpu_alignment_clear(c4gpu_alignment *a);
 
 /* Device-resident batches (bench / shim hot loop): upload once, run many times. */
@@ -252,6 +278,12 @@ void         c4gpu_batch_destroy(c4gpu_batch *b);
 /* One pass of the hot path over the resident batch. `what`: 0 = score pass only (FIND_SCORE),
  * 1 = region pass only, 2 = full Optimal_find_path.  Results stay on the object. */
 int          c4gpu_batch_run(c4gpu_batch *b, int what, int dpmemory_mb, c4gpu_score threshold);
+/* The sub-optimal loop on the resident batch: after c4gpu_batch_run(b, 2, ...), each call blocks the
+ * alignments found so far (SubOpt_add_alignment, gam.c:673) and finds the next best path of every pair
+ * that still had one in the previous round; pairs whose score drops below `threshold` leave the loop.
+ * Returns the number of alignments found in this round (0 = loop finished), -1 on error.
+ * c4gpu_batch_alignment then returns this round's alignment (valid = 0 for pairs that have left). */
+int          c4gpu_batch_next_paths(c4gpu_batch *b, int dpmemory_mb, c4gpu_score threshold);
 int          c4gpu_batch_scores(c4gpu_batch *b, c4gpu_score *scores, c4gpu_region *regions);
 int          c4gpu_batch_alignment(c4gpu_batch *b, int32_t i, c4gpu_alignment *out);
 /* Accumulated device time (ms), launches and lattice cells of the Viterbi kernel of one mode

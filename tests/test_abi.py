@@ -88,3 +88,30 @@ def test_printers_match_the_oracle(lib, params):
                     lib.c4gpu_alignment_format(m, a, what, *args, b1, len(b1))
                     olib.oracle_alignment_format(m, a, what, *args, b2, len(b2))
                     assert b1.value == b2.value
+
+
+def test_subopt_point_sets_match_reference(lib, params):
+    """c4gpu_subopt_add_alignment (host side, no device) against the blocked point set the reference itself
+    held after each alignment of its sub-optimal loop (SubOpt_add_alignment, subopt.c:131)."""
+    from golden_util import SUBOPT_SETS, load_set, get_model
+    checked = 0
+    for name in sorted(SUBOPT_SETS):
+        model = get_model(lib, params, name)
+        for rec in load_set(name):
+            so = lib.c4gpu_subopt_create(len(rec["query"]), len(rec["target"]))
+            for aln in rec["subopt"]:
+                a = _abi.Alignment()
+                a.score, a.region, a.n_ops, a.valid = aln["path_score"], _abi.Region(*aln["region"]), len(aln["ops"]), 1
+                tr = (C.c_int32 * max(1, a.n_ops))(*[o[0] for o in aln["ops"]])
+                ln = (C.c_int32 * max(1, a.n_ops))(*[o[1] for o in aln["ops"]])
+                a.op_transition, a.op_length = C.cast(tr, C.POINTER(C.c_int32)), C.cast(ln, C.POINTER(C.c_int32))
+                assert lib.c4gpu_subopt_add_alignment(so, model, a) == 0
+                if "points" not in aln:
+                    continue
+                n = lib.c4gpu_subopt_points(so, None, None, 0)
+                q, t = (C.c_int32 * max(1, n))(), (C.c_int32 * max(1, n))()
+                lib.c4gpu_subopt_points(so, q, t, n)
+                assert [[q[i], t[i]] for i in range(n)] == aln["points"], (name, rec["id"])
+                checked += 1
+            lib.c4gpu_subopt_destroy(so)
+    assert checked > 50

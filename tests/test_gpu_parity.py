@@ -10,7 +10,7 @@ import pytest
 import exonerate_amd as ex
 from exonerate_amd import _abi
 import oracle_lib
-from golden_util import SETS, load_set, expected
+from golden_util import SETS, SUBOPT_SETS, load_set, expected
 
 pytestmark = pytest.mark.gpu
 
@@ -141,6 +141,89 @@ def test_raw_viterbi_modes_match_oracle(eng):
     # slot 1 (intron shadow) of a non-intron state is never read again: the engine reports 0 there
     assert got["final_cell"][0] == vo.final_cell[0] and got["final_cell"][vo.cell_size - 1] == vo.final_cell[vo.cell_size - 1]
     olib.oracle_viterbi_out_clear(vo)
+
+
+@pytest.mark.parametrize("name", sorted(SUBOPT_SETS))
+def test_suboptimal_loop_matches_reference_vectors(eng, name):
+    """GAM_Result_exhaustive_create's loop with SubOpt blocking on the device (viterbi.c:701-704) against
+    the successive alignments the reference itself produced — all pairs of the set in one batch per round."""
+    mt, qa, ta = SUBOPT_SETS[name]
+    model = ex.Model(mt, qa, ta)
+    recs = load_set(name)
+    pairs = [(r["query"], r["target"]) for r in recs]
+    found = eng.find_all_paths(model, pairs, dpmemory=recs[0]["dpmemory"], threshold=recs[0]["threshold"],
+                               max_paths=3 if "global" in name else 6)
+    for rec, alns in zip(recs, found):
+        assert len(alns) == len(rec["subopt"]), rec["id"]
+        for a, exp in zip(alns, rec["subopt"]):
+            assert (a.score, list(a.region), [list(o) for o in a.ops], a.vulgar(rec["id"])) == \
+                   (exp["path_score"], exp["region"], exp["ops"], exp["vulgar"]), rec["id"]
+
+
+def test_resident_batch_suboptimal_loop(eng):
+    """c4gpu_batch_next_paths == the per-call loop == the reference vectors."""
+    recs = load_set("est2genome_subopt")
+    model = ex.Model("est2genome")
+    batch = ex.ResidentBatch(eng, model, [(r["query"], r["target"]) for r in recs])
+    thr = recs[0]["threshold"]
+    batch.run(2, 32, thr)
+    rounds = [[batch.alignment(i) for i in range(len(recs))]]
+    while len(rounds) < 6 and batch.next_paths(32, thr) > 0:
+        rounds.append([batch.alignment(i) for i in range(len(recs))])
+    batch.close()
+    for i, rec in enumerate(recs):
+        got = [r[i] for r in rounds if r[i] is not None]
+        assert [(a.score, a.vulgar(rec["id"])) for a in got] == \
+               [(e["path_score"], e["vulgar"]) for e in rec["subopt"]][:len(got)], rec["id"]
+        assert len(got) == min(len(rec["subopt"]), 6)
+
+
+def test_seeded_suboptimal_pairs_match_oracle(eng):
+    """Larger seeded repeats (several 64*R strips, reduced-space route at -D 1) against the oracle's loop."""
+    rng = random.Random(77)
+    for model_type, qlen, dpm in (("affine:local", 400, 1), ("est2genome", 300, 1), ("est2genome", 520, 32)):
+        model = ex.Model(model_type)
+        pairs = []
+        for k in range(3):
+            q = _rand(rng, qlen + 7 * k)
+            if model_type == "est2genome":
+                c = qlen // 2
+                gene = _mutate(rng, q[:c], 0.03) + "GT" + _rand(rng, 400) + "AG" + _mutate(rng, q[c:], 0.03)
+                t = _rand(rng, 80) + gene + _rand(rng, 200) + _mutate(rng, gene, 0.05) + _rand(rng, 60)
+            else:
+                t = _rand(rng, 30) + _mutate(rng, q, 0.05) + _rand(rng, 90) + _mutate(rng, q, 0.15) + _rand(rng, 20)
+            pairs.append((q, t))
+        found = eng.find_all_paths(model, pairs, dpmemory=dpm, threshold=100, max_paths=4)
+        for (q, t), alns in zip(pairs, found):
+            exp = oracle_lib.find_paths_subopt(model.c, model.params, q.encode(), t.encode(), dpm, 100, 4)
+            assert [a.as_dict() for a in alns] == [d for d, _ in exp]
+            assert len(alns) >= 2
+
+
+def test_raw_viterbi_with_blocked_cells_matches_oracle(eng):
+    """Viterbi_DP_Func level with a soi: the region pass of the second alignment."""
+    olib = oracle_lib.load()
+    model = ex.Model("affine:local")
+    rng = random.Random(11)
+    q = _rand(rng, 300)
+    t = _rand(rng, 20) + _mutate(rng, q, 0.05) + _rand(rng, 50) + _mutate(rng, q, 0.1)
+    first = eng.find_path(model, [(q, t)])[0]
+    so = ex.SubOpt(len(q), len(t))
+    so.add_alignment(first)
+    oso = olib.oracle_subopt_create(len(q), len(t))
+    olib.oracle_subopt_add_alignment(oso, model.c, first._c())
+    assert so.points() == oracle_lib.subopt_points(oso)
+    region = (0, 0, len(q), len(t))
+    got = eng.viterbi(model, ex.MODE_FIND_REGION, [(q, t)], [{"pair": 0, "region": region, "subopt": so}])[0]
+    vo = oracle_lib.ViterbiOut()
+    olib.oracle_viterbi_subopt(model.c, model.params, ex.MODE_FIND_REGION, q.encode(), len(q), t.encode(), len(t),
+                               _abi.Region(*region), None, 0, oso, vo)
+    assert (got["score"], got["query_start"], got["target_start"], got["query_end"], got["target_end"]) == \
+           (vo.score, vo.query_start, vo.target_start, vo.query_end, vo.target_end)
+    assert got["score"] < first.score
+    olib.oracle_viterbi_out_clear(vo)
+    olib.oracle_subopt_destroy(oso)
+    so.close()
 
 
 def test_residue_outside_alphabet_is_rejected(eng):
