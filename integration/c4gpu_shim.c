@@ -3,7 +3,7 @@
  * It provides `Bootstrapper_lookup`, the name-keyed plug-in table Viterbi_create consults
  * (src/c4/viterbi.c:81-90).  For names of accelerated (model x mode) functions it returns a
  * Viterbi_DP_Func (src/c4/viterbi.h:95-98) backed by the GPU engine; for everything else, and for calls
- * with sub-optimal blocking (soi != NULL), it hands over to the reference's own generated CPU function
+ * (sub-optimal blocking, soi != NULL, IS accelerated: the index is mirrored into a c4gpu_subopt) it hands over to the reference's own generated CPU function
  * (`Bootstrapper_lookup_cpu` = the generated lookup of the compiled-model archive, renamed at link time by
  * integration/Makefile).  Host code, model builders, FASTA I/O, GAM, printers: all untouched reference C.
  *
@@ -193,7 +193,8 @@ static C4_Score shim_dp(C4_Model *model, Region *region, Viterbi_Data *vd, SubOp
     register gchar *qstr, *tstr;
     register gint i, j, k, l, cs = vd->vr->cell_size;
     register C4_Score score;
-    if(soi || (!shim_get_ctx()) || shim_forcegtag() || (!shim_flatten(model, ud, &fm))){
+    c4gpu_subopt *blocked = NULL;
+    if((!shim_get_ctx()) || shim_forcegtag() || (!shim_flatten(model, ud, &fm))){
         if(!cpu_func)
             g_error("c4gpu shim: no CPU implementation to fall back to");
         return cpu_func(model, region, vd, soi, user_data);
@@ -216,14 +217,30 @@ static C4_Score shim_dp(C4_Model *model, Region *region, Viterbi_Data *vd, SubOp
         }
     if(mode == C4GPU_MODE_FIND_CHECKPOINTS)
         job.checkpoint_count = vd->checkpoint->checkpoint_list->len;
-    if(c4gpu_viterbi_batch(shim_ctx, &fm, &params, mode, &pair, 1, &job, 1, &r) != 0){
+    if(soi){
+        /* the index holds the blocked cells of this region in region coordinates, one row per target
+         * position plus a trailing blank row (subopt.c:270-318): hand them over as sequence coordinates */
+        blocked = c4gpu_subopt_create(ud->query->len, ud->target->len);
+        for(k = 0; k < (gint)soi->row_list->len - 1; k++){
+            SubOpt_Index_Row *row = soi->row_list->pdata[k];
+            for(l = 0; l < row->total; l++)
+                c4gpu_subopt_add_point(blocked, region->query_start + row->query_pos[l],
+                                                region->target_start + row->target_pos);
+            }
+        job.subopt = blocked;
+        }
+    i = c4gpu_viterbi_batch(shim_ctx, &fm, &params, mode, &pair, 1, &job, 1, &r);
+    if(blocked)
+        c4gpu_subopt_destroy(blocked);
+    if(i != 0){
         g_warning("c4gpu: %s -- using the CPU Viterbi for this call", c4gpu_last_error());
         g_free(qstr); g_free(tstr);
         return cpu_func(model, region, vd, soi, user_data);
         }
     if(shim_verbose)
-        g_message("c4gpu: %s mode %d region %d %d %d %d -> %d", model->name, mode, region->query_start,
-                  region->target_start, region->query_length, region->target_length, r.score);
+        g_message("c4gpu: %s mode %d region %d %d %d %d%s -> %d", model->name, mode, region->query_start,
+                  region->target_start, region->query_length, region->target_length,
+                  soi?" with blocked cells":"", r.score);
     score = r.score;
     /* out-parameters by mode (viterbi.c:464-478,633-653,813-832) */
     vd->curr_query_end = r.query_end;

@@ -68,3 +68,34 @@ def test_exonerate_gpu_output_is_byte_identical(tmp_path, model, extra):
     assert "c4gpu:" in gpu_err, "the GPU engine was not used:\n" + gpu_err[-1500:]
     assert gpu_out == ref_out
     assert ref_out.count("vulgar:") >= 3
+
+
+@pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
+                    reason="reference binaries are built in the build container (make -C integration)")
+@pytest.mark.parametrize("model", ["est2genome", "affine:local"])
+def test_exonerate_gpu_suboptimal_alignments(tmp_path, model):
+    """Targets with two copies of the gene: the default exhaustive run reports both (GAM's sub-optimal loop,
+    gam.c:1158-1172); the calls that carry a SubOpt_Index go to the device as well."""
+    rng = random.Random(31)
+    dna = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    mut = lambda s, r: "".join((rng.choice("ACGT") if rng.random() < r else c) for c in s)
+    qs, ts = [], []
+    for n in range(2):
+        q = dna(400 + 50 * n)
+        if model == "est2genome":
+            gene = q[:180] + "GT" + dna(700) + "AG" + q[180:]
+        else:
+            gene = q
+        t = dna(300) + mut(gene, 0.02) + dna(500) + mut(gene, 0.06) + dna(400)
+        qs.append(("qy%d" % n, q))
+        ts.append(("tg%d" % n, t))
+    qf, tf = str(tmp_path / "q.fa"), str(tmp_path / "t.fa")
+    _fasta(qf, qs)
+    _fasta(tf, ts)
+    args = ["-m", model, "-E", "yes", "-S", "yes", "--showalignment", "no", "--showvulgar", "yes", "-V", "0",
+            "--score", "300", qf, tf]
+    ref_out, _ = _run(CPU_EXE, args)
+    gpu_out, gpu_err = _run(GPU_EXE, args, {"C4GPU_VERBOSE": "1"})
+    assert "with blocked cells" in gpu_err
+    assert gpu_out == ref_out
+    assert ref_out.count("vulgar:") >= 4          # both copies, for both queries
