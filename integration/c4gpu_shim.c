@@ -343,3 +343,208 @@ gpointer Bootstrapper_lookup(gchar *name){
     shim_slot[shim_slot_count].cpu = cpu;
     return (gpointer)shim_funcs[shim_slot_count++];
     }
+
+/* ---- the batching seam ------------------------------------------------------------------------------------ */
+/* One pair per Viterbi call leaves a 256-CU device idle.  The exhaustive front end hands every pair to
+ * GAM_Result_exhaustive_create (analysis.c:218-230 -> gam.c:1139) and prints what comes back at once; this
+ * replacement (the archive's own definition is renamed GAM_Result_exhaustive_create_cpu by the Makefile)
+ * only COLLECTS (gam, query, target) and returns NULL.  Every C4GPU_BATCH pairs, and before the final
+ * GAM_report, the collected pairs go through c4gpu_batch_run / c4gpu_batch_next_paths in one piece; then
+ * each pair is replayed IN SUBMISSION ORDER through the reference's own GAM_Result_exhaustive_create_cpu,
+ * whose Optimal_find_path calls (also fronted here) are answered from the batch results.  Thresholds that
+ * move while results are submitted (--bestn, gam.c:683-692) are honoured in the replay: the k-th best path
+ * of a pair does not depend on the threshold, only whether it is reported does. */
+#include "gam.h"
+#include "optimal.h"
+#include "alignment.h"
+#include "modeltype.h"
+
+extern GAM_Result *GAM_Result_exhaustive_create_cpu(GAM *gam, Sequence *query, Sequence *target);
+extern void GAM_report_cpu(GAM *gam);
+extern Alignment *Optimal_find_path_cpu(Optimal *optimal, Region *region, gpointer user_data,
+                                        C4_Score threshold, SubOpt *subopt);
+
+typedef struct {
+    GAM *gam;
+    Sequence *query, *target;
+    c4gpu_alignment *round;        /* round[k] = k-th alignment of the pair; valid == 0 ends the loop */
+    gint round_total;
+    gboolean done;
+} ShimPending;
+
+static GPtrArray *shim_pending = NULL;
+static ShimPending *shim_replay_pair = NULL;
+static gint shim_replay_call = 0;
+
+static gint shim_batch_size(void){
+    static gint size = -1;
+    if(size < 0)
+        size = g_getenv("C4GPU_BATCH") ? atoi(g_getenv("C4GPU_BATCH")) : 4096;
+    return size;
+    }
+
+static gboolean shim_can_batch(GAM *gam, Sequence *query, Sequence *target){
+    register gpointer ud;
+    register gboolean ok;
+    c4gpu_model fm;
+    if((shim_batch_size() <= 0) || (!gam->optimal) || (!shim_get_ctx()) || shim_forcegtag())
+        return FALSE;
+    if((gam->gas->refinement != GAM_Refinement_NONE) || gam->gas->percent_threshold)
+        return FALSE;  /* refinement re-enters Optimal_find_path; %-thresholds can sit below --score */
+    if((gam->optimal->type & (Optimal_Type_SCORE|Optimal_Type_PATH|Optimal_Type_REDUCED_SPACE))
+       != (Optimal_Type_SCORE|Optimal_Type_PATH|Optimal_Type_REDUCED_SPACE))
+        return FALSE;
+    ud = Model_Type_create_data(gam->gas->type, query, target);
+    ok = shim_flatten(gam->optimal->find_path->model, ud, &fm);
+    Model_Type_destroy_data(gam->gas->type, ud);
+    return ok;
+    }
+
+static void shim_flush(void){
+    register guint i, n;
+    register gint k, rounds_max = g_getenv("C4GPU_BATCH_ROUNDS") ? atoi(g_getenv("C4GPU_BATCH_ROUNDS")) : 4;
+    register GAM *gam;
+    register ShimPending *sp;
+    register c4gpu_batch *batch = NULL;
+    register gpointer ud;
+    register C4_Score threshold;
+    register gint dpmemory;
+    c4gpu_model fm;
+    c4gpu_params params;
+    c4gpu_pair *pair;
+    gchar **str;
+    GPtrArray *todo = shim_pending;
+    if((!todo) || (!todo->len))
+        return;
+    shim_pending = NULL;          /* pairs submitted while replaying start a new collection */
+    n = todo->len;
+    sp = todo->pdata[0];
+    gam = sp->gam;
+    threshold = gam->gas->threshold;
+    dpmemory = gam->optimal->find_path->vas->traceback_memory_limit;
+    pair = g_new0(c4gpu_pair, n);
+    str = g_new0(gchar*, 2*n);
+    for(i = 0; i < n; i++){
+        sp = todo->pdata[i];
+        str[2*i] = Sequence_get_str(sp->query);
+        str[2*i+1] = Sequence_get_str(sp->target);
+        pair[i].query = (const uint8_t*)str[2*i];    pair[i].query_len = sp->query->len;
+        pair[i].target = (const uint8_t*)str[2*i+1]; pair[i].target_len = sp->target->len;
+        }
+    sp = todo->pdata[0];
+    ud = Model_Type_create_data(gam->gas->type, sp->query, sp->target);
+    if(shim_flatten(gam->optimal->find_path->model, ud, &fm)){
+        shim_params(ud, &params);
+        batch = c4gpu_batch_create(shim_ctx, &fm, &params, pair, n);
+        }
+    Model_Type_destroy_data(gam->gas->type, ud);
+    if(batch && (c4gpu_batch_run(batch, 2, dpmemory, threshold) == 0)){
+        if(!gam->gas->use_subopt)
+            rounds_max = 1;
+        for(k = 0; k < rounds_max; k++){
+            register gint found = 1;
+            if(k && ((found = c4gpu_batch_next_paths(batch, dpmemory, threshold)) < 0))
+                break;
+            for(i = 0; i < n; i++){
+                sp = todo->pdata[i];
+                if(sp->done)
+                    continue;                          /* this pair left the loop in an earlier round */
+                sp->round = g_renew(c4gpu_alignment, sp->round, k+1);
+                if(c4gpu_batch_alignment(batch, i, &sp->round[k]) != 0)
+                    memset(&sp->round[k], 0, sizeof(c4gpu_alignment));
+                sp->round_total = k+1;
+                sp->done = !sp->round[k].valid;        /* the entry that ends the pair's loop is kept */
+                }
+            if(!found){
+                k++;
+                break;
+                }
+            }
+        if(shim_verbose)
+            g_message("c4gpu: batch of %d pairs, %d round(s) on the device", n, k);
+    } else {
+        g_warning("c4gpu: %s -- batch falls back to per-call", c4gpu_last_error());
+        }
+    if(batch)
+        c4gpu_batch_destroy(batch);
+    for(i = 0; i < 2*n; i++)
+        g_free(str[i]);
+    g_free(str);
+    g_free(pair);
+    /* replay in submission order through the reference's own code */
+    for(i = 0; i < n; i++){
+        register GAM_Result *gam_result;
+        sp = todo->pdata[i];
+        shim_replay_pair = sp;
+        shim_replay_call = 0;
+        gam_result = GAM_Result_exhaustive_create_cpu(sp->gam, sp->query, sp->target);
+        shim_replay_pair = NULL;
+        if(gam_result){
+            GAM_Result_submit(gam_result);
+            GAM_Result_destroy(gam_result);
+            }
+        for(k = 0; k < sp->round_total; k++)
+            c4gpu_alignment_clear(&sp->round[k]);
+        g_free(sp->round);
+        GAM_destroy(sp->gam);
+        Sequence_destroy(sp->query);
+        Sequence_destroy(sp->target);
+        g_free(sp);
+        }
+    g_ptr_array_free(todo, TRUE);
+    return;
+    }
+
+GAM_Result *GAM_Result_exhaustive_create(GAM *gam, Sequence *query, Sequence *target){
+    register ShimPending *sp;
+    if(shim_replay_pair || (!shim_can_batch(gam, query, target))){
+        shim_flush();             /* keep the output order */
+        return GAM_Result_exhaustive_create_cpu(gam, query, target);
+        }
+    if(shim_pending && shim_pending->len
+    && (((ShimPending*)shim_pending->pdata[0])->gam != gam))
+        shim_flush();
+    if(!shim_pending)
+        shim_pending = g_ptr_array_new();
+    sp = g_new0(ShimPending, 1);
+    sp->gam = GAM_share(gam);
+    sp->query = Sequence_share(query);
+    sp->target = Sequence_share(target);
+    g_ptr_array_add(shim_pending, sp);
+    if((gint)shim_pending->len >= shim_batch_size())
+        shim_flush();
+    return NULL;                  /* the result is submitted by the flush, in submission order */
+    }
+
+void GAM_report(GAM *gam){        /* analysis.c:1421: after the last pair */
+    shim_flush();
+    GAM_report_cpu(gam);
+    return;
+    }
+
+Alignment *Optimal_find_path(Optimal *optimal, Region *region, gpointer user_data,
+                             C4_Score threshold, SubOpt *subopt){
+    register ShimPending *sp = shim_replay_pair;
+    register c4gpu_alignment *a;
+    register Alignment *alignment;
+    register Region *ar;
+    register C4_Model *model = optimal->find_path->model;
+    register gint k;
+    if((!sp) || (shim_replay_call >= sp->round_total)
+    || region->query_start || region->target_start
+    || (region->query_length != (gint)sp->query->len) || (region->target_length != (gint)sp->target->len)){
+        if(sp)
+            shim_replay_call = G_MAXINT/2;     /* once off the recorded sequence, stay off it */
+        return Optimal_find_path_cpu(optimal, region, user_data, threshold, subopt);
+        }
+    a = &sp->round[shim_replay_call++];
+    if((!a->valid) || (a->score < threshold))
+        return NULL;                            /* optimal.c:144-145,408-411 */
+    ar = Region_create(a->region.query_start, a->region.target_start,
+                       a->region.query_length, a->region.target_length);
+    alignment = Alignment_create(model, ar, a->score);
+    Region_destroy(ar);
+    for(k = 0; k < a->n_ops; k++)
+        Alignment_add(alignment, model->transition_list->pdata[a->op_transition[k]], a->op_length[k]);
+    return alignment;
+    }

@@ -27,12 +27,16 @@ def _run(exe, args, env=None):
 
 @pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
                     reason="reference binaries are built in the build container (make -C integration)")
-@pytest.mark.parametrize("model,extra", [
-    ("est2genome", []), ("est2genome", ["-D", "1"]), ("affine:local", []), ("affine:global", []),
-    ("protein2dna", []), ("protein2genome", []),
+@pytest.mark.parametrize("model,extra,batch", [
+    ("est2genome", [], "4096"), ("est2genome", ["-D", "1"], "4096"), ("affine:local", [], "4096"),
+    ("affine:global", [], "4096"), ("protein2dna", [], "4096"), ("protein2genome", [], "4096"),
+    # C4GPU_BATCH=0: every Viterbi call goes to the device on its own (the plain Bootstrapper_lookup shim);
+    # 2: several flushes of the batching seam; --bestn: thresholds that move while results are submitted
+    ("est2genome", [], "0"), ("affine:local", ["-D", "1"], "0"), ("protein2genome", [], "0"),
+    ("est2genome", [], "2"), ("affine:local", ["--bestn", "1"], "4"), ("est2genome", ["--bestn", "2", "-S", "yes"], "4096"),
 ])
-def test_exonerate_gpu_output_is_byte_identical(tmp_path, model, extra):
-    rng = random.Random(len(model) * 7 + len(extra))
+def test_exonerate_gpu_output_is_byte_identical(tmp_path, model, extra, batch):
+    rng = random.Random(len(model) * 7 + len([e for e in extra if e in ("-D", "1")]))
     dna = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
     aa = lambda n: "".join(rng.choice("ARNDCQEGHILKMFPSTWYV") for _ in range(n))
     table = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"
@@ -61,19 +65,21 @@ def test_exonerate_gpu_output_is_byte_identical(tmp_path, model, extra):
     qf, tf = str(tmp_path / "q.fa"), str(tmp_path / "t.fa")
     _fasta(qf, qs)
     _fasta(tf, ts)
-    args = ["-m", model, "-E", "yes", "-S", "no", "--showalignment", "yes", "--showvulgar", "yes",
-            "--showcigar", "yes", "-V", "0"] + extra + [qf, tf]
+    args = ["-m", model, "-E", "yes", "--showalignment", "yes", "--showvulgar", "yes",
+            "--showcigar", "yes", "-V", "0"] + ([] if "-S" in extra else ["-S", "no"]) + extra + [qf, tf]
     ref_out, _ = _run(CPU_EXE, args)
-    gpu_out, gpu_err = _run(GPU_EXE, args, {"C4GPU_VERBOSE": "1"})
+    gpu_out, gpu_err = _run(GPU_EXE, args, {"C4GPU_VERBOSE": "1", "C4GPU_BATCH": batch})
     assert "c4gpu:" in gpu_err, "the GPU engine was not used:\n" + gpu_err[-1500:]
+    assert ("c4gpu: batch of" in gpu_err) == (batch != "0"), gpu_err[-1500:]
     assert gpu_out == ref_out
-    assert ref_out.count("vulgar:") >= 3
+    assert ref_out.count("vulgar:") >= (1 if "--bestn" in extra else 3)
 
 
 @pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
                     reason="reference binaries are built in the build container (make -C integration)")
-@pytest.mark.parametrize("model", ["est2genome", "affine:local"])
-def test_exonerate_gpu_suboptimal_alignments(tmp_path, model):
+@pytest.mark.parametrize("model,batch", [("est2genome", "4096"), ("affine:local", "4096"), ("est2genome", "0"),
+                                         ("affine:local", "3")])
+def test_exonerate_gpu_suboptimal_alignments(tmp_path, model, batch):
     """Targets with two copies of the gene: the default exhaustive run reports both (GAM's sub-optimal loop,
     gam.c:1158-1172); the calls that carry a SubOpt_Index go to the device as well."""
     rng = random.Random(31)
@@ -95,7 +101,10 @@ def test_exonerate_gpu_suboptimal_alignments(tmp_path, model):
     args = ["-m", model, "-E", "yes", "-S", "yes", "--showalignment", "no", "--showvulgar", "yes", "-V", "0",
             "--score", "300", qf, tf]
     ref_out, _ = _run(CPU_EXE, args)
-    gpu_out, gpu_err = _run(GPU_EXE, args, {"C4GPU_VERBOSE": "1"})
-    assert "with blocked cells" in gpu_err
+    gpu_out, gpu_err = _run(GPU_EXE, args, {"C4GPU_VERBOSE": "1", "C4GPU_BATCH": batch})
+    if batch == "0":
+        assert "with blocked cells" in gpu_err        # per-call: the SubOpt_Index itself crossed the boundary
+    else:
+        assert "round(s) on the device" in gpu_err and "with blocked cells" not in gpu_err
     assert gpu_out == ref_out
     assert ref_out.count("vulgar:") >= 4          # both copies, for both queries
