@@ -137,9 +137,12 @@ class SubOpt:
 def _pairs(pairs):
     arr = (_abi.Pair * max(1, len(pairs)))()
     keep = []
+    seen = {}                      # equal sequences share one buffer: the library uploads each buffer once
     for i, (q, t) in enumerate(pairs):
         q = q if isinstance(q, bytes) else q.encode()
         t = t if isinstance(t, bytes) else t.encode()
+        q = seen.setdefault(q, q)
+        t = seen.setdefault(t, t)
         keep.append((q, t))
         arr[i].query, arr[i].query_len, arr[i].target, arr[i].target_len = q, len(q), t, len(t)
     return arr, keep

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "c4gpu.h"
@@ -136,8 +137,8 @@ __global__ void encode_kernel(const uint8_t *__restrict__ in, uint8_t *__restric
 // protein2dna target: row of the residue encoded by the codon starting at each position
 // (Translate_base, translate.h:73-76, then the submat index)
 __global__ void codon_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const long long *off,
-                             const int *len, const PrepTables *__restrict__ tab, int *bad) {
-    const int pair = blockIdx.y;
+                             const int *len, int n_seqs, const PrepTables *__restrict__ tab, int *bad) {
+  for (int pair = blockIdx.y; pair < n_seqs; pair += gridDim.y) {
     const uint8_t *s = in + off[pair];
     uint8_t *o = out + off[pair];
     const int n = len[pair];
@@ -150,13 +151,14 @@ __global__ void codon_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict
         }
         o[x] = code;
     }
+  }
 }
 
 // split-codon calcs (phase.c:188-208) re-read bases around an intron: per position the 4-bit base masks
 // (Translate nt2d, translate.h:40-50) of positions p, p-1, p-2, p-3
 __global__ void tn4_kernel(const uint8_t *__restrict__ in, uint16_t *__restrict__ out, const long long *off,
-                           const int *len, const PrepTables *__restrict__ tab) {
-    const int pair = blockIdx.y;
+                           const int *len, int n_seqs, const PrepTables *__restrict__ tab) {
+  for (int pair = blockIdx.y; pair < n_seqs; pair += gridDim.y) {
     const uint8_t *s = in + off[pair];
     uint16_t *o = out + off[pair];
     const int n = len[pair];
@@ -166,16 +168,18 @@ __global__ void tn4_kernel(const uint8_t *__restrict__ in, uint16_t *__restrict_
             if (x - d >= 0) v |= (unsigned)tab->nt2d[s[x - d]] << (4 * d);
         o[x] = (uint16_t)v;
     }
+  }
 }
 
 // SplicePredictor_predict_array_int (splice.c:383-397): float accumulation left to right over the PSSM
 // window clipped to the sequence (Splice_predict_position, splice.c:320-344), rounded half away from
 // zero in double (SplicePredictor_round, splice.c:379-381).  Plain adds only: no contraction possible.
-__global__ void splice_kernel(const uint8_t *__restrict__ seq, const long long *off, const int *len,
+__global__ void splice_kernel(const uint8_t *__restrict__ seq, const long long *off, const int *len, int n_seqs,
                               const c4gpu_splice_model *__restrict__ models, int *__restrict__ out,
                               long long stride) {
-    const int pair = blockIdx.y, type = blockIdx.z;
-    const c4gpu_splice_model *sp = &models[type];
+  const int type = blockIdx.z;
+  const c4gpu_splice_model *sp = &models[type];
+  for (int pair = blockIdx.y; pair < n_seqs; pair += gridDim.y) {
     const uint8_t *s = seq + off[pair];
     const int n = len[pair];
     int *o = out + (long long)type * stride + off[pair];
@@ -188,6 +192,7 @@ __global__ void splice_kernel(const uint8_t *__restrict__ seq, const long long *
         const double r = score < 0 ? (double)score - 0.5 : (double)score + 0.5;
         o[pos] = (int)r;
     }
+  }
 }
 
 // ---- resident sequences of a batch --------------------------------------------------------------------------
@@ -222,21 +227,40 @@ struct ResidentSeqs {
     DevBuf<int> bad;
     DevSeqs dev;
 
+    // Pairs that hand over the same host buffer (same pointer and length: one genomic contig against many
+    // queries, all-vs-all front ends) share one device copy and one set of derived arrays.
+    int n_utargets = 0;
+    DevBuf<long long> d_utoff;
+    DevBuf<int> d_utlen;
+
     int build(c4gpu_ctx *ctx, int family, const c4gpu_params *params, const c4gpu_pair *pairs, int n) {
         n_pairs = n;
         qoff.resize(n); toff.resize(n); qlen.resize(n); tlen.resize(n);
         total_q = total_t = 0;
+        std::map<std::pair<const uint8_t *, int>, long long> qseen, tseen;
+        std::vector<int> uq, ut;                      // first pair that holds each unique sequence
+        std::vector<long long> utoff;
+        std::vector<int> utlen;
         for (int i = 0; i < n; i++) {
-            qoff[i] = total_q; toff[i] = total_t;
             qlen[i] = pairs[i].query_len; tlen[i] = pairs[i].target_len;
-            total_q += (pairs[i].query_len + 3) & ~3LL;
-            total_t += (pairs[i].target_len + 3) & ~3LL;
+            auto qk = std::make_pair(pairs[i].query, qlen[i]);
+            auto qi = qseen.find(qk);
+            if (qi == qseen.end()) {
+                qseen[qk] = total_q; qoff[i] = total_q; uq.push_back(i);
+                total_q += (qlen[i] + 3) & ~3LL;
+            } else qoff[i] = qi->second;
+            auto tk = std::make_pair(pairs[i].target, tlen[i]);
+            auto ti = tseen.find(tk);
+            if (ti == tseen.end()) {
+                tseen[tk] = total_t; toff[i] = total_t; ut.push_back(i);
+                utoff.push_back(total_t); utlen.push_back(tlen[i]);
+                total_t += (tlen[i] + 3) & ~3LL;
+            } else toff[i] = ti->second;
         }
+        n_utargets = (int)ut.size();
         std::vector<uint8_t> hq(total_q + 64, 'A'), ht(total_t + 64, 'A');
-        for (int i = 0; i < n; i++) {
-            if (qlen[i]) memcpy(&hq[qoff[i]], pairs[i].query, qlen[i]);
-            if (tlen[i]) memcpy(&ht[toff[i]], pairs[i].target, tlen[i]);
-        }
+        for (int i : uq) if (qlen[i]) memcpy(&hq[qoff[i]], pairs[i].query, qlen[i]);
+        for (int i : ut) if (tlen[i]) memcpy(&ht[toff[i]], pairs[i].target, tlen[i]);
         PrepTables pt;
         memcpy(pt.submat_index, params->submat_index, 256);
         memcpy(pt.nt2d, params->nt2d, 256);
@@ -245,7 +269,8 @@ struct ResidentSeqs {
         hipStream_t s = ctx->stream;
         if (tables.upload(&pt, 1, s) || qraw.upload(hq.data(), hq.size(), s) || traw.upload(ht.data(), ht.size(), s) ||
             qcode.alloc(hq.size()) || tcode.alloc(ht.size()) || d_qoff.upload(qoff.data(), n, s) ||
-            d_toff.upload(toff.data(), n, s) || d_qlen.upload(qlen.data(), n, s) || d_tlen.upload(tlen.data(), n, s))
+            d_toff.upload(toff.data(), n, s) || d_qlen.upload(qlen.data(), n, s) || d_tlen.upload(tlen.data(), n, s) ||
+            d_utoff.upload(utoff.data(), n_utargets, s) || d_utlen.upload(utlen.data(), n_utargets, s))
             return -1;
         int zero = 0;
         if (bad.upload(&zero, 1, s)) return -1;
@@ -253,9 +278,9 @@ struct ResidentSeqs {
         hipLaunchKernelGGL(encode_kernel, dim3(blocks), dim3(256), 0, s, qraw.p, qcode.p, (long long)hq.size(), tables.p, bad.p);
         int max_t = 1;
         for (int i = 0; i < n; i++) max_t = std::max(max_t, tlen[i]);
-        const int xb = std::min(256, (max_t + 255) / 256);
+        const int xb = std::min(256, (max_t + 255) / 256), yb = std::max(1, std::min(n_utargets, 32768));
         if (family_is_p2d(family)) {
-            hipLaunchKernelGGL(codon_kernel, dim3(xb, n), dim3(256), 0, s, traw.p, tcode.p, d_toff.p, d_tlen.p, tables.p, bad.p);
+            hipLaunchKernelGGL(codon_kernel, dim3(xb, yb), dim3(256), 0, s, traw.p, tcode.p, d_utoff.p, d_utlen.p, n_utargets, tables.p, bad.p);
         } else {
             hipLaunchKernelGGL(encode_kernel, dim3(blocks), dim3(256), 0, s, traw.p, tcode.p, (long long)ht.size(), tables.p, bad.p);
         }
@@ -263,7 +288,7 @@ struct ResidentSeqs {
         dev.ss_stride = 0;
         if (family_has_splice(family)) {
             if (splice_models.upload(params->splice, 4, s) || ss.alloc((size_t)4 * ht.size())) return -1;
-            hipLaunchKernelGGL(splice_kernel, dim3(xb, n, 4), dim3(256), 0, s, traw.p, d_toff.p, d_tlen.p,
+            hipLaunchKernelGGL(splice_kernel, dim3(xb, yb, 4), dim3(256), 0, s, traw.p, d_utoff.p, d_utlen.p, n_utargets,
                                splice_models.p, ss.p, (long long)ht.size());
             dev.ss = ss.p;
             dev.ss_stride = (long long)ht.size();
@@ -271,7 +296,7 @@ struct ResidentSeqs {
         dev.tn4 = nullptr;
         if (family_has_phase(family)) {
             if (tn4.alloc(ht.size())) return -1;
-            hipLaunchKernelGGL(tn4_kernel, dim3(xb, n), dim3(256), 0, s, traw.p, tn4.p, d_toff.p, d_tlen.p, tables.p);
+            hipLaunchKernelGGL(tn4_kernel, dim3(xb, yb), dim3(256), 0, s, traw.p, tn4.p, d_utoff.p, d_utlen.p, n_utargets, tables.p);
             dev.tn4 = tn4.p;
         }
         HIP_OK(hipGetLastError());

@@ -62,3 +62,64 @@ def affine_dna_pairs(n_pairs, qlen=1000, seed=20260930, first=0):
         q = _rand(rng, qlen)
         pairs.append((q.tobytes(), _mutate(rng, q, 0.10).tobytes()))
     return pairs
+
+
+_CODONS = None
+
+
+def _codon_table():
+    """amino acid -> list of codons (standard genetic code)."""
+    global _CODONS
+    if _CODONS is None:
+        table = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"
+        _CODONS = {}
+        for i, a in enumerate("TCAG"):
+            for j, b in enumerate("TCAG"):
+                for k, c in enumerate("TCAG"):
+                    _CODONS.setdefault(table[i * 16 + j * 4 + k], []).append((a + b + c).encode())
+    return _CODONS
+
+
+def _encode_protein(rng, prot):
+    cod = _codon_table()
+    return b"".join(cod[chr(a)][int(rng.integers(0, len(cod[chr(a)])))] for a in prot)
+
+
+def protein_vs_contig(n_proteins, plen=500, contig_len=1000000, seed=20260931, introns=False, mutation=0.05):
+    """C3 (protein2dna) / C5 (protein2genome, introns=True): `n_proteins` proteins against ONE contig that
+    holds a codon-encoded, `mutation`-mutated copy of each at a known place.  Returns (proteins, contig,
+    [(start, end) of each planted gene])."""
+    rng = np.random.default_rng([seed, 0])
+    proteins = [_rand(rng, plen, AA) for _ in range(n_proteins)]
+    genes = []
+    for p in proteins:
+        m = _mutate(rng, p, mutation, AA)
+        coding = _encode_protein(rng, m)
+        if introns:
+            cuts = np.sort(rng.choice(np.arange(30, len(coding) - 30), size=int(rng.integers(1, 4)), replace=False))
+            parts, last = [], 0
+            for c in list(cuts) + [len(coding)]:
+                parts.append(coding[last:c])
+                last = c
+            g = parts[0]
+            for ex in parts[1:]:
+                g += b"GT" + _rand(rng, int(rng.integers(100, 3000)) - 4).tobytes() + b"AG" + ex
+            coding = g
+        genes.append(coding)
+    total = sum(len(g) for g in genes)
+    gaps = contig_len - total
+    assert gaps > 0, "contig too short for the planted genes"
+    cutp = np.sort(rng.integers(0, gaps + 1, size=n_proteins))
+    out, places, last, pos = [], [], 0, 0
+    for g, c in zip(genes, cutp):
+        flank = _rand(rng, int(c - last)).tobytes()
+        out.append(flank)
+        pos += len(flank)
+        places.append((pos, pos + len(g)))
+        out.append(g)
+        pos += len(g)
+        last = c
+    out.append(_rand(rng, contig_len - pos).tobytes())
+    contig = b"".join(out)
+    assert len(contig) == contig_len
+    return [p.tobytes() for p in proteins], contig, places

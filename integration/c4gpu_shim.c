@@ -424,12 +424,24 @@ static void shim_flush(void){
     dpmemory = gam->optimal->find_path->vas->traceback_memory_limit;
     pair = g_new0(c4gpu_pair, n);
     str = g_new0(gchar*, 2*n);
-    for(i = 0; i < n; i++){
-        sp = todo->pdata[i];
-        str[2*i] = Sequence_get_str(sp->query);
-        str[2*i+1] = Sequence_get_str(sp->target);
-        pair[i].query = (const uint8_t*)str[2*i];    pair[i].query_len = sp->query->len;
-        pair[i].target = (const uint8_t*)str[2*i+1]; pair[i].target_len = sp->target->len;
+    {   /* one flattened copy per Sequence: pairs that share a Sequence share the buffer, and the library
+         * keeps one device copy (and one set of splice arrays) per buffer */
+        register GHashTable *flat = g_hash_table_new(g_direct_hash, g_direct_equal);
+        for(i = 0; i < n; i++){
+            register gchar *qs, *ts;
+            sp = todo->pdata[i];
+            if(!(qs = g_hash_table_lookup(flat, sp->query))){
+                qs = str[2*i] = Sequence_get_str(sp->query);
+                g_hash_table_insert(flat, sp->query, qs);
+                }
+            if(!(ts = g_hash_table_lookup(flat, sp->target))){
+                ts = str[2*i+1] = Sequence_get_str(sp->target);
+                g_hash_table_insert(flat, sp->target, ts);
+                }
+            pair[i].query = (const uint8_t*)qs;  pair[i].query_len = sp->query->len;
+            pair[i].target = (const uint8_t*)ts; pair[i].target_len = sp->target->len;
+            }
+        g_hash_table_destroy(flat);
         }
     sp = todo->pdata[0];
     ud = Model_Type_create_data(gam->gas->type, sp->query, sp->target);
