@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -404,6 +405,15 @@ struct Engine {
 
     int run_impl(const ResidentSeqs &seqs, int mode, bool cont, const std::vector<JobSpec> &specs,
                  std::vector<JobOut> &out, const std::vector<RegionPoints> *pts) {
+        static const bool trace = getenv("C4GPU_TRACE") != nullptr;
+        const auto t_begin = std::chrono::steady_clock::now();
+        struct Trace {
+            bool on; std::chrono::steady_clock::time_point t0; int mode, n;
+            ~Trace() {
+                if (on) fprintf(stderr, "c4gpu trace: run mode %d jobs %d host+device %.3f ms\n", mode, n,
+                                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+            }
+        } tr{trace, t_begin, mode, (int)specs.size()};
         const int n = (int)specs.size();
         out.assign(n, JobOut());
         if (!n) return 0;
@@ -473,7 +483,12 @@ struct Engine {
         HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, ki->func, 64 * ki->waves, 0));
         if (blocks_per_cu < 1) blocks_per_cu = 1;
         long long grid = std::min<long long>(n, (long long)blocks_per_cu * ctx->prop.multiProcessorCount);
-        const long long bnd_per_wave = 2 * (max_T + 1) * (long long)std::max(ki->bnd, 1);
+        // strip carry rows in HBM are only needed when a job has more strips than one workgroup holds at once
+        // (one for the single-wave kernels, `waves` for the cooperating ones)
+        long long carry_T = 0;
+        for (int x = 0; x < n; x++)
+            if ((jobs[x].Q + 1 + 64 * ki->R - 1) / (64 * ki->R) > ki->waves) carry_T = max_T;
+        const long long bnd_per_wave = 2 * ((carry_T ? carry_T : 0) + 1) * (long long)std::max(ki->bnd, 1);
         const long long bytes_per_wave = bnd_per_wave * 4 + max_tb * 4 + max_ckpt * 4 + max_runs * 4;
         // compact run array: paths are mostly long runs, so a fraction of the worst case is plenty; a
         // launch that overflows it is repeated with the worst case
@@ -505,7 +520,7 @@ struct Engine {
                 a.seqs.sub_colptr = d_sub_colptr.p; a.seqs.sub_rows = d_sub_q.p;
             }
             a.vsas = d_vsa.p; a.ops = nullptr; a.queue = d_queue.p; a.grid = (int)grid; a.stream = s;
-            a.scratch.bnd = d_bnd.p; a.scratch.bnd_stride = bnd_per_wave;
+            a.scratch.bnd = d_bnd.p; a.scratch.bnd_stride = bnd_per_wave; a.scratch.carry = carry_T ? 1 : 0;
             a.scratch.tb = max_tb ? d_tb.p : nullptr; a.scratch.tb_stride = max_tb;
             a.scratch.ckpt = max_ckpt ? d_ckpt.p : nullptr; a.scratch.ckpt_stride = max_ckpt;
             a.scratch.ckpt_dump = d_ckpt_dump.p;

@@ -81,6 +81,7 @@ struct DevResult {
 struct DevVsa { int qs, ts, ql, tl, first_state, pad[3]; int final_cell[CELL_MAX]; };
 struct DevScratch {                      // per persistent wave slabs
     int *bnd;       long long bnd_stride;
+    int carry;                                    // 0: bnd holds one dummy column per workgroup
     uint32_t *tb;   long long tb_stride;
     int *ckpt;      long long ckpt_stride;
     int *ckpt_dump;
@@ -413,8 +414,10 @@ struct WaveDP {
     lds_int *ring_in, *ring_out;
     bool use_ring_in, use_ring_out;                     // the row above / below lives in LDS (LDS offset 0 is a
                                                         // valid address, so a null test cannot tell)
+    bool carry_ok;      // the launch allocated HBM carry rows (some job has more strips than waves per job)
     __device__ __forceinline__ void prefetch_carry(int s_next, const int *bnd_in) {
-        const int jc = s_next < 0 ? 0 : (s_next > T ? T : s_next);
+        const int jx = s_next < 0 ? 0 : (s_next > T ? T : s_next);
+        const int jc = (carry_ok | use_ring_in) ? jx : 0;      // without carry rows every load hits column 0
         if (use_ring_in) {
             for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
                 const lds_int *p = ring_in + (jc & (RING - 1)) * BND + slot;
@@ -647,8 +650,8 @@ struct WaveDP {
             });
             if constexpr (!CONT) strip_begin();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const int *bnd_in = bnd + (long long)((b + 1) & 1) * (T + 1) * BND;
-            int *bnd_out = bnd + (long long)(b & 1) * (T + 1) * BND;
+            const int *bnd_in = bnd + (carry_ok ? (long long)((b + 1) & 1) * (T + 1) * BND : 0);
+            int *bnd_out = bnd + (carry_ok ? (long long)(b & 1) * (T + 1) * BND : 0);
             const bool first = (b == 0), last = (b == nstrips - 1);
             const int nsteps = T + 64;
             const int main_lo = 63 + M::MAXAT, main_hi = T;          // steps where every lane is interior in j
@@ -735,8 +738,8 @@ struct WaveDP {
             });
             strip_begin();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const int *bnd_in = bnd + (long long)((sb + 1) & 1) * (T + 1) * BND;
-            int *bnd_out = bnd + (long long)(sb & 1) * (T + 1) * BND;
+            const int *bnd_in = bnd + (carry_ok ? (long long)((sb + 1) & 1) * (T + 1) * BND : 0);
+            int *bnd_out = bnd + (carry_ok ? (long long)(sb & 1) * (T + 1) * BND : 0);
             use_ring_in = wid > 0;  use_ring_out = wid < NW - 1;
             ring_in = rings + (wid > 0 ? wid - 1 : 0) * RING * BND;
             ring_out = rings + (wid < NW - 1 ? wid : 0) * RING * BND;
@@ -945,6 +948,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
         DP dp;
         dp.kp = &kp_lds;
         dp.lane = threadIdx.x;
+        dp.carry_ok = scratch.carry != 0;
         int *ckpt = ckpt_slab;
         if constexpr (MODE == MODE_CKPT)
             if (job.ckpt_off >= 0) ckpt = scratch.ckpt_dump + job.ckpt_off;
@@ -1028,6 +1032,7 @@ void viterbi_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *jobs,
         DP dp;
         dp.kp = &kp_lds;
         dp.lane = threadIdx.x & 63;
+        dp.carry_ok = scratch.carry != 0;
         dp.template run_mw<NW>(job, seqs, bnd, (typename DP::lds_int *)rings, wid);
         dp.reduce_best();
         if (dp.lane == 0) {
