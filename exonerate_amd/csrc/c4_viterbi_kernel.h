@@ -264,29 +264,41 @@ struct WaveDP {
             if constexpr (t.aq > 0) valid = valid & i_ok;
             if constexpr (t.at > 0 && !JINT) valid = valid & (j >= t.at);
             if constexpr (t.in == M::START && !LOCAL)
-                valid = valid & scope_ok(start_scope, i - t.aq == 0, j - t.at == 0);
+                valid = valid & (CONT ? ((i - t.aq == 0) & (j - t.at == 0))
+                                      : scope_ok(start_scope, i - t.aq == 0, j - t.at == 0));
             if constexpr (t.out == M::END && !LOCAL)
-                valid = valid & scope_ok(end_scope, i == Q, j == T);
+                valid = valid & (CONT ? ((i == Q) & (j == T)) : scope_ok(end_scope, i == Q, j == T));
             // sub-optimal blocking: MATCH transitions do not enter a blocked cell (viterbi.c:701-704)
             if constexpr (SUB && t.label == LABEL_MATCH) valid = valid & !blocked;
-            // continuation seeding (viterbi.c:705-714): first cell into the first state, at the corner only
+            // A continuation runs with CORNER scopes (viterbi.c:68-76): a transition out of START is valid in
+            // the origin cell only.  Instantiations that cannot hold the origin (rows below the lane's first,
+            // steps where every lane is past column 0) drop those transitions at compile time.
+            if constexpr (CONT && t.in == M::START && ((RR > 0 && t.aq == 0) || (JINT && t.at == 0))) return;
+            // ... and a transition into END only in the far corner (Q, T): one cell of the whole job
+            if constexpr (CONT && t.out == M::END) {
+                if (!__builtin_amdgcn_ballot_w64(valid)) return;
+            }
+            // continuation seeding (viterbi.c:705-714): first cell into the first state, at the corner only;
+            // behind a wave-uniform branch, it happens in one cell of the whole job
             if constexpr (CONT && t.in == M::START) {
-                static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
-                    const bool seed = valid & (first_state == S);
-                    const int old_sc = c.sc[S], fc0 = first_cell[0];
-                    c.sc[S] = seed ? fc0 : old_sc;
-                    static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
-                        if constexpr (X > 0) {
-                            if constexpr (slot_live(S, E)) {
-                                // register slot -> reference cell slot (the base slot is re-derived)
-                                const int old_ex = c.ex[S][E];
-                                const int fce = (NAUX && E == AUX) ? seed_aux : first_cell[1 + E - (E > AUX ? NAUX : 0)];
-                                c.ex[S][E] = seed ? fce : old_ex;
+                if (__builtin_amdgcn_ballot_w64(valid)) {
+                    static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                        const bool seed = valid & (first_state == S);
+                        const int old_sc = c.sc[S], fc0 = first_cell[0];
+                        c.sc[S] = seed ? fc0 : old_sc;
+                        static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
+                            if constexpr (X > 0) {
+                                if constexpr (slot_live(S, E)) {
+                                    // register slot -> reference cell slot (the base slot is re-derived)
+                                    const int old_ex = c.ex[S][E];
+                                    const int fce = (NAUX && E == AUX) ? seed_aux : first_cell[1 + E - (E > AUX ? NAUX : 0)];
+                                    c.ex[S][E] = seed ? fce : old_ex;
+                                }
                             }
-                        }
+                        });
+                        set[S] = set[S] | seed;
                     });
-                    set[S] = set[S] | seed;
-                });
+                }
             }
             // source cell: same cell (silent), row above (lane-local or the neighbour's), earlier columns
             constexpr int PD = (PH - t.at + NCOL) % NCOL;
