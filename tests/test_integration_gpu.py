@@ -108,3 +108,28 @@ def test_exonerate_gpu_suboptimal_alignments(tmp_path, model, batch):
         assert "round(s) on the device" in gpu_err and "with blocked cells" not in gpu_err
     assert gpu_out == ref_out
     assert ref_out.count("vulgar:") >= 4          # both copies, for both queries
+
+
+@pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
+                    reason="reference binaries are built in the build container (make -C integration)")
+@pytest.mark.parametrize("refine", ["region", "full"])
+def test_exonerate_gpu_heuristic_with_refinement(tmp_path, refine):
+    """The default (heuristic, BSDP) mode with --refine: seeding, BSDP and its small derived-model DPs stay on
+    the reference's CPU code; the refinement's Optimal_find_path (gam.c:605-655) runs on the device."""
+    rng = random.Random(5)
+    dna = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    qs, ts = [], []
+    for n in range(3):
+        q = dna(600 + 100 * n)
+        t = dna(2000) + q[:200] + "GT" + dna(1500) + "AG" + q[200:420] + "GT" + dna(3000) + "AG" + q[420:] + dna(2500)
+        qs.append(("qy%d" % n, q))
+        ts.append(("tg%d" % n, t))
+    qf, tf = str(tmp_path / "q.fa"), str(tmp_path / "t.fa")
+    _fasta(qf, qs)
+    _fasta(tf, ts)
+    args = ["-m", "est2genome", "--refine", refine, "--showalignment", "yes", "--showvulgar", "yes", "-V", "0", qf, tf]
+    ref_out, _ = _run(CPU_EXE, args)
+    gpu_out, gpu_err = _run(GPU_EXE, args, {"C4GPU_VERBOSE": "1"})
+    assert "c4gpu: est2genome mode" in gpu_err, gpu_err[-1500:]
+    assert gpu_out == ref_out
+    assert ref_out.count("vulgar:") >= 3
