@@ -31,12 +31,36 @@ extern gpointer Bootstrapper_lookup_cpu(gchar *name);
 static c4gpu_ctx *shim_ctx = NULL;
 static gboolean shim_tried = FALSE, shim_verbose = FALSE;
 
+/* ---- command line: --gpu / --gpudevice / --gpubatch beside -C/--compiled (codegen.c:25-37) ---------------- */
+/* exonerate.c:85 calls Codegen_ArgumentSet_create(arg) once while it assembles its option sets; the archive's
+ * definition is renamed Codegen_ArgumentSet_create_cpu by the Makefile and this one adds ours after it. */
+extern Codegen_ArgumentSet *Codegen_ArgumentSet_create_cpu(Argument *arg);
+static struct { gboolean use_gpu; gint device; gint batch; } shim_args = {TRUE, 0, 4096};
+
+Codegen_ArgumentSet *Codegen_ArgumentSet_create(Argument *arg){
+    register Codegen_ArgumentSet *cas = Codegen_ArgumentSet_create_cpu(arg);
+    register ArgumentSet *as;
+    if(arg){
+        as = ArgumentSet_create("GPU options (libc4gpu, MI355X)");
+        ArgumentSet_add_option(as, '\0', "gpu", NULL,
+                "Run the optimal (exhaustive / refinement) Viterbi passes on the GPU", "TRUE",
+                Argument_parse_boolean, &shim_args.use_gpu);
+        ArgumentSet_add_option(as, '\0', "gpudevice", "ordinal",
+                "HIP device to use", "0", Argument_parse_int, &shim_args.device);
+        ArgumentSet_add_option(as, '\0', "gpubatch", "pairs",
+                "Pairs of an exhaustive run collected per GPU batch (0 = one Viterbi call at a time)", "4096",
+                Argument_parse_int, &shim_args.batch);
+        Argument_absorb_ArgumentSet(arg, as);
+        }
+    return cas;
+    }
+
 static c4gpu_ctx *shim_get_ctx(void){
     if(!shim_tried){
         shim_tried = TRUE;
         shim_verbose = (g_getenv("C4GPU_VERBOSE") != NULL);
-        if(!g_getenv("C4GPU_DISABLE")){
-            shim_ctx = c4gpu_ctx_create(g_getenv("C4GPU_DEVICE") ? atoi(g_getenv("C4GPU_DEVICE")) : 0);
+        if(shim_args.use_gpu && (!g_getenv("C4GPU_DISABLE"))){
+            shim_ctx = c4gpu_ctx_create(g_getenv("C4GPU_DEVICE") ? atoi(g_getenv("C4GPU_DEVICE")) : shim_args.device);
             if(!shim_ctx)
                 g_warning("c4gpu: %s -- using the CPU Viterbi", c4gpu_last_error());
             }
@@ -331,7 +355,7 @@ gpointer Bootstrapper_lookup(gchar *name){
     register int mode = shim_mode_of(name);
     register Viterbi_DP_Func cpu = (Viterbi_DP_Func)Bootstrapper_lookup_cpu(name);
     /* only the Optimal (full Viterbi) functions are ours: "optimal_58_<model>_32_find_32_<mode>" */
-    if((mode < 0) || strncmp(name, "optimal_58_", 11) || g_getenv("C4GPU_DISABLE"))
+    if((mode < 0) || strncmp(name, "optimal_58_", 11) || g_getenv("C4GPU_DISABLE") || (!shim_args.use_gpu))
         return (gpointer)cpu;
     for(i = 0; i < shim_slot_count; i++)
         if(!strcmp(shim_slot[i].name, name))
@@ -379,7 +403,7 @@ static gint shim_replay_call = 0;
 static gint shim_batch_size(void){
     static gint size = -1;
     if(size < 0)
-        size = g_getenv("C4GPU_BATCH") ? atoi(g_getenv("C4GPU_BATCH")) : 4096;
+        size = g_getenv("C4GPU_BATCH") ? atoi(g_getenv("C4GPU_BATCH")) : shim_args.batch;
     return size;
     }
 

@@ -133,3 +133,25 @@ def test_exonerate_gpu_heuristic_with_refinement(tmp_path, refine):
     assert "c4gpu: est2genome mode" in gpu_err, gpu_err[-1500:]
     assert gpu_out == ref_out
     assert ref_out.count("vulgar:") >= 3
+
+
+@pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
+                    reason="reference binaries are built in the build container (make -C integration)")
+def test_exonerate_gpu_command_line_switch(tmp_path):
+    """--gpu no (beside -C/--compiled, codegen.c:25-37) keeps every call on the reference's CPU code;
+    --gpubatch 0 selects the per-call shim."""
+    rng = random.Random(9)
+    dna = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    q = dna(300)
+    qf, tf = str(tmp_path / "q.fa"), str(tmp_path / "t.fa")
+    _fasta(qf, [("qy", q)])
+    _fasta(tf, [("tg", dna(200) + q[:150] + "GT" + dna(400) + "AG" + q[150:] + dna(100))])
+    args = ["-m", "est2genome", "-E", "yes", "-S", "no", "--showalignment", "no", "--showvulgar", "yes", "-V", "0", qf, tf]
+    ref_out, _ = _run(CPU_EXE, args)
+    off_out, off_err = _run(GPU_EXE, ["--gpu", "no"] + args, {"C4GPU_VERBOSE": "1"})
+    assert "c4gpu" not in off_err and off_out.replace("--gpu no ", "") == ref_out
+    one_out, one_err = _run(GPU_EXE, ["--gpubatch", "0"] + args, {"C4GPU_VERBOSE": "1"})
+    assert "c4gpu: est2genome mode" in one_err and "batch of" not in one_err
+    assert one_out.replace("--gpubatch 0 ", "") == ref_out
+    help_out = subprocess.run([GPU_EXE, "--help"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
+    assert "--gpu" in help_out and "--gpubatch" in help_out
