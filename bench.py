@@ -74,6 +74,42 @@ def cpu_baseline(args, rank, model, pairs, batch, eng):
             "checked_bit_exact_vs_gpu": True}
 
 
+def cpu_baseline_all_cores(pairs, batch):
+    """the reference's only multi-core story is N independent processes
+    (--querychunkid/--querychunktotal, exonerate.c:64-75): one reference process per host core, each on its own
+    pair of the batch, all at once.  Every vulgar line is also compared with the GPU's."""
+    import subprocess, tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "exonerate-compiled")
+    if not os.path.exists(exe):
+        return None
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    n = max(1, min(cores, len(pairs), 64))
+    cells = sum((len(pairs[k][0]) + 1) * (len(pairs[k][1]) + 1) for k in range(n))
+    with tempfile.TemporaryDirectory() as d:
+        for k in range(n):
+            open(os.path.join(d, "q%d.fa" % k), "w").write(">qy\n%s\n" % pairs[k][0].decode())
+            open(os.path.join(d, "t%d.fa" % k), "w").write(">tg\n%s\n" % pairs[k][1].decode())
+        c0 = time.perf_counter()
+        procs = [subprocess.Popen([exe, "-m", "est2genome", "-E", "yes", "-S", "no", "--revcomp", "no",
+                                   "--showalignment", "no", "--showvulgar", "yes", "-V", "0",
+                                   os.path.join(d, "q%d.fa" % k), os.path.join(d, "t%d.fa" % k)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for k in range(n)]
+        outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+        wall = time.perf_counter() - c0
+    same = 0
+    for k, o in enumerate(outs):
+        ref = [l.strip() for l in o.splitlines() if l.startswith("vulgar:")]
+        got = batch.alignment(k)
+        assert ref and got is not None and got.vulgar("qy", "tg") == ref[0], "pair %d: GPU vulgar differs from the reference" % k
+        same += 1
+    return {"value": cells / wall, "unit": "cells/s", "cores": n, "kind": "reference",
+            "sample": "pairs 0..%d of the batch, one reference process per core, %.1f s wall" % (n - 1, wall),
+            "vulgar_identical_to_gpu": same}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,6 +225,11 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, rank, model, pairs, batch, eng)
             out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["value"] / world
+            if out["cpu_baseline"]["kind"] == "reference":
+                allc = cpu_baseline_all_cores(pairs, batch)
+                if allc:
+                    out["cpu_baseline_all_cores"] = allc
+                    out["speedup_vs_cpu_all_cores"] = value / allc["value"] / world
     batch.close()
     eng.close()
     if use_dist:
