@@ -15,6 +15,10 @@ SETS = {
     "est2genome_D0": ("est2genome", 0, 0), "protein2dna_D0": ("protein2dna", 1, 0),
     "est2genome_big": ("est2genome", 0, 0),
     "protein2genome": ("protein2genome", 1, 0), "protein2genome_D0": ("protein2genome", 1, 0),
+    "ungapped_dna": ("ungapped", 0, 0), "ungapped_protein": ("ungapped", 1, 1), "ungapped_dna_D0": ("ungapped", 0, 0),
+    "protein2dna_bestfit": ("protein2dna:bestfit", 1, 0), "protein2dna_bestfit_D0": ("protein2dna:bestfit", 1, 0),
+    "protein2genome_bestfit": ("protein2genome:bestfit", 1, 0),
+    "protein2genome_bestfit_D0": ("protein2genome:bestfit", 1, 0),
 }
 
 

@@ -229,6 +229,14 @@ def main():
     t = rand_dna(rng2, 300) + q[:250] + "GT" + rand_dna(rng2, 700) + "AG" + q[250:520] + "GT" + \
         rand_dna(rng2, 1500) + "AG" + q[520:] + rand_dna(rng2, 400)
     sets.append(("est2genome_big", "est2genome", [("estbig0", q, t)], 32, ()))
+    # the remaining accelerated model types: ungapped (dna, protein, protein vs dna) and the bestfit forms
+    sets.append(("ungapped_dna", "ungapped", [c for c in dna if len(c[1]) > 0 and len(c[2]) > 0], 32, ()))
+    sets.append(("ungapped_protein", "ungapped:protein", [c for c in prot if len(c[1]) > 0 and len(c[2]) > 0], 32, ()))
+    sets.append(("ungapped_dna_D0", "ungapped", big, 0, ()))
+    sets.append(("protein2dna_bestfit", "protein2dna:bestfit", [c for c in p2d if len(c[2]) > 30], 32, ()))
+    sets.append(("protein2dna_bestfit_D0", "protein2dna:bestfit", [c for c in p2d if len(c[2]) > 30], 0, ()))
+    sets.append(("protein2genome_bestfit", "protein2genome:bestfit", p2g, 32, ()))
+    sets.append(("protein2genome_bestfit_D0", "protein2genome:bestfit", p2g, 0, ()))
     # sub-optimal alignments (SubOpt blocking, src/c4/subopt.c) through the GAM loop
     so = ("--suboptmax", "6", "--suboptthreshold", "30")
     rs = random.Random(4242)
