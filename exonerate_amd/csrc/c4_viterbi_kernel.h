@@ -426,6 +426,7 @@ struct WaveDP {
     lds_int *ring_in, *ring_out;
     bool use_ring_in, use_ring_out;                     // the row above / below lives in LDS (LDS offset 0 is a
                                                         // valid address, so a null test cannot tell)
+    int cp_next_j, cp_next_i;   // FIND_CHECKPOINTS: column / index of the next checkpoint this lane will cross
     bool carry_ok;      // the launch allocated HBM carry rows (some job has more strips than waves per job)
     __device__ __forceinline__ void prefetch_carry(int s_next, const int *bnd_in) {
         const int jx = s_next < 0 ? 0 : (s_next > T ? T : s_next);
@@ -581,31 +582,46 @@ struct WaveDP {
                 });
             }
         }
-        // (7) checkpoint rows (Viterbi_Checkpoint_process, viterbi.c:605-631)
+        // (7) checkpoint rows (Viterbi_Checkpoint_process, viterbi.c:605-631).  At checkpoint column c the
+        // reference copies rows c, c-1, .. c-(MAXAT-1) and then stamps their SRP slots.  A column never
+        // changes after it has been computed, so each of those rows is copied out at the step that
+        // computes it (while its cells are in registers anyway): older columns then only keep the
+        // states later transitions still read, exactly as in the other modes.  The SRP stamp stays at
+        // column c: until then transitions must read the previous checkpoint's SRP.
         if constexpr (MODE == MODE_CKPT) {
-            const bool at_cp = jact && j > 0 && (j % section_length == 0) && (j / section_length - 1 < cp_count);
-            if (at_cp) {
-                const int cpi = j / section_length - 1;
+            const bool cp_live = jact & (cp_next_i < cp_count);
+            static_for<M::MAXAT>([&](auto ROW_) __attribute__((always_inline)) { constexpr int ROW = ROW_;
+                if (cp_live & (j + ROW == cp_next_j)) {
+                    static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                        const int i = i0 + RR;
+                        if (i <= Q) {
+                            int *p = ckpt + ((((long long)cp_next_i * M::MAXAT + ROW) * (Q + 1) + i) * M::NS) * CS;
+                            static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                                export_cell<S>(col[PH][RR], p + S * CS);
+                            });
+                        }
+                    });
+                }
+            });
+            if (cp_live & (j == cp_next_j)) {
+                // the stamps only depend on the lane's rows: keep the compiler from hoisting ~100 of them
+                // out of the column loop into registers that would then be live through every step
+                int i0v = i0;
+                asm volatile("" : "+v"(i0v));
                 static_for<M::MAXAT>([&](auto ROW_) __attribute__((always_inline)) { constexpr int ROW = ROW_;
                     constexpr int PR = (PH - ROW + NCOL) % NCOL;
                     static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
-                        const int i = i0 + RR;
-                        C &cell = col[PR][RR];
-                        if (i <= Q) {
-                            int *p = ckpt + ((((long long)cpi * M::MAXAT + ROW) * (Q + 1) + i) * M::NS) * CS;
-                            static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
-                                export_cell<S>(cell, p + S * CS);
-                            });
-                        }
+                        const int i = i0v + RR;
                         static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
-                            cell.ex[S][SRP] = ((i * M::NS) + S) * M::MAXAT + ROW;     // viterbi.c:515-522
+                            col[PR][RR].ex[S][SRP] = ((i * M::NS) + S) * M::MAXAT + ROW;     // viterbi.c:515-522
                         });
                     });
                     // our copies of row i0-1 at these columns get the same edit
                     static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
-                        nbr[PR].ex[S][SRP] = (((i0 - 1) * M::NS) + S) * M::MAXAT + ROW;
+                        nbr[PR].ex[S][SRP] = (((i0v - 1) * M::NS) + S) * M::MAXAT + ROW;
                     });
                 });
+                cp_next_i += 1; cp_next_j += section_length;
             }
         }
     }
@@ -661,6 +677,7 @@ struct WaveDP {
                 });
             });
             if constexpr (!CONT) strip_begin();
+            cp_next_j = section_length > 0 ? section_length : 0x7fffffff; cp_next_i = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             const int *bnd_in = bnd + (carry_ok ? (long long)((b + 1) & 1) * (T + 1) * BND : 0);
             int *bnd_out = bnd + (carry_ok ? (long long)(b & 1) * (T + 1) * BND : 0);
