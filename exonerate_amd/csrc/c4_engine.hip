@@ -414,6 +414,10 @@ struct Engine {
                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
             }
         } tr{trace, t_begin, mode, (int)specs.size()};
+        auto lap = [&](const char *what) {
+            if (trace) fprintf(stderr, "c4gpu trace:   %-18s at %.3f ms\n", what,
+                               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+        };
         const int n = (int)specs.size();
         out.assign(n, JobOut());
         if (!n) return 0;
@@ -441,7 +445,11 @@ struct Engine {
         std::vector<int> order(n);
         std::iota(order.begin(), order.end(), 0);
         auto cells = [&](int i) { return (long long)(specs[i].region.query_length + 1) * (specs[i].region.target_length + 1); };
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cells(a) > cells(b); });
+        {
+            std::vector<long long> key(n);
+            for (int i = 0; i < n; i++) key[i] = cells(i);
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] > key[b]; });
+        }
         std::vector<DevJob> jobs(n);
         long long ops_total = 0, vsa_total = 0, dump_total = 0, max_T = 0, max_tb = 0, max_ckpt = 0, total_cells = 0;
         long long max_runs = 0, sub_cols = 0;
@@ -478,6 +486,7 @@ struct Engine {
                 if (s.dump_checkpoints) { j.ckpt_off = dump_total; dump_total += ck; }
             }
         }
+        lap("jobs built");
         // persistent grid: as many waves as the device keeps resident, bounded by the scratch it implies
         int blocks_per_cu = 0;
         HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, ki->func, 64 * ki->waves, 0));
@@ -527,6 +536,7 @@ struct Engine {
             a.scratch.runs = d_runs.p; a.scratch.runs_stride = max_runs;
             a.scratch.runs_out = d_runs_out.p; a.scratch.runs_capacity = runs_capacity;
             a.scratch.runs_used = d_runs_used.p;
+            lap("uploaded");
             if (ctx->timing) HIP_OK(hipEventRecord(ctx->ev0, s));
             HIP_OK(ki->launch(a));
             if (ctx->timing) HIP_OK(hipEventRecord(ctx->ev1, s));
@@ -535,6 +545,7 @@ struct Engine {
                 d_vsa.download(vsa.data(), vsa_total, s) || d_ckpt_dump.download(dump.data(), dump_total, s))
                 return -1;
             HIP_OK(hipStreamSynchronize(s));
+            lap("kernel + results");
             if (ctx->timing) {
                 float ms = 0;
                 HIP_OK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
@@ -550,6 +561,7 @@ struct Engine {
             HIP_OK(hipStreamSynchronize(s));
             break;
         }
+        lap("runs downloaded");
         for (int x = 0; x < n; x++) {
             JobOut &o = out[order[x]];
             o.res = res[x];
