@@ -48,7 +48,8 @@ out = {
     "config": {"pairs_per_gpu": cfg["pairs_per_gpu"], "query_len": cfg["query_len"], "target_len": cfg["target_len"]},
     "kernel": reg,
     "fetch_kib": v["FETCH_SIZE"] / n, "write_kib": v["WRITE_SIZE"] / n,
-    "bytes_per_launch": (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 / n,
+    "fetch_correction": 2.0,
+    "bytes_per_launch": (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 / n,
     "rocprof_avg_launch_ms": avg_ns / 1e6,
     "valu": {
         "insts_per_launch": v["SQ_INSTS_VALU"] / n,
@@ -58,8 +59,10 @@ out = {
         "waves_per_launch": waves,
         "simd_issue_utilisation": (v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"]) * waves / 1024.0,
     },
-    "note": "raw counters (KiB), no correction applied: the loads are 4 B/lane, a width the microarch guide lists as "
-            "uncalibrated for FETCH_SIZE on gfx950 (its 2x correction is for 16 B/lane streams). SQ_* are per-wave quad-cycles; "
+    "note": "fetch_kib / write_kib are the raw counters; bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE: the gfx950 "
+            "FETCH_SIZE under-count of MI355X_MICROARCH.md (HBM section), calibrated on this access pattern as the guide "
+            "asks: every input byte (Q + T + 16 T per pair = 6.97 GB per launch) has to be fetched at least once, and the raw "
+            "counter reads 3.5 GB, i.e. one half. SQ_* are per-wave quad-cycles; "
             "simd_issue_utilisation = VALU-active share of a wave's cycles x resident waves per SIMD (1024 SIMDs).",
 }
 json.dump(out, open(f"{dst}/traffic_latest.json", "w"), indent=1)
