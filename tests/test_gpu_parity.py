@@ -110,6 +110,27 @@ def test_seeded_pairs_match_oracle(eng, model_type, qlen, tlen, dpm):
         assert a.as_dict() == exp
 
 
+@pytest.mark.parametrize("model_type,qlen,tlen", [("est2genome", 1300, 5000), ("affine:local", 2100, 2300),
+                                                   ("affine:global", 1500, 1400)])
+def test_long_queries_cross_several_super_strips(eng, model_type, qlen, tlen):
+    """Queries longer than one workgroup's 4 x 64 x R rows: the cooperating-wave kernels hand rows from one
+    super-strip to the next through the HBM carry rows (and the one-wave kernels through theirs)."""
+    rng = random.Random(qlen)
+    model = ex.Model(model_type)
+    q = _rand(rng, qlen)
+    if model_type == "est2genome":
+        c = qlen // 3
+        t = _rand(rng, 200) + _mutate(rng, q[:c], 0.03) + "GT" + _rand(rng, tlen // 3) + "AG" + _mutate(rng, q[c:], 0.03) + _rand(rng, 300)
+    else:
+        t = _rand(rng, 60) + _mutate(rng, q, 0.08) + _rand(rng, max(0, tlen - qlen))
+    pairs = [(q, t), (q[:qlen - 37], t)]
+    scores = eng.find_score(model, pairs)
+    alns = eng.find_path(model, pairs, dpmemory=32)
+    for (qq, tt), s_, a in zip(pairs, scores, alns):
+        assert s_ == oracle_lib.find_score(model.c, model.params, qq.encode(), tt.encode())
+        assert a.as_dict() == oracle_lib.find_path(model.c, model.params, qq.encode(), tt.encode(), dpmemory=32)
+
+
 def test_raw_viterbi_modes_match_oracle(eng):
     """Viterbi_DP_Func level: region + checkpoint (continuation) passes against oracle_viterbi."""
     import ctypes as C
