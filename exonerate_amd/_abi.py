@@ -56,7 +56,9 @@ class Model(C.Structure):
 
 class SpliceModel(C.Structure):
     _fields_ = [("model_length", C.c_int32), ("splice_after", C.c_int32),
-                ("index", C.c_uint8 * 256), ("data", (C.c_float * 5) * SPLICE_MAX_LEN)]
+                ("index", C.c_uint8 * 256), ("data", (C.c_float * 5) * SPLICE_MAX_LEN),
+                ("gtag_only", C.c_int32), ("expect_one", C.c_uint8), ("expect_two", C.c_uint8),
+                ("pad_", C.c_uint8 * 2)]
 
 
 class Params(C.Structure):
@@ -117,6 +119,7 @@ PROTOTYPES = [
     ("c4gpu_ctx_device_info", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int),
                                         C.POINTER(C.c_int64)]),
     ("c4gpu_params_default", None, [C.POINTER(Params)]),
+    ("c4gpu_params_set_forcegtag", None, [C.POINTER(Params), C.c_int]),
     ("c4gpu_model_get", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(Params), C.POINTER(Model)]),
     ("c4gpu_model_make_continuation", None, [C.POINTER(Model), C.POINTER(Model)]),
     ("c4gpu_model_plugin_name", C.c_int, [C.POINTER(Model), C.c_int, C.c_int, C.c_char_p, C.c_size_t]),

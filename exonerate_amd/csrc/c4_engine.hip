@@ -190,6 +190,11 @@ __global__ void splice_kernel(const uint8_t *__restrict__ seq, const long long *
         if (seq_start + calc_length > n) calc_length = n - seq_start;
         float score = 0.0f;
         for (int i = 0; i < calc_length; i++) score = score + sp->data[model_start + i][sp->index[s[seq_start + i]]];
+        if (sp->gtag_only) {                    // Splice_predict_is_on_GTAG, splice.c:312-318 (past the end: the NUL)
+            const int b1 = s[pos], b2 = pos + 1 < n ? s[pos + 1] : 0;
+            const int u1 = (b1 >= 'a' && b1 <= 'z') ? b1 - 32 : b1, u2 = (b2 >= 'a' && b2 <= 'z') ? b2 - 32 : b2;
+            if (u1 != sp->expect_one || u2 != sp->expect_two) score = -987654321.0f;
+        }
         const double r = score < 0 ? (double)score - 0.5 : (double)score + 0.5;
         o[pos] = (int)r;
     }

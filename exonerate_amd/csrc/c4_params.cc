@@ -144,6 +144,16 @@ extern "C" void c4gpu_params_default(c4gpu_params *out) {
     for (int t = 0; t < 4; t++) build_splice(&out->splice[t], t);
 }
 
+// SplicePredictor_GTAGonly_create, splice.c:213-240
+extern "C" void c4gpu_params_set_forcegtag(c4gpu_params *p, int on) {
+    static const char pair[4][2] = {{'G', 'T'}, {'A', 'G'}, {'C', 'T'}, {'A', 'C'}};   // C4GPU_SS5_FORWARD, SS3_FORWARD, SS3_REVERSE, SS5_REVERSE
+    for (int t = 0; t < 4; t++) {
+        p->splice[t].gtag_only = on ? 1 : 0;
+        p->splice[t].expect_one = (uint8_t)pair[t][0];
+        p->splice[t].expect_two = (uint8_t)pair[t][1];
+    }
+}
+
 // SplicePredictor_get_max_score, splice.c:399-410 (float accumulation, row order)
 extern "C" float c4gpu_splice_max_score(const c4gpu_splice_model *sp) {
     float score = 0.0f;

@@ -115,6 +115,9 @@ typedef struct {
     int32_t model_length, splice_after;
     uint8_t index[256];                     /* residue -> column 0..4 */
     float   data[C4GPU_SPLICE_MAX_LEN][5];
+    int32_t gtag_only;                      /* --forcegtag (splice.c:42-44,290-293): sites whose two bases */
+    uint8_t expect_one, expect_two;         /* (upper-cased) are not these score -987654321.0f (splice.c:335) */
+    uint8_t pad_[2];
 } c4gpu_splice_model;
 
 /* The scoring data the per-cell calcs read: what `user_data` + the static ArgumentSets hold in the
@@ -202,6 +205,8 @@ int         c4gpu_ctx_device_info(c4gpu_ctx *ctx, char *name, size_t name_len, i
 /* Defaults of the reference's ArgumentSets: nucleic / blosum62 matrices, standard genetic code,
  * primate splice PSSMs, -12/-4, -18/-8, intron 30..200000/-30, frameshift -28. */
 void        c4gpu_params_default(c4gpu_params *out);
+/* --forcegtag yes|no: SplicePredictor_GTAGonly_create (splice.c:213-240) for the four site types. */
+void        c4gpu_params_set_forcegtag(c4gpu_params *params, int on);
 
 /* Model_Type_get_model (modeltype.c): "affine:local", "affine:global", "affine:bestfit",
  * "affine:overlap", "ungapped", "est2genome", "protein2dna", "protein2dna:bestfit", "protein2genome",

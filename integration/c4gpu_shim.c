@@ -190,6 +190,11 @@ static void shim_params(Ungapped_Data *ud, c4gpu_params *p){
         for(k = 0; k < 4; k++){
             if(sp[k]->model_length > C4GPU_SPLICE_MAX_LEN)
                 continue;
+            p->splice[k].gtag_only = sp[k]->gtag_only ? 1 : 0;   /* --forcegtag, splice.c:290-293 */
+            if(sp[k]->gtag_only){
+                p->splice[k].expect_one = sp[k]->gtag_only->expect_one;
+                p->splice[k].expect_two = sp[k]->gtag_only->expect_two;
+                }
             p->splice[k].model_length = sp[k]->model_length;
             p->splice[k].splice_after = sp[k]->model_splice_after;
             memcpy(p->splice[k].index, sp[k]->index, 256);
@@ -201,10 +206,6 @@ static void shim_params(Ungapped_Data *ud, c4gpu_params *p){
     }
 
 /* ---- one Viterbi call ----------------------------------------------------------------------------------- */
-
-static gboolean shim_forcegtag(void){
-    return Splice_ArgumentSet_create(NULL)->force_gtag;
-    }
 
 static C4_Score shim_dp(C4_Model *model, Region *region, Viterbi_Data *vd, SubOpt_Index *soi,
                         gpointer user_data, int mode, Viterbi_DP_Func cpu_func){
@@ -218,7 +219,7 @@ static C4_Score shim_dp(C4_Model *model, Region *region, Viterbi_Data *vd, SubOp
     register gint i, j, k, l, cs = vd->vr->cell_size;
     register C4_Score score;
     c4gpu_subopt *blocked = NULL;
-    if((!shim_get_ctx()) || shim_forcegtag() || (!shim_flatten(model, ud, &fm))){
+    if((!shim_get_ctx()) || (!shim_flatten(model, ud, &fm))){
         if(!cpu_func)
             g_error("c4gpu shim: no CPU implementation to fall back to");
         return cpu_func(model, region, vd, soi, user_data);
@@ -411,7 +412,7 @@ static gboolean shim_can_batch(GAM *gam, Sequence *query, Sequence *target){
     register gpointer ud;
     register gboolean ok;
     c4gpu_model fm;
-    if((shim_batch_size() <= 0) || (!gam->optimal) || (!shim_get_ctx()) || shim_forcegtag())
+    if((shim_batch_size() <= 0) || (!gam->optimal) || (!shim_get_ctx()))
         return FALSE;
     if((gam->gas->refinement != GAM_Refinement_NONE) || gam->gas->percent_threshold)
         return FALSE;  /* refinement re-enters Optimal_find_path; %-thresholds can sit below --score */

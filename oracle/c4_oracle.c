@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <ctype.h>
 
 #include "c4_oracle.h"
 
@@ -40,6 +41,11 @@ void oracle_splice_predict(const c4gpu_splice_model *sp, const uint8_t *seq, int
         for(i = 0; i < calc_length; i++){
             pos_score = sp->data[model_start+i][sp->index[seq[seq_start+i]]];
             score += pos_score;
+            }
+        if(sp->gtag_only){                      /* splice.c:312-318,334-336: seq[pos+1] may be the NUL */
+            int one = toupper(seq[pos]), two = (pos + 1 < len) ? toupper(seq[pos+1]) : 0;
+            if((one != sp->expect_one) || (two != sp->expect_two))
+                score = -987654321.0;
             }
         pred[pos] = (int32_t)((score < 0) ? (score - 0.5) : (score + 0.5));
         }

@@ -19,6 +19,8 @@ SETS = {
     "protein2dna_bestfit": ("protein2dna:bestfit", 1, 0), "protein2dna_bestfit_D0": ("protein2dna:bestfit", 1, 0),
     "protein2genome_bestfit": ("protein2genome:bestfit", 1, 0),
     "protein2genome_bestfit_D0": ("protein2genome:bestfit", 1, 0),
+    "est2genome_forcegtag": ("est2genome", 0, 0), "est2genome_forcegtag_D0": ("est2genome", 0, 0),
+    "protein2genome_forcegtag": ("protein2genome", 1, 0),
 }
 
 
@@ -35,6 +37,15 @@ SUBOPT_SETS = {
 def load_set(name):
     with open(os.path.join(GOLDEN_DIR, name + ".jsonl")) as f:
         return [json.loads(l) for l in f if l.strip()]
+
+
+def set_params(lib, name):
+    """Parameters a set was generated with (the defaults, or --forcegtag for the *_forcegtag sets)."""
+    p = _abi.Params()
+    lib.c4gpu_params_default(p)
+    if "forcegtag" in name:
+        lib.c4gpu_params_set_forcegtag(p, 1)
+    return p
 
 
 def get_model(lib, params, name):

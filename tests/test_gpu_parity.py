@@ -24,7 +24,10 @@ def eng():
 
 def _model(name):
     mt, qa, ta = SETS[name]
-    return ex.Model(mt, qa, ta)
+    params = ex.default_params()
+    if "forcegtag" in name:
+        _abi.load().c4gpu_params_set_forcegtag(params, 1)
+    return ex.Model(mt, qa, ta, params=params)
 
 
 @pytest.mark.parametrize("name", sorted(SETS))

@@ -33,6 +33,7 @@ def _run(exe, args, env=None):
     # C4GPU_BATCH=0: every Viterbi call goes to the device on its own (the plain Bootstrapper_lookup shim);
     # 2: several flushes of the batching seam; --bestn: thresholds that move while results are submitted
     ("est2genome", [], "0"), ("affine:local", ["-D", "1"], "0"), ("protein2genome", [], "0"),
+    ("est2genome", ["--forcegtag", "yes"], "4096"), ("protein2genome", ["--forcegtag", "yes"], "0"),
     ("est2genome", [], "2"), ("affine:local", ["--bestn", "1"], "4"), ("est2genome", ["--bestn", "2", "-S", "yes"], "4096"),
 ])
 def test_exonerate_gpu_output_is_byte_identical(tmp_path, model, extra, batch):

@@ -7,11 +7,12 @@ inputs of the reference's model known-answer tests.  Integer work: every compari
 import pytest
 from exonerate_amd import _abi
 import oracle_lib
-from golden_util import SETS, SUBOPT_SETS, load_set, get_model, expected
+from golden_util import SETS, SUBOPT_SETS, load_set, get_model, set_params, expected
 
 
 @pytest.mark.parametrize("name", sorted(SETS))
 def test_oracle_matches_reference_vectors(lib, params, name):
+    params = set_params(lib, name)
     model = get_model(lib, params, name)
     recs = load_set(name)
     assert recs
@@ -64,12 +65,14 @@ def test_oracle_splice_arrays_match_reference(lib, params):
     olib = oracle_lib.load()
     keys = {"ss5_forward": _abi.SS5_FORWARD, "ss3_forward": _abi.SS3_FORWARD,
             "ss3_reverse": _abi.SS3_REVERSE, "ss5_reverse": _abi.SS5_REVERSE}
-    for rec in load_set("est2genome"):
-        t = rec["target"].encode()
-        for key, k in keys.items():
-            out = (C.c_int32 * len(t))()
-            olib.oracle_splice_predict(params.splice[k], t, len(t), out)
-            assert list(out) == rec[key], (rec["id"], key)
+    for name in ("est2genome", "est2genome_forcegtag"):
+        params = set_params(lib, name)
+        for rec in load_set(name):
+            t = rec["target"].encode()
+            for key, k in keys.items():
+                out = (C.c_int32 * len(t))()
+                olib.oracle_splice_predict(params.splice[k], t, len(t), out)
+                assert list(out) == rec[key], (name, rec["id"], key)
 
 
 def test_memory_decisions(lib, params):

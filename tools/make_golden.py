@@ -237,6 +237,11 @@ def main():
     sets.append(("protein2dna_bestfit_D0", "protein2dna:bestfit", [c for c in p2d if len(c[2]) > 30], 0, ()))
     sets.append(("protein2genome_bestfit", "protein2genome:bestfit", p2g, 32, ()))
     sets.append(("protein2genome_bestfit_D0", "protein2genome:bestfit", p2g, 0, ()))
+    # --forcegtag: splice sites off GT..AG (CT..AC on the reverse strand) become impossible (splice.c:334-336)
+    fg = ("--forcegtag", "yes")
+    sets.append(("est2genome_forcegtag", "est2genome", est, 32, fg + ("--withsplice", "yes")))
+    sets.append(("est2genome_forcegtag_D0", "est2genome", est, 0, fg))
+    sets.append(("protein2genome_forcegtag", "protein2genome", p2g, 32, fg))
     # sub-optimal alignments (SubOpt blocking, src/c4/subopt.c) through the GAM loop
     so = ("--suboptmax", "6", "--suboptthreshold", "30")
     rs = random.Random(4242)
