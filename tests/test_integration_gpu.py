@@ -156,3 +156,25 @@ def test_exonerate_gpu_command_line_switch(tmp_path):
     assert one_out.replace("--gpubatch 0 ", "") == ref_out
     help_out = subprocess.run([GPU_EXE, "--help"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
     assert "--gpu" in help_out and "--gpubatch" in help_out
+
+
+@pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
+                    reason="reference binaries are built in the build container (make -C integration)")
+def test_multi_process_query_shards_restore_submission_order(tmp_path):
+    """integration/exonerate_multigpu.py: one process per GPU, sharded by query (the reference's own
+    --querychunkid scheme); here 3 processes share device 0.  Output = the single-process output."""
+    import sys
+    rng = random.Random(12)
+    dna = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    qs = [("qy%d" % n, dna(300 + 40 * n)) for n in range(7)]
+    ts = [("tg%d" % n, dna(150) + qs[n][1][:140] + "GT" + dna(300) + "AG" + qs[n][1][140:] + dna(90)) for n in range(7)]
+    qf, tf = str(tmp_path / "q.fa"), str(tmp_path / "t.fa")
+    _fasta(qf, qs)
+    _fasta(tf, ts)
+    args = ["-m", "est2genome", "-E", "yes", "-S", "no", "--showalignment", "no", "--showvulgar", "yes", "-V", "0", qf, tf]
+    ref_out, _ = _run(CPU_EXE, args)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "integration", "exonerate_multigpu.py"), "--gpus", "3",
+                        "--devices", "0,0,0", "--"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    assert r.stdout.decode() == ref_out
+    assert ref_out.count("vulgar:") >= 7
