@@ -219,6 +219,12 @@ static C4_Score shim_dp(C4_Model *model, Region *region, Viterbi_Data *vd, SubOp
     register gint i, j, k, l, cs = vd->vr->cell_size;
     register C4_Score score;
     c4gpu_subopt *blocked = NULL;
+    static gdouble min_cells = -1.0;
+    if(min_cells < 0.0)
+        min_cells = g_getenv("C4GPU_MIN_CELLS") ? atof(g_getenv("C4GPU_MIN_CELLS")) : 1e5;
+    /* a single small rectangle is faster on the host than one launch + copies (a batch is another matter) */
+    if(cpu_func && (((gdouble)region->query_length + 1.0) * ((gdouble)region->target_length + 1.0) < min_cells))
+        return cpu_func(model, region, vd, soi, user_data);
     if((!shim_get_ctx()) || (!shim_flatten(model, ud, &fm))){
         if(!cpu_func)
             g_error("c4gpu shim: no CPU implementation to fall back to");
@@ -398,6 +404,7 @@ typedef struct {
 } ShimPending;
 
 static GPtrArray *shim_pending = NULL;
+static gdouble shim_pending_bytes = 0.0;   /* device footprint of the collected pairs (no sharing assumed) */
 static ShimPending *shim_replay_pair = NULL;
 static gint shim_replay_call = 0;
 
@@ -442,6 +449,7 @@ static void shim_flush(void){
     if((!todo) || (!todo->len))
         return;
     shim_pending = NULL;          /* pairs submitted while replaying start a new collection */
+    shim_pending_bytes = 0.0;
     n = todo->len;
     sp = todo->pdata[0];
     gam = sp->gam;
@@ -548,7 +556,10 @@ GAM_Result *GAM_Result_exhaustive_create(GAM *gam, Sequence *query, Sequence *ta
     sp->query = Sequence_share(query);
     sp->target = Sequence_share(target);
     g_ptr_array_add(shim_pending, sp);
-    if((gint)shim_pending->len >= shim_batch_size())
+    /* residues + codes + 4 int32 splice arrays + tn4 per target position; flush well inside the HBM */
+    shim_pending_bytes += 22.0 * target->len + 2.0 * query->len;
+    if(((gint)shim_pending->len >= shim_batch_size())
+    || (shim_pending_bytes > (g_getenv("C4GPU_BATCH_GB") ? atof(g_getenv("C4GPU_BATCH_GB")) : 96.0) * 1e9))
         shim_flush();
     return NULL;                  /* the result is submitted by the flush, in submission order */
     }
