@@ -924,13 +924,10 @@ int c4gpu_splice_predict(c4gpu_ctx *ctx, const c4gpu_params *params, const uint8
     return 0;
 }
 
-int c4gpu_viterbi_batch(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params, int mode,
-                        const c4gpu_pair *pairs, int32_t n_pairs, const c4gpu_viterbi_job *jobs, int32_t n_jobs,
-                        c4gpu_viterbi_result *results) {
-    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
-    Engine eng;
-    ResidentSeqs seqs;
-    if (eng.init(ctx, model, params) || seqs.build(ctx, eng.family, params, pairs, n_pairs)) return -1;
+}  // extern "C"
+
+static int viterbi_jobs(Engine &eng, const ResidentSeqs &seqs, int mode, const c4gpu_viterbi_job *jobs,
+                        int32_t n_jobs, c4gpu_viterbi_result *results) {
     // jobs with and without continuation run different kernels (the model copy with CORNER scopes)
     for (int cont = 0; cont < 2; cont++) {
         std::vector<JobSpec> specs;
@@ -975,6 +972,25 @@ int c4gpu_viterbi_batch(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_pa
         }
     }
     return 0;
+}
+
+
+extern "C" {
+
+int c4gpu_viterbi_batch(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params, int mode,
+                        const c4gpu_pair *pairs, int32_t n_pairs, const c4gpu_viterbi_job *jobs, int32_t n_jobs,
+                        c4gpu_viterbi_result *results) {
+    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+    Engine eng;
+    ResidentSeqs seqs;
+    if (eng.init(ctx, model, params) || seqs.build(ctx, eng.family, params, pairs, n_pairs)) return -1;
+    return viterbi_jobs(eng, seqs, mode, jobs, n_jobs, results);
+}
+
+int c4gpu_batch_viterbi(c4gpu_batch *b, int mode, const c4gpu_viterbi_job *jobs, int32_t n_jobs,
+                        c4gpu_viterbi_result *results) {
+    if (hipSetDevice(b->ctx->device) != hipSuccess) return -1;
+    return viterbi_jobs(b->eng, b->seqs, mode, jobs, n_jobs, results);
 }
 
 void c4gpu_viterbi_result_clear(c4gpu_viterbi_result *r) {

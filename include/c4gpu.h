@@ -283,6 +283,10 @@ void         c4gpu_batch_destroy(c4gpu_batch *b);
 /* One pass of the hot path over the resident batch. `what`: 0 = score pass only (FIND_SCORE),
  * 1 = region pass only, 2 = full Optimal_find_path.  Results stay on the object. */
 int          c4gpu_batch_run(c4gpu_batch *b, int what, int dpmemory_mb, c4gpu_score threshold);
+/* c4gpu_viterbi_batch on the pairs already resident (jobs[i].pair indexes them): what a caller that makes
+ * many Viterbi_DP_Func calls on the same pair uses to upload it once. */
+int          c4gpu_batch_viterbi(c4gpu_batch *b, int mode, const c4gpu_viterbi_job *jobs, int32_t n_jobs,
+                                 c4gpu_viterbi_result *results);
 /* The sub-optimal loop on the resident batch: after c4gpu_batch_run(b, 2, ...), each call blocks the
  * alignments found so far (SubOpt_add_alignment, gam.c:673) and finds the next best path of every pair
  * that still had one in the previous round; pairs whose score drops below `threshold` leave the loop.

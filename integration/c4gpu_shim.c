@@ -230,11 +230,8 @@ static C4_Score shim_dp(C4_Model *model, Region *region, Viterbi_Data *vd, SubOp
             g_error("c4gpu shim: no CPU implementation to fall back to");
         return cpu_func(model, region, vd, soi, user_data);
         }
-    shim_params(ud, &params);
     qstr = Sequence_get_str(ud->query);
     tstr = Sequence_get_str(ud->target);
-    pair.query = (const uint8_t*)qstr;  pair.query_len = ud->query->len;
-    pair.target = (const uint8_t*)tstr; pair.target_len = ud->target->len;
     memset(&job, 0, sizeof(job));
     job.pair = 0;
     job.region.query_start = region->query_start;   job.region.target_start = region->target_start;
@@ -260,7 +257,34 @@ static C4_Score shim_dp(C4_Model *model, Region *region, Viterbi_Data *vd, SubOp
             }
         job.subopt = blocked;
         }
-    i = c4gpu_viterbi_batch(shim_ctx, &fm, &params, mode, &pair, 1, &job, 1, &r);
+    /* The reference makes many Viterbi calls on one pair (region, checkpoints, every sub-alignment): the
+     * pair stays resident on the device between them.  Identity = content (a freed Sequence's address may
+     * be reused), the model by name and, for calls without a continuation, its scopes. */
+    {
+        static c4gpu_batch *resident = NULL;
+        static guint64 resident_key = 0;
+        static gchar resident_model[C4GPU_NAME_LEN];
+        static gint resident_scope[2];
+        register guint64 key = 1469598103934665603ULL;
+        register const guchar *c;
+        for(c = (const guchar*)qstr; *c; c++) key = (key ^ *c) * 1099511628211ULL;
+        key = (key ^ 0xff) * 1099511628211ULL;
+        for(c = (const guchar*)tstr; *c; c++) key = (key ^ *c) * 1099511628211ULL;
+        key ^= ((guint64)ud->query->len << 32) ^ (guint64)ud->target->len;
+        if((!resident) || (key != resident_key) || strcmp(resident_model, fm.name)
+        || ((!vd->continuation) && ((resident_scope[0] != fm.start_scope) || (resident_scope[1] != fm.end_scope)))){
+            if(resident)
+                c4gpu_batch_destroy(resident);
+            shim_params(ud, &params);
+            pair.query = (const uint8_t*)qstr;  pair.query_len = ud->query->len;
+            pair.target = (const uint8_t*)tstr; pair.target_len = ud->target->len;
+            resident = c4gpu_batch_create(shim_ctx, &fm, &params, &pair, 1);
+            resident_key = key;
+            g_strlcpy(resident_model, fm.name, C4GPU_NAME_LEN);
+            resident_scope[0] = fm.start_scope; resident_scope[1] = fm.end_scope;
+            }
+        i = resident ? c4gpu_batch_viterbi(resident, mode, &job, 1, &r) : -1;
+    }
     if(blocked)
         c4gpu_subopt_destroy(blocked);
     if(i != 0){
