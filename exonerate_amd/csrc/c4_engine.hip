@@ -439,12 +439,16 @@ struct Engine {
         // job (strip carry rows stay in LDS instead of HBM); C4GPU_MW=0 forces the one-wave kernels
         static const int mw_env = getenv("C4GPU_MW") ? atoi(getenv("C4GPU_MW")) : 1;
         if (mw_env && !pts && !cont && (mode == MODE_SCORE || mode == MODE_REGION)) {
-            const KernelInfo *kmw = get_kernel_mw(family, mode, use_local, pack);
+            const KernelInfo *kmw = get_kernel_mw(family, mode, use_local, pack, 4);
             if (kmw) {
                 long long strips = 0;
                 for (int i = 0; i < n; i++) strips += (specs[i].region.query_length + 1 + 64 * kmw->R - 1) / (64 * kmw->R);
                 if (strips >= 3LL * n) ki = kmw;
             }
+            // 8 waves x 2 rows per lane cover the same rows per workgroup with twice the waves: taken when the
+            // launch has too few jobs to occupy the device with 4 waves each (C4GPU_MW=4 keeps 4)
+            const KernelInfo *kmw8 = (ki == kmw && mw_env != 4) ? get_kernel_mw(family, mode, use_local, pack, 8) : nullptr;
+            if (kmw8 && (long long)n * 8 <= 2LL * 4 * ctx->prop.multiProcessorCount) ki = kmw8;
         }
         // longest first (persistent waves pull from the queue head)
         std::vector<int> order(n);

@@ -36,8 +36,9 @@ struct KernelInfo {
 // family x mode x continuation x local-scope specialisation; NULL launch = not compiled
 // sub: the variant with sub-optimal blocking (DevSeqs::sub_colptr / sub_rows must be set)
 const KernelInfo *get_kernel(int family, int mode, bool cont, bool local, bool pack, int wpe = 0, bool sub = false);
-// multi-wave kernels (4 cooperating waves per job) for FIND_SCORE / FIND_REGION without continuation
-const KernelInfo *get_kernel_mw(int family, int mode, bool local, bool pack);
+// multi-wave kernels (`waves` = 4 or 8 cooperating waves per job) for FIND_SCORE / FIND_REGION without
+// continuation
+const KernelInfo *get_kernel_mw(int family, int mode, bool local, bool pack, int waves = 4);
 
 #define C4K_DEFINE_KERNEL(SYMBOL, M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV)                                          \
     static hipError_t SYMBOL##_launch(const LaunchArgs &a) {                                               \
