@@ -368,6 +368,11 @@ struct Engine {
         memset(&kp, 0, sizeof kp);
         for (int i = 0; i < m->n_calcs; i++) kp.calc_value[i] = m->calcs[i].value;
         kp.min_intron = params->min_intron; kp.max_intron = params->max_intron;
+        if (params->max_intron < params->min_intron) {
+            // the reference would reject every intron (length < min or > max is always true); the device
+            // test folds both comparisons into one and needs a non-negative span for that
+            kp.min_intron = kp.max_intron = 0x7fffffff;     // span 0 at a length no intron has: always rejected
+        }
         kp.start_scope = m->start_scope; kp.end_scope = m->end_scope;
         bool protein = false;
         for (int i = 0; i < m->n_calcs; i++)

@@ -198,6 +198,7 @@ struct WaveDP {
     const int *ss0, *ss1, *ss2, *ss3;
     int Q, T, q0, t0, lane, tshift;
     int first_state, final_state, min_intron, max_intron, seed_aux;
+    unsigned intron_span;       // max_intron - min_intron (>= 0: c4gpu_params are validated by the host)
     const int *first_cell;
     int start_scope, end_scope;
 
@@ -320,8 +321,9 @@ struct WaveDP {
                     constexpr int des = F::consumed_designation(k);
                     static_assert(des >= 0, "post-splice calc without a shadow");
                     static_assert(slot_live(t.in, des), "consumed slot must be live");
+                    // length < min || length > max as one unsigned comparison of (length - min)
                     const int intron_length = (t0 + j - t.at) - src.ex[t.in][des] + 2;
-                    const bool bad = (intron_length < min_intron) | (intron_length > max_intron);
+                    const bool bad = (unsigned)(intron_length - min_intron) > intron_span;
                     const int ssv = pre[cd.param];
                     tscore += bad ? LOW : ssv;
                 } else if constexpr (cd.kind == CALC_PHASE_POST) {
@@ -643,6 +645,7 @@ struct WaveDP {
         first_state = job.first_state; final_state = CONT ? job.final_state : M::END;
         first_cell = job.first_cell;
         min_intron = kp->min_intron; max_intron = kp->max_intron;
+        intron_span = (unsigned)(max_intron - min_intron);
         start_scope = CONT ? SCOPE_CORNER : kp->start_scope;
         end_scope = CONT ? SCOPE_CORNER : kp->end_scope;
         qc = seqs.qcode + seqs.qoff[job.pair];
@@ -732,6 +735,7 @@ struct WaveDP {
         first_state = job.first_state; final_state = M::END;
         first_cell = job.first_cell;
         min_intron = kp->min_intron; max_intron = kp->max_intron;
+        intron_span = (unsigned)(max_intron - min_intron);
         start_scope = kp->start_scope; end_scope = kp->end_scope;
         qc = seqs.qcode + seqs.qoff[job.pair];
         tc = seqs.tcode + seqs.toff[job.pair];
