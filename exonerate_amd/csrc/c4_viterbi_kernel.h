@@ -244,7 +244,7 @@ struct WaveDP {
     // state in scratch memory instead of VGPRs.
     template <int RR, int PH, bool JINT>
     __device__ __forceinline__ void eval_cell(int i, int j, bool active, int mscore, const int (&pre)[4],
-                                              int qrow, int tn4col, bool blocked, uint32_t &tbword) {
+                                              int qrow, int tn4col, bool blocked, uint32_t &tbword, bool &end_ok) {
         C &c = col[PH][RR];
         bool set[M::NS];
         static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
@@ -381,30 +381,9 @@ struct WaveDP {
             set[t.out] = was_set | valid;
         });
         tbword = tbw;
-        // end cell (viterbi.c:778-791).  In continuation mode the score is read off the corner cell later.
-        // A new maximum is rare (it only grows along the alignment), so the bookkeeping sits behind a
-        // wave-uniform branch.
-        if constexpr (!CONT) {
-            const int tsc = c.sc[M::END];
-            const bool end_set = set[M::END], b_set = best_set;
-            const int b = best;
-            const bool upd = active & end_set & (!b_set | (b < tsc));
-            if (__builtin_amdgcn_ballot_w64(upd)) {
-                const int bi = best_i, bj = best_j;
-                best = upd ? tsc : b;
-                best_i = upd ? i : bi;
-                best_j = upd ? j : bj;
-                if constexpr (MODE == MODE_REGION) {
-                    const int nqs = c.ex[M::END][RSQ], oqs = best_qs;
-                    best_qs = upd ? nqs : oqs;
-                    if constexpr (!PACK) {
-                        const int nts = c.ex[M::END][RST], ots = best_ts;
-                        best_ts = upd ? nts : ots;
-                    }
-                }
-                best_set = b_set | upd;
-            }
-        }
+        // whether this cell can be the end cell (viterbi.c:778-791): the comparison with the best so far is
+        // done once per step over the lane's R cells (step, below)
+        end_ok = active & set[M::END];
     }
 
     // ---- cross-lane / cross-strip exchange ----------------------------------------------------------------
@@ -534,10 +513,46 @@ struct WaveDP {
         prefetch_column(j + 1);
         // (3) the R cells of this lane, top to bottom
         uint32_t tbw[R];
+        bool end_ok[R];
         static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
             const int i = i0 + RR;
-            eval_cell<RR, PH, JINT>(i, j, jact && i <= Q, ms[RR], sp, qcode[RR], tn4col, (blk >> RR) & 1u, tbw[RR]);
+            eval_cell<RR, PH, JINT>(i, j, jact && i <= Q, ms[RR], sp, qcode[RR], tn4col, (blk >> RR) & 1u, tbw[RR],
+                                    end_ok[RR]);
         });
+        // (3b) end cell (viterbi.c:778-791): strict improvement in row-major order.  In continuation mode the
+        // score is read off the corner cell later.  A new maximum is rare (it only grows along the
+        // alignment): one masked maximum over the lane's cells per step decides whether any of them can
+        // improve, and the bookkeeping itself sits behind a wave-uniform branch.
+        if constexpr (!CONT) {
+            constexpr int NEVER = (-2147483647 - 1);         // below every score the DP can produce
+            int m = NEVER;
+            static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                const int tsc = col[PH][RR].sc[M::END];
+                const int mk = end_ok[RR] ? tsc : NEVER;
+                m = m > mk ? m : mk;
+            });
+            const bool cand = (m != NEVER) & (!best_set | (best < m));
+            if (__builtin_amdgcn_ballot_w64(cand)) {
+                static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                    const C &c = col[PH][RR];
+                    const int tsc = c.sc[M::END], b = best, bi = best_i, bj = best_j;
+                    const bool b_set = best_set;
+                    const bool upd = end_ok[RR] & (!b_set | (b < tsc));
+                    best = upd ? tsc : b;
+                    best_i = upd ? i0 + RR : bi;
+                    best_j = upd ? j : bj;
+                    if constexpr (MODE == MODE_REGION) {
+                        const int nqs = c.ex[M::END][RSQ], oqs = best_qs;
+                        best_qs = upd ? nqs : oqs;
+                        if constexpr (!PACK) {
+                            const int nts = c.ex[M::END][RST], ots = best_ts;
+                            best_ts = upd ? nts : ots;
+                        }
+                    }
+                    best_set = b_set | upd;
+                });
+            }
+        }
         // (4) traceback words, step-major (fully coalesced)
         if constexpr (MODE == MODE_PATH) {
             uint32_t *p = tb_slab + tb_base + ((long long)s * 64 + lane) * R;
