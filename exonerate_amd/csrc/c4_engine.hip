@@ -249,6 +249,10 @@ struct ResidentSeqs {
         std::vector<int> utlen;
         for (int i = 0; i < n; i++) {
             qlen[i] = pairs[i].query_len; tlen[i] = pairs[i].target_len;
+            if (qlen[i] < 0 || tlen[i] < 0 || tlen[i] >= (1 << 30) || qlen[i] >= (1 << 30)) {
+                c4h::set_error("sequence length outside [0, 2^30): the kernels address a sequence with 32-bit byte offsets");
+                return -1;
+            }
             auto qk = std::make_pair(pairs[i].query, qlen[i]);
             auto qi = qseen.find(qk);
             if (qi == qseen.end()) {

@@ -211,9 +211,11 @@ struct WaveDP {
     int corner[CELL_MAX];
     bool corner_set;
 
-    __device__ __forceinline__ int splice(int k, int tpos) const {
+    // uniform base pointer + 32-bit byte offset: the form the global_load "saddr" encoding takes (base in
+    // SGPRs, one VGPR offset shared by the four splice arrays) instead of a 64-bit address per load
+    __device__ __forceinline__ int splice(int k, unsigned byte_off) const {
         const int *p = k == 0 ? ss0 : k == 1 ? ss1 : k == 2 ? ss2 : ss3;
-        return p[tpos];
+        return *reinterpret_cast<const int *>(reinterpret_cast<const char *>(p) + byte_off);
     }
 
     // cell slots in the reference layout (for cells that leave the kernel)
@@ -448,16 +450,17 @@ struct WaveDP {
         }
         int ti = t0 + j - mat;
         ti = ti < 0 ? 0 : (ti > tlast ? tlast : ti);
-        nx_tcode = tc[ti];
+        nx_tcode = tc[(unsigned)ti];
         if constexpr (F::has_phase()) {
             int tq = t0 + j - 1;
             tq = tq < 0 ? 0 : (tq > tlast ? tlast : tq);
-            nx_tn4 = tn4p[tq];
+            nx_tn4 = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(tn4p) + ((unsigned)tq << 1));
         }
         if constexpr (F::has_splice()) {
             int tp = t0 + j - 2;
             tp = tp < 0 ? 0 : (tp > tlast ? tlast : tp);
-            static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; nx_sp[K] = splice(K, tp); });
+            const unsigned sp_off = (unsigned)tp << 2;         // targets are below 2^30 residues
+            static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; nx_sp[K] = splice(K, sp_off); });
         }
     }
 
