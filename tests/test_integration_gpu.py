@@ -178,3 +178,29 @@ def test_multi_process_query_shards_restore_submission_order(tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-1500:]
     assert r.stdout.decode() == ref_out
     assert ref_out.count("vulgar:") >= 7
+
+
+@pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
+                    reason="reference binaries are built in the build container (make -C integration)")
+@pytest.mark.parametrize("model", ["est2genome", "affine:local"])
+def test_low_complexity_inputs_tie_everywhere(tmp_path, model):
+    """Tandem repeats, homopolymers and a target made of many copies of the query at (near) north-star size:
+    thousands of equal-score cells and paths, so the end cell (first in row-major order), the winning
+    transition (lowest id) and the region start all hinge on tie-breaking.  Byte-identical to the reference."""
+    rng = random.Random(77)
+    dna = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    unit = dna(97)
+    q3 = dna(600)
+    qs = [("tandem", "ACGT" * 200), ("polya", "A" * 700), ("copies", q3), ("unit", (unit * 9)[:800])]
+    ts = [("tandem_t", "ACGT" * 10000), ("polya_t", "A" * 30000), ("copies_t", (q3[:300] + "GT" + "C" * 80 + "AG" + q3[300:]) * 30),
+          ("unit_t", unit * 300)]
+    qf, tf = str(tmp_path / "q.fa"), str(tmp_path / "t.fa")
+    _fasta(qf, qs)
+    _fasta(tf, ts)
+    args = ["-m", model, "-E", "yes", "-S", "no", "--showalignment", "no", "--showvulgar", "yes", "--showcigar", "yes",
+            "-V", "0", qf, tf]
+    ref_out, _ = _run(CPU_EXE, args)
+    gpu_out, gpu_err = _run(GPU_EXE, args, {"C4GPU_VERBOSE": "1"})
+    assert "c4gpu: batch of" in gpu_err
+    assert gpu_out == ref_out
+    assert ref_out.count("vulgar:") >= 4
