@@ -53,6 +53,23 @@ class Model:
             raise C4GpuError("unknown or unsupported model type %r" % model_type)
         self.model_type = model_type
 
+    @classmethod
+    def derived(cls, model_type, src_state, dst_state, start_scope, end_scope, query_alphabet=None,
+                target_alphabet=None, params=None):
+        """C4_DerivedModel_create on a model type: BSDP's join / terminal models (c4gpu_model_get_derived)."""
+        self = cls.__new__(cls)
+        self.params = params if params is not None else default_params()
+        qa, ta = cls._ALPHABETS.get(model_type, (ALPHABET_DNA, ALPHABET_DNA))
+        qa = qa if query_alphabet is None else query_alphabet
+        ta = ta if target_alphabet is None else target_alphabet
+        self.c = _abi.Model()
+        self.transition_map = (C.c_int32 * _abi.MAX_TRANSITIONS)()
+        if _lib().c4gpu_model_get_derived(model_type.encode(), qa, ta, self.params, src_state, dst_state, start_scope,
+                                          end_scope, self.c, self.transition_map) != 0:
+            raise C4GpuError("no derived model %r %d -> %d" % (model_type, src_state, dst_state))
+        self.model_type = model_type
+        return self
+
     @property
     def name(self):
         return self.c.name.decode()

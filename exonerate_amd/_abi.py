@@ -121,6 +121,9 @@ PROTOTYPES = [
     ("c4gpu_params_default", None, [C.POINTER(Params)]),
     ("c4gpu_params_set_forcegtag", None, [C.POINTER(Params), C.c_int]),
     ("c4gpu_model_get", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(Params), C.POINTER(Model)]),
+    ("c4gpu_model_get_derived", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.POINTER(Model), C.POINTER(C.c_int32)]),
+    ("c4m_derive", C.c_void_p, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
     ("c4gpu_model_make_continuation", None, [C.POINTER(Model), C.POINTER(Model)]),
     ("c4gpu_model_plugin_name", C.c_int, [C.POINTER(Model), C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     ("c4gpu_model_is_accelerated", C.c_int, [C.POINTER(Model)]),

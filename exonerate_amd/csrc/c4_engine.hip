@@ -110,11 +110,28 @@ int model_family(const c4gpu_model &m) {
     if (model_matches<UngappedP2DDesc>(m)) return FAM_UNGAPPED_P2D;
     if (model_matches<Protein2DnaDesc>(m)) return FAM_PROTEIN2DNA;
     if (model_matches<Protein2GenomeDesc>(m)) return FAM_PROTEIN2GENOME;
+    if (model_matches<AffineStartDesc>(m)) return FAM_AFFINE_START;
+    if (model_matches<AffineEndDesc>(m)) return FAM_AFFINE_END;
+    if (model_matches<AffineJoinDesc>(m)) return FAM_AFFINE_JOIN;
+    if (model_matches<Est2GenomeFwdStartDesc>(m)) return FAM_EST2GENOME_FWD_START;
+    if (model_matches<Est2GenomeFwdEndDesc>(m)) return FAM_EST2GENOME_FWD_END;
+    if (model_matches<Est2GenomeFwdJoinDesc>(m)) return FAM_EST2GENOME_FWD_JOIN;
+    if (model_matches<Est2GenomeRevStartDesc>(m)) return FAM_EST2GENOME_REV_START;
+    if (model_matches<Est2GenomeRevEndDesc>(m)) return FAM_EST2GENOME_REV_END;
+    if (model_matches<Est2GenomeRevJoinDesc>(m)) return FAM_EST2GENOME_REV_JOIN;
+    if (model_matches<Protein2DnaStartDesc>(m)) return FAM_PROTEIN2DNA_START;
+    if (model_matches<Protein2DnaEndDesc>(m)) return FAM_PROTEIN2DNA_END;
+    if (model_matches<Protein2DnaJoinDesc>(m)) return FAM_PROTEIN2DNA_JOIN;
     return -1;
 }
 
-bool family_is_p2d(int fam) { return fam == FAM_UNGAPPED_P2D || fam == FAM_PROTEIN2DNA || fam == FAM_PROTEIN2GENOME; }
-bool family_has_splice(int fam) { return fam == FAM_EST2GENOME || fam == FAM_PROTEIN2GENOME; }
+bool family_is_p2d(int fam) {
+    return fam == FAM_UNGAPPED_P2D || fam == FAM_PROTEIN2DNA || fam == FAM_PROTEIN2GENOME ||
+           (fam >= FAM_PROTEIN2DNA_START && fam <= FAM_PROTEIN2DNA_JOIN);
+}
+bool family_has_splice(int fam) {
+    return fam == FAM_EST2GENOME || fam == FAM_PROTEIN2GENOME || (fam >= FAM_EST2GENOME_FWD_START && fam <= FAM_EST2GENOME_REV_JOIN);
+}
 bool family_has_phase(int fam) { return fam == FAM_PROTEIN2GENOME; }
 
 // ---- sequence preparation kernels -------------------------------------------------------------------------

@@ -341,6 +341,120 @@ int c4m_insert(c4m_model *target, const c4m_model *insert, int src, int dst) {
     return 0;
 }
 
+// ---- derived models -------------------------------------------------------------------------------------------
+// C4_DerivedModel_create (c4.c:2292-2337) over C4_Model_select (c4.c:2217-2285): the sub-model of every path
+// from state `src` to state `dst` of a CLOSED model — BSDP's join and terminal models (heuristic.c:242-330).
+// Creation order is the reference's: transitions out of src (from START), transitions into dst (to END), then
+// a depth-first walk over the states reused so far; states, calcs and shadows are created on first use.
+namespace {
+
+// C4_Model_path_is_possible, c4.c:1307-1341: dst reachable from src over at least one transition
+bool derive_path_possible(const c4m_model *m, int src, int dst, std::vector<char> &visited) {
+    visited[src] = 1;
+    for (int h : m->states[src].out_tr) {
+        const int next = m->tr[h].output;
+        if (next == dst) return true;
+        if (!visited[next] && derive_path_possible(m, next, dst, visited)) return true;
+    }
+    return false;
+}
+bool derive_reach(const c4m_model *m, int src, int dst) {
+    std::vector<char> visited(m->states.size(), 0);
+    return derive_path_possible(m, src, dst, visited);
+}
+
+struct Derive {
+    const c4m_model *old_model;
+    c4m_model *new_model;
+    std::vector<int> state_map, calc_map;                 // old index -> new index or -1
+    std::vector<std::vector<int>> proto_states, proto_transitions;   // per old shadow: new src states / dst transitions
+    std::vector<char> proto_used;
+    std::vector<int> transition_map;                      // new handle -> old handle
+
+    void reuse_state(int old_state) {                     // C4_Model_segment_reuse_state, c4.c:2047
+        if (old_state == 0 || old_state == 1 || state_map[old_state] >= 0) return;
+        const int ns = c4m_add_state(new_model, old_model->states[old_state].name.c_str());
+        state_map[old_state] = ns;
+        for (int sh : old_model->states[old_state].src_shadows) { proto_used[sh] = 1; proto_states[sh].push_back(ns); }
+    }
+    void add_transition(int old_handle, bool from_start, bool to_end) {   // C4_Model_segment_add_transition, c4.c:2072
+        const Transition &t = old_model->tr[old_handle];
+        if (!from_start) reuse_state(t.input);
+        if (!to_end) reuse_state(t.output);
+        int calc = -1;
+        if (t.calc >= 0) {
+            if (calc_map[t.calc] < 0) {
+                const Calc &c = old_model->calcs[t.calc];
+                calc_map[t.calc] = c4m_add_calc(new_model, c.name.c_str(), c.kind, c.value, c.param, c.max_score, c.protect);
+            }
+            calc = calc_map[t.calc];
+        }
+        const int nh = c4m_add_transition(new_model, t.name.c_str(), from_start ? C4M_START : state_map[t.input],
+                                          to_end ? C4M_END : state_map[t.output], t.aq, t.at, calc, t.label);
+        if ((int)transition_map.size() <= nh) transition_map.resize(nh + 1, -1);
+        transition_map[nh] = old_handle;
+        for (int sh : t.dst_shadows) { proto_used[sh] = 1; proto_transitions[sh].push_back(nh); }
+    }
+    void recur(int state, std::vector<char> &visited) {   // C4_Model_segment_recur, c4.c:2127
+        if (state_map[state] < 0 || visited[state] || state == 0 || state == 1) return;
+        visited[state] = 1;
+        const std::vector<int> outs = old_model->states[state].out_tr;
+        for (int h : outs) {
+            if (old_model->tr[h].output == 1) continue;
+            add_transition(h, false, false);
+            recur(old_model->tr[h].output, visited);
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" c4m_model *c4m_derive(const c4m_model *model, int src_state, int dst_state, int start_scope, int end_scope,
+                                 int *transition_map, int transition_map_len) {
+    if (!model || model->open) return nullptr;
+    if (src_state < 0) src_state = 0;
+    if (dst_state < 0) dst_state = 1;
+    const std::string name = "Segment(\"" + model->states[src_state].name + "\"->\"" + model->states[dst_state].name +
+                             "\"):[" + model->name + "]";
+    Derive d;
+    d.old_model = model;
+    d.new_model = c4m_model_create(name.c_str());
+    c4m_model_set_alphabets(d.new_model, model->query_alphabet, model->target_alphabet);
+    d.state_map.assign(model->states.size(), -1);
+    d.calc_map.assign(model->calcs.size(), -1);
+    d.proto_states.resize(model->shadows.size());
+    d.proto_transitions.resize(model->shadows.size());
+    d.proto_used.assign(model->shadows.size(), 0);
+    // shadows that start at src start at the new START (c4.c:2240-2247)
+    for (int sh : model->states[src_state].src_shadows) { d.proto_used[sh] = 1; d.proto_states[sh].push_back(0); }
+    for (int h : model->states[src_state].out_tr)                       // transitions from start
+        if (derive_reach(model, model->tr[h].output, dst_state)) d.add_transition(h, true, false);
+    for (int h : model->states[dst_state].in_tr)                        // transitions to end
+        if (derive_reach(model, src_state, model->tr[h].input)) d.add_transition(h, false, true);
+    std::vector<char> visited(model->states.size(), 0);
+    for (size_t s = 0; s < model->states.size(); s++) d.recur((int)s, visited);
+    for (size_t sh = 0; sh < model->shadows.size(); sh++) {              // C4_ProtoShadow_generate, c4.c:2013
+        if (!d.proto_used[sh]) continue;
+        if (d.proto_states[sh].empty() || d.proto_transitions[sh].empty()) { c4m_model_destroy(d.new_model); return nullptr; }
+        const int ns = c4m_add_shadow(d.new_model, model->shadows[sh].name.c_str(),
+                                      d.proto_states[sh][0] == 0 ? C4M_START : d.proto_states[sh][0],
+                                      d.proto_transitions[sh][0], model->shadows[sh].on_target);
+        for (size_t j = 1; j < d.proto_states[sh].size(); j++) c4m_shadow_add_src_state(d.new_model, ns, d.proto_states[sh][j]);
+        for (size_t j = 1; j < d.proto_transitions[sh].size(); j++)
+            c4m_shadow_add_dst_transition(d.new_model, ns, d.proto_transitions[sh][j]);
+    }
+    if (c4m_model_close(d.new_model) != 0) { c4m_model_destroy(d.new_model); return nullptr; }
+    c4m_configure_start_state(d.new_model, start_scope);
+    c4m_configure_end_state(d.new_model, end_scope);
+    // transition_map[derived id] = original id (C4_DerivedModel::transition_map, c4.c:2322-2333)
+    if (transition_map)
+        for (size_t nh = 0; nh < d.transition_map.size(); nh++) {
+            const int id = d.new_model->tr[nh].id;
+            if (id >= 0 && id < transition_map_len) transition_map[id] = model->tr[d.transition_map[nh]].id;
+        }
+    return d.new_model;
+}
+
 int c4m_select_transitions(const c4m_model *m, int label, int *handles, int max) {
     int n = 0;
     for (int h : m->order)
@@ -587,10 +701,40 @@ c4m_model *c4m_protein2genome_create(int type, const c4gpu_params *p) {
     return m;
 }
 
+static c4m_model *model_of_type(const char *type, int qa, int ta, const c4gpu_params *params);
+
 // Model_Type_get_model, src/model/modeltype.c
 int c4gpu_model_get(const char *type, int qa, int ta, const c4gpu_params *params, c4gpu_model *out) {
     c4gpu_params defaults;
     if (!params) { c4gpu_params_default(&defaults); params = &defaults; }
+    c4m_model *m = model_of_type(type, qa, ta, params);
+    if (!m) return -1;
+    int rc = c4m_flatten(m, out);
+    c4m_model_destroy(m);
+    return rc;
+}
+
+// C4_DerivedModel_create on a model type: BSDP's join / terminal models (heuristic.c:242-330)
+int c4gpu_model_get_derived(const char *type, int qa, int ta, const c4gpu_params *params, int src_state,
+                            int dst_state, int start_scope, int end_scope, c4gpu_model *out,
+                            int32_t *transition_map) {
+    c4gpu_params defaults;
+    if (!params) { c4gpu_params_default(&defaults); params = &defaults; }
+    c4m_model *m = model_of_type(type, qa, ta, params);
+    if (!m) return -1;
+    int map[C4GPU_MAX_TRANSITIONS];
+    for (int i = 0; i < C4GPU_MAX_TRANSITIONS; i++) map[i] = -1;
+    c4m_model *d = c4m_derive(m, src_state, dst_state, start_scope, end_scope, map, C4GPU_MAX_TRANSITIONS);
+    c4m_model_destroy(m);
+    if (!d) return -1;
+    int rc = c4m_flatten(d, out);
+    c4m_model_destroy(d);
+    if (transition_map && rc == 0)
+        for (int i = 0; i < out->n_transitions; i++) transition_map[i] = map[i];
+    return rc;
+}
+
+static c4m_model *model_of_type(const char *type, int qa, int ta, const c4gpu_params *params) {
     c4m_model *m = nullptr;
     std::string t = type;
     if (t == "ungapped" || t == "u") m = c4m_ungapped_create(qa, ta, params);
@@ -603,10 +747,7 @@ int c4gpu_model_get(const char *type, int qa, int ta, const c4gpu_params *params
     else if (t == "protein2dna:bestfit" || t == "p2d:b") m = c4m_protein2dna_create(C4M_AFFINE_BESTFIT, params);
     else if (t == "protein2genome" || t == "p2g") m = c4m_protein2genome_create(C4M_AFFINE_LOCAL, params);
     else if (t == "protein2genome:bestfit" || t == "p2g:b") m = c4m_protein2genome_create(C4M_AFFINE_BESTFIT, params);
-    if (!m) return -1;
-    int rc = c4m_flatten(m, out);
-    c4m_model_destroy(m);
-    return rc;
+    return m;
 }
 
 // Viterbi_create with use_continuation (src/c4/viterbi.c:68-76): C4_Model_copy + CORNER/CORNER.

@@ -213,6 +213,15 @@ void        c4gpu_params_set_forcegtag(c4gpu_params *params, int on);
  * "protein2genome:bestfit".  Returns 0 on success. */
 int         c4gpu_model_get(const char *model_type, int query_alphabet, int target_alphabet,
                             const c4gpu_params *params, c4gpu_model *out);
+/* C4_DerivedModel_create (c4.c:2292-2337) on the model of that type: the closed sub-model of every path from
+ * state src_state to state dst_state (state ids of the original model; 0 = START, 1 = END), with the given
+ * scopes — BSDP's join models (match state -> match state, CORNER/CORNER, heuristic.c:255) and terminal
+ * models (START -> match state with the model's start scope / CORNER; match state -> END, heuristic.c:301-309).
+ * transition_map (may be NULL, C4GPU_MAX_TRANSITIONS entries) receives per derived transition id the original
+ * transition id.  Returns 0, or -1 when the type is unknown or no path exists. */
+int         c4gpu_model_get_derived(const char *model_type, int query_alphabet, int target_alphabet,
+                                    const c4gpu_params *params, int src_state, int dst_state,
+                                    int start_scope, int end_scope, c4gpu_model *out, int32_t *transition_map);
 /* Viterbi_create's continuation copy: same tables, CORNER/CORNER scopes (viterbi.c:68-76). */
 void        c4gpu_model_make_continuation(const c4gpu_model *model, c4gpu_model *out);
 /* Codegen_clean_path_component("optimal:<name> find <what>") — the Bootstrapper_lookup key

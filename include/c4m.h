@@ -50,6 +50,14 @@ void c4m_make_stereo(c4m_model *m, const char *suffix_a, const char *suffix_b);
 /* insert a CLOSED model between two states of an OPEN one; -1/-1 = START/END */
 int  c4m_insert(c4m_model *target, const c4m_model *insert, int src_state, int dst_state);
 
+/* C4_DerivedModel_create (c4.c:2292-2337, on C4_Model_select c4.c:2217): the closed sub-model of every path
+ * from src_state to dst_state of a CLOSED model (C4M_START / C4M_END allowed), with the given scopes — BSDP's
+ * join and terminal models (heuristic.c:242-330); named Segment("src"->"dst"):[model].  transition_map (may
+ * be NULL) receives, per derived transition id, the id of the original transition (C4_DerivedModel's
+ * transition_map).  NULL when no path exists.  cell_start/cell_end callbacks (span models) are not modelled. */
+c4m_model *c4m_derive(const c4m_model *model, int src_state, int dst_state, int start_scope, int end_scope,
+                      int *transition_map, int transition_map_len);
+
 /* queries on the (open or closed) model */
 int  c4m_select_single_transition(const c4m_model *m, int label);   /* handle or -1 */
 int  c4m_select_transitions(const c4m_model *m, int label, int *handles, int max);

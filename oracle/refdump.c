@@ -59,9 +59,10 @@ static gint calc_index(C4_Model *m, C4_Calc *c){
 
 static void dump_model(C4_Model *m, const char *key){
     register guint i, j;
+    gchar *escaped_name = g_strescape(m->name, NULL);     /* derived models: Segment("a"->"b"):[..] */
     printf("{\"key\":\"%s\",\"name\":\"%s\",\"start_scope\":%d,\"end_scope\":%d,"
            "\"max_query_advance\":%d,\"max_target_advance\":%d,\"shadow_designations\":%d,\n",
-           key, m->name, m->start_state->scope, m->end_state->scope,
+           key, escaped_name, m->start_state->scope, m->end_state->scope,
            m->max_query_advance, m->max_target_advance, m->total_shadow_designations);
     printf(" \"start_state\":%d,\"end_state\":%d,\n", state_index(m, m->start_state->state),
            state_index(m, m->end_state->state));
@@ -143,6 +144,72 @@ static void dump_tables(void){
         C4_Model *m = Model_Type_get_model(list[i].type, list[i].q, list[i].t);
         if(i) printf(",\n");
         dump_model(m, list[i].key);
+        C4_Model_destroy(m);
+        }
+    printf("]\n");
+    }
+
+/* BSDP's derived models (heuristic.c:242-330): for every state a MATCH-labelled transition enters, the start
+ * terminal START -> state, the end terminal state -> END, and the joins state -> state'. */
+static void dump_derived_one(C4_Model *m, const char *key, C4_State *src, C4_State *dst,
+                             C4_Scope start_scope, C4_Scope end_scope, gboolean *first){
+    register C4_DerivedModel *dm;
+    register guint i;
+    gchar *dkey;
+    if(!C4_Model_path_is_possible(m, src, dst))
+        return;
+    dm = C4_DerivedModel_create(m, src, dst, start_scope, NULL, NULL, end_scope, NULL, NULL);
+    dkey = g_strdup_printf("%s|%d|%d|%d|%d", key, state_index(m, src), state_index(m, dst),
+                           start_scope, end_scope);
+    if(!*first) printf(",\n");
+    *first = FALSE;
+    printf("{\"derived_key\":\"%s\",\"transition_map\":[", dkey);
+    for(i = 0; i < dm->derived->transition_list->len; i++)
+        printf("%s%d", i?",":"", dm->transition_map[i]->id);
+    printf("],\"table\":\n");
+    dump_model(dm->derived, dkey);
+    printf("}");
+    g_free(dkey);
+    C4_DerivedModel_destroy(dm);
+    }
+
+static void dump_derived(void){
+    struct { const char *key; Model_Type type; Alphabet_Type q, t; } list[] = {
+        {"affine:local:dna", Model_Type_AFFINE_LOCAL, Alphabet_Type_DNA, Alphabet_Type_DNA},
+        {"affine:global:dna", Model_Type_AFFINE_GLOBAL, Alphabet_Type_DNA, Alphabet_Type_DNA},
+        {"affine:local:protein", Model_Type_AFFINE_LOCAL, Alphabet_Type_PROTEIN, Alphabet_Type_PROTEIN},
+        {"est2genome", Model_Type_EST2GENOME, Alphabet_Type_DNA, Alphabet_Type_DNA},
+        {"protein2dna", Model_Type_PROTEIN2DNA, Alphabet_Type_PROTEIN, Alphabet_Type_DNA},
+        {"protein2genome", Model_Type_PROTEIN2GENOME, Alphabet_Type_PROTEIN, Alphabet_Type_DNA},
+        };
+    register guint i, j, k;
+    gboolean first = TRUE;
+    printf("[\n");
+    for(i = 0; i < sizeof(list)/sizeof(list[0]); i++){
+        C4_Model *m = Model_Type_get_model(list[i].type, list[i].q, list[i].t);
+        GPtrArray *match_states = g_ptr_array_new();
+        for(j = 0; j < m->transition_list->len; j++){
+            C4_Transition *t = m->transition_list->pdata[j];
+            gboolean seen = FALSE;
+            if(t->label != C4_Label_MATCH)
+                continue;
+            for(k = 0; k < match_states->len; k++)
+                if(match_states->pdata[k] == t->output)
+                    seen = TRUE;
+            if(!seen)
+                g_ptr_array_add(match_states, t->output);
+            }
+        for(j = 0; j < match_states->len; j++){
+            C4_State *s = match_states->pdata[j];
+            dump_derived_one(m, list[i].key, m->start_state->state, s, m->start_state->scope,
+                             C4_Scope_CORNER, &first);
+            dump_derived_one(m, list[i].key, s, m->end_state->state, C4_Scope_CORNER,
+                             m->end_state->scope, &first);
+            for(k = 0; k < match_states->len; k++)
+                dump_derived_one(m, list[i].key, s, match_states->pdata[k], C4_Scope_CORNER,
+                                 C4_Scope_CORNER, &first);
+            }
+        g_ptr_array_free(match_states, TRUE);
         C4_Model_destroy(m);
         }
     printf("]\n");
@@ -315,7 +382,7 @@ static void run_subopt(Optimal *optimal, Region *region, gpointer user_data,
     }
 
 static void run_golden(gchar *model_name, gchar *input_path, gboolean with_splice,
-                       gboolean revcomp_target, gint subopt_max, gint subopt_threshold){
+                       gboolean revcomp_target, gint subopt_max, gint subopt_threshold, gchar *derived){
     register Model_Type type;
     register FILE *fp = fopen(input_path, "r");
     register Alphabet *dna = Alphabet_create(Alphabet_Type_DNA, FALSE),
@@ -344,6 +411,15 @@ static void run_golden(gchar *model_name, gchar *input_path, gboolean with_splic
     qa = query_is_protein?protein:dna;
     ta = target_is_protein?protein:dna;
     model = Model_Type_get_model(type, qa->type, ta->type);
+    if(derived && strcmp(derived, "none")){
+        /* "src,dst,start_scope,end_scope": one of BSDP's derived models (heuristic.c:242-330) */
+        gchar **d = g_strsplit(derived, ",", 4);
+        register C4_DerivedModel *dm = C4_DerivedModel_create(model,
+                model->state_list->pdata[atoi(d[0])], model->state_list->pdata[atoi(d[1])],
+                atoi(d[2]), NULL, NULL, atoi(d[3]), NULL, NULL);
+        model = C4_Model_share(dm->derived);      /* the original stays referenced by dm (leaked: one-shot tool) */
+        g_strfreev(d);
+        }
     optimal = Optimal_create(model, NULL,
                   Optimal_Type_SCORE|Optimal_Type_PATH|Optimal_Type_REDUCED_SPACE, FALSE);
     while(fgets(line, cap, fp)){
@@ -368,8 +444,12 @@ static void run_golden(gchar *model_name, gchar *input_path, gboolean with_splic
         user_data = Model_Type_create_data(type, query, target);
         region = Region_create(0, 0, query->len, target->len);
         score = Optimal_find_score(optimal, region, user_data, NULL);
-        printf("{\"id\":\"%s\",\"model\":\"%s\",\"qlen\":%d,\"tlen\":%d,\"score\":%d",
-               f[0], model->name, query->len, target->len, score);
+        {
+            gchar *escaped_name = g_strescape(model->name, NULL);
+            printf("{\"id\":\"%s\",\"model\":\"%s\",\"qlen\":%d,\"tlen\":%d,\"score\":%d",
+                   f[0], escaped_name, query->len, target->len, score);
+            g_free(escaped_name);
+        }
         alignment = Optimal_find_path(optimal, region, user_data,
                                       C4_IMPOSSIBLY_LOW_SCORE, NULL);
         if(alignment){
@@ -424,6 +504,7 @@ int Argument_main(Argument *arg){
     gchar *cmd, *model_name, *input_path;
     gboolean with_splice, revcomp_target;
     gint subopt_max, subopt_threshold;
+    gchar *derived;
     ArgumentSet_add_option(as, '\0', "cmd", "name", "tables|data|golden", "tables",
                            Argument_parse_string, &cmd);
     ArgumentSet_add_option(as, 'm', "model", "name", "model name", "affine:local",
@@ -436,6 +517,8 @@ int Argument_main(Argument *arg){
                            Argument_parse_boolean, &revcomp_target);
     ArgumentSet_add_option(as, '\0', "suboptmax", "n", "also dump up to n successive sub-optimal paths", "0",
                            Argument_parse_int, &subopt_max);
+    ArgumentSet_add_option(as, '\0', "derived", "src,dst,ss,es", "run the golden set on a derived model", "none",
+                           Argument_parse_string, &derived);
     ArgumentSet_add_option(as, '\0', "suboptthreshold", "score", "threshold of the sub-optimal loop", "30",
                            Argument_parse_int, &subopt_threshold);
     Argument_absorb_ArgumentSet(arg, as);
@@ -455,9 +538,11 @@ int Argument_main(Argument *arg){
         dump_tables();
     else if(!strcmp(cmd, "data"))
         dump_data();
+    else if(!strcmp(cmd, "derived"))
+        dump_derived();
     else if(!strcmp(cmd, "golden"))
         run_golden(g_strdup(model_name), input_path, with_splice, revcomp_target,
-                   subopt_max, subopt_threshold);
+                   subopt_max, subopt_threshold, derived);
     else
         g_error("unknown cmd [%s]", cmd);
     return 0;

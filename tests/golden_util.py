@@ -34,6 +34,17 @@ SUBOPT_SETS = {
 }
 
 
+# BSDP's derived models: golden file -> (model type, query alphabet, target alphabet, (src, dst, start scope, end scope))
+DERIVED_SETS = {}
+for _tag, _mt, _qa, _ta, _ms in (("affine_local", "affine:local", 0, 0, (2,)), ("est2genome", "est2genome", 0, 0, (2, 5)),
+                                 ("protein2dna", "protein2dna", 1, 0, (2,))):
+    for _m in _ms:
+        _sfx = "" if len(_ms) == 1 else ("_fwd" if _m == 2 else "_rev")
+        DERIVED_SETS["derived_%s%s_start" % (_tag, _sfx)] = (_mt, _qa, _ta, (0, _m, 0, 4))
+        DERIVED_SETS["derived_%s%s_end" % (_tag, _sfx)] = (_mt, _qa, _ta, (_m, 1, 4, 0))
+        DERIVED_SETS["derived_%s%s_join" % (_tag, _sfx)] = (_mt, _qa, _ta, (_m, _m, 4, 4))
+
+
 def load_set(name):
     with open(os.path.join(GOLDEN_DIR, name + ".jsonl")) as f:
         return [json.loads(l) for l in f if l.strip()]
@@ -49,6 +60,11 @@ def set_params(lib, name):
 
 
 def get_model(lib, params, name):
+    if name in DERIVED_SETS:
+        mt, qa, ta, (src, dst, ss, es) = DERIVED_SETS[name]
+        m = _abi.Model()
+        assert lib.c4gpu_model_get_derived(mt.encode(), qa, ta, params, src, dst, ss, es, m, None) == 0
+        return m
     mt, qa, ta = SETS[name] if name in SETS else SUBOPT_SETS[name]
     m = _abi.Model()
     assert lib.c4gpu_model_get(mt.encode(), qa, ta, params, m) == 0

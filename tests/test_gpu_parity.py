@@ -10,7 +10,7 @@ import pytest
 import exonerate_amd as ex
 from exonerate_amd import _abi
 import oracle_lib
-from golden_util import SETS, SUBOPT_SETS, load_set, expected
+from golden_util import SETS, SUBOPT_SETS, DERIVED_SETS, load_set, expected
 
 pytestmark = pytest.mark.gpu
 
@@ -23,6 +23,9 @@ def eng():
 
 
 def _model(name):
+    if name in DERIVED_SETS:
+        mt, qa, ta, (src, dst, ss, es) = DERIVED_SETS[name]
+        return ex.Model.derived(mt, src, dst, ss, es, qa, ta)
     mt, qa, ta = SETS[name]
     params = ex.default_params()
     if "forcegtag" in name:
@@ -30,7 +33,7 @@ def _model(name):
     return ex.Model(mt, qa, ta, params=params)
 
 
-@pytest.mark.parametrize("name", sorted(SETS))
+@pytest.mark.parametrize("name", sorted(SETS) + sorted(DERIVED_SETS))
 def test_find_score_and_path_match_reference_vectors(eng, name):
     model = _model(name)
     recs = load_set(name)
@@ -306,3 +309,38 @@ print("OK")
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, timeout=600)
     assert out.returncode == 0 and b"OK" in out.stdout, out.stderr.decode()[-2000:]
+
+
+def test_thousands_of_bsdp_sized_jobs_on_derived_models(eng):
+    """K5: BSDP's unit of work — rectangles of at most 49 x 49 cells of ONE pair under a derived model
+    (join: CORNER to CORNER between two HSPs; terminal: open scope on one side) — as one launch of thousands
+    of jobs (Viterbi_DP_Func level), every score and every path checked against the oracle."""
+    import ctypes as C
+    import time
+    olib = oracle_lib.load()
+    rng = random.Random(2024)
+    q = _rand(rng, 1500)
+    t = _mutate(rng, q, 0.12) + _rand(rng, 300)
+    for mt, spec in (("affine:local", (2, 2, 4, 4)), ("affine:local", (0, 2, 0, 4)), ("est2genome", (2, 2, 4, 4)),
+                     ("est2genome", (5, 1, 4, 0))):
+        model = ex.Model.derived(mt, *spec)
+        jobs = []
+        for k in range(3000):
+            ql, tl = rng.randint(1, 49), rng.randint(2, 49)
+            qs, ts = rng.randint(0, len(q) - ql), rng.randint(0, len(t) - tl)
+            jobs.append({"pair": 0, "region": (qs, ts, ql, tl)})
+        t0 = time.perf_counter()
+        got = eng.viterbi(model, ex.MODE_FIND_PATH, [(q, t)], jobs)
+        dt = time.perf_counter() - t0
+        scores = eng.viterbi(model, ex.MODE_FIND_SCORE, [(q, t)], jobs)
+        print("%s %s: %d path jobs in %.1f ms" % (mt, spec, len(jobs), dt * 1e3))
+        for k in range(0, len(jobs), 7):
+            vo = oracle_lib.ViterbiOut()
+            olib.oracle_viterbi(model.c, model.params, ex.MODE_FIND_PATH, q.encode(), len(q), t.encode(), len(t),
+                                _abi.Region(*jobs[k]["region"]), None, 0, vo)
+            g = got[k]
+            assert (g["score"], g["query_start"], g["target_start"], g["query_end"], g["target_end"]) == \
+                   (vo.score, vo.query_start, vo.target_start, vo.query_end, vo.target_end), (mt, spec, jobs[k])
+            assert g["ops"] == [vo.ops[x] for x in range(vo.n_ops)], (mt, spec, jobs[k])
+            assert scores[k]["score"] == vo.score
+            olib.oracle_viterbi_out_clear(vo)

@@ -95,3 +95,42 @@ def test_invalid_models_are_rejected(lib):
     lib.c4m_add_state(m, b"nowhere")
     assert lib.c4m_model_close(m) == -1      # C4_Model_is_valid, c4.c:1385
     lib.c4m_model_destroy(m)
+
+
+DERIVED = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "derived_tables.json")))
+
+
+@pytest.mark.parametrize("gold", DERIVED, ids=lambda g: g["derived_key"])
+def test_derived_tables_match_reference(lib, params, gold):
+    """C4_DerivedModel_create (c4.c:2292) for BSDP's join / terminal models (heuristic.c:242-330): the closed
+    tables and the transition map of c4gpu_model_get_derived against the reference's (refdump --cmd derived)."""
+    key, src, dst, ss, es = gold["derived_key"].split("|")
+    name, qa, ta = IN_SCOPE[key]
+    m = _abi.Model()
+    tmap = (C.c_int32 * _abi.MAX_TRANSITIONS)()
+    g = gold["table"]
+    if len(g["transitions"]) > _abi.MAX_TRANSITIONS:
+        pytest.skip("derived model larger than the flattened table")
+    assert lib.c4gpu_model_get_derived(name.encode(), qa, ta, params, int(src), int(dst), int(ss), int(es), m, tmap) == 0
+    assert m.name.decode() == g["name"][:_abi.NAME_LEN - 1]        # the flattened name field is 48 bytes
+    assert [m.state_names[i].value.decode() for i in range(m.n_states)] == g["states"]
+    assert (m.start_scope, m.end_scope) == (g["start_scope"], g["end_scope"])
+    assert (m.max_query_advance, m.max_target_advance) == (g["max_query_advance"], g["max_target_advance"])
+    assert m.total_shadow_designations == g["shadow_designations"]
+    assert m.n_transitions == len(g["transitions"])
+    for i, t_ in enumerate(g["transitions"]):
+        t = m.transitions[i]
+        got = (t.name.decode(), t.input, t.output, t.advance_query, t.advance_target, t.calc, t.label)
+        exp = (t_["name"], t_["in"], t_["out"], t_["aq"], t_["at"], t_["calc"], t_["label"])
+        assert got == exp, (i, got, exp)
+        mask = 0
+        for s in t_["dst_shadows"]:
+            mask |= 1 << s
+        assert t.dst_shadow_mask == mask
+    assert [tmap[i] for i in range(m.n_transitions)] == gold["transition_map"]
+    assert [(m.calcs[i].name.decode(), m.calcs[i].max_score, m.calcs[i].protect) for i in range(m.n_calcs)] == \
+           [(c["name"], c["max_score"], c["protect"]) for c in g["calcs"]]
+    assert m.n_shadows == len(g["shadows"])
+    for i, s_ in enumerate(g["shadows"]):
+        s = m.shadows[i]
+        assert s.name.decode() == s_["name"] and s.designation == s_["designation"]

@@ -7,10 +7,10 @@ inputs of the reference's model known-answer tests.  Integer work: every compari
 import pytest
 from exonerate_amd import _abi
 import oracle_lib
-from golden_util import SETS, SUBOPT_SETS, load_set, get_model, set_params, expected
+from golden_util import SETS, SUBOPT_SETS, DERIVED_SETS, load_set, get_model, set_params, expected
 
 
-@pytest.mark.parametrize("name", sorted(SETS))
+@pytest.mark.parametrize("name", sorted(SETS) + sorted(DERIVED_SETS))
 def test_oracle_matches_reference_vectors(lib, params, name):
     params = set_params(lib, name)
     model = get_model(lib, params, name)

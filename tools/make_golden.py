@@ -242,6 +242,22 @@ def main():
     sets.append(("est2genome_forcegtag", "est2genome", est, 32, fg + ("--withsplice", "yes")))
     sets.append(("est2genome_forcegtag_D0", "est2genome", est, 0, fg))
     sets.append(("protein2genome_forcegtag", "protein2genome", p2g, 32, fg))
+    # BSDP's derived models (C4_DerivedModel_create, heuristic.c:242-330) on rectangles of the size BSDP gives
+    # them: start terminal (model start scope -> CORNER), end terminal, join (CORNER -> CORNER)
+    small = random.Random(515)
+    sd = [("drv%02d" % k, rand_dna(small, small.randint(2, 48)), rand_dna(small, small.randint(2, 48))) for k in range(10)]
+    sd += [("drvsim%02d" % k, q, mutate(small, q, 0.15, "ACGT")) for k, q in
+           enumerate(rand_dna(small, small.randint(8, 48)) for _ in range(10))]
+    sd = [c for c in sd if len(c[2]) >= 2]
+    se = [c for c in est if 2 <= len(c[1]) <= 60 and len(c[2]) <= 400][:8] + sd[:8]
+    sp = [c for c in p2d if 2 <= len(c[1]) <= 40 and 6 <= len(c[2]) <= 200][:12]
+    for tag, model, cases, match_states in (("affine_local", "affine:local", sd, (2,)), ("est2genome", "est2genome", se, (2, 5)),
+                                            ("protein2dna", "protein2dna", sp, (2,))):
+        for ms in match_states:
+            sfx = "" if len(match_states) == 1 else ("_fwd" if ms == 2 else "_rev")
+            sets.append(("derived_%s%s_start" % (tag, sfx), model, cases, 32, ("--derived", "0,%d,0,4" % ms)))
+            sets.append(("derived_%s%s_end" % (tag, sfx), model, cases, 32, ("--derived", "%d,1,4,0" % ms)))
+            sets.append(("derived_%s%s_join" % (tag, sfx), model, cases, 32, ("--derived", "%d,%d,4,4" % (ms, ms))))
     # sub-optimal alignments (SubOpt blocking, src/c4/subopt.c) through the GAM loop
     so = ("--suboptmax", "6", "--suboptthreshold", "30")
     rs = random.Random(4242)
