@@ -481,9 +481,13 @@ struct Engine {
         std::iota(order.begin(), order.end(), 0);
         auto cells = [&](int i) { return (long long)(specs[i].region.query_length + 1) * (specs[i].region.target_length + 1); };
         {
+            // ... unless the launch is tens of thousands of small jobs (the sub-alignments between checkpoints):
+            // any order balances those, and sorting them is then the largest item on the host
             std::vector<long long> key(n);
-            for (int i = 0; i < n; i++) key[i] = cells(i);
-            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] > key[b]; });
+            long long biggest = 0;
+            for (int i = 0; i < n; i++) { key[i] = cells(i); biggest = std::max(biggest, key[i]); }
+            if (!(n > 32768 && biggest < (1 << 20)))
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] > key[b]; });
         }
         std::vector<DevJob> jobs(n);
         long long ops_total = 0, vsa_total = 0, dump_total = 0, max_T = 0, max_tb = 0, max_ckpt = 0, total_cells = 0;
