@@ -44,6 +44,10 @@ struct c4gpu_ctx {
     double kernel_ms[4] = {0, 0, 0, 0};            // indexed by Viterbi mode
     int64_t kernel_launches[4] = {0, 0, 0, 0}, kernel_cells[4] = {0, 0, 0, 0};
     bool timing = false;
+    // share of pairs whose region-pass score reached the threshold in recent Optimal_find_path batches
+    // (-1: not known yet): decides whether a score-only pass goes first (find_path_batch, step 1);
+    // kept apart for first alignments [0] and the later rounds of the sub-optimal loop [1], which mostly fail
+    double hit_rate[2] = {-1.0, -1.0};
 };
 
 namespace {
@@ -421,6 +425,13 @@ struct Engine {
             else { blocked.push_back(i); pts.push_back(std::move(rp)); }
         }
         if (blocked.empty()) return run_impl(seqs, mode, cont, specs, out, nullptr);
+        // a handful of calls without blocked cells would occupy a corner of the device for as long as a full
+        // launch: they ride along in the blocking kernels with empty lists
+        if (plain.size() * 4 < blocked.size()) {
+            std::vector<RegionPoints> all(n);
+            for (size_t x = 0; x < blocked.size(); x++) all[blocked[x]] = std::move(pts[x]);
+            return run_impl(seqs, mode, cont, specs, out, &all);
+        }
         out.assign(n, JobOut());
         std::vector<JobSpec> part;
         std::vector<JobOut> part_out;
@@ -560,6 +571,7 @@ struct Engine {
             a.kp = kparams.p; a.seqs = seqs.dev; a.jobs = d_jobs.p; a.n_jobs = n; a.results = d_results.p;
             a.seqs.sub_colptr = nullptr; a.seqs.sub_rows = nullptr;
             if (pts) {
+                sub_q.push_back(0);                      // the kernels' row prefetch may touch one entry past the last list
                 if (d_sub_t.upload(sub_t.data(), sub_t.size(), s) || d_sub_q.upload(sub_q.data(), sub_q.size(), s) ||
                     d_sub_colptr.alloc(sub_cols)) return -1;
                 hipLaunchKernelGGL(subopt_colptr_kernel, dim3(std::min(n, 65535)), dim3(256), 0, s, d_jobs.p, n,
@@ -732,6 +744,50 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
             if (!model_is_global(m)) region_pairs.push_back(i);        // Optimal_find_region, optimal.c:135
         }
     }
+    const size_t step1_total = region_pairs.size();
+    double &hit_rate = eng.ctx->hit_rate[subs ? 1 : 0];
+    // A pair whose best score is below the threshold ends here (optimal.c:144-145).  The score alone costs
+    // 0.64 of a region pass (no region-start payload), so where few pairs reach the threshold — all-vs-all
+    // runs, the last round of the sub-optimal loop — a FIND_SCORE pass goes first and only the survivors get
+    // the region pass.  Same recurrence, same score (FIND_SCORE and FIND_REGION differ in payload only); the
+    // choice follows the hit rate of the previous batches of this context, sampled on the first large one.
+    {
+        const char *sf_env = getenv("C4GPU_SCORE_FIRST");                  // 0 never, 1 always, unset adaptive
+        const bool can = threshold > C4GPU_IMPOSSIBLY_LOW_SCORE && region_pairs.size() >= 512;
+        const size_t total = region_pairs.size();
+        auto score_filter = [&](size_t first, size_t count, size_t *kept) -> int {
+            specs.clear();
+            for (size_t x = first; x < first + count; x++) { JobSpec s; s.pair = region_pairs[x]; s.region = plan[region_pairs[x]].ar; specs.push_back(s); }
+            if (eng.run(seqs, MODE_SCORE, false, specs, outs)) return -1;
+            *kept = 0;
+            for (size_t x = 0; x < count; x++) {
+                if (outs[x].res.score < threshold) plan[region_pairs[first + x]].active = false;
+                else (*kept)++;
+            }
+            return 0;
+        };
+        bool score_first = false;
+        size_t sampled = 0, kept = 0, all_kept = 0;
+        if (can && sf_env) score_first = atoi(sf_env) != 0;
+        else if (can && hit_rate >= 0) score_first = hit_rate < 0.3;
+        else if (can) {
+            // one device-filling launch costs about the same as a small one: sample that many pairs
+            sampled = std::min<size_t>(8 * (size_t)eng.ctx->prop.multiProcessorCount, total);
+            if (score_filter(0, sampled, &kept)) return -1;
+            all_kept = kept;
+            score_first = (double)kept / (double)sampled < 0.3;
+        }
+        if (score_first && sampled < total) {
+            if (score_filter(sampled, total - sampled, &kept)) return -1;
+            all_kept += kept;
+        }
+        if (score_first || sampled) {
+            std::vector<int> survivors;
+            for (int i : region_pairs) if (plan[i].active) survivors.push_back(i);
+            region_pairs.swap(survivors);
+        }
+        (void)all_kept;
+    }
     specs.clear();
     for (int i : region_pairs) { JobSpec s; s.pair = i; s.region = plan[i].ar; specs.push_back(s); }
     if (eng.run(seqs, MODE_REGION, false, specs, outs)) return -1;
@@ -745,6 +801,12 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
         if (m->start_scope != C4GPU_SCOPE_TARGET) p.ar.target_start = r.ts;
         p.ar.query_length = r.qe - (m->start_scope != C4GPU_SCOPE_QUERY ? r.qs : 0);
         p.ar.target_length = r.te - (m->start_scope != C4GPU_SCOPE_TARGET ? r.ts : 0);
+    }
+    if (step1_total >= 64 && threshold > C4GPU_IMPOSSIBLY_LOW_SCORE) {
+        size_t hits = 0;
+        for (int i : region_pairs) hits += plan[i].active ? 1 : 0;
+        const double rate = (double)hits / (double)step1_total;
+        hit_rate = hit_rate < 0 ? rate : 0.5 * hit_rate + 0.5 * rate;
     }
     // -- step 2: quadratic-space path wherever the (alignment) region fits (optimal.c:349-364, 382-390)
     specs.clear(); owner.clear();

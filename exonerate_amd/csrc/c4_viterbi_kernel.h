@@ -440,13 +440,23 @@ struct WaveDP {
     int nx_tcode, nx_sp[4], nx_tn4, tlast;
     const uint16_t *tn4p;
     const int *sub_cp, *sub_rows;       // SUB: column pointers of this job, blocked rows of the launch
-    int nx_sub_lo, nx_sub_hi;
+    // two-stage prefetch: the column pointers of column j+2 and, through the pointers requested one step
+    // earlier, the first blocked row of column j+1 — nothing the step waits for was requested in that step
+    int nx_sub_lo, nx_sub_hi, nx_sub_row0;      // column j+1 (consumed by the next step)
+    int nx2_sub_lo, nx2_sub_hi;                 // column j+2
+    __device__ __forceinline__ void sub_load_ptrs(int j, int &lo, int &hi) const {
+        const int jc = j < 0 ? 0 : (j > T ? T : j);
+        lo = sub_cp[jc];
+        hi = sub_cp[jc + 1];
+    }
     __device__ __forceinline__ void prefetch_column(int j) {
         constexpr int mat = F::match_at();
         if constexpr (SUB) {
-            const int jc = j < 0 ? 0 : (j > T ? T : j);
-            nx_sub_lo = sub_cp[jc];
-            nx_sub_hi = sub_cp[jc + 1];
+            // called with the NEXT step's column j: what was requested for it last step moves up, its first
+            // blocked row is requested through those pointers, and the pointers of column j+1 are requested
+            nx_sub_lo = nx2_sub_lo; nx_sub_hi = nx2_sub_hi;
+            nx_sub_row0 = sub_rows[nx_sub_lo];          // the point arrays carry one spare entry at the end
+            sub_load_ptrs(j + 1, nx2_sub_lo, nx2_sub_hi);
         }
         int ti = t0 + j - mat;
         ti = ti < 0 ? 0 : (ti > tlast ? tlast : ti);
@@ -479,9 +489,14 @@ struct WaveDP {
         // the list walk sits behind a wave-uniform branch
         unsigned blk = 0;
         if constexpr (SUB) {
+            // an earlier alignment has one match cell per column it crosses, so a column's list is almost
+            // always empty or one row long: that row arrives with the prefetch; longer lists (several
+            // earlier alignments through one column) are walked behind a wave-uniform branch
             const int lo = nx_sub_lo, hi = nx_sub_hi;
-            if (__builtin_amdgcn_ballot_w64(hi > lo)) {
-                for (int p = lo; p < hi; p++) {
+            const int r0 = nx_sub_row0 - i0;
+            blk = ((hi > lo) & (r0 >= 0) & (r0 < R)) ? (1u << r0) : 0u;
+            if (__builtin_amdgcn_ballot_w64(hi - lo > 1)) {
+                for (int p = lo + 1; p < hi; p++) {
                     const int r = sub_rows[p] - i0;
                     blk |= (r >= 0 && r < R) ? (1u << r) : 0u;
                 }
@@ -716,6 +731,7 @@ struct WaveDP {
                                 job.cp_count);
                 });
             };
+            if constexpr (SUB) sub_load_ptrs(0 - lane, nx2_sub_lo, nx2_sub_hi);
             prefetch_column(0 - lane);
             prefetch_carry(0, bnd_in);
             int s = 0;
@@ -809,6 +825,7 @@ struct WaveDP {
             if (idle) {
                 for (int k = 0; k < nchunks; k++) __syncthreads();
             } else {
+                if constexpr (SUB) sub_load_ptrs(0 - lane, nx2_sub_lo, nx2_sub_hi);
                 prefetch_column(0 - lane);
                 prefetch_carry(0, bnd_in);
                 int k = 0;

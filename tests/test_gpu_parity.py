@@ -344,3 +344,28 @@ def test_thousands_of_bsdp_sized_jobs_on_derived_models(eng):
             assert g["ops"] == [vo.ops[x] for x in range(vo.n_ops)], (mt, spec, jobs[k])
             assert scores[k]["score"] == vo.score
             olib.oracle_viterbi_out_clear(vo)
+
+
+def test_score_pass_first_gives_the_same_alignments(eng, monkeypatch):
+    """find_path_batch may put a FIND_SCORE pass in front of the region pass when few pairs reach the
+    threshold (all-vs-all runs): forced on, forced off and adaptive give identical results."""
+    from exonerate_amd import workloads
+    base = workloads.est2genome_pairs(24, 300, 40000)
+    pairs = []
+    for k in range(600):                      # 1 in 25 pairs is a true cDNA/gene pair, the rest are unrelated
+        q, t = base[k % 24]
+        pairs.append((q, t) if k % 25 == 0 else (q, base[(k + 7) % 24][1]))
+    model = ex.Model("est2genome")
+    runs = {}
+    for mode in ("0", "1", None, None):
+        if mode is None:
+            monkeypatch.delenv("C4GPU_SCORE_FIRST", raising=False)
+        else:
+            monkeypatch.setenv("C4GPU_SCORE_FIRST", mode)
+        alns = eng.find_path(model, pairs, dpmemory=1, threshold=400)
+        runs.setdefault(str(mode), []).append([a.as_dict() if a else None for a in alns])
+    assert runs["0"][0] == runs["1"][0] == runs["None"][0] == runs["None"][1]
+    hits = [a for a in runs["0"][0] if a]
+    assert 20 <= len(hits) <= 40
+    q, t = pairs[0]
+    assert runs["0"][0][0] == oracle_lib.find_path(model.c, model.params, q, t, dpmemory=1, threshold=400)
