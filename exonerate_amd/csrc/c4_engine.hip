@@ -885,8 +885,12 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
             // optimal.c:214-217 passes vsa->final_cell as the buffer the recursive pass overwrites; siblings
             // scheduled in the same round used the old value: it must not have changed
             if (!first_round && !children.empty() &&
-                memcmp(children.back().final_cell, sg[k].final_cell, sizeof(int) * (1 + m->total_shadow_designations)) != 0)
+                memcmp(children.back().final_cell, sg[k].final_cell, sizeof(int) * (1 + m->total_shadow_designations)) != 0) {
+                if (getenv("C4GPU_TRACE"))
+                    fprintf(stderr, "c4gpu trace: pair %d nested segment %d: final cell %d/%d after the nested pass, %d/%d predicted\n",
+                            refs[x].pair, k, children.back().final_cell[0], children.back().final_cell[1], sg[k].final_cell[0], sg[k].final_cell[1]);
                 redo[refs[x].pair] = 1;
+            }
             sg.erase(sg.begin() + k);
             sg.insert(sg.begin() + k, children.begin(), children.end());
         }
@@ -925,8 +929,13 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
             // The reference threads the final cell of each sub-DP into the next one (optimal.c:283,301);
             // we predicted it from the checkpoint rows to run all sub-DPs in one launch: verify, and redo the
             // pair strictly sequentially if the prediction was wrong.
-            if (memcmp(outs[x].res.final_cell, sg[refs2[x].seg].final_cell, sizeof(int) * path_cs) != 0)
+            if (memcmp(outs[x].res.final_cell, sg[refs2[x].seg].final_cell, sizeof(int) * path_cs) != 0) {
+                if (getenv("C4GPU_TRACE") && !redo[i])
+                    fprintf(stderr, "c4gpu trace: pair %d sub-alignment %d: final cell %d/%d computed, %d/%d predicted\n", i,
+                            refs2[x].seg, outs[x].res.final_cell[0], outs[x].res.final_cell[1],
+                            sg[refs2[x].seg].final_cell[0], sg[refs2[x].seg].final_cell[1]);
                 redo[i] = 1;
+            }
             for (uint32_t r : outs[x].runs) c4h::alignment_add(&a, &cap[i], (int)(r >> 24), (int)(r & 0xffffff));
         }
     }
