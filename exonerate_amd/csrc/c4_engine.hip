@@ -917,26 +917,59 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
         const int path_cs = 1 + m->total_shadow_designations;
         static const bool force_seq = getenv("C4GPU_FORCE_SEQUENTIAL") != nullptr;    // test hook
         if (force_seq) for (int i : red) redo[i] = 1;
+        // The reference threads the final cell of each sub-DP into the next one (optimal.c:283,301); we
+        // predicted it from the checkpoint rows to run all sub-DPs in one launch.  Verify: up to and including
+        // the first sub-alignment whose final cell differs from the prediction, the batch did what the
+        // reference does; the ones after it were seeded with a cell the reference would not have used.
+        struct Repair { int pair, next_seg; int seed[CELL_MAX]; };
+        std::vector<Repair> repairs;
+        std::vector<int> repairing(n, -1);                 // first sub-alignment to recompute, per pair
         for (size_t x = 0; x < refs2.size(); x++) {
-            const int i = refs2[x].pair;
+            const int i = refs2[x].pair, k = refs2[x].seg;
             c4gpu_alignment &a = alignments[i];
             std::vector<Segment> &sg = plan[i].segs;
-            if (refs2[x].seg == 0) {
+            if (k == 0) {
                 a.score = red_score[i];
                 a.region = plan[i].ar;
                 a.valid = 1;
             }
-            // The reference threads the final cell of each sub-DP into the next one (optimal.c:283,301);
-            // we predicted it from the checkpoint rows to run all sub-DPs in one launch: verify, and redo the
-            // pair strictly sequentially if the prediction was wrong.
-            if (memcmp(outs[x].res.final_cell, sg[refs2[x].seg].final_cell, sizeof(int) * path_cs) != 0) {
-                if (getenv("C4GPU_TRACE") && !redo[i])
-                    fprintf(stderr, "c4gpu trace: pair %d sub-alignment %d: final cell %d/%d computed, %d/%d predicted\n", i,
-                            refs2[x].seg, outs[x].res.final_cell[0], outs[x].res.final_cell[1],
-                            sg[refs2[x].seg].final_cell[0], sg[refs2[x].seg].final_cell[1]);
-                redo[i] = 1;
-            }
+            if (redo[i] || repairing[i] >= 0) continue;     // redone below from the first stale sub-alignment
             for (uint32_t r : outs[x].runs) c4h::alignment_add(&a, &cap[i], (int)(r >> 24), (int)(r & 0xffffff));
+            if (memcmp(outs[x].res.final_cell, sg[k].final_cell, sizeof(int) * path_cs) != 0) {
+                if (getenv("C4GPU_TRACE"))
+                    fprintf(stderr, "c4gpu trace: pair %d sub-alignment %d: final cell %d/%d computed, %d/%d predicted\n", i,
+                            k, outs[x].res.final_cell[0], outs[x].res.final_cell[1], sg[k].final_cell[0], sg[k].final_cell[1]);
+                if (k + 1 < (int)sg.size()) {
+                    Repair rp; rp.pair = i; rp.next_seg = k + 1;
+                    memcpy(rp.seed, outs[x].res.final_cell, sizeof rp.seed);
+                    repairs.push_back(rp);
+                    repairing[i] = k + 1;
+                }
+            }
+        }
+        // Optimal_compute_subalignments (optimal.c:266-313) for the stale tails, all affected pairs in
+        // lock-step: one small launch per remaining sub-alignment, each seeded with the cell its predecessor
+        // actually produced.
+        while (!repairs.empty()) {
+            specs.clear();
+            for (const Repair &rp : repairs) {
+                const std::vector<Segment> &sg = plan[rp.pair].segs;
+                JobSpec s; s.pair = rp.pair; s.region = sg[rp.next_seg].region;
+                s.first_state = sg[rp.next_seg].first_state;
+                memcpy(s.first_cell, rp.seed, sizeof s.first_cell);
+                s.final_state = (rp.next_seg + 1 < (int)sg.size()) ? sg[rp.next_seg + 1].first_state : m->end_state;
+                specs.push_back(s);
+            }
+            if (eng.run(seqs, MODE_PATH, true, specs, outs)) return -1;
+            std::vector<Repair> next;
+            for (size_t x = 0; x < repairs.size(); x++) {
+                Repair rp = repairs[x];
+                c4gpu_alignment &a = alignments[rp.pair];
+                for (uint32_t r : outs[x].runs) c4h::alignment_add(&a, &cap[rp.pair], (int)(r >> 24), (int)(r & 0xffffff));
+                memcpy(rp.seed, outs[x].res.final_cell, sizeof rp.seed);
+                if (++rp.next_seg < (int)plan[rp.pair].segs.size()) next.push_back(rp);
+            }
+            repairs.swap(next);
         }
     }
     for (int i : red)

@@ -369,3 +369,20 @@ def test_score_pass_first_gives_the_same_alignments(eng, monkeypatch):
     assert 20 <= len(hits) <= 40
     q, t = pairs[0]
     assert runs["0"][0][0] == oracle_lib.find_path(model.c, model.params, q, t, dpmemory=1, threshold=400)
+
+
+def test_stale_sub_alignment_tails_are_recomputed(eng, monkeypatch, capfd):
+    """With intron length limits a sub-DP seeded at its corner can end above the cell the checkpoint pass
+    predicted (no optimal substructure); the sub-alignments after it are then recomputed in the reference's
+    order.  Pair 214 of the north-star batch does this in its second sub-optimal round (1 kb x 100 kb, checked
+    against the oracle's loop at full size)."""
+    from exonerate_amd import workloads
+    model = ex.Model("est2genome")
+    q, t = workloads.est2genome_pairs(1, 1000, 100000, first=214)[0]
+    monkeypatch.setenv("C4GPU_TRACE", "1")
+    found = eng.find_all_paths(model, [(q, t)], dpmemory=32, threshold=300, max_paths=2)[0]
+    err = capfd.readouterr().err
+    assert "predicted" in err, "this input no longer exercises the repair route"
+    exp = oracle_lib.find_paths_subopt(model.c, model.params, q, t, 32, 300, 2)
+    assert [a.as_dict() for a in found] == [d for d, _ in exp]
+    assert len(found) == 2
