@@ -475,8 +475,8 @@ struct Engine {
         // whole-rectangle passes whose query spans several 64*R-row strips run on 4 cooperating waves per
         // job (strip carry rows stay in LDS instead of HBM); C4GPU_MW=0 forces the one-wave kernels
         static const int mw_env = getenv("C4GPU_MW") ? atoi(getenv("C4GPU_MW")) : 1;
-        if (mw_env && !pts && !cont && (mode == MODE_SCORE || mode == MODE_REGION)) {
-            const KernelInfo *kmw = get_kernel_mw(family, mode, use_local, pack, 4);
+        if (mw_env && !cont && (mode == MODE_SCORE || mode == MODE_REGION)) {
+            const KernelInfo *kmw = get_kernel_mw(family, mode, use_local, pack, 4, pts != nullptr);
             if (kmw) {
                 long long strips = 0;
                 for (int i = 0; i < n; i++) strips += (specs[i].region.query_length + 1 + 64 * kmw->R - 1) / (64 * kmw->R);
@@ -484,7 +484,7 @@ struct Engine {
             }
             // 8 waves x 2 rows per lane cover the same rows per workgroup with twice the waves: taken when the
             // launch has too few jobs to occupy the device with 4 waves each (C4GPU_MW=4 keeps 4)
-            const KernelInfo *kmw8 = (ki == kmw && mw_env != 4) ? get_kernel_mw(family, mode, use_local, pack, 8) : nullptr;
+            const KernelInfo *kmw8 = (ki == kmw && mw_env != 4 && !pts) ? get_kernel_mw(family, mode, use_local, pack, 8) : nullptr;
             if (kmw8 && (long long)n * 8 <= 2LL * 4 * ctx->prop.multiProcessorCount) ki = kmw8;
         }
         // longest first (persistent waves pull from the queue head)

@@ -43,7 +43,7 @@ struct KernelInfo {
 const KernelInfo *get_kernel(int family, int mode, bool cont, bool local, bool pack, int wpe = 0, bool sub = false);
 // multi-wave kernels (`waves` = 4 or 8 cooperating waves per job) for FIND_SCORE / FIND_REGION without
 // continuation
-const KernelInfo *get_kernel_mw(int family, int mode, bool local, bool pack, int waves = 4);
+const KernelInfo *get_kernel_mw(int family, int mode, bool local, bool pack, int waves = 4, bool sub = false);
 
 #define C4K_DEFINE_KERNEL(SYMBOL, M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV)                                          \
     static hipError_t SYMBOL##_launch(const LaunchArgs &a) {                                               \
@@ -65,16 +65,16 @@ const KernelInfo *get_kernel_mw(int family, int mode, bool local, bool pack, int
         return &ki;                                                                                        \
     }
 
-#define C4K_DEFINE_KERNEL_MW(SYMBOL, M, RVAL, MODE, LOCAL, PACK, NWV, WPE)                                   \
+#define C4K_DEFINE_KERNEL_MW(SYMBOL, M, RVAL, MODE, LOCAL, PACK, NWV, WPE, SUBV)                                 \
     static hipError_t SYMBOL##_launch(const LaunchArgs &a) {                                               \
-        hipLaunchKernelGGL((viterbi_kernel_mw<M, RVAL, MODE, LOCAL, PACK, NWV, WPE>), dim3(a.grid),          \
+        hipLaunchKernelGGL((viterbi_kernel_mw<M, RVAL, MODE, LOCAL, PACK, NWV, WPE, SUBV>), dim3(a.grid),          \
                            dim3(64 * NWV), 0, a.stream, a.kp, a.seqs, a.jobs, a.n_jobs, a.results,          \
                            a.scratch, a.queue);                                                            \
         return hipGetLastError();                                                                          \
     }                                                                                                      \
     const KernelInfo *SYMBOL() {                                                                           \
         static const KernelInfo ki = {SYMBOL##_launch,                                                     \
-                                      (const void *)viterbi_kernel_mw<M, RVAL, MODE, LOCAL, PACK, NWV, WPE>, \
+                                      (const void *)viterbi_kernel_mw<M, RVAL, MODE, LOCAL, PACK, NWV, WPE, SUBV>, \
                                       #SYMBOL,                                                             \
                                       RVAL,                                                                \
                                       WaveDP<M, RVAL, MODE, false, LOCAL, PACK>::CS,                       \

@@ -1073,11 +1073,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
 // -------------------------------------------------------------------------------------------------------------
 // Kernel: NW cooperating waves per job (FIND_SCORE / FIND_REGION over whole rectangles).
 // -------------------------------------------------------------------------------------------------------------
-template <class M, int R, int MODE, bool LOCAL, bool PACK, int NW, int WPE>
+template <class M, int R, int MODE, bool LOCAL, bool PACK, int NW, int WPE, bool SUB = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
 void viterbi_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, int n_jobs, DevResult *results,
                        DevScratch scratch, int *queue) {
-    using DP = WaveDP<M, R, MODE, false, LOCAL, PACK>;
+    using DP = WaveDP<M, R, MODE, false, LOCAL, PACK, SUB>;
     __shared__ KParams kp_lds;
     __shared__ int next_job;
     __shared__ int rings[(NW > 1 ? NW - 1 : 1) * DP::RING * DP::BND];
