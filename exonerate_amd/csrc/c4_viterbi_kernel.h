@@ -257,7 +257,14 @@ struct WaveDP {
             // the START cell's slots are zero unless seeded by a continuation (calloc'd, never written)
             static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; c.ex[M::START][E] = 0; });
         }
-        const bool i_ok = (RR > 0) | (i > 0);
+        // Row 0 has no row above it: transitions that advance the query are invalid there (layout.c:122-154).
+        // In the local score / region passes (START reachable with score 0 in every cell) the mask is not
+        // needed: the phantom row above reads as unset (-987654321), what such a transition then proposes stays
+        // within a few thousand of that value, and every state that can lie on a path to END has a candidate
+        // that is hundreds of millions higher in the same cell — the same reason the reference's own "unset
+        // states still propagate" never shows in a result.  States that are unset in row 0 hold a different
+        // near-minimum number; nothing reads them on the way to a reported score, end cell or region start.
+        const bool i_ok = (RR > 0) | (i > 0) | (LOCAL && (MODE == MODE_SCORE || MODE == MODE_REGION));
         uint32_t tbw = 0;
         static_for<M::NT>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
             constexpr int k = K;
