@@ -547,7 +547,8 @@ struct Engine {
         long long carry_T = 0;
         for (int x = 0; x < n; x++)
             if ((jobs[x].Q + 1 + 64 * ki->R - 1) / (64 * ki->R) > ki->waves) carry_T = max_T;
-        const long long bnd_per_wave = 2 * ((carry_T ? carry_T : 0) + 1) * (long long)std::max(ki->bnd, 1);
+        // per workgroup: one "empty" column (what the first strip reads as its row above) + two carry rows
+        const long long bnd_per_wave = (2 * ((carry_T ? carry_T : 0) + 1) + 1) * (long long)std::max(ki->bnd, 1);
         const long long bytes_per_wave = bnd_per_wave * 4 + max_tb * 4 + max_ckpt * 4 + max_runs * 4;
         // compact run array: paths are mostly long runs, so a fraction of the worst case is plenty; a
         // launch that overflows it is repeated with the worst case

@@ -418,9 +418,18 @@ struct WaveDP {
                                                         // valid address, so a null test cannot tell)
     int cp_next_j, cp_next_i;   // FIND_CHECKPOINTS: column / index of the next checkpoint this lane will cross
     bool carry_ok;      // the launch allocated HBM carry rows (some job has more strips than waves per job)
+    bool carry_cols;    // this strip reads real carry columns from HBM (else: one column, see empty_column)
+    // The first strip has no row above it: its lane 0 reads an "empty" column (every state unset: -987654321,
+    // slots 0) through the same prefetch as a real carry row, so the step needs no first-strip selects.
+    __device__ __forceinline__ static void write_empty_column(int *col) {
+        for_exported([&](auto S_, int slot) __attribute__((always_inline)) {
+            col[slot] = LOW;
+            static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; col[slot + 1 + E] = 0; });
+        });
+    }
     __device__ __forceinline__ void prefetch_carry(int s_next, const int *bnd_in) {
         const int jx = s_next < 0 ? 0 : (s_next > T ? T : s_next);
-        const int jc = (carry_ok | use_ring_in) ? jx : 0;      // without carry rows every load hits column 0
+        const int jc = (carry_cols | use_ring_in) ? jx : 0;    // no row above / no carry rows: every load hits column 0
         if (use_ring_in) {
             for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
                 const lds_int *p = ring_in + (jc & (RING - 1)) * BND + slot;
@@ -525,11 +534,11 @@ struct WaveDP {
         // (requested one step ago)
         for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
             const int c_sc = nx_carry.sc[S];
-            nbr[PH].sc[S] = dpp_shr1(first_strip ? LOW : c_sc, expo.sc[S]);
+            nbr[PH].sc[S] = dpp_shr1(c_sc, expo.sc[S]);        // first strip: the carry source is the empty column
             static_for<XS>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
                 if constexpr (X > 0) if constexpr (slot_live(S, E)) {
                     const int c_ex = nx_carry.ex[S][E];
-                    nbr[PH].ex[S][E] = dpp_shr1(first_strip ? 0 : c_ex, expo.ex[S][E]);
+                    nbr[PH].ex[S][E] = dpp_shr1(c_ex, expo.ex[S][E]);
                 }
             });
         });
@@ -722,9 +731,11 @@ struct WaveDP {
             if constexpr (!CONT) strip_begin();
             cp_next_j = section_length > 0 ? section_length : 0x7fffffff; cp_next_i = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const int *bnd_in = bnd + (carry_ok ? (long long)((b + 1) & 1) * (T + 1) * BND : 0);
-            int *bnd_out = bnd + (carry_ok ? (long long)(b & 1) * (T + 1) * BND : 0);
             const bool first = (b == 0), last = (b == nstrips - 1);
+            // slab layout: [empty column][carry row A (T+1 columns)][carry row B]
+            carry_cols = carry_ok & !first;
+            const int *bnd_in = first ? bnd : bnd + BND + (carry_ok ? (long long)((b + 1) & 1) * (T + 1) * BND : 0);
+            int *bnd_out = bnd + BND + (carry_ok ? (long long)(b & 1) * (T + 1) * BND : 0);
             const int nsteps = T + 64;
             const int main_lo = 63 + M::MAXAT, main_hi = T;          // steps where every lane is interior in j
             // steps run in groups of NCOL with compile-time ring phases (s % NCOL); the padding steps past
@@ -812,8 +823,9 @@ struct WaveDP {
             });
             strip_begin();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const int *bnd_in = bnd + (carry_ok ? (long long)((sb + 1) & 1) * (T + 1) * BND : 0);
-            int *bnd_out = bnd + (carry_ok ? (long long)(sb & 1) * (T + 1) * BND : 0);
+            carry_cols = carry_ok & (sb > 0);
+            const int *bnd_in = (sb == 0) ? bnd : bnd + BND + (carry_ok ? (long long)((sb + 1) & 1) * (T + 1) * BND : 0);
+            int *bnd_out = bnd + BND + (carry_ok ? (long long)(sb & 1) * (T + 1) * BND : 0);
             use_ring_in = wid > 0;  use_ring_out = wid < NW - 1;
             ring_in = rings + (wid > 0 ? wid - 1 : 0) * RING * BND;
             ring_out = rings + (wid < NW - 1 ? wid : 0) * RING * BND;
@@ -1011,6 +1023,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
     __syncthreads();
     const int wave = blockIdx.x;
     int *bnd = scratch.bnd + (long long)wave * scratch.bnd_stride;
+    if (threadIdx.x == 0) DP::write_empty_column(bnd);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
     uint32_t *tb = scratch.tb ? scratch.tb + (long long)wave * scratch.tb_stride : nullptr;
     int *ckpt_slab = scratch.ckpt ? scratch.ckpt + (long long)wave * scratch.ckpt_stride : nullptr;
     for (;;) {
@@ -1097,6 +1112,9 @@ void viterbi_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *jobs,
     __syncthreads();
     const int wid = threadIdx.x >> 6;
     int *bnd = scratch.bnd + (long long)blockIdx.x * scratch.bnd_stride;
+    if (threadIdx.x == 0) DP::write_empty_column(bnd);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
     for (;;) {
         if (threadIdx.x == 0) next_job = atomicAdd(queue, 1);
         __syncthreads();
