@@ -470,6 +470,7 @@ static void shim_flush(void){
     c4gpu_pair *pair;
     gchar **str;
     GPtrArray *todo = shim_pending;
+    gint64 t_start = g_get_monotonic_time(), t_gpu0 = 0, t_gpu1 = 0;
     if((!todo) || (!todo->len))
         return;
     shim_pending = NULL;          /* pairs submitted while replaying start a new collection */
@@ -501,6 +502,7 @@ static void shim_flush(void){
         g_hash_table_destroy(flat);
         }
     sp = todo->pdata[0];
+    t_gpu0 = g_get_monotonic_time();
     ud = Model_Type_create_data(gam->gas->type, sp->query, sp->target);
     if(shim_flatten(gam->optimal->find_path->model, ud, &fm)){
         shim_params(ud, &params);
@@ -536,6 +538,7 @@ static void shim_flush(void){
         }
     if(batch)
         c4gpu_batch_destroy(batch);
+    t_gpu1 = g_get_monotonic_time();
     for(i = 0; i < 2*n; i++)
         g_free(str[i]);
     g_free(str);
@@ -561,6 +564,10 @@ static void shim_flush(void){
         g_free(sp);
         }
     g_ptr_array_free(todo, TRUE);
+    if(shim_verbose)
+        g_message("c4gpu: flush of %d pairs: %.0f ms flattening, %.0f ms on the device (upload, passes, read-back), "
+                  "%.0f ms replaying through the reference", n, (t_gpu0 - t_start) / 1e3, (t_gpu1 - t_gpu0) / 1e3,
+                  (g_get_monotonic_time() - t_gpu1) / 1e3);
     return;
     }
 
