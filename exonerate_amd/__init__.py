@@ -305,6 +305,11 @@ class ResidentBatch:
         if _lib().c4gpu_batch_run(self.h, what, dpmemory, threshold) != 0:
             raise _err("c4gpu_batch_run")
 
+    def set_thresholds(self, per_pair):
+        """Per-pair score thresholds (exonerate's --percent); None switches them off."""
+        arr = None if per_pair is None else (C.c_int32 * max(1, self.n))(*per_pair)
+        _lib().c4gpu_batch_set_thresholds(self.h, arr)
+
     def next_paths(self, dpmemory=32, threshold=IMPOSSIBLY_LOW_SCORE):
         """Next round of the sub-optimal loop (c4gpu_batch_next_paths); returns the number found."""
         n = _lib().c4gpu_batch_next_paths(self.h, dpmemory, threshold)

@@ -155,6 +155,7 @@ PROTOTYPES = [
                                         C.POINTER(Pair), C.c_int32]),
     ("c4gpu_batch_destroy", None, [C.c_void_p]),
     ("c4gpu_batch_run", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int32]),
+    ("c4gpu_batch_set_thresholds", C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     ("c4gpu_batch_viterbi", C.c_int, [C.c_void_p, C.c_int, C.POINTER(ViterbiJob), C.c_int32,
                                       C.POINTER(ViterbiResult)]),
     ("c4gpu_batch_scores", C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(Region)]),

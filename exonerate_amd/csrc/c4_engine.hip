@@ -721,9 +721,14 @@ int sequential_reduced_path(Engine &eng, const ResidentSeqs &seqs, int pair, int
 // the path (optimal.c:368-413); active (may be NULL): pairs to run, the others get no alignment.
 int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gpu_score threshold,
                     c4gpu_alignment *alignments, const std::vector<const c4gpu_subopt *> *subs = nullptr,
-                    const uint8_t *active = nullptr) {
+                    const uint8_t *active = nullptr, const std::vector<c4gpu_score> *pair_thresholds = nullptr) {
     const c4gpu_model *m = eng.model;
     const int n = seqs.n_pairs;
+    // per-pair thresholds (GAM_get_query_threshold with --percent, gam.c:677-705): never below `threshold`
+    const c4gpu_score base_threshold = threshold;
+    auto thr = [&](int pair) {
+        return (pair_thresholds && (*pair_thresholds)[pair] > base_threshold) ? (*pair_thresholds)[pair] : base_threshold;
+    };
     struct SubScope {                // every eng.run below sees the pairs' blocked cells
         Engine &e;
         SubScope(Engine &e_, const std::vector<const c4gpu_subopt *> *s) : e(e_) { e.pair_sub = s; }
@@ -762,7 +767,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
             if (eng.run(seqs, MODE_SCORE, false, specs, outs)) return -1;
             *kept = 0;
             for (size_t x = 0; x < count; x++) {
-                if (outs[x].res.score < threshold) plan[region_pairs[first + x]].active = false;
+                if (outs[x].res.score < thr(region_pairs[first + x])) plan[region_pairs[first + x]].active = false;
                 else (*kept)++;
             }
             return 0;
@@ -795,7 +800,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
     for (size_t x = 0; x < region_pairs.size(); x++) {
         PairPlan &p = plan[region_pairs[x]];
         const DevResult &r = outs[x].res;
-        if (r.score < threshold) { p.active = false; continue; }
+        if (r.score < thr(region_pairs[x])) { p.active = false; continue; }
         p.region_score = r.score;
         // Viterbi_Data_finalise, viterbi.c:633-653
         if (m->start_scope != C4GPU_SCOPE_QUERY) p.ar.query_start = r.qs;
@@ -977,7 +982,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
         if (redo[i] && sequential_reduced_path(eng, seqs, i, dpmemory_mb, plan[i].ar, &alignments[i])) return -1;
     for (int i = 0; i < n; i++) {
         c4gpu_alignment &a = alignments[i];
-        if (a.valid && a.score < threshold) c4gpu_alignment_clear(&a);     // optimal.c:408-411
+        if (a.valid && a.score < thr(i)) c4gpu_alignment_clear(&a);     // optimal.c:408-411
     }
     return 0;
 }
@@ -997,6 +1002,7 @@ struct c4gpu_batch {
     // the sub-optimal loop (c4gpu_batch_next_paths): one SubOpt per pair, pairs still in the loop
     std::vector<c4gpu_subopt *> subopts;
     std::vector<uint8_t> in_loop;
+    std::vector<c4gpu_score> pair_thresholds;        // c4gpu_batch_set_thresholds; empty = none
     void clear_loop() {
         for (c4gpu_subopt *so : subopts) c4gpu_subopt_destroy(so);
         subopts.clear(); in_loop.clear();
@@ -1218,9 +1224,16 @@ int c4gpu_batch_run(c4gpu_batch *b, int what, int dpmemory_mb, c4gpu_score thres
     for (auto &a : b->alignments) c4gpu_alignment_clear(&a);
     b->alignments.assign(n, c4gpu_alignment{});
     b->clear_loop();
-    if (find_path_batch(b->eng, b->seqs, dpmemory_mb, threshold, b->alignments.data())) return -1;
+    if (find_path_batch(b->eng, b->seqs, dpmemory_mb, threshold, b->alignments.data(), nullptr, nullptr,
+                        b->pair_thresholds.empty() ? nullptr : &b->pair_thresholds)) return -1;
     b->scores.resize(n); b->regions.resize(n);
     for (int i = 0; i < n; i++) { b->scores[i] = b->alignments[i].score; b->regions[i] = b->alignments[i].region; }
+    return 0;
+}
+
+int c4gpu_batch_set_thresholds(c4gpu_batch *b, const c4gpu_score *per_pair) {
+    if (!per_pair) { b->pair_thresholds.clear(); return 0; }
+    b->pair_thresholds.assign(per_pair, per_pair + b->seqs.n_pairs);
     return 0;
 }
 
@@ -1248,7 +1261,8 @@ int c4gpu_batch_next_paths(c4gpu_batch *b, int dpmemory_mb, c4gpu_score threshol
     }
     for (auto &a : b->alignments) c4gpu_alignment_clear(&a);
     if (!still) return 0;
-    if (find_path_batch(b->eng, b->seqs, dpmemory_mb, threshold, b->alignments.data(), &subs, b->in_loop.data())) return -1;
+    if (find_path_batch(b->eng, b->seqs, dpmemory_mb, threshold, b->alignments.data(), &subs, b->in_loop.data(),
+                        b->pair_thresholds.empty() ? nullptr : &b->pair_thresholds)) return -1;
     int found = 0;
     for (int i = 0; i < n; i++) {
         found += b->alignments[i].valid ? 1 : 0;

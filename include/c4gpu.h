@@ -292,6 +292,10 @@ void         c4gpu_batch_destroy(c4gpu_batch *b);
 /* One pass of the hot path over the resident batch. `what`: 0 = score pass only (FIND_SCORE),
  * 1 = region pass only, 2 = full Optimal_find_path.  Results stay on the object. */
 int          c4gpu_batch_run(c4gpu_batch *b, int what, int dpmemory_mb, c4gpu_score threshold);
+/* Per-pair score thresholds for the full runs (what = 2) and c4gpu_batch_next_paths: what
+ * GAM_get_query_threshold gives a query under --percent (gam.c:466-487,677-705; never below --score).  A pair
+ * is held to max(threshold argument, per_pair[i]).  NULL switches them off. */
+int          c4gpu_batch_set_thresholds(c4gpu_batch *b, const c4gpu_score *per_pair);
 /* c4gpu_viterbi_batch on the pairs already resident (jobs[i].pair indexes them): what a caller that makes
  * many Viterbi_DP_Func calls on the same pair uses to upload it once. */
 int          c4gpu_batch_viterbi(c4gpu_batch *b, int mode, const c4gpu_viterbi_job *jobs, int32_t n_jobs,

@@ -445,8 +445,8 @@ static gboolean shim_can_batch(GAM *gam, Sequence *query, Sequence *target){
     c4gpu_model fm;
     if((shim_batch_size() <= 0) || (!gam->optimal) || (!shim_get_ctx()))
         return FALSE;
-    if((gam->gas->refinement != GAM_Refinement_NONE) || gam->gas->percent_threshold)
-        return FALSE;  /* refinement re-enters Optimal_find_path; %-thresholds can sit below --score */
+    if(gam->gas->refinement != GAM_Refinement_NONE)
+        return FALSE;  /* refinement re-enters Optimal_find_path with other regions */
     if((gam->optimal->type & (Optimal_Type_SCORE|Optimal_Type_PATH|Optimal_Type_REDUCED_SPACE))
        != (Optimal_Type_SCORE|Optimal_Type_PATH|Optimal_Type_REDUCED_SPACE))
         return FALSE;
@@ -454,6 +454,30 @@ static gboolean shim_can_batch(GAM *gam, Sequence *query, Sequence *target){
     ok = shim_flatten(gam->optimal->find_path->model, ud, &fm);
     Model_Type_destroy_data(gam->gas->type, ud);
     return ok;
+    }
+
+/* GAM_QueryInfo_create (gam.c:466-487): the --percent threshold of a query = the best self-comparison score
+ * over the model's match types x percent / 100, never below --score.  The function is file-static in the
+ * reference; the structures it walks are public. */
+static C4_Score shim_query_threshold(GAM *gam, Sequence *query){
+    register C4_Score threshold = 0;
+    register guint i;
+    register gint j;
+    if(!gam->gas->percent_threshold)
+        return gam->gas->threshold;
+    for(i = 0; i < gam->match_list->len; i++){
+        register Match *match = gam->match_list->pdata[i];
+        register Match_Score th = 0;
+        for(j = 0; j < (gint)query->len; j += match->query->advance)
+            th += match->query->self_func(match->query, query, j);
+        if(threshold < th)
+            threshold = th;
+        }
+    threshold *= gam->gas->percent_threshold;
+    threshold /= 100;
+    if(threshold < gam->gas->threshold)
+        threshold = gam->gas->threshold;
+    return threshold;
     }
 
 static void shim_flush(void){
@@ -509,6 +533,23 @@ static void shim_flush(void){
         batch = c4gpu_batch_create(shim_ctx, &fm, &params, pair, n);
         }
     Model_Type_destroy_data(gam->gas->type, ud);
+    if(batch && gam->gas->percent_threshold){
+        /* one threshold per query (cached by Sequence): pairs below it stop after the score pass */
+        register GHashTable *seen = g_hash_table_new(g_direct_hash, g_direct_equal);
+        c4gpu_score *per_pair = g_new(c4gpu_score, n);
+        for(i = 0; i < n; i++){
+            gpointer v;
+            sp = todo->pdata[i];
+            if(!g_hash_table_lookup_extended(seen, sp->query, NULL, &v)){
+                v = GINT_TO_POINTER(shim_query_threshold(gam, sp->query));
+                g_hash_table_insert(seen, sp->query, v);
+                }
+            per_pair[i] = GPOINTER_TO_INT(v);
+            }
+        c4gpu_batch_set_thresholds(batch, per_pair);
+        g_free(per_pair);
+        g_hash_table_destroy(seen);
+        }
     if(batch && (c4gpu_batch_run(batch, 2, dpmemory, threshold) == 0)){
         if(!gam->gas->use_subopt)
             rounds_max = 1;

@@ -34,6 +34,7 @@ def _run(exe, args, env=None):
     # 2: several flushes of the batching seam; --bestn: thresholds that move while results are submitted
     ("est2genome", [], "0"), ("affine:local", ["-D", "1"], "0"), ("protein2genome", [], "0"),
     ("est2genome", ["--forcegtag", "yes"], "4096"), ("protein2genome", ["--forcegtag", "yes"], "0"),
+    ("est2genome", ["--percent", "60"], "4096"), ("affine:local", ["--percent", "30", "-S", "yes"], "5"),
     ("est2genome", [], "2"), ("affine:local", ["--bestn", "1"], "4"), ("est2genome", ["--bestn", "2", "-S", "yes"], "4096"),
 ])
 def test_exonerate_gpu_output_is_byte_identical(tmp_path, model, extra, batch):
@@ -74,6 +75,8 @@ def test_exonerate_gpu_output_is_byte_identical(tmp_path, model, extra, batch):
     assert ("c4gpu: batch of" in gpu_err) == (batch != "0"), gpu_err[-1500:]
     assert gpu_out == ref_out
     assert ref_out.count("vulgar:") >= (1 if "--bestn" in extra else 3)
+    if "--percent" in extra:
+        assert ref_out.count("vulgar:") < 9       # the unrelated query/target combinations are filtered
 
 
 @pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
