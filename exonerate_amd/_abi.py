@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libc4gpu.so")
 
-MAX_STATES, MAX_TRANSITIONS, MAX_CALCS, MAX_SHADOWS, NAME_LEN = 16, 32, 16, 4, 48
+MAX_STATES, MAX_TRANSITIONS, MAX_CALCS, MAX_SHADOWS, NAME_LEN = 16, 48, 16, 4, 48
 SPLICE_MAX_LEN = 32
 CELL_MAX = 1 + MAX_SHADOWS + 3
 IMPOSSIBLY_LOW_SCORE = -987654321
@@ -37,7 +37,7 @@ class Transition(C.Structure):
 
 class Shadow(C.Structure):
     _fields_ = [("name", C.c_char * NAME_LEN), ("designation", C.c_int32), ("on_target", C.c_int32),
-                ("src_state_mask", C.c_uint32), ("dst_transition_mask", C.c_uint32)]
+                ("src_state_mask", C.c_uint32), ("dst_transition_mask", C.c_uint64)]
 
 
 class Model(C.Structure):

@@ -126,17 +126,21 @@ int model_family(const c4gpu_model &m) {
     if (model_matches<Protein2DnaStartDesc>(m)) return FAM_PROTEIN2DNA_START;
     if (model_matches<Protein2DnaEndDesc>(m)) return FAM_PROTEIN2DNA_END;
     if (model_matches<Protein2DnaJoinDesc>(m)) return FAM_PROTEIN2DNA_JOIN;
+    if (model_matches<Protein2GenomeStartDesc>(m)) return FAM_PROTEIN2GENOME_START;
+    if (model_matches<Protein2GenomeEndDesc>(m)) return FAM_PROTEIN2GENOME_END;
+    if (model_matches<Protein2GenomeJoinDesc>(m)) return FAM_PROTEIN2GENOME_JOIN;
     return -1;
 }
 
 bool family_is_p2d(int fam) {
     return fam == FAM_UNGAPPED_P2D || fam == FAM_PROTEIN2DNA || fam == FAM_PROTEIN2GENOME ||
-           (fam >= FAM_PROTEIN2DNA_START && fam <= FAM_PROTEIN2DNA_JOIN);
+           (fam >= FAM_PROTEIN2DNA_START && fam <= FAM_PROTEIN2GENOME_JOIN);
 }
 bool family_has_splice(int fam) {
-    return fam == FAM_EST2GENOME || fam == FAM_PROTEIN2GENOME || (fam >= FAM_EST2GENOME_FWD_START && fam <= FAM_EST2GENOME_REV_JOIN);
+    return fam == FAM_EST2GENOME || fam == FAM_PROTEIN2GENOME || (fam >= FAM_EST2GENOME_FWD_START && fam <= FAM_EST2GENOME_REV_JOIN) ||
+           (fam >= FAM_PROTEIN2GENOME_START && fam <= FAM_PROTEIN2GENOME_JOIN);
 }
-bool family_has_phase(int fam) { return fam == FAM_PROTEIN2GENOME; }
+bool family_has_phase(int fam) { return fam == FAM_PROTEIN2GENOME || (fam >= FAM_PROTEIN2GENOME_START && fam <= FAM_PROTEIN2GENOME_JOIN); }
 
 // ---- sequence preparation kernels -------------------------------------------------------------------------
 struct PrepTables {

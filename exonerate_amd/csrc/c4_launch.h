@@ -11,7 +11,8 @@ enum Family { FAM_UNGAPPED = 0, FAM_AFFINE, FAM_EST2GENOME, FAM_UNGAPPED_P2D, FA
               FAM_AFFINE_START, FAM_AFFINE_END, FAM_AFFINE_JOIN,
               FAM_EST2GENOME_FWD_START, FAM_EST2GENOME_FWD_END, FAM_EST2GENOME_FWD_JOIN,
               FAM_EST2GENOME_REV_START, FAM_EST2GENOME_REV_END, FAM_EST2GENOME_REV_JOIN,
-              FAM_PROTEIN2DNA_START, FAM_PROTEIN2DNA_END, FAM_PROTEIN2DNA_JOIN, FAM_COUNT };
+              FAM_PROTEIN2DNA_START, FAM_PROTEIN2DNA_END, FAM_PROTEIN2DNA_JOIN,
+              FAM_PROTEIN2GENOME_START, FAM_PROTEIN2GENOME_END, FAM_PROTEIN2GENOME_JOIN, FAM_COUNT };
 
 struct LaunchArgs {
     const KParams *kp;

@@ -512,7 +512,7 @@ int c4m_flatten(const c4m_model *m, c4gpu_model *out) {
         o.designation = sh.designation;
         o.on_target = sh.on_target;
         for (int st : sh.src_states) o.src_state_mask |= 1u << st;
-        for (int h : sh.dst_transitions) o.dst_transition_mask |= 1u << m->tr[h].id;
+        for (int h : sh.dst_transitions) o.dst_transition_mask |= 1ull << m->tr[h].id;
     }
     return 0;
 }

@@ -30,7 +30,7 @@ namespace c4k {
 
 struct TrDesc { int in, out, aq, at, calc, label; unsigned dst_shadow_mask; };
 struct CalcDesc { int kind, param, protect; };
-struct ShDesc { int designation, on_target; unsigned src_state_mask, dst_transition_mask; };
+struct ShDesc { int designation, on_target; unsigned src_state_mask; unsigned long long dst_transition_mask; };
 
 #include "c4_device_models.inc"
 

@@ -31,7 +31,7 @@ typedef int32_t c4gpu_score;
 #define C4GPU_IMPOSSIBLY_HIGH_SCORE (987654321)
 
 #define C4GPU_MAX_STATES       16
-#define C4GPU_MAX_TRANSITIONS  32
+#define C4GPU_MAX_TRANSITIONS  48
 #define C4GPU_MAX_CALCS        16
 #define C4GPU_MAX_SHADOWS       4
 #define C4GPU_NAME_LEN         48
@@ -92,7 +92,7 @@ typedef struct {
     int32_t designation;                    /* cell slot = designation + 1 */
     int32_t on_target;                      /* 1: start_func returns target_pos; 0: query_pos */
     uint32_t src_state_mask;                /* states the shadow starts from */
-    uint32_t dst_transition_mask;           /* transitions it ends on */
+    uint64_t dst_transition_mask;           /* transitions it ends on (ids up to C4GPU_MAX_TRANSITIONS - 1) */
 } c4gpu_shadow;
 
 /* A *closed* C4_Model flattened to a POD (src/c4/c4.h:172-194). */

@@ -155,7 +155,7 @@ static gboolean shim_flatten(C4_Model *m, Ungapped_Data *ud, c4gpu_model *out){
         for(j = 0; j < s->src_state_list->len; j++)
             o->src_state_mask |= 1u << ((C4_State*)s->src_state_list->pdata[j])->id;
         for(j = 0; j < s->dst_transition_list->len; j++)
-            o->dst_transition_mask |= 1u << ((C4_Transition*)s->dst_transition_list->pdata[j])->id;
+            o->dst_transition_mask |= ((uint64_t)1) << ((C4_Transition*)s->dst_transition_list->pdata[j])->id;
         }
     return c4gpu_model_is_accelerated(out);
     }

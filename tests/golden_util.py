@@ -37,7 +37,7 @@ SUBOPT_SETS = {
 # BSDP's derived models: golden file -> (model type, query alphabet, target alphabet, (src, dst, start scope, end scope))
 DERIVED_SETS = {}
 for _tag, _mt, _qa, _ta, _ms in (("affine_local", "affine:local", 0, 0, (2,)), ("est2genome", "est2genome", 0, 0, (2, 5)),
-                                 ("protein2dna", "protein2dna", 1, 0, (2,))):
+                                 ("protein2dna", "protein2dna", 1, 0, (2,)), ("protein2genome", "protein2genome", 1, 0, (2,))):
     for _m in _ms:
         _sfx = "" if len(_ms) == 1 else ("_fwd" if _m == 2 else "_rev")
         DERIVED_SETS["derived_%s%s_start" % (_tag, _sfx)] = (_mt, _qa, _ta, (0, _m, 0, 4))

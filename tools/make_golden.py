@@ -251,8 +251,9 @@ def main():
     sd = [c for c in sd if len(c[2]) >= 2]
     se = [c for c in est if 2 <= len(c[1]) <= 60 and len(c[2]) <= 400][:8] + sd[:8]
     sp = [c for c in p2d if 2 <= len(c[1]) <= 40 and 6 <= len(c[2]) <= 200][:12]
+    sg = [c for c in p2g if 2 <= len(c[1]) <= 40 and 6 <= len(c[2]) <= 400][:10]
     for tag, model, cases, match_states in (("affine_local", "affine:local", sd, (2,)), ("est2genome", "est2genome", se, (2, 5)),
-                                            ("protein2dna", "protein2dna", sp, (2,))):
+                                            ("protein2dna", "protein2dna", sp, (2,)), ("protein2genome", "protein2genome", sg, (2,))):
         for ms in match_states:
             sfx = "" if len(match_states) == 1 else ("_fwd" if ms == 2 else "_rev")
             sets.append(("derived_%s%s_start" % (tag, sfx), model, cases, 32, ("--derived", "0,%d,0,4" % ms)))
