@@ -209,6 +209,18 @@ static void dump_derived(void){
                 dump_derived_one(m, list[i].key, s, match_states->pdata[k], C4_Scope_CORNER,
                                  C4_Scope_CORNER, &first);
             }
+        /* span models (heuristic.c:461-472): match state -> span state, span state -> match state */
+        for(j = 0; j < m->span_list->len; j++){
+            C4_Span *span = m->span_list->pdata[j];
+            for(k = 0; k < match_states->len; k++){
+                dump_derived_one(m, list[i].key, match_states->pdata[k], span->span_state, C4_Scope_CORNER,
+                                 C4_Scope_ANYWHERE, &first);
+                dump_derived_one(m, list[i].key, span->span_state, match_states->pdata[k], C4_Scope_ANYWHERE,
+                                 C4_Scope_CORNER, &first);
+                dump_derived_one(m, list[i].key, match_states->pdata[k], span->span_state, C4_Scope_CORNER,
+                                 C4_Scope_CORNER, &first);
+                }
+            }
         g_ptr_array_free(match_states, TRUE);
         C4_Model_destroy(m);
         }
