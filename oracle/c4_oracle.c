@@ -248,6 +248,10 @@ typedef struct {
     int32_t qlen, tlen;
     int32_t *ss[4];                 /* whole-target splice predictions, lazily built */
     int32_t curr_intron_start;      /* Intron_ChainData.curr_intron_start, intron.h */
+    /* span models: what the model's cell_start_func returns / its cell_end_func receives (viterbi.c:728-741,
+     * 793-799), as matrices over the region: [(i * (T+1)) + j][cell_size] */
+    const c4gpu_score *start_cells;
+    c4gpu_score *end_cells;
 } odata;
 
 static void odata_init(odata *od, const c4gpu_model *model, const c4gpu_params *params,
@@ -496,7 +500,7 @@ static c4gpu_score viterbi_run(const oviterbi *v, const c4gpu_region *region, ov
     const c4gpu_model *m = v->m;
     const int Q = region->query_length, T = region->target_length, S = m->n_states,
               cs = v->cell_size, mta = m->max_target_advance;
-    c4gpu_score t, score = LOW, *src, *dst, *swap;
+    c4gpu_score t, score = LOW, *src, *dst, *swap, dummy_start[CELL_MAX];
     int i, j, k, l, end_is_set = 0, final_state, state_is_set[C4GPU_MAX_STATES];
     final_state = cont ? cont->final_state : m->end_state;
     for(j = 0; j <= T; j++){
@@ -526,7 +530,14 @@ static c4gpu_score viterbi_run(const oviterbi *v, const c4gpu_region *region, ov
                         src = CELL(v, vd->prev_row[0], 0, m->start_state);
                         t = src[0];
                         }
-                    /* no in-scope model has a cell_start_func (viterbi.c:728-741) */
+                    else if(od->start_cells){                       /* cell_start_func, viterbi.c:728-741 */
+                        const c4gpu_score *sc = od->start_cells
+                            + ((size_t)(i - tr->advance_query) * (T+1) + (j - tr->advance_target)) * cs;
+                        for(l = 0; l < cs; l++)
+                            dummy_start[l] = sc[l];
+                        src = dummy_start;
+                        t = src[0];
+                        }
                 } else {
                     t = src[0];
                     }
@@ -578,6 +589,12 @@ static c4gpu_score viterbi_run(const oviterbi *v, const c4gpu_region *region, ov
                         vd->curr_query_start = cell[v->rsq_id];
                     if(v->rst_id != -1)
                         vd->curr_target_start = cell[v->rst_id];
+                    }
+                if(od->end_cells){                                   /* cell_end_func, viterbi.c:793-799 */
+                    c4gpu_score *ec = od->end_cells + ((size_t)i * (T+1) + j) * cs;
+                    cell = CELL(v, vd->prev_row[0], i, m->end_state);
+                    for(l = 0; l < cs; l++)
+                        ec[l] = cell[l];
                     }
                 }
             }
@@ -680,6 +697,20 @@ int oracle_viterbi(const c4gpu_model *model, const c4gpu_params *params, int mod
                                  checkpoint_count, NULL, out);
     }
 
+/* a span DP: FIND_SCORE / FIND_PATH with the cell_start_func / cell_end_func seam (either may be NULL) */
+static const c4gpu_score *g_span_start = NULL;
+static c4gpu_score *g_span_end = NULL;
+int oracle_viterbi_span(const c4gpu_model *model, const c4gpu_params *params, int mode,
+                   const uint8_t *query, int32_t qlen, const uint8_t *target, int32_t tlen,
+                   const c4gpu_region *region, const c4gpu_score *start_cells, c4gpu_score *end_cells,
+                   oracle_viterbi_out *out){
+    int rc;
+    g_span_start = start_cells; g_span_end = end_cells;
+    rc = oracle_viterbi_subopt(model, params, mode, query, qlen, target, tlen, region, NULL, 0, NULL, out);
+    g_span_start = NULL; g_span_end = NULL;
+    return rc;
+    }
+
 /* Viterbi_calculate, viterbi.c:846-865: the index is built per call from the pair's SubOpt */
 int oracle_viterbi_subopt(const c4gpu_model *model, const c4gpu_params *params, int mode,
                    const uint8_t *query, int32_t qlen, const uint8_t *target, int32_t tlen,
@@ -692,6 +723,7 @@ int oracle_viterbi_subopt(const c4gpu_model *model, const c4gpu_params *params, 
     int l;
     memset(out, 0, sizeof(*out));
     odata_init(&od, model, params, query, qlen, target, tlen);
+    od.start_cells = g_span_start; od.end_cells = g_span_end;
     oviterbi_init(&v, model, mode, continuation ? 1 : 0);
     ovdata_init(&vd, &v, region, checkpoint_count);
     out->score = viterbi_run(&v, region, &vd, &od, continuation, soi);

@@ -69,6 +69,12 @@ int  oracle_viterbi_subopt(const c4gpu_model *model, const c4gpu_params *params,
                     const uint8_t *query, int32_t qlen, const uint8_t *target, int32_t tlen,
                     const c4gpu_region *region, const c4gpu_continuation *continuation,
                     int checkpoint_count, const oracle_subopt *subopt, oracle_viterbi_out *out);
+/* span models (BSDP): the cell_start_func / cell_end_func seam of the Viterbi (viterbi.c:728-741,793-799) as
+ * matrices over the region, [(i * (T+1)) + j][cell_size]; end_cells must be initialised by the caller */
+int  oracle_viterbi_span(const c4gpu_model *model, const c4gpu_params *params, int mode,
+                    const uint8_t *query, int32_t qlen, const uint8_t *target, int32_t tlen,
+                    const c4gpu_region *region, const c4gpu_score *start_cells, c4gpu_score *end_cells,
+                    oracle_viterbi_out *out);
 void oracle_viterbi_out_clear(oracle_viterbi_out *out);
 
 /* Viterbi_use_reduced_space (viterbi.c:128) / Viterbi_checkpoint_rows (viterbi.c:207) */

@@ -227,6 +227,113 @@ static void dump_derived(void){
     printf("]\n");
     }
 
+/* ---- span models: the cell_end_func / cell_start_func seam of the Viterbi (viterbi.c:728-741,793-799) ----- */
+/* BSDP runs a span as two DPs that exchange an integration matrix (heuristic.c:385-443, sar.c:898-921).  Here
+ * the exchange is the identity: every END cell the src DP reports is offered to the dst DP as the START cell
+ * of the same position.  That pins exactly what the Viterbi does with the two callbacks. */
+static C4_Score *span_matrix = NULL;      /* [Q+1][T+1][cell_size], score LOW where nothing was reported */
+static gint span_q0, span_t0, span_tlen, span_cs;
+static C4_Score span_dummy[8];
+
+static void span_report_end(C4_Score *cell, gint cell_size, gint query_pos, gint target_pos, gpointer user_data){
+    register gint l;
+    register C4_Score *dst = span_matrix + (((query_pos - span_q0) * (span_tlen + 1)) + (target_pos - span_t0)) * span_cs;
+    for(l = 0; l < cell_size; l++)
+        dst[l] = cell[l];
+    return;
+    }
+
+static C4_Score *span_init_start(gint query_pos, gint target_pos, gpointer user_data){
+    register C4_Score *src = span_matrix + (((query_pos - span_q0) * (span_tlen + 1)) + (target_pos - span_t0)) * span_cs;
+    if(src[0] == C4_IMPOSSIBLY_LOW_SCORE)
+        return span_dummy;
+    return src;
+    }
+
+static void run_span(gchar *model_name, gchar *input_path, gint match_state, gint span_state){
+    register Model_Type type = Model_Type_from_string(model_name);
+    register FILE *fp = fopen(input_path, "r");
+    register Alphabet *dna = Alphabet_create(Alphabet_Type_DNA, FALSE);
+    register C4_Model *model = Model_Type_get_model(type, Alphabet_Type_DNA, Alphabet_Type_DNA);
+    register C4_DerivedModel *src_dm = C4_DerivedModel_create(model, model->state_list->pdata[match_state],
+            model->state_list->pdata[span_state], C4_Scope_CORNER, NULL, NULL,
+            C4_Scope_ANYWHERE, span_report_end, NULL);
+    register C4_DerivedModel *dst_dm = C4_DerivedModel_create(model, model->state_list->pdata[span_state],
+            model->state_list->pdata[match_state], C4_Scope_ANYWHERE, span_init_start, NULL,
+            C4_Scope_CORNER, NULL, NULL);
+    register Optimal *src_optimal = Optimal_create(src_dm->derived, NULL, Optimal_Type_SCORE|Optimal_Type_PATH, FALSE);
+    register Optimal *dst_optimal = Optimal_create(dst_dm->derived, NULL, Optimal_Type_SCORE|Optimal_Type_PATH, FALSE);
+    register gchar *line = g_malloc(1<<20);
+    register gint l;
+    span_cs = 1 + src_dm->derived->total_shadow_designations;
+    span_dummy[0] = C4_IMPOSSIBLY_LOW_SCORE;
+    for(l = 1; l < 8; l++)
+        span_dummy[l] = 0;
+    while(fgets(line, 1<<20, fp)){
+        gchar **f;
+        Sequence *query, *target;
+        gpointer user_data;
+        Region *region;
+        C4_Score src_score, dst_score;
+        Alignment *alignment;
+        register gint i, j, first = 1;
+        g_strchomp(line);
+        if((!line[0]) || (line[0] == '#'))
+            continue;
+        f = g_strsplit(line, "\t", 3);
+        query = Sequence_create(f[0], NULL, f[1], 0, Sequence_Strand_FORWARD, dna);
+        target = Sequence_create("tg", NULL, f[2], 0, Sequence_Strand_FORWARD, dna);
+        user_data = Model_Type_create_data(type, query, target);
+        region = Region_create(0, 0, query->len, target->len);
+        span_q0 = 0; span_t0 = 0; span_tlen = target->len;
+        span_matrix = g_new(C4_Score, (query->len + 1) * (target->len + 1) * span_cs);
+        for(i = 0; i < (query->len + 1) * (target->len + 1); i++){
+            span_matrix[i*span_cs] = C4_IMPOSSIBLY_LOW_SCORE;
+            for(l = 1; l < span_cs; l++)
+                span_matrix[i*span_cs+l] = 0;
+            }
+        src_score = Optimal_find_score(src_optimal, region, user_data, NULL);
+        printf("{\"id\":\"%s\",\"qlen\":%d,\"tlen\":%d,\"cell_size\":%d,\"src_score\":%d,\"end_cells\":[",
+               f[0], query->len, target->len, span_cs, src_score);
+        for(i = 0; i <= query->len; i++)
+            for(j = 0; j <= target->len; j++){
+                C4_Score *c = span_matrix + ((i * (target->len + 1)) + j) * span_cs;
+                if(c[0] == C4_IMPOSSIBLY_LOW_SCORE)
+                    continue;
+                printf("%s[%d,%d", first?"":",", i, j);
+                for(l = 0; l < span_cs; l++)
+                    printf(",%d", c[l]);
+                printf("]");
+                first = 0;
+                }
+        dst_score = Optimal_find_score(dst_optimal, region, user_data, NULL);
+        printf("],\"dst_score\":%d", dst_score);
+        alignment = Optimal_find_path(dst_optimal, region, user_data, C4_IMPOSSIBLY_LOW_SCORE, NULL);
+        if(alignment){
+            register guint k;
+            printf(",\"path_score\":%d,\"region\":[%d,%d,%d,%d],\"ops\":[", alignment->score,
+                   alignment->region->query_start, alignment->region->target_start,
+                   alignment->region->query_length, alignment->region->target_length);
+            for(k = 0; k < alignment->operation_list->len; k++){
+                AlignmentOperation *ao = alignment->operation_list->pdata[k];
+                printf("%s[%d,%d]", k?",":"", ao->transition->id, ao->length);
+                }
+            printf("]");
+            Alignment_destroy(alignment);
+            }
+        printf("}\n");
+        fflush(stdout);
+        g_free(span_matrix);
+        Model_Type_destroy_data(type, user_data);
+        Region_destroy(region);
+        Sequence_destroy(query);
+        Sequence_destroy(target);
+        g_strfreev(f);
+        }
+    fclose(fp);
+    return;
+    }
+
 static void dump_submat(const char *name, Submat *s, gboolean last){
     register gint i, j;
     printf(" \"%s\":[", name);
@@ -552,6 +659,10 @@ int Argument_main(Argument *arg){
         dump_data();
     else if(!strcmp(cmd, "derived"))
         dump_derived();
+    else if(!strcmp(cmd, "span")){
+        gchar **d = g_strsplit(derived, ",", 2);   /* --derived "<match state>,<span state>" */
+        run_span(g_strdup(model_name), input_path, atoi(d[0]), atoi(d[1]));
+        }
     else if(!strcmp(cmd, "golden"))
         run_golden(g_strdup(model_name), input_path, with_splice, revcomp_target,
                    subopt_max, subopt_threshold, derived);

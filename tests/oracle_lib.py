@@ -63,6 +63,9 @@ def load():
                                               C.c_char_p, C.c_int32, C.c_char_p, C.c_int32,
                                               C.POINTER(_abi.Region), C.POINTER(_abi.Continuation), C.c_int,
                                               C.c_void_p, C.POINTER(ViterbiOut)]
+        lib.oracle_viterbi_span.argtypes = [C.POINTER(_abi.Model), C.POINTER(_abi.Params), C.c_int,
+                                            C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(_abi.Region),
+                                            C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(ViterbiOut)]
         lib.oracle_cells_visited.restype = C.c_int64
         lib.oracle_cells_visited.argtypes = [C.c_int]
         _lib = lib
@@ -122,3 +125,35 @@ def find_paths_subopt(model, params, q, t, dpmemory, threshold, max_paths, qid="
     finally:
         lib.oracle_subopt_destroy(so)
     return out
+
+
+def span_pair(src_model, dst_model, params, q, t):
+    """The two DPs of a span with the identity exchange of tools/make_golden.py (refdump --cmd span): returns
+    (src score, reported END cells as {(i, j): cell}, dst score, dst path dict)."""
+    lib = load()
+    Q, T, cs = len(q), len(t), 1 + src_model.total_shadow_designations
+    region = _abi.Region(0, 0, Q, T)
+    n = (Q + 1) * (T + 1) * cs
+    mat = (C.c_int32 * n)()
+    for x in range((Q + 1) * (T + 1)):
+        mat[x * cs] = _abi.IMPOSSIBLY_LOW_SCORE
+    vo = ViterbiOut()
+    lib.oracle_viterbi_span(src_model, params, 0, q, Q, t, T, region, None, mat, vo)
+    src_score = vo.score
+    lib.oracle_viterbi_out_clear(vo)
+    cells = {}
+    for i in range(Q + 1):
+        for j in range(T + 1):
+            x = (i * (T + 1) + j) * cs
+            if mat[x] != _abi.IMPOSSIBLY_LOW_SCORE:
+                cells[(i, j)] = [mat[x + l] for l in range(cs)]
+    vo = ViterbiOut()
+    lib.oracle_viterbi_span(dst_model, params, 0, q, Q, t, T, region, mat, None, vo)
+    dst_score = vo.score
+    lib.oracle_viterbi_out_clear(vo)
+    vo = ViterbiOut()
+    lib.oracle_viterbi_span(dst_model, params, 1, q, Q, t, T, region, mat, None, vo)
+    path = {"score": vo.score, "query_start": vo.query_start, "target_start": vo.target_start,
+            "query_end": vo.query_end, "target_end": vo.target_end, "ops": [vo.ops[k] for k in range(vo.n_ops)]}
+    lib.oracle_viterbi_out_clear(vo)
+    return src_score, cells, dst_score, path

@@ -43,6 +43,36 @@ def test_oracle_suboptimal_loop_matches_reference(lib, params, name):
                 assert pts == exp["points"], rec["id"]
 
 
+def _rle(ops):
+    out = []
+    for o in ops:
+        if out and out[-1][0] == o:
+            out[-1][1] += 1
+        else:
+            out.append([o, 1])
+    return out
+
+
+@pytest.mark.parametrize("name,match_state,span_state", [("span_est2genome_fwd", 2, 8), ("span_est2genome_rev", 5, 9)])
+def test_oracle_span_seam_matches_reference(lib, params, name, match_state, span_state):
+    """cell_end_func / cell_start_func (viterbi.c:728-741,793-799) on BSDP's span models: the END cells the src
+    DP reports, and score and path of the dst DP that starts from them, as the reference produced them."""
+    src = _abi.Model(); dst = _abi.Model()
+    assert lib.c4gpu_model_get_derived(b"est2genome", 0, 0, params, match_state, span_state, 4, 0, src, None) == 0
+    assert lib.c4gpu_model_get_derived(b"est2genome", 0, 0, params, span_state, match_state, 0, 4, dst, None) == 0
+    for rec in load_set(name):
+        q, t = rec["query"].encode(), rec["target"].encode()
+        src_score, cells, dst_score, path = oracle_lib.span_pair(src, dst, params, q, t)
+        assert src_score == rec["src_score"], rec["id"]
+        assert cells == {(c[0], c[1]): c[2:] for c in rec["end_cells"]}, rec["id"]
+        assert dst_score == rec["dst_score"], rec["id"]
+        if "path_score" in rec:
+            assert path["score"] == rec["path_score"]
+            assert [path["query_start"], path["target_start"], path["query_end"] - path["query_start"],
+                    path["target_end"] - path["target_start"]] == rec["region"], rec["id"]
+            assert _rle(path["ops"]) == rec["ops"], rec["id"]
+
+
 def test_reference_known_answer_tests(lib, params):
     """src/model/affine.test.c:107-110 (-151/18/32/18) and est2genome.test.c:63 (157)."""
     kat = {"affine_global_protein": -151, "affine_bestfit_protein": 18, "affine_local_protein": 32,

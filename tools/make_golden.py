@@ -197,6 +197,22 @@ def run(model, cases, dpmemory, extra=()):
     return recs
 
 
+def run_span(cases, match_state, span_state):
+    with tempfile.NamedTemporaryFile("w", suffix=".tsv", delete=False) as f:
+        for cid, q, t in cases:
+            f.write("%s\t%s\t%s\n" % (cid, q, t))
+        path = f.name
+    cmd = [REFDUMP, "--cmd", "span", "--model", "est2genome", "--input", path, "--derived", "%d,%d" % (match_state, span_state)]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout.decode()
+    os.unlink(path)
+    recs = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+    assert len(recs) == len(cases)
+    for r, (cid, q, t) in zip(recs, cases):
+        assert r["id"] == cid
+        r["query"], r["target"] = q, t
+    return recs
+
+
 def main():
     rng = random.Random(20260928)
     sets = []
@@ -276,6 +292,24 @@ def main():
     sets.append(("protein2genome_subopt_D0", "protein2genome", sub_p2g, 0, so))
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])
+    # span models (BSDP): src DP reporting END cells, dst DP starting from them (refdump --cmd span)
+    sr = random.Random(909)
+    span_cases = []
+    for k in range(8):
+        q = rand_dna(sr, sr.randint(12, 30))
+        c = len(q) // 2
+        rev = k % 2
+        t = rand_dna(sr, sr.randint(0, 6)) + q[:c] + ("CT" if rev else "GT") + rand_dna(sr, sr.randint(30, 70)) + \
+            ("AC" if rev else "AG") + mutate(sr, q[c:], 0.05, "ACGT") + rand_dna(sr, sr.randint(0, 6))
+        span_cases.append(("span%02d" % k, q, t))
+    for name, ms, ss in (("span_est2genome_fwd", 2, 8), ("span_est2genome_rev", 5, 9)):
+        if only and name not in only:
+            continue
+        recs = run_span(span_cases, ms, ss)
+        with open(os.path.join(OUT, name + ".jsonl"), "w") as f:
+            for r in recs:
+                f.write(json.dumps(r, separators=(",", ":")) + "\n")
+        print(name, len(recs), "dst scores", [r["dst_score"] for r in recs])
     for name, model, cases, dpm, extra in sets:
         if only and name not in only:
             continue
