@@ -267,6 +267,11 @@ class Engine:
                     cj[i].continuation.first_cell[l] = v
             cj[i].checkpoint_count = j.get("checkpoints", 0)
             cj[i].subopt = j["subopt"].h if j.get("subopt") is not None else None
+            # span models: ctypes int32 arrays over the region, [(i * (T+1)) + j][1 + designations]
+            if j.get("start_cells") is not None:
+                cj[i].start_cells = C.cast(j["start_cells"], C.POINTER(C.c_int32))
+            if j.get("end_cells") is not None:
+                cj[i].end_cells = C.cast(j["end_cells"], C.POINTER(C.c_int32))
         res = (_abi.ViterbiResult * max(1, len(jobs)))()
         if _lib().c4gpu_viterbi_batch(self.ctx, model.c, model.params, mode, arr, len(pairs), cj, len(jobs),
                                       res) != 0:

@@ -9,6 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libc4gpu.so")
 
+ABI_VERSION = 2            # C4GPU_ABI_VERSION of include/c4gpu.h these structures mirror
 MAX_STATES, MAX_TRANSITIONS, MAX_CALCS, MAX_SHADOWS, NAME_LEN = 16, 48, 16, 4, 48
 SPLICE_MAX_LEN = 32
 CELL_MAX = 1 + MAX_SHADOWS + 3
@@ -98,7 +99,8 @@ class Continuation(C.Structure):
 
 class ViterbiJob(C.Structure):
     _fields_ = [("pair", C.c_int32), ("region", Region), ("use_continuation", C.c_int32),
-                ("continuation", Continuation), ("checkpoint_count", C.c_int32), ("subopt", C.c_void_p)]
+                ("continuation", Continuation), ("checkpoint_count", C.c_int32), ("subopt", C.c_void_p),
+                ("start_cells", C.POINTER(C.c_int32)), ("end_cells", C.POINTER(C.c_int32))]
 
 
 class ViterbiResult(C.Structure):
@@ -214,6 +216,10 @@ def load(path=None):
             "libc4gpu.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
             "there is no Python/CPU fallback for the C4 engine" % p)
     lib = C.CDLL(p)
+    lib.c4gpu_abi_version.restype = C.c_int
+    if lib.c4gpu_abi_version() != ABI_VERSION:
+        raise OSError("libc4gpu.so has ABI version %d, exonerate_amd/_abi.py mirrors version %d: rebuild "
+                      "(python -c 'import __graft_entry__ as g; g.build()')" % (lib.c4gpu_abi_version(), ABI_VERSION))
     for name, res, args in PROTOTYPES:
         fn = getattr(lib, name)          # AttributeError if the ABI header and the library diverge
         fn.restype = res

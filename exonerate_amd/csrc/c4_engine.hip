@@ -129,6 +129,10 @@ int model_family(const c4gpu_model &m) {
     if (model_matches<Protein2GenomeStartDesc>(m)) return FAM_PROTEIN2GENOME_START;
     if (model_matches<Protein2GenomeEndDesc>(m)) return FAM_PROTEIN2GENOME_END;
     if (model_matches<Protein2GenomeJoinDesc>(m)) return FAM_PROTEIN2GENOME_JOIN;
+    if (model_matches<Est2GenomeFwdSpanSrcDesc>(m)) return FAM_EST2GENOME_FWD_SPAN_SRC;
+    if (model_matches<Est2GenomeFwdSpanDstDesc>(m)) return FAM_EST2GENOME_FWD_SPAN_DST;
+    if (model_matches<Est2GenomeRevSpanSrcDesc>(m)) return FAM_EST2GENOME_REV_SPAN_SRC;
+    if (model_matches<Est2GenomeRevSpanDstDesc>(m)) return FAM_EST2GENOME_REV_SPAN_DST;
     return -1;
 }
 
@@ -138,7 +142,8 @@ bool family_is_p2d(int fam) {
 }
 bool family_has_splice(int fam) {
     return fam == FAM_EST2GENOME || fam == FAM_PROTEIN2GENOME || (fam >= FAM_EST2GENOME_FWD_START && fam <= FAM_EST2GENOME_REV_JOIN) ||
-           (fam >= FAM_PROTEIN2GENOME_START && fam <= FAM_PROTEIN2GENOME_JOIN);
+           (fam >= FAM_PROTEIN2GENOME_START && fam <= FAM_PROTEIN2GENOME_JOIN) ||
+           (fam >= FAM_EST2GENOME_FWD_SPAN_SRC && fam <= FAM_EST2GENOME_REV_SPAN_DST);
 }
 bool family_has_phase(int fam) { return fam == FAM_PROTEIN2GENOME || (fam >= FAM_PROTEIN2GENOME_START && fam <= FAM_PROTEIN2GENOME_JOIN); }
 
@@ -357,6 +362,8 @@ struct JobSpec {                  // host description of one Viterbi call
     int first_cell[CELL_MAX] = {0};
     bool dump_checkpoints = false;
     const c4gpu_subopt *sub = nullptr;   // sub-optimal blocking for this call (else the engine's per-pair table)
+    const int32_t *span_in = nullptr;    // span models: start cells (host), END cells (host, updated in place)
+    int32_t *span_out = nullptr;
 };
 typedef std::vector<std::pair<int32_t, int32_t>> RegionPoints;   // (target, query) in region coordinates, ascending
 struct JobOut {
@@ -381,7 +388,7 @@ struct Engine {
     DevBuf<uint8_t> d_ops;
     DevBuf<int> d_bnd, d_ckpt, d_ckpt_dump, d_queue;
     DevBuf<uint32_t> d_tb;
-    DevBuf<int> d_sub_t, d_sub_q, d_sub_colptr;
+    DevBuf<int> d_sub_t, d_sub_q, d_sub_colptr, d_span;
     // per-pair SubOpt of the Optimal_find_path in progress (NULL entries / NULL table: nothing blocked)
     const std::vector<const c4gpu_subopt *> *pair_sub = nullptr;
 
@@ -419,6 +426,8 @@ struct Engine {
     // others (it returns NULL) to the plain ones.
     int run(const ResidentSeqs &seqs, int mode, bool cont, const std::vector<JobSpec> &specs, std::vector<JobOut> &out) {
         const int n = (int)specs.size();
+        for (int i = 0; i < n; i++)
+            if (specs[i].span_in || specs[i].span_out) return run_impl(seqs, mode, cont, specs, out, nullptr);
         std::vector<int> plain, blocked;
         std::vector<RegionPoints> pts;
         for (int i = 0; i < n; i++) {
@@ -474,8 +483,15 @@ struct Engine {
         for (int i = 0; i < n && pack; i++)
             pack = nbits(specs[i].region.query_length) + nbits(specs[i].region.target_length) <= 31;
         static const int wpe_env = getenv("C4GPU_WPE") ? atoi(getenv("C4GPU_WPE")) : 0;
-        const KernelInfo *ki = get_kernel(family, mode, cont, use_local, pack, pts ? 0 : wpe_env, pts != nullptr);
+        int span = 0;
+        for (int i = 0; i < n; i++) {
+            const int sp = specs[i].span_in ? 1 : (specs[i].span_out ? 2 : 0);
+            if (i && sp != span) { c4h::set_error("jobs with and without span matrices in one call"); return -1; }
+            span = sp;
+        }
+        const KernelInfo *ki = get_kernel(family, mode, cont, use_local, pack, pts ? 0 : wpe_env, pts != nullptr, span);
         if (!ki) { c4h::set_error("no compiled kernel for this model/mode"); return -1; }
+        const int span_cs = 1 + model->total_shadow_designations;
         // whole-rectangle passes whose query spans several 64*R-row strips run on 4 cooperating waves per
         // job (strip carry rows stay in LDS instead of HBM); C4GPU_MW=0 forces the one-wave kernels
         static const int mw_env = getenv("C4GPU_MW") ? atoi(getenv("C4GPU_MW")) : 1;
@@ -506,12 +522,16 @@ struct Engine {
         }
         std::vector<DevJob> jobs(n);
         long long ops_total = 0, vsa_total = 0, dump_total = 0, max_T = 0, max_tb = 0, max_ckpt = 0, total_cells = 0;
-        long long max_runs = 0, sub_cols = 0;
+        long long max_runs = 0, sub_cols = 0, span_total = 0;
         std::vector<int> sub_t, sub_q;
         for (int x = 0; x < n; x++) {
             const JobSpec &s = specs[order[x]];
             DevJob &j = jobs[x];
             memset(&j, 0, sizeof j);
+            if (span) {
+                j.span_off = span_total;
+                span_total += (long long)(s.region.query_length + 1) * (s.region.target_length + 1) * span_cs;
+            }
             if (pts) {
                 const RegionPoints &rp = (*pts)[order[x]];
                 j.sub_off = sub_cols; j.sub_pt_off = (int)sub_t.size(); j.sub_pt_n = (int)rp.size();
@@ -575,6 +595,18 @@ struct Engine {
             LaunchArgs a;
             a.kp = kparams.p; a.seqs = seqs.dev; a.jobs = d_jobs.p; a.n_jobs = n; a.results = d_results.p;
             a.seqs.sub_colptr = nullptr; a.seqs.sub_rows = nullptr;
+            a.seqs.span_in = nullptr; a.seqs.span_out = nullptr;
+            if (span) {                                      // matrices of all jobs, in job order
+                std::vector<int> host(span_total);
+                for (int x = 0; x < n; x++) {
+                    const JobSpec &sp = specs[order[x]];
+                    const int32_t *src = span == 1 ? sp.span_in : sp.span_out;
+                    const long long cnt = (long long)(jobs[x].Q + 1) * (jobs[x].T + 1) * span_cs;
+                    memcpy(host.data() + jobs[x].span_off, src, sizeof(int) * cnt);
+                }
+                if (d_span.upload(host.data(), span_total, s)) return -1;
+                a.seqs.span_in = d_span.p; a.seqs.span_out = d_span.p;
+            }
             if (pts) {
                 sub_q.push_back(0);                      // the kernels' row prefetch may touch one entry past the last list
                 if (d_sub_t.upload(sub_t.data(), sub_t.size(), s) || d_sub_q.upload(sub_q.data(), sub_q.size(), s) ||
@@ -615,6 +647,15 @@ struct Engine {
             runs.resize(used);
             if (d_runs_out.download(runs.data(), used, s)) return -1;
             HIP_OK(hipStreamSynchronize(s));
+            if (span == 2) {                                 // END cells back into the callers' matrices
+                std::vector<int> host(span_total);
+                if (d_span.download(host.data(), span_total, s)) return -1;
+                HIP_OK(hipStreamSynchronize(s));
+                for (int x = 0; x < n; x++) {
+                    const long long cnt = (long long)(jobs[x].Q + 1) * (jobs[x].T + 1) * span_cs;
+                    memcpy(specs[order[x]].span_out, host.data() + jobs[x].span_off, sizeof(int) * cnt);
+                }
+            }
             break;
         }
         lap("runs downloaded");
@@ -1090,6 +1131,7 @@ static int viterbi_jobs(Engine &eng, const ResidentSeqs &seqs, int mode, const c
             s.cp_count = jobs[i].checkpoint_count;
             s.dump_checkpoints = (mode == C4GPU_MODE_FIND_CHECKPOINTS);
             s.sub = jobs[i].subopt;
+            s.span_in = jobs[i].start_cells; s.span_out = jobs[i].end_cells;
             specs.push_back(s); idx.push_back(i);
         }
         if ((mode == C4GPU_MODE_FIND_CHECKPOINTS || mode == C4GPU_MODE_FIND_REGION) && !specs.empty() &&

@@ -12,7 +12,10 @@ enum Family { FAM_UNGAPPED = 0, FAM_AFFINE, FAM_EST2GENOME, FAM_UNGAPPED_P2D, FA
               FAM_EST2GENOME_FWD_START, FAM_EST2GENOME_FWD_END, FAM_EST2GENOME_FWD_JOIN,
               FAM_EST2GENOME_REV_START, FAM_EST2GENOME_REV_END, FAM_EST2GENOME_REV_JOIN,
               FAM_PROTEIN2DNA_START, FAM_PROTEIN2DNA_END, FAM_PROTEIN2DNA_JOIN,
-              FAM_PROTEIN2GENOME_START, FAM_PROTEIN2GENOME_END, FAM_PROTEIN2GENOME_JOIN, FAM_COUNT };
+              FAM_PROTEIN2GENOME_START, FAM_PROTEIN2GENOME_END, FAM_PROTEIN2GENOME_JOIN,
+              // est2genome's span models (heuristic.c:461-472): match state -> intron state, intron state -> match state
+              FAM_EST2GENOME_FWD_SPAN_SRC, FAM_EST2GENOME_FWD_SPAN_DST, FAM_EST2GENOME_REV_SPAN_SRC, FAM_EST2GENOME_REV_SPAN_DST,
+              FAM_COUNT };
 
 struct LaunchArgs {
     const KParams *kp;
@@ -41,21 +44,23 @@ struct KernelInfo {
 
 // family x mode x continuation x local-scope specialisation; NULL launch = not compiled
 // sub: the variant with sub-optimal blocking (DevSeqs::sub_colptr / sub_rows must be set)
-const KernelInfo *get_kernel(int family, int mode, bool cont, bool local, bool pack, int wpe = 0, bool sub = false);
+// span: 0, or BSDP's span seam (1 = start cells read from a matrix, 2 = END cells copied out to one)
+const KernelInfo *get_kernel(int family, int mode, bool cont, bool local, bool pack, int wpe = 0, bool sub = false,
+                             int span = 0);
 // multi-wave kernels (`waves` = 4 or 8 cooperating waves per job) for FIND_SCORE / FIND_REGION without
 // continuation
 const KernelInfo *get_kernel_mw(int family, int mode, bool local, bool pack, int waves = 4, bool sub = false);
 
-#define C4K_DEFINE_KERNEL(SYMBOL, M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV)                                          \
+#define C4K_DEFINE_KERNEL_SPAN(SYMBOL, M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV, SPANV)                                          \
     static hipError_t SYMBOL##_launch(const LaunchArgs &a) {                                               \
-        hipLaunchKernelGGL((viterbi_kernel<M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV>), dim3(a.grid), dim3(64), 0,        \
+        hipLaunchKernelGGL((viterbi_kernel<M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV, SPANV>), dim3(a.grid), dim3(64), 0,        \
                            a.stream, a.kp, a.seqs, a.jobs, a.n_jobs, a.results, a.vsas, a.ops, a.scratch,  \
                            a.queue);                                                                       \
         return hipGetLastError();                                                                          \
     }                                                                                                      \
     const KernelInfo *SYMBOL() {                                                                           \
         static const KernelInfo ki = {SYMBOL##_launch,                                                     \
-                                      (const void *)viterbi_kernel<M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV>,            \
+                                      (const void *)viterbi_kernel<M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV, SPANV>,            \
                                       #SYMBOL,                                                             \
                                       RVAL,                                                                \
                                       WaveDP<M, RVAL, MODE, CONT, LOCAL, PACK>::CS,                              \
@@ -65,6 +70,9 @@ const KernelInfo *get_kernel_mw(int family, int mode, bool local, bool pack, int
                                       1};                                                           \
         return &ki;                                                                                        \
     }
+
+#define C4K_DEFINE_KERNEL(SYMBOL, M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV) \
+    C4K_DEFINE_KERNEL_SPAN(SYMBOL, M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV, 0)
 
 #define C4K_DEFINE_KERNEL_MW(SYMBOL, M, RVAL, MODE, LOCAL, PACK, NWV, WPE, SUBV)                                 \
     static hipError_t SYMBOL##_launch(const LaunchArgs &a) {                                               \

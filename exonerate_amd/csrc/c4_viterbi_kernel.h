@@ -61,6 +61,9 @@ struct DevSeqs {
     // sub-optimal blocking (SUB kernels): per job T+2 column pointers into sub_rows, which holds the blocked
     // query rows (region coordinates) of each column, ascending
     const int *sub_colptr, *sub_rows;
+    // span models: start cells in / END cells out, [(i * (T+1)) + j][1 + designations] per job (DevJob::span_off)
+    const int *span_in;
+    int *span_out;
 };
 struct DevJob {
     int pair, q0, t0, Q, T;
@@ -72,6 +75,7 @@ struct DevJob {
     long long ckpt_off;                  // >= 0: also dump checkpoint cells there (tests); -1: wave slab only
     long long sub_off;                   // SUB kernels: this job's column pointers start at sub_colptr + sub_off
     int sub_pt_off, sub_pt_n;            // its points in the launch's point arrays (colptr construction)
+    long long span_off;                  // SPAN kernels: this job's matrix starts at span_in/span_out + span_off
 };
 struct DevResult {
     int score, qs, ts, qe, te, end_set, last_srp, n_ops, flags, n_vsa, cell_size, pad;
@@ -154,7 +158,10 @@ __device__ __forceinline__ bool scope_ok(int scope, bool at_q, bool at_t) {
 // (query_start << tshift) | target_start; the host picks PACK when bits(Q) + bits(T) <= 31.
 // SUB: sub-optimal blocking (SubOpt_Index, src/c4/subopt.c): MATCH transitions skip the blocked cells listed
 // per column in DevSeqs::sub_colptr / sub_rows.
-template <class M, int R, int MODE, bool CONT, bool LOCAL, bool PACK = false, bool SUB = false>
+// SPAN: BSDP's span models exchange cells with the host through the model's cell_start_func / cell_end_func
+// (viterbi.c:728-741,793-799): 1 = transitions out of START read the start cell of their position from a
+// matrix (score and shadow slots), 2 = every cell that reaches END is copied out to a matrix.
+template <class M, int R, int MODE, bool CONT, bool LOCAL, bool PACK = false, bool SUB = false, int SPAN = 0>
 struct WaveDP {
     using F = Facts<M>;
     static constexpr int NDES = M::NDES;
@@ -183,6 +190,7 @@ struct WaveDP {
         if (NAUX && e == AUX) e = 0;
         if (e >= NDES) return true;
         bool live[M::NS] = {};
+        if (SPAN == 2) live[M::END] = true;          // the END cell leaves the kernel (cell_end_func)
         for (int it = 0; it < M::NS; it++)
             for (int k = 0; k < M::NT; k++) {
                 const int in = M::tr[k].in, out = M::tr[k].out;
@@ -312,9 +320,19 @@ struct WaveDP {
             }
             // source cell: same cell (silent), row above (lane-local or the neighbour's), earlier columns
             constexpr int PD = (PH - t.at + NCOL) % NCOL;
-            const C &src = (t.aq == 0) ? col[PD][RR] : (RR > 0 ? col[PD][RR > 0 ? RR - 1 : 0] : nbr[PD]);
+            const C &cell_src = (t.aq == 0) ? col[PD][RR] : (RR > 0 ? col[PD][RR > 0 ? RR - 1 : 0] : nbr[PD]);
+            // cell_start_func (viterbi.c:728-741): the START cell of position (i - aq, j - at) comes from the
+            // job's matrix, score and shadow slots (clamped, unconditional loads; invalid transitions ignore them)
+            C start_cell;
+            if constexpr (SPAN == 1 && t.in == M::START && !CONT) {
+                const int si = i - t.aq < 0 ? 0 : i - t.aq, sj = j - t.at < 0 ? 0 : (j - t.at > T ? T : j - t.at);
+                const int *sc = span_in_p + ((long long)(si > Q ? Q : si) * (T + 1) + sj) * (1 + NDES);
+                start_cell.sc[M::START] = sc[0];
+                static_for<NDES>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; start_cell.ex[M::START][E] = sc[1 + E]; });
+            }
+            const C &src = (SPAN == 1 && t.in == M::START && !CONT) ? start_cell : cell_src;
             int tscore;
-            if constexpr (t.in == M::START) tscore = CONT ? src.sc[M::START] : 0;
+            if constexpr (t.in == M::START) tscore = CONT ? src.sc[M::START] : (SPAN == 1 ? src.sc[M::START] : 0);
             else tscore = src.sc[t.in];
             // calc (C4_Calc_score, c4.c:1700)
             if constexpr (t.calc >= 0) {
@@ -455,6 +473,8 @@ struct WaveDP {
     // uses, because every transition that would read them is masked invalid.
     int nx_tcode, nx_sp[4], nx_tn4, tlast;
     const uint16_t *tn4p;
+    const int *span_in_p;               // SPAN == 1: this job's start cells
+    int *span_out_p;                    // SPAN == 2: this job's END cell matrix
     const int *sub_cp, *sub_rows;       // SUB: column pointers of this job, blocked rows of the launch
     // two-stage prefetch: the column pointers of column j+2 and, through the pointers requested one step
     // earlier, the first blocked row of column j+1 — nothing the step waits for was requested in that step
@@ -553,6 +573,18 @@ struct WaveDP {
             eval_cell<RR, PH, JINT>(i, j, jact && i <= Q, ms[RR], sp, qcode[RR], tn4col, (blk >> RR) & 1u, tbw[RR],
                                     end_ok[RR]);
         });
+        // cell_end_func (viterbi.c:793-799): every cell in which END is set is copied out
+        if constexpr (SPAN == 2) {
+            static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                if (end_ok[RR]) {
+                    int *ec = span_out_p + ((long long)(i0 + RR) * (T + 1) + j) * (1 + NDES);
+                    ec[0] = col[PH][RR].sc[M::END];
+                    static_for<NDES>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
+                        ec[1 + E] = slot_live(M::END, E) ? col[PH][RR].ex[M::END][E] : 0;
+                    });
+                }
+            });
+        }
         // (3b) end cell (viterbi.c:778-791): strict improvement in row-major order.  In continuation mode the
         // score is read off the corner cell later.  A new maximum is rare (it only grows along the
         // alignment): one masked maximum over the lane's cells per step decides whether any of them can
@@ -691,6 +723,8 @@ struct WaveDP {
             }
         }
         if constexpr (SUB) { sub_cp = seqs.sub_colptr + job.sub_off; sub_rows = seqs.sub_rows; }
+        if constexpr (SPAN == 1) span_in_p = seqs.span_in + job.span_off;
+        if constexpr (SPAN == 2) span_out_p = seqs.span_out + job.span_off;
         first_state = job.first_state; final_state = CONT ? job.final_state : M::END;
         first_cell = job.first_cell;
         min_intron = kp->min_intron; max_intron = kp->max_intron;
@@ -1006,11 +1040,11 @@ struct WaveDP {
 // Kernel: persistent waves, one job at a time per wave.
 // -------------------------------------------------------------------------------------------------------------
 // WPE: waves per SIMD the register allocator must leave room for (1 = no cap: 512 unified registers)
-template <class M, int R, int MODE, bool CONT, bool LOCAL, bool PACK, int WPE, bool SUB = false>
+template <class M, int R, int MODE, bool CONT, bool LOCAL, bool PACK, int WPE, bool SUB = false, int SPAN = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void viterbi_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs,
                                                      int n_jobs, DevResult *results, DevVsa *vsas, uint8_t *ops,
                                                      DevScratch scratch, int *queue) {
-    using DP = WaveDP<M, R, MODE, CONT, LOCAL, PACK, SUB>;
+    using DP = WaveDP<M, R, MODE, CONT, LOCAL, PACK, SUB, SPAN>;
     __shared__ KParams kp_lds;
     __shared__ int next_job;
     __shared__ long long run_off;

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define C4GPU_ABI_VERSION 1
+#define C4GPU_ABI_VERSION 2
 
 /* src/c4/c4.h:28-30 */
 typedef int32_t c4gpu_score;
@@ -175,6 +175,13 @@ typedef struct {
     int32_t      checkpoint_count;          /* FIND_CHECKPOINTS: Viterbi_checkpoint_rows (viterbi.c:207) */
     const c4gpu_subopt *subopt;             /* NULL, or what Viterbi_calculate builds its SubOpt_Index from
                                                (viterbi.c:846-865): MATCH transitions skip blocked cells */
+    /* BSDP's span models (heuristic.c:385-443): the model's cell_start_func / cell_end_func as matrices over the
+     * job's region, [(i * (target_length + 1)) + j][1 + shadow designations] ints, host memory.
+     * start_cells: what cell_start_func returns at (i, j) (viterbi.c:728-741); FIND_SCORE / FIND_PATH.
+     * end_cells: receives the END cell of every (i, j) that reaches END (viterbi.c:793-799); other entries are
+     * left as the caller initialised them; FIND_SCORE.  Both NULL for every other model. */
+    const c4gpu_score *start_cells;
+    c4gpu_score *end_cells;
 } c4gpu_viterbi_job;
 
 typedef struct {

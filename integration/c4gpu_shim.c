@@ -59,7 +59,10 @@ static c4gpu_ctx *shim_get_ctx(void){
     if(!shim_tried){
         shim_tried = TRUE;
         shim_verbose = (g_getenv("C4GPU_VERBOSE") != NULL);
-        if(shim_args.use_gpu && (!g_getenv("C4GPU_DISABLE"))){
+        if(shim_args.use_gpu && (!g_getenv("C4GPU_DISABLE")) && (c4gpu_abi_version() != C4GPU_ABI_VERSION)){
+            g_warning("c4gpu: libc4gpu.so has ABI version %d, this binary was built for %d -- using the CPU Viterbi",
+                      c4gpu_abi_version(), C4GPU_ABI_VERSION);
+        } else if(shim_args.use_gpu && (!g_getenv("C4GPU_DISABLE"))){
             shim_ctx = c4gpu_ctx_create(g_getenv("C4GPU_DEVICE") ? atoi(g_getenv("C4GPU_DEVICE")) : shim_args.device);
             if(!shim_ctx)
                 g_warning("c4gpu: %s -- using the CPU Viterbi", c4gpu_last_error());

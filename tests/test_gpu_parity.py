@@ -386,3 +386,51 @@ def test_stale_sub_alignment_tails_are_recomputed(eng, monkeypatch, capfd):
     exp = oracle_lib.find_paths_subopt(model.c, model.params, q, t, 32, 300, 2)
     assert [a.as_dict() for a in found] == [d for d, _ in exp]
     assert len(found) == 2
+
+
+@pytest.mark.parametrize("name,match_state,span_state", [("span_est2genome_fwd", 2, 8), ("span_est2genome_rev", 5, 9)])
+def test_span_seam_matches_reference_vectors(eng, name, match_state, span_state):
+    """BSDP's span models on the device: the src DP copies out every END cell (cell_end_func), the dst DP reads
+    its START cells from a matrix (cell_start_func) — viterbi.c:728-741,793-799 — against what the reference
+    itself produced (refdump --cmd span), all pairs of the set in one launch per DP."""
+    import ctypes as C
+    src = ex.Model.derived("est2genome", match_state, span_state, 4, 0)
+    dst = ex.Model.derived("est2genome", span_state, match_state, 0, 4)
+    recs = load_set(name)
+    pairs = [(r["query"], r["target"]) for r in recs]
+    cs = 1 + src.c.total_shadow_designations
+    mats, jobs = [], []
+    for k, r in enumerate(recs):
+        Q, T = len(r["query"]), len(r["target"])
+        m = (C.c_int32 * ((Q + 1) * (T + 1) * cs))()
+        for x in range((Q + 1) * (T + 1)):
+            m[x * cs] = _abi.IMPOSSIBLY_LOW_SCORE
+        mats.append(m)
+        jobs.append({"pair": k, "region": (0, 0, Q, T), "end_cells": m})
+    got = eng.viterbi(src, ex.MODE_FIND_SCORE, pairs, jobs)
+    for r, g, m in zip(recs, got, mats):
+        Q, T = len(r["query"]), len(r["target"])
+        assert g["score"] == r["src_score"], r["id"]
+        cells = {}
+        for i in range(Q + 1):
+            for j in range(T + 1):
+                x = (i * (T + 1) + j) * cs
+                if m[x] != _abi.IMPOSSIBLY_LOW_SCORE:
+                    cells[(i, j)] = [m[x + l] for l in range(cs)]
+        assert cells == {(c[0], c[1]): c[2:] for c in r["end_cells"]}, r["id"]
+    jobs = [{"pair": k, "region": (0, 0, len(r["query"]), len(r["target"])), "start_cells": mats[k]} for k, r in enumerate(recs)]
+    scores = eng.viterbi(dst, ex.MODE_FIND_SCORE, pairs, jobs)
+    paths = eng.viterbi(dst, ex.MODE_FIND_PATH, pairs, jobs)
+    for r, s_, p in zip(recs, scores, paths):
+        assert s_["score"] == r["dst_score"], r["id"]
+        if "path_score" in r:
+            assert p["score"] == r["path_score"]
+            assert [p["query_start"], p["target_start"], p["query_end"] - p["query_start"],
+                    p["target_end"] - p["target_start"]] == r["region"], r["id"]
+            rle = []
+            for o in p["ops"]:
+                if rle and rle[-1][0] == o:
+                    rle[-1][1] += 1
+                else:
+                    rle.append([o, 1])
+            assert rle == r["ops"], r["id"]
