@@ -127,6 +127,20 @@ struct Facts {
     static constexpr int match_at() { for (int k = 0; k < M::NT; k++) if (M::tr[k].calc >= 0 && M::calc[M::tr[k].calc].kind >= CALC_MATCH_DNA && M::calc[M::tr[k].calc].kind <= CALC_MATCH_P2D) return M::tr[k].at; return 1; }
     static constexpr bool has_phase() { for (int c = 0; c < M::NC; c++) if (M::calc[c].kind == CALC_PHASE_POST) return true; return false; }
     static constexpr bool has_splice() { for (int c = 0; c < M::NC; c++) if (M::calc[c].kind == CALC_SPLICE_PRE || M::calc[c].kind == CALC_SPLICE_POST) return true; return false; }
+    // every state a MATCH-labelled transition enters also has a silent, calc-free transition from START (score 0
+    // wherever START is valid): a blocked match transition may then compete with the unset score instead of
+    // being skipped
+    static constexpr bool match_states_have_start() {
+        for (int k = 0; k < M::NT; k++) {
+            if (M::tr[k].label != 1) continue;
+            bool found = false;
+            for (int x = 0; x < M::NT; x++)
+                if (M::tr[x].in == M::START && M::tr[x].out == M::tr[k].out && M::tr[x].aq == 0 && M::tr[x].at == 0 &&
+                    M::tr[x].calc < 0) found = true;
+            if (!found) return false;
+        }
+        return true;
+    }
     static_assert(M::MAXAQ == 1, "lanes exchange exactly one query row per step");
     static_assert(total_bits <= 32, "traceback word");
 };
@@ -179,6 +193,8 @@ struct WaveDP {
     static constexpr int W = 64 * R;                    // query rows per strip
     static constexpr int NCOL = M::MAXAT + 1;           // live columns, kept as a ring (no register rotation)
     static constexpr int NEXP = F::n_exported();
+    // sub-optimal blocking in the local score / region passes: see eval_cell
+    static constexpr bool BLOCK_AS_LOW = LOCAL && (MODE == MODE_SCORE || MODE == MODE_REGION) && F::match_states_have_start();
     static constexpr int BND = NEXP * (1 + XS);         // ints per column in the strip carry row
     using C = Cell<M, X>;
 
@@ -287,7 +303,11 @@ struct WaveDP {
             if constexpr (t.out == M::END && !LOCAL)
                 valid = valid & (CONT ? ((i == Q) & (j == T)) : scope_ok(end_scope, i == Q, j == T));
             // sub-optimal blocking: MATCH transitions do not enter a blocked cell (viterbi.c:701-704)
-            if constexpr (SUB && t.label == LABEL_MATCH) valid = valid & !blocked;
+            // In the local score / region passes the match state always has START's candidate (score 0) in the
+            // same cell, so a blocked match transition may as well compete with the unset score and lose: the
+            // validity of everything stays a compile-time fact there (see the row-0 note above).
+            if constexpr (SUB && t.label == LABEL_MATCH && !BLOCK_AS_LOW)
+                valid = valid & !blocked;
             // A continuation runs with CORNER scopes (viterbi.c:68-76): a transition out of START is valid in
             // the origin cell only.  Instantiations that cannot hold the origin (rows below the lane's first,
             // steps where every lane is past column 0) drop those transitions at compile time.
@@ -372,6 +392,8 @@ struct WaveDP {
                 if constexpr (cd.protect & 2) tscore = tscore < LOW ? LOW : tscore;
                 if constexpr (cd.protect & 1) tscore = tscore > HIGH ? HIGH : tscore;
             }
+            if constexpr (SUB && t.label == LABEL_MATCH && BLOCK_AS_LOW)
+                tscore = blocked ? LOW : tscore;
             const bool was_set = set[t.out];
             const int old_sc = c.sc[t.out];
             const bool win = valid & (!was_set | (old_sc < tscore));
@@ -482,8 +504,9 @@ struct WaveDP {
     int nx2_sub_lo, nx2_sub_hi;                 // column j+2
     __device__ __forceinline__ void sub_load_ptrs(int j, int &lo, int &hi) const {
         const int jc = j < 0 ? 0 : (j > T ? T : j);
-        lo = sub_cp[jc];
-        hi = sub_cp[jc + 1];
+        const char *p = reinterpret_cast<const char *>(sub_cp) + ((unsigned)jc << 2);      // uniform base + 32-bit offset
+        lo = reinterpret_cast<const int *>(p)[0];
+        hi = reinterpret_cast<const int *>(p)[1];
     }
     __device__ __forceinline__ void prefetch_column(int j) {
         constexpr int mat = F::match_at();
@@ -491,7 +514,8 @@ struct WaveDP {
             // called with the NEXT step's column j: what was requested for it last step moves up, its first
             // blocked row is requested through those pointers, and the pointers of column j+1 are requested
             nx_sub_lo = nx2_sub_lo; nx_sub_hi = nx2_sub_hi;
-            nx_sub_row0 = sub_rows[nx_sub_lo];          // the point arrays carry one spare entry at the end
+            nx_sub_row0 = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(sub_rows) + ((unsigned)nx_sub_lo << 2));
+                                                        // (the point arrays carry one spare entry at the end)
             sub_load_ptrs(j + 1, nx2_sub_lo, nx2_sub_hi);
         }
         int ti = t0 + j - mat;
