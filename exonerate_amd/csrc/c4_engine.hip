@@ -235,16 +235,16 @@ __global__ void splice_kernel(const uint8_t *__restrict__ seq, const long long *
 // Column pointers of the blocked-cell lists (the device form of SubOpt_Index's rows, subopt.c:250-333): for
 // every job and every column 0..T+1 the index of the first point at or after that column.
 __global__ void subopt_colptr_kernel(const DevJob *jobs, int n_jobs, const int *pts_t, int *colptr) {
+    // colptr[c] = number of the job's points in columns < c.  The points are sorted by column, so point k
+    // owns the columns after its predecessor's up to its own: one pass of T+2 writes per job, no searches.
     for (int x = blockIdx.x; x < n_jobs; x += gridDim.x) {
         const DevJob &j = jobs[x];
         const int *pt = pts_t + j.sub_pt_off;
-        for (int c = threadIdx.x; c <= j.T + 1; c += blockDim.x) {
-            int lo = 0, hi = j.sub_pt_n;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (pt[mid] < c) lo = mid + 1; else hi = mid;
-            }
-            colptr[j.sub_off + c] = j.sub_pt_off + lo;
+        const int n = j.sub_pt_n;
+        for (int k = threadIdx.x; k <= n; k += blockDim.x) {
+            const int first = k == 0 ? 0 : pt[k - 1] + 1;
+            const int last = k == n ? j.T + 1 : pt[k];          // inclusive
+            for (int c = first; c <= last; c++) colptr[j.sub_off + c] = j.sub_pt_off + k;
         }
     }
 }

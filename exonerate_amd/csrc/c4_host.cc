@@ -1,5 +1,6 @@
 // c4_host.cc — host-side pieces of the C ABI that need no device: the reference's memory decisions
 // (which decide WHICH Viterbi passes run, hence results) and the sugar/cigar/vulgar printers.
+#include <algorithm>
 #include <climits>
 #include <cstdint>
 #include <cstdio>
@@ -86,13 +87,22 @@ void subopt_region_points(const c4gpu_subopt *so, const c4gpu_region &r,
                           std::vector<std::pair<int32_t, int32_t>> &out) {
     out.clear();
     if (!so) return;
-    auto it = so->points.lower_bound(std::make_pair(r.target_start, INT32_MIN));
+    auto it = std::lower_bound(so->points.begin(), so->points.end(), std::make_pair(r.target_start, INT32_MIN));
     for (; it != so->points.end() && it->first <= r.target_start + r.target_length; ++it)
         if (it->second >= r.query_start && it->second <= r.query_start + r.query_length)
             out.emplace_back(it->first - r.target_start, it->second - r.query_start);
 }
 
 }  // namespace c4h
+
+void c4gpu_subopt::merge(std::vector<std::pair<int32_t, int32_t>> &fresh) {
+    if (fresh.empty()) return;
+    if (!std::is_sorted(fresh.begin(), fresh.end())) std::sort(fresh.begin(), fresh.end());
+    const size_t old = points.size();
+    points.insert(points.end(), fresh.begin(), fresh.end());
+    std::inplace_merge(points.begin(), points.begin() + old, points.end());
+    points.erase(std::unique(points.begin(), points.end()), points.end());
+}
 
 extern "C" {
 
@@ -105,7 +115,8 @@ void c4gpu_subopt_destroy(c4gpu_subopt *so) { delete so; }
 
 int c4gpu_subopt_add_point(c4gpu_subopt *so, int32_t query_pos, int32_t target_pos) {
     if (!so) return -1;
-    so->points.insert(std::make_pair(target_pos, query_pos));
+    std::vector<std::pair<int32_t, int32_t>> one(1, std::make_pair(target_pos, query_pos));
+    so->merge(one);
     return 0;
 }
 
@@ -126,6 +137,7 @@ int32_t c4gpu_subopt_points(const c4gpu_subopt *so, int32_t *query_pos, int32_t 
 int c4gpu_subopt_add_alignment(c4gpu_subopt *so, const c4gpu_model *model, const c4gpu_alignment *a) {
     if (!so || !model || !a) return -1;
     int32_t q = a->region.query_start, t = a->region.target_start;
+    std::vector<std::pair<int32_t, int32_t>> fresh;           // an alignment's cells come out in ascending order
     for (int32_t k = 0; k < a->n_ops; k++) {
         const int tr = a->op_transition[k];
         if (tr < 0 || tr >= model->n_transitions) { c4h::set_error("alignment operation outside the model"); return -1; }
@@ -138,17 +150,17 @@ int c4gpu_subopt_add_alignment(c4gpu_subopt *so, const c4gpu_model *model, const
                 const int dq = x.advance_query / g, dt = x.advance_target / g;
                 for (int32_t step = 0; step < len; step++)
                     for (int sub = 0; sub * dq < x.advance_query; sub++)
-                        so->points.insert(std::make_pair(t + step * x.advance_target + sub * dt,
-                                                         q + step * x.advance_query + sub * dq));
+                        fresh.emplace_back(t + step * x.advance_target + sub * dt, q + step * x.advance_query + sub * dq);
                 for (int sub = 1; sub * dq < x.advance_query; sub++) {
                     const int32_t lq = q - x.advance_query + sub * dq, lt = t - x.advance_target + sub * dt;
-                    if (lq >= 0 && lt >= 0) so->points.insert(std::make_pair(lt, lq));
+                    if (lq >= 0 && lt >= 0) fresh.emplace_back(lt, lq);
                 }
             }
         }
         q += x.advance_query * len;
         t += x.advance_target * len;
     }
+    so->merge(fresh);
     so->path_count++;
     return 0;
 }

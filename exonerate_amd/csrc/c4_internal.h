@@ -7,12 +7,14 @@
 #include "c4gpu.h"
 
 // SubOpt (src/c4/subopt.h:33-48): the reference keeps the points in a RangeTree; all it ever asks of it is
-// membership and "every point inside a rectangle", which an ordered set keyed (target, query) answers in
-// the order SubOpt_Index_create sorts them (subopt.c:239-248,268).
+// membership and "every point inside a rectangle", which a sorted, duplicate-free array keyed (target, query)
+// answers in the order SubOpt_Index_create sorts them (subopt.c:239-248,268).
 struct c4gpu_subopt {
     int32_t query_length, target_length;
-    std::set<std::pair<int32_t, int32_t>> points;      // (target_pos, query_pos), sequence coordinates
+    std::vector<std::pair<int32_t, int32_t>> points;   // (target_pos, query_pos), sequence coordinates, sorted
     int32_t path_count;
+    // merge a batch of new points (any order, duplicates allowed) into the sorted array
+    void merge(std::vector<std::pair<int32_t, int32_t>> &fresh);
 };
 
 namespace c4h {
