@@ -1,0 +1,91 @@
+"""Differential runs of the drop-in binary against the reference binary on seeded random inputs and flag
+combinations (small sequences, many pairs): exhaustive mode of every in-scope model with and without the
+sub-optimal loop, tiny --dpmemory (reduced-space route on small regions), --bestn, --percent, --forcegtag,
+thresholds, both batching modes.  Byte-identical stdout is the bar."""
+import os, random, subprocess
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GPU_EXE = os.path.join(ROOT, "integration", "_build", "exonerate-gpu")
+CPU_EXE = os.path.join(ROOT, "oracle", "_ref", "exonerate-compiled")
+
+TABLE = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"
+CODON = {}
+for _i, _a in enumerate("TCAG"):
+    for _j, _b in enumerate("TCAG"):
+        for _k, _c in enumerate("TCAG"):
+            CODON.setdefault(TABLE[_i * 16 + _j * 4 + _k], []).append(_a + _b + _c)
+
+
+def _inputs(rng, model, n):
+    dna = lambda k, alpha="ACGT": "".join(rng.choice(alpha) for _ in range(k))
+    aa = lambda k: "".join(rng.choice("ARNDCQEGHILKMFPSTWYV") for _ in range(k))
+    mut = lambda s, r, alpha: "".join((rng.choice(alpha) if rng.random() < r else c) for c in s)
+    qs, ts = [], []
+    for k in range(n):
+        if model.startswith("protein"):
+            q = aa(rng.randint(8, 60))
+            coding = "".join(rng.choice(CODON[x]) for x in mut(q, 0.1, "ARNDCQEGHILKMFPSTWYV"))
+            if model == "protein2genome" and len(coding) > 30:
+                c = rng.randint(10, len(coding) - 10)
+                coding = coding[:c] + "GT" + dna(rng.randint(30, 120)) + "AG" + coding[c:]
+            if rng.random() < 0.3:
+                p = rng.randint(3, len(coding) - 3)
+                coding = coding[:p] + rng.choice("ACGT") + coding[p:]          # frameshift
+            t = dna(rng.randint(0, 80)) + coding + dna(rng.randint(0, 80))
+        else:
+            q = dna(rng.randint(15, 200), "ACGTN" if k % 5 == 0 else "ACGT")
+            if model == "est2genome" and len(q) > 40:
+                c = rng.randint(15, len(q) - 15)
+                rev = rng.random() < 0.3
+                body = mut(q[:c], 0.04, "ACGT") + ("CT" if rev else "GT") + dna(rng.randint(30, 200)) + \
+                    ("AC" if rev else "AG") + mut(q[c:], 0.04, "ACGT")
+            else:
+                body = mut(q, rng.choice([0.0, 0.05, 0.2]), "ACGT")
+            t = dna(rng.randint(0, 60)) + body + dna(rng.randint(0, 60))
+            if rng.random() < 0.25:
+                t += dna(rng.randint(5, 30)) + mut(body, 0.1, "ACGT")               # a second copy
+        qs.append(("q%d" % k, q))
+        ts.append(("t%d" % k, t))
+    return qs, ts
+
+
+CASES = []
+_rng = random.Random(20260928)
+for _model in ("affine:local", "affine:global", "affine:bestfit", "affine:overlap", "est2genome", "protein2dna",
+               "protein2genome", "ungapped"):
+    for _rep in range(4):
+        flags = ["-S", _rng.choice(["yes", "no"])]
+        if _rng.random() < 0.5:
+            flags += ["-D", _rng.choice(["0", "1"])]
+        if _rng.random() < 0.3:
+            flags += ["--bestn", str(_rng.randint(1, 3))]
+        if _rng.random() < 0.3:
+            flags += ["--percent", str(_rng.choice([20, 50, 80]))]
+        if _rng.random() < 0.3:
+            flags += ["--score", str(_rng.choice([30, 60, 150]))]
+        if _model in ("est2genome", "protein2genome") and _rng.random() < 0.3:
+            flags += ["--forcegtag", "yes"]
+        CASES.append((_model, tuple(flags), _rng.choice(["4096", "0", "3"]), _rng.randint(0, 10**6)))
+
+
+@pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
+                    reason="reference binaries are built in the build container (make -C integration)")
+@pytest.mark.parametrize("model,flags,batch,seed", CASES)
+def test_random_inputs_and_flags(tmp_path, model, flags, batch, seed):
+    rng = random.Random(seed)
+    qs, ts = _inputs(rng, model, 5)
+    qf, tf = str(tmp_path / "q.fa"), str(tmp_path / "t.fa")
+    for path, recs in ((qf, qs), (tf, ts)):
+        with open(path, "w") as f:
+            for name, seq in recs:
+                f.write(">%s\n%s\n" % (name, seq))
+    args = ["-m", model, "-E", "yes", "--showalignment", "yes", "--showvulgar", "yes", "--showcigar", "yes",
+            "-V", "0"] + list(flags) + [qf, tf]
+    ref = subprocess.run([CPU_EXE] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    env = dict(os.environ, C4GPU_BATCH=batch, C4GPU_MIN_CELLS="0")
+    gpu = subprocess.run([GPU_EXE] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert ref.returncode == 0, ref.stderr.decode()[-500:]
+    assert gpu.returncode == 0, gpu.stderr.decode()[-1500:]
+    assert gpu.stdout == ref.stdout, (model, flags, batch)
