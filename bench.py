@@ -222,7 +222,9 @@ def main():
                                  "valu_pmc (profiles/) is the SQ-counter view of that bound (DESIGN.md section 5)"},
             "kernel_ms": {"region": stats[2]["ms"], "checkpoint": stats[3]["ms"], "path": stats[1]["ms"]},
         }
-        if not args.no_cpu_baseline:
+        # the CPU legs run at N=1 only: at N>1 the other ranks would sit in the process-group teardown while
+        # rank 0 times a host program
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, rank, model, pairs, batch, eng)
             out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["value"] / world
             if out["cpu_baseline"]["kind"] == "reference":

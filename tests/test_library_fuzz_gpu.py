@@ -1,0 +1,88 @@
+"""Library-level differential fuzz: Engine.find_path / find_all_paths against the oracle on seeded random
+batches — every in-scope model family, query lengths that cross the one-wave / multi-wave / multi-strip
+boundaries (1 .. 2300 rows), tiny --dpmemory (reduced-space route with checkpoint passes), thresholds and up
+to three sub-optimal rounds.  Alignments are compared operation by operation (bit-exact)."""
+import random
+import pytest
+
+import exonerate_amd as ex
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+TABLE = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"
+CODON = {}
+for _i, _a in enumerate("TCAG"):
+    for _j, _b in enumerate("TCAG"):
+        for _k, _c in enumerate("TCAG"):
+            CODON.setdefault(TABLE[_i * 16 + _j * 4 + _k], []).append(_a + _b + _c)
+AA = "ARNDCQEGHILKMFPSTWYV"
+MODELS = ["affine:local", "affine:global", "affine:bestfit", "affine:overlap", "est2genome", "est2genome",
+          "protein2dna", "protein2genome", "protein2dna:bestfit", "protein2genome:bestfit"]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = ex.Engine(0)
+    yield e
+    e.close()
+
+
+def _pairs(rng, mt):
+    dna = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    mut = lambda s, r: "".join((rng.choice("ACGT") if rng.random() < r else c) for c in s)
+    pairs = []
+    if mt.startswith("protein"):
+        for _ in range(rng.randint(1, 4)):
+            ql = rng.choice([rng.randint(3, 40), rng.randint(100, 300), rng.randint(400, 700)])
+            q = "".join(rng.choice(AA) for _ in range(ql))
+            noisy = "".join((rng.choice(AA) if rng.random() < 0.08 else c) for c in q)
+            coding = "".join(rng.choice(CODON[x]) for x in noisy)
+            if "genome" in mt and len(coding) > 60:
+                for _ in range(rng.randint(1, 3)):
+                    c = rng.randint(10, len(coding) - 10)
+                    coding = coding[:c] + "GT" + dna(rng.randint(40, 900)) + "AG" + coding[c:]
+            if rng.random() < 0.4:                                   # frameshift
+                p = rng.randint(3, len(coding) - 3)
+                coding = coding[:p] + rng.choice("ACGT") + coding[p:]
+            pairs.append((q, dna(rng.randint(0, 400)) + coding + dna(rng.randint(0, 900))))
+        return pairs
+    for _ in range(rng.randint(1, 5)):
+        ql = rng.choice([rng.randint(1, 70), rng.randint(200, 700), rng.randint(900, 1400), rng.randint(2000, 2300)])
+        q = dna(ql)
+        if mt == "est2genome" and ql > 60:
+            c = rng.randint(20, ql - 20)
+            body = mut(q[:c], 0.03) + "GT" + dna(rng.randint(40, 3000)) + "AG" + mut(q[c:], 0.03)
+        else:
+            body = mut(q, rng.choice([0.02, 0.1, 0.3]))
+        t = dna(rng.randint(0, 300)) + body + dna(rng.randint(0, 1500))
+        if rng.random() < 0.3:                                       # a second copy: sub-optimal rounds find it
+            t = t + dna(50) + mut(body, 0.08)
+        if mt not in ("affine:local", "est2genome") and len(t) > 3000:
+            t = t[:3000]
+        pairs.append((q, t))
+    return pairs
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_library_fuzz(eng, seed):
+    rng = random.Random(9000 + seed)
+    for _ in range(3):
+        mt = rng.choice(MODELS)
+        model = ex.Model(mt)
+        pairs = _pairs(rng, mt)
+        dpm = rng.choice([0, 1, 32])
+        thr = rng.choice([-987654321, 50, 200])
+        rounds = rng.choice([1, 1, 2, 3])
+        if rounds == 1:
+            got = [[a] if a else [] for a in eng.find_path(model, pairs, dpmemory=dpm, threshold=thr)]
+        else:
+            got = eng.find_all_paths(model, pairs, dpmemory=dpm, threshold=max(thr, 40), max_paths=rounds)
+        for (q, t), alns in zip(pairs, got):
+            if rounds == 1:
+                e = oracle_lib.find_path(model.c, model.params, q.encode(), t.encode(), dpmemory=dpm, threshold=thr)
+                exp = [e] if e else []
+            else:
+                exp = [d for d, _ in oracle_lib.find_paths_subopt(model.c, model.params, q.encode(), t.encode(),
+                                                                  dpm, max(thr, 40), rounds)]
+            assert [a.as_dict() for a in alns] == exp, (mt, len(q), len(t), dpm, thr, rounds)
