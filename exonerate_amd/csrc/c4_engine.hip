@@ -133,19 +133,31 @@ int model_family(const c4gpu_model &m) {
     if (model_matches<Est2GenomeFwdSpanDstDesc>(m)) return FAM_EST2GENOME_FWD_SPAN_DST;
     if (model_matches<Est2GenomeRevSpanSrcDesc>(m)) return FAM_EST2GENOME_REV_SPAN_SRC;
     if (model_matches<Est2GenomeRevSpanDstDesc>(m)) return FAM_EST2GENOME_REV_SPAN_DST;
+    if (model_matches<Protein2GenomePhase0SpanSrcDesc>(m)) return FAM_PROTEIN2GENOME_PHASE0_SPAN_SRC;
+    if (model_matches<Protein2GenomePhase0SpanDstDesc>(m)) return FAM_PROTEIN2GENOME_PHASE0_SPAN_DST;
+    if (model_matches<Protein2GenomePhase1SpanSrcDesc>(m)) return FAM_PROTEIN2GENOME_PHASE1_SPAN_SRC;
+    if (model_matches<Protein2GenomePhase1SpanDstDesc>(m)) return FAM_PROTEIN2GENOME_PHASE1_SPAN_DST;
+    if (model_matches<Protein2GenomePhase2SpanSrcDesc>(m)) return FAM_PROTEIN2GENOME_PHASE2_SPAN_SRC;
+    if (model_matches<Protein2GenomePhase2SpanDstDesc>(m)) return FAM_PROTEIN2GENOME_PHASE2_SPAN_DST;
     return -1;
 }
 
+static bool family_is_p2g_span(int fam) {
+    return fam >= FAM_PROTEIN2GENOME_PHASE0_SPAN_SRC && fam <= FAM_PROTEIN2GENOME_PHASE2_SPAN_DST;
+}
 bool family_is_p2d(int fam) {
     return fam == FAM_UNGAPPED_P2D || fam == FAM_PROTEIN2DNA || fam == FAM_PROTEIN2GENOME ||
-           (fam >= FAM_PROTEIN2DNA_START && fam <= FAM_PROTEIN2GENOME_JOIN);
+           (fam >= FAM_PROTEIN2DNA_START && fam <= FAM_PROTEIN2GENOME_JOIN) || family_is_p2g_span(fam);
 }
 bool family_has_splice(int fam) {
     return fam == FAM_EST2GENOME || fam == FAM_PROTEIN2GENOME || (fam >= FAM_EST2GENOME_FWD_START && fam <= FAM_EST2GENOME_REV_JOIN) ||
            (fam >= FAM_PROTEIN2GENOME_START && fam <= FAM_PROTEIN2GENOME_JOIN) ||
-           (fam >= FAM_EST2GENOME_FWD_SPAN_SRC && fam <= FAM_EST2GENOME_REV_SPAN_DST);
+           (fam >= FAM_EST2GENOME_FWD_SPAN_SRC && fam <= FAM_EST2GENOME_REV_SPAN_DST) || family_is_p2g_span(fam);
 }
-bool family_has_phase(int fam) { return fam == FAM_PROTEIN2GENOME || (fam >= FAM_PROTEIN2GENOME_START && fam <= FAM_PROTEIN2GENOME_JOIN); }
+bool family_has_phase(int fam) {
+    return fam == FAM_PROTEIN2GENOME || (fam >= FAM_PROTEIN2GENOME_START && fam <= FAM_PROTEIN2GENOME_JOIN) ||
+           family_is_p2g_span(fam);
+}
 
 // ---- sequence preparation kernels -------------------------------------------------------------------------
 struct PrepTables {

@@ -15,6 +15,10 @@ enum Family { FAM_UNGAPPED = 0, FAM_AFFINE, FAM_EST2GENOME, FAM_UNGAPPED_P2D, FA
               FAM_PROTEIN2GENOME_START, FAM_PROTEIN2GENOME_END, FAM_PROTEIN2GENOME_JOIN,
               // est2genome's span models (heuristic.c:461-472): match state -> intron state, intron state -> match state
               FAM_EST2GENOME_FWD_SPAN_SRC, FAM_EST2GENOME_FWD_SPAN_DST, FAM_EST2GENOME_REV_SPAN_SRC, FAM_EST2GENOME_REV_SPAN_DST,
+              // protein2genome's: one span per intron phase (span states 10, 11, 12)
+              FAM_PROTEIN2GENOME_PHASE0_SPAN_SRC, FAM_PROTEIN2GENOME_PHASE0_SPAN_DST,
+              FAM_PROTEIN2GENOME_PHASE1_SPAN_SRC, FAM_PROTEIN2GENOME_PHASE1_SPAN_DST,
+              FAM_PROTEIN2GENOME_PHASE2_SPAN_SRC, FAM_PROTEIN2GENOME_PHASE2_SPAN_DST,
               FAM_COUNT };
 
 struct LaunchArgs {

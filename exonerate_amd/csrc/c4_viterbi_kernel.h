@@ -349,6 +349,14 @@ struct WaveDP {
                 const int *sc = span_in_p + ((long long)(si > Q ? Q : si) * (T + 1) + sj) * (1 + NDES);
                 start_cell.sc[M::START] = sc[0];
                 static_for<NDES>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_; start_cell.ex[M::START][E] = sc[1 + E]; });
+                if constexpr (NAUX == 1) {
+                    // the base slot is not part of the reference's cell: re-derive it from the shadow (the two
+                    // bases in front of the intron that is open in the start cell), as a continuation does
+                    const int cis = sc[1];
+                    const int cq = cis < 1 ? 0 : (cis - 1 > tlast ? tlast : cis - 1);
+                    const int b = tn4p[cq] & 0xff;
+                    start_cell.ex[M::START][AUX] = (cis >= 1) & (cis - 1 <= tlast) ? b : 0;
+                }
             }
             const C &src = (SPAN == 1 && t.in == M::START && !CONT) ? start_cell : cell_src;
             int tscore;

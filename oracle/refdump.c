@@ -254,7 +254,10 @@ static void run_span(gchar *model_name, gchar *input_path, gint match_state, gin
     register Model_Type type = Model_Type_from_string(model_name);
     register FILE *fp = fopen(input_path, "r");
     register Alphabet *dna = Alphabet_create(Alphabet_Type_DNA, FALSE);
-    register C4_Model *model = Model_Type_get_model(type, Alphabet_Type_DNA, Alphabet_Type_DNA);
+    register gboolean protein_query = !strncmp(model_name, "protein2", 8);
+    register Alphabet *qalpha = protein_query ? Alphabet_create(Alphabet_Type_PROTEIN, FALSE) : dna;
+    register C4_Model *model = Model_Type_get_model(type, protein_query ? Alphabet_Type_PROTEIN : Alphabet_Type_DNA,
+                                                    Alphabet_Type_DNA);
     register C4_DerivedModel *src_dm = C4_DerivedModel_create(model, model->state_list->pdata[match_state],
             model->state_list->pdata[span_state], C4_Scope_CORNER, NULL, NULL,
             C4_Scope_ANYWHERE, span_report_end, NULL);
@@ -281,7 +284,7 @@ static void run_span(gchar *model_name, gchar *input_path, gint match_state, gin
         if((!line[0]) || (line[0] == '#'))
             continue;
         f = g_strsplit(line, "\t", 3);
-        query = Sequence_create(f[0], NULL, f[1], 0, Sequence_Strand_FORWARD, dna);
+        query = Sequence_create(f[0], NULL, f[1], 0, Sequence_Strand_FORWARD, qalpha);
         target = Sequence_create("tg", NULL, f[2], 0, Sequence_Strand_FORWARD, dna);
         user_data = Model_Type_create_data(type, query, target);
         region = Region_create(0, 0, query->len, target->len);

@@ -75,3 +75,10 @@ def expected(rec):
     """What the reference printed for this record, in the shape oracle_lib.alignment_to_dict gives."""
     return {"score": rec["path_score"], "region": rec["region"], "ops": rec["ops"],
             "sugar": rec["sugar"], "cigar": rec["cigar"], "vulgar": rec["vulgar"]}
+
+
+# BSDP span models: (set, model, query alphabet (1 = protein), match state, span state)
+SPAN_SETS = [("span_est2genome_fwd", "est2genome", 0, 2, 8), ("span_est2genome_rev", "est2genome", 0, 5, 9),
+             ("span_protein2genome_phase0", "protein2genome", 1, 2, 10),
+             ("span_protein2genome_phase1", "protein2genome", 1, 2, 11),
+             ("span_protein2genome_phase2", "protein2genome", 1, 2, 12)]

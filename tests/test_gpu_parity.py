@@ -10,7 +10,7 @@ import pytest
 import exonerate_amd as ex
 from exonerate_amd import _abi
 import oracle_lib
-from golden_util import SETS, SUBOPT_SETS, DERIVED_SETS, load_set, expected
+from golden_util import SETS, SUBOPT_SETS, DERIVED_SETS, SPAN_SETS, load_set, expected
 
 pytestmark = pytest.mark.gpu
 
@@ -388,14 +388,14 @@ def test_stale_sub_alignment_tails_are_recomputed(eng, monkeypatch, capfd):
     assert len(found) == 2
 
 
-@pytest.mark.parametrize("name,match_state,span_state", [("span_est2genome_fwd", 2, 8), ("span_est2genome_rev", 5, 9)])
-def test_span_seam_matches_reference_vectors(eng, name, match_state, span_state):
+@pytest.mark.parametrize("name,mtype,qa,match_state,span_state", SPAN_SETS)
+def test_span_seam_matches_reference_vectors(eng, name, mtype, qa, match_state, span_state):
     """BSDP's span models on the device: the src DP copies out every END cell (cell_end_func), the dst DP reads
     its START cells from a matrix (cell_start_func) — viterbi.c:728-741,793-799 — against what the reference
     itself produced (refdump --cmd span), all pairs of the set in one launch per DP."""
     import ctypes as C
-    src = ex.Model.derived("est2genome", match_state, span_state, 4, 0)
-    dst = ex.Model.derived("est2genome", span_state, match_state, 0, 4)
+    src = ex.Model.derived(mtype, match_state, span_state, 4, 0, qa, 0)
+    dst = ex.Model.derived(mtype, span_state, match_state, 0, 4, qa, 0)
     recs = load_set(name)
     pairs = [(r["query"], r["target"]) for r in recs]
     cs = 1 + src.c.total_shadow_designations

@@ -7,7 +7,7 @@ inputs of the reference's model known-answer tests.  Integer work: every compari
 import pytest
 from exonerate_amd import _abi
 import oracle_lib
-from golden_util import SETS, SUBOPT_SETS, DERIVED_SETS, load_set, get_model, set_params, expected
+from golden_util import SETS, SUBOPT_SETS, DERIVED_SETS, SPAN_SETS, load_set, get_model, set_params, expected
 
 
 @pytest.mark.parametrize("name", sorted(SETS) + sorted(DERIVED_SETS))
@@ -53,13 +53,13 @@ def _rle(ops):
     return out
 
 
-@pytest.mark.parametrize("name,match_state,span_state", [("span_est2genome_fwd", 2, 8), ("span_est2genome_rev", 5, 9)])
-def test_oracle_span_seam_matches_reference(lib, params, name, match_state, span_state):
+@pytest.mark.parametrize("name,mtype,qa,match_state,span_state", SPAN_SETS)
+def test_oracle_span_seam_matches_reference(lib, params, name, mtype, qa, match_state, span_state):
     """cell_end_func / cell_start_func (viterbi.c:728-741,793-799) on BSDP's span models: the END cells the src
     DP reports, and score and path of the dst DP that starts from them, as the reference produced them."""
     src = _abi.Model(); dst = _abi.Model()
-    assert lib.c4gpu_model_get_derived(b"est2genome", 0, 0, params, match_state, span_state, 4, 0, src, None) == 0
-    assert lib.c4gpu_model_get_derived(b"est2genome", 0, 0, params, span_state, match_state, 0, 4, dst, None) == 0
+    assert lib.c4gpu_model_get_derived(mtype.encode(), qa, 0, params, match_state, span_state, 4, 0, src, None) == 0
+    assert lib.c4gpu_model_get_derived(mtype.encode(), qa, 0, params, span_state, match_state, 0, 4, dst, None) == 0
     for rec in load_set(name):
         q, t = rec["query"].encode(), rec["target"].encode()
         src_score, cells, dst_score, path = oracle_lib.span_pair(src, dst, params, q, t)

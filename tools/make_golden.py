@@ -197,12 +197,12 @@ def run(model, cases, dpmemory, extra=()):
     return recs
 
 
-def run_span(cases, match_state, span_state):
+def run_span(cases, match_state, span_state, model="est2genome"):
     with tempfile.NamedTemporaryFile("w", suffix=".tsv", delete=False) as f:
         for cid, q, t in cases:
             f.write("%s\t%s\t%s\n" % (cid, q, t))
         path = f.name
-    cmd = [REFDUMP, "--cmd", "span", "--model", "est2genome", "--input", path, "--derived", "%d,%d" % (match_state, span_state)]
+    cmd = [REFDUMP, "--cmd", "span", "--model", model, "--input", path, "--derived", "%d,%d" % (match_state, span_state)]
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout.decode()
     os.unlink(path)
     recs = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
@@ -306,6 +306,25 @@ def main():
         if only and name not in only:
             continue
         recs = run_span(span_cases, ms, ss)
+        with open(os.path.join(OUT, name + ".jsonl"), "w") as f:
+            for r in recs:
+                f.write(json.dumps(r, separators=(",", ":")) + "\n")
+        print(name, len(recs), "dst scores", [r["dst_score"] for r in recs])
+    # protein2genome's three spans (intron in phase 0, 1, 2: span states 10, 11, 12)
+    pr = random.Random(910)
+    p2g_span_cases = []
+    for k in range(9):
+        q = "".join(pr.choice(AA) for _ in range(pr.randint(5, 11)))
+        coding = "".join(pr.choice(CODON[a]) for a in mutate(pr, q, 0.05, AA))
+        c = 3 * pr.randint(1, len(q) - 2) + (k % 3)
+        t = rand_dna(pr, pr.choice([0, 0, 3])) + coding[:c] + "GT" + rand_dna(pr, pr.randint(30, 60)) + "AG" + \
+            coding[c:] + rand_dna(pr, pr.choice([0, 0, 2]))
+        p2g_span_cases.append(("pspan%02d" % k, q, t))
+    for name, ms, ss in (("span_protein2genome_phase0", 2, 10), ("span_protein2genome_phase1", 2, 11),
+                         ("span_protein2genome_phase2", 2, 12)):
+        if only and name not in only:
+            continue
+        recs = run_span(p2g_span_cases, ms, ss, "protein2genome")
         with open(os.path.join(OUT, name + ".jsonl"), "w") as f:
             for r in recs:
                 f.write(json.dumps(r, separators=(",", ":")) + "\n")
