@@ -791,6 +791,12 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
         SubScope(Engine &e_, const std::vector<const c4gpu_subopt *> *s) : e(e_) { e.pair_sub = s; }
         ~SubScope() { e.pair_sub = nullptr; }
     } sub_scope(eng, subs);
+    static const bool trace = getenv("C4GPU_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (trace) fprintf(stderr, "c4gpu trace: find_path_batch: %-28s at %.3f ms\n", what,
+                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    };
     std::vector<PairPlan> plan(n);
     std::vector<JobSpec> specs;
     std::vector<JobOut> outs;
@@ -871,6 +877,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
         const double rate = (double)hits / (double)step1_total;
         hit_rate = hit_rate < 0 ? rate : 0.5 * hit_rate + 0.5 * rate;
     }
+    lap("region pass done");
     // -- step 2: quadratic-space path wherever the (alignment) region fits (optimal.c:349-364, 382-390)
     specs.clear(); owner.clear();
     for (int i = 0; i < n; i++) {
@@ -896,6 +903,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
         for (uint32_t r : outs[x].runs) c4h::alignment_add(&a, &cap, (int)(r >> 24), (int)(r & 0xffffff));
         a.valid = 1;
     }
+    lap("quadratic paths done");
     // -- step 3: reduced space: checkpoint passes, recursively (optimal.c:160-230,315-345)
     std::vector<int> red;
     for (int i = 0; i < n; i++)
@@ -929,7 +937,9 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
             }
         }
         if (specs.empty()) break;
+        lap("checkpoint jobs listed");
         if (eng.run(seqs, MODE_CKPT, true, specs, outs)) return -1;
+        lap("checkpoint pass done");
         // expand from the back so that segment indices stay valid
         for (int x = (int)refs.size() - 1; x >= 0; x--) {
             std::vector<Segment> &sg = plan[refs[x].pair].segs;
@@ -959,6 +969,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
         }
         first_round = false;
     }
+    lap("segments expanded");
     // -- step 4: the sub-alignments themselves (Optimal_compute_subalignments, optimal.c:266-313)
     specs.clear();
     struct Ref2 { int pair, seg; };
@@ -974,7 +985,9 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
             refs2.push_back(Ref2{i, (int)k});
         }
     }
+    lap("sub-alignment jobs listed");
     if (eng.run(seqs, MODE_PATH, true, specs, outs)) return -1;
+    lap("sub-alignment pass done");
     {
         std::vector<int> cap(n, 0);
         const int path_cs = 1 + m->total_shadow_designations;
@@ -1035,6 +1048,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
             repairs.swap(next);
         }
     }
+    lap("alignments assembled");
     for (int i : red)
         if (redo[i] && sequential_reduced_path(eng, seqs, i, dpmemory_mb, plan[i].ar, &alignments[i])) return -1;
     for (int i = 0; i < n; i++) {
