@@ -378,9 +378,25 @@ struct JobSpec {                  // host description of one Viterbi call
     int32_t *span_out = nullptr;
 };
 typedef std::vector<std::pair<int32_t, int32_t>> RegionPoints;   // (target, query) in region coordinates, ascending
+// the runs of one path: the sub-alignments between checkpoints are a handful of runs each and there are
+// hundreds of thousands of them per batch, so short lists live inline (no allocation per job)
+struct RunList {
+    static constexpr int INLINE = 6;
+    int n = 0;
+    uint32_t small[INLINE];
+    std::vector<uint32_t> big;
+    const uint32_t *begin() const { return n <= INLINE ? small : big.data(); }
+    const uint32_t *end() const { return begin() + n; }
+    void assign_reversed(const uint32_t *first, int count) {
+        n = count;
+        uint32_t *dst = small;
+        if (count > INLINE) { big.resize(count); dst = big.data(); }
+        for (int k = 0; k < count; k++) dst[k] = first[count - 1 - k];
+    }
+};
 struct JobOut {
     DevResult res;
-    std::vector<uint32_t> runs;   // PATH: (transition << 24 | length) runs, START -> END
+    RunList runs;                 // PATH: (transition << 24 | length) runs, START -> END
     std::vector<DevVsa> vsa;      // CKPT: sub-alignments, last section first
     std::vector<int> checkpoints; // CKPT + dump_checkpoints
 };
@@ -676,8 +692,7 @@ struct Engine {
             o.res = res[x];
             if (res[x].flags & FLAG_OPS_OVERFLOW) { c4h::set_error("traceback path longer than its buffer"); return -1; }
             if (mode == MODE_PATH) {        // the walk wrote END -> START
-                o.runs.assign(runs.begin() + res[x].ops_off, runs.begin() + res[x].ops_off + res[x].n_ops);
-                std::reverse(o.runs.begin(), o.runs.end());
+                o.runs.assign_reversed(runs.data() + res[x].ops_off, res[x].n_ops);
             }
             if (mode == MODE_CKPT) {
                 o.vsa.assign(vsa.begin() + jobs[x].vsa_off, vsa.begin() + jobs[x].vsa_off + res[x].n_vsa);
@@ -974,6 +989,11 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
     specs.clear();
     struct Ref2 { int pair, seg; };
     std::vector<Ref2> refs2;
+    {
+        size_t total = 0;
+        for (int i : red) total += plan[i].segs.size();
+        specs.reserve(total); refs2.reserve(total);
+    }
     for (int i : red) {
         std::vector<Segment> &sg = plan[i].segs;
         for (size_t k = 0; k < sg.size(); k++) {
