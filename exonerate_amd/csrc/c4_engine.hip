@@ -417,6 +417,15 @@ struct Engine {
     DevBuf<int> d_bnd, d_ckpt, d_ckpt_dump, d_queue;
     DevBuf<uint32_t> d_tb;
     DevBuf<int> d_sub_t, d_sub_q, d_sub_colptr, d_span;
+    // reusable host staging of run_impl (a sub-alignment launch lists ~10^5 jobs: fresh vectors of that size
+    // are page-faulted in on every call)
+    std::vector<int> h_order;
+    std::vector<long long> h_key;
+    std::vector<DevJob> h_jobs;
+    std::vector<DevResult> h_res;
+    std::vector<uint32_t> h_runs;
+    std::vector<JobSpec> fp_specs;          // ... and of find_path_batch
+    std::vector<JobOut> fp_outs;
     // per-pair SubOpt of the Optimal_find_path in progress (NULL entries / NULL table: nothing blocked)
     const std::vector<const c4gpu_subopt *> *pair_sub = nullptr;
 
@@ -536,19 +545,22 @@ struct Engine {
             if (kmw8 && (long long)n * 8 <= 2LL * 4 * ctx->prop.multiProcessorCount) ki = kmw8;
         }
         // longest first (persistent waves pull from the queue head)
-        std::vector<int> order(n);
+        std::vector<int> &order = h_order;
+        order.resize(n);
         std::iota(order.begin(), order.end(), 0);
         auto cells = [&](int i) { return (long long)(specs[i].region.query_length + 1) * (specs[i].region.target_length + 1); };
         {
             // ... unless the launch is tens of thousands of small jobs (the sub-alignments between checkpoints):
             // any order balances those, and sorting them is then the largest item on the host
-            std::vector<long long> key(n);
+            std::vector<long long> &key = h_key;
+            key.resize(n);
             long long biggest = 0;
             for (int i = 0; i < n; i++) { key[i] = cells(i); biggest = std::max(biggest, key[i]); }
             if (!(n > 32768 && biggest < (1 << 20)))
                 std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] > key[b]; });
         }
-        std::vector<DevJob> jobs(n);
+        std::vector<DevJob> &jobs = h_jobs;
+        jobs.resize(n);
         long long ops_total = 0, vsa_total = 0, dump_total = 0, max_T = 0, max_tb = 0, max_ckpt = 0, total_cells = 0;
         long long max_runs = 0, sub_cols = 0, span_total = 0;
         std::vector<int> sub_t, sub_q;
@@ -608,8 +620,10 @@ struct Engine {
         const long long budget = (long long)(ctx->prop.totalGlobalMem / 4);
         if (bytes_per_wave * grid > budget) grid = std::max<long long>(1, budget / std::max<long long>(1, bytes_per_wave));
         hipStream_t s = ctx->stream;
-        std::vector<DevResult> res(n);
-        std::vector<uint32_t> runs;
+        std::vector<DevResult> &res = h_res;
+        res.resize(n);
+        std::vector<uint32_t> &runs = h_runs;
+        runs.clear();
         std::vector<DevVsa> vsa(vsa_total);
         std::vector<int> dump(dump_total);
         for (int attempt = 0; attempt < 2; attempt++) {
@@ -813,8 +827,9 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     };
     std::vector<PairPlan> plan(n);
-    std::vector<JobSpec> specs;
-    std::vector<JobOut> outs;
+    std::vector<JobSpec> &specs = eng.fp_specs;
+    std::vector<JobOut> &outs = eng.fp_outs;
+    specs.clear();
     std::vector<int> owner;
     for (int i = 0; i < n; i++) memset(&alignments[i], 0, sizeof(c4gpu_alignment));
     // -- step 1: where the whole rectangle is too large for a traceback, find the region first
