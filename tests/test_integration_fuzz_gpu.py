@@ -51,11 +51,12 @@ def _inputs(rng, model, n):
     return qs, ts
 
 
+# C4_FUZZ_SEED / C4_FUZZ_REPS: longer one-off campaigns with other seeds (default: the 32 committed cases)
 CASES = []
-_rng = random.Random(20260928)
+_rng = random.Random(int(os.environ.get("C4_FUZZ_SEED", "20260928")))
 for _model in ("affine:local", "affine:global", "affine:bestfit", "affine:overlap", "est2genome", "protein2dna",
                "protein2genome", "ungapped"):
-    for _rep in range(4):
+    for _rep in range(int(os.environ.get("C4_FUZZ_REPS", "4"))):
         flags = ["-S", _rng.choice(["yes", "no"])]
         if _rng.random() < 0.5:
             flags += ["-D", _rng.choice(["0", "1"])]
