@@ -244,19 +244,29 @@ __global__ void splice_kernel(const uint8_t *__restrict__ seq, const long long *
 }
 
 // ---- resident sequences of a batch --------------------------------------------------------------------------
-// Column pointers of the blocked-cell lists (the device form of SubOpt_Index's rows, subopt.c:250-333): for
-// every job and every column 0..T+1 the index of the first point at or after that column.
-__global__ void subopt_colptr_kernel(const DevJob *jobs, int n_jobs, const int *pts_t, int *colptr) {
-    // colptr[c] = number of the job's points in columns < c.  The points are sorted by column, so point k
-    // owns the columns after its predecessor's up to its own: one pass of T+2 writes per job, no searches.
+// Column entries of the blocked-cell lists (the device form of SubOpt_Index's rows, subopt.c:250-333): for
+// every job and every column 0..T+1 two ints: the first blocked row of the column (or SUB_NONE), and twice
+// the index of the first point at or after that column, plus 1 when the column holds more than one point.
+__global__ void subopt_colptr_kernel(const DevJob *jobs, int n_jobs, const int *pts_t, const int *pts_q, int *colent) {
+    // The points are sorted by column, so point k owns the columns after its predecessor's up to its own:
+    // one pass of T+2 writes per job, no searches.
+    constexpr int SUB_NONE = -0x40000000;
     for (int x = blockIdx.x; x < n_jobs; x += gridDim.x) {
         const DevJob &j = jobs[x];
         const int *pt = pts_t + j.sub_pt_off;
+        const int *pq = pts_q + j.sub_pt_off;
         const int n = j.sub_pt_n;
         for (int k = threadIdx.x; k <= n; k += blockDim.x) {
             const int first = k == 0 ? 0 : pt[k - 1] + 1;
             const int last = k == n ? j.T + 1 : pt[k];          // inclusive
-            for (int c = first; c <= last; c++) colptr[j.sub_off + c] = j.sub_pt_off + k;
+            const int idx2 = 2 * (j.sub_pt_off + k);
+            for (int c = first; c <= last; c++) {
+                const bool own = k < n && c == last;            // the column of point k itself
+                const bool more = own && k + 1 < n && pt[k + 1] == c;
+                int *e = colent + 2 * (j.sub_off + c);
+                e[0] = own ? pq[k] : SUB_NONE;
+                e[1] = idx2 | (more ? 1 : 0);
+            }
         }
     }
 }
@@ -652,9 +662,9 @@ struct Engine {
             if (pts) {
                 sub_q.push_back(0);                      // the kernels' row prefetch may touch one entry past the last list
                 if (d_sub_t.upload(sub_t.data(), sub_t.size(), s) || d_sub_q.upload(sub_q.data(), sub_q.size(), s) ||
-                    d_sub_colptr.alloc(sub_cols)) return -1;
+                    d_sub_colptr.alloc(2 * sub_cols)) return -1;
                 hipLaunchKernelGGL(subopt_colptr_kernel, dim3(std::min(n, 65535)), dim3(256), 0, s, d_jobs.p, n,
-                                   d_sub_t.p, d_sub_colptr.p);
+                                   d_sub_t.p, d_sub_q.p, d_sub_colptr.p);
                 HIP_OK(hipGetLastError());
                 a.seqs.sub_colptr = d_sub_colptr.p; a.seqs.sub_rows = d_sub_q.p;
             }

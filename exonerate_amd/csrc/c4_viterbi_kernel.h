@@ -58,7 +58,8 @@ struct DevSeqs {
     const int *ss;                       // [4][ss_stride] splice-site scores, same offsets as tcode
     const uint16_t *tn4;                 // per target position: 4-bit base masks of positions p, p-1, p-2, p-3
     long long ss_stride;
-    // sub-optimal blocking (SUB kernels): per job T+2 column pointers into sub_rows, which holds the blocked
+    // sub-optimal blocking (SUB kernels): per job T+2 column entries {first blocked row, 2 * index into sub_rows +
+    // more-rows flag} (two ints each), sub_rows holds the blocked
     // query rows (region coordinates) of each column, ascending
     const int *sub_colptr, *sub_rows;
     // span models: start cells in / END cells out, [(i * (T+1)) + j][1 + designations] per job (DevJob::span_off)
@@ -505,26 +506,21 @@ struct WaveDP {
     const uint16_t *tn4p;
     const int *span_in_p;               // SPAN == 1: this job's start cells
     int *span_out_p;                    // SPAN == 2: this job's END cell matrix
-    const int *sub_cp, *sub_rows;       // SUB: column pointers of this job, blocked rows of the launch
-    // two-stage prefetch: the column pointers of column j+2 and, through the pointers requested one step
-    // earlier, the first blocked row of column j+1 — nothing the step waits for was requested in that step
-    int nx_sub_lo, nx_sub_hi, nx_sub_row0;      // column j+1 (consumed by the next step)
-    int nx2_sub_lo, nx2_sub_hi;                 // column j+2
-    __device__ __forceinline__ void sub_load_ptrs(int j, int &lo, int &hi) const {
+    const int *sub_cp, *sub_rows;       // SUB: per-column entries of this job, blocked rows of the launch
+    // per column one 8-byte entry {first blocked row (or SUB_NONE), 2 * index of that row in sub_rows + "more
+    // rows follow"}: one load, one step ahead, no load that depends on another
+    static constexpr int SUB_NONE = -0x40000000;
+    int nx_sub_row0, nx_sub_lo2;                // column j+1 (consumed by the next step)
+    __device__ __forceinline__ void sub_load(int j, int &row0, int &lo2) const {
         const int jc = j < 0 ? 0 : (j > T ? T : j);
-        const char *p = reinterpret_cast<const char *>(sub_cp) + ((unsigned)jc << 2);      // uniform base + 32-bit offset
-        lo = reinterpret_cast<const int *>(p)[0];
-        hi = reinterpret_cast<const int *>(p)[1];
+        const char *p = reinterpret_cast<const char *>(sub_cp) + ((unsigned)jc << 3);      // uniform base + 32-bit offset
+        row0 = reinterpret_cast<const int *>(p)[0];
+        lo2 = reinterpret_cast<const int *>(p)[1];
     }
     __device__ __forceinline__ void prefetch_column(int j) {
         constexpr int mat = F::match_at();
         if constexpr (SUB) {
-            // called with the NEXT step's column j: what was requested for it last step moves up, its first
-            // blocked row is requested through those pointers, and the pointers of column j+1 are requested
-            nx_sub_lo = nx2_sub_lo; nx_sub_hi = nx2_sub_hi;
-            nx_sub_row0 = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(sub_rows) + ((unsigned)nx_sub_lo << 2));
-                                                        // (the point arrays carry one spare entry at the end)
-            sub_load_ptrs(j + 1, nx2_sub_lo, nx2_sub_hi);
+            sub_load(j, nx_sub_row0, nx_sub_lo2);
         }
         int ti = t0 + j - mat;
         ti = ti < 0 ? 0 : (ti > tlast ? tlast : ti);
@@ -560,13 +556,17 @@ struct WaveDP {
             // an earlier alignment has one match cell per column it crosses, so a column's list is almost
             // always empty or one row long: that row arrives with the prefetch; longer lists (several
             // earlier alignments through one column) are walked behind a wave-uniform branch
-            const int lo = nx_sub_lo, hi = nx_sub_hi;
-            const int r0 = nx_sub_row0 - i0;
-            blk = ((hi > lo) & (r0 >= 0) & (r0 < R)) ? (1u << r0) : 0u;
-            if (__builtin_amdgcn_ballot_w64(hi - lo > 1)) {
-                for (int p = lo + 1; p < hi; p++) {
-                    const int r = sub_rows[p] - i0;
-                    blk |= (r >= 0 && r < R) ? (1u << r) : 0u;
+            const int lo2 = nx_sub_lo2;
+            const unsigned r0 = (unsigned)(nx_sub_row0 - i0);          // SUB_NONE - i0 is far outside [0, R)
+            blk = r0 < (unsigned)R ? (1u << r0) : 0u;
+            if (__builtin_amdgcn_ballot_w64((lo2 & 1) != 0)) {
+                if (lo2 & 1) {
+                    const int jc = j < 0 ? 0 : (j > T ? T : j);
+                    const int hi = sub_cp[2 * (jc + 1) + 1] >> 1;      // the next column's first row
+                    for (int p = (lo2 >> 1) + 1; p < hi; p++) {
+                        const unsigned r = (unsigned)(sub_rows[p] - i0);
+                        blk |= r < (unsigned)R ? (1u << r) : 0u;
+                    }
                 }
             }
         }
@@ -754,7 +754,7 @@ struct WaveDP {
                 seed_aux = (cis >= 1 && cis - 1 <= tlast) ? (tn4p[cis - 1] & 0xff) : 0;
             }
         }
-        if constexpr (SUB) { sub_cp = seqs.sub_colptr + job.sub_off; sub_rows = seqs.sub_rows; }
+        if constexpr (SUB) { sub_cp = seqs.sub_colptr + 2 * job.sub_off; sub_rows = seqs.sub_rows; }
         if constexpr (SPAN == 1) span_in_p = seqs.span_in + job.span_off;
         if constexpr (SPAN == 2) span_out_p = seqs.span_out + job.span_off;
         first_state = job.first_state; final_state = CONT ? job.final_state : M::END;
@@ -815,7 +815,6 @@ struct WaveDP {
                                 job.cp_count);
                 });
             };
-            if constexpr (SUB) sub_load_ptrs(0 - lane, nx2_sub_lo, nx2_sub_hi);
             prefetch_column(0 - lane);
             prefetch_carry(0, bnd_in);
             int s = 0;
@@ -849,7 +848,7 @@ struct WaveDP {
                 seed_aux = (cis >= 1 && cis - 1 <= tlast) ? (tn4p[cis - 1] & 0xff) : 0;
             }
         }
-        if constexpr (SUB) { sub_cp = seqs.sub_colptr + job.sub_off; sub_rows = seqs.sub_rows; }
+        if constexpr (SUB) { sub_cp = seqs.sub_colptr + 2 * job.sub_off; sub_rows = seqs.sub_rows; }
         first_state = job.first_state; final_state = M::END;
         first_cell = job.first_cell;
         min_intron = kp->min_intron; max_intron = kp->max_intron;
@@ -910,8 +909,7 @@ struct WaveDP {
             if (idle) {
                 for (int k = 0; k < nchunks; k++) __syncthreads();
             } else {
-                if constexpr (SUB) sub_load_ptrs(0 - lane, nx2_sub_lo, nx2_sub_hi);
-                prefetch_column(0 - lane);
+                    prefetch_column(0 - lane);
                 prefetch_carry(0, bnd_in);
                 int k = 0;
                 for (; k < nchunks && k * CH < main_lo; k++) {
