@@ -356,7 +356,7 @@ struct WaveDP {
                     const int cis = sc[1];
                     const int cq = cis < 1 ? 0 : (cis - 1 > tlast ? tlast : cis - 1);
                     const int b = tn4p[cq] & 0xff;
-                    start_cell.ex[M::START][AUX] = (cis >= 1) & (cis - 1 <= tlast) ? b : 0;
+                    start_cell.ex[M::START][AUX] = ((cis >= 1) & (cis - 1 <= tlast)) ? b : 0;
                 }
             }
             const C &src = (SPAN == 1 && t.in == M::START && !CONT) ? start_cell : cell_src;
