@@ -57,6 +57,11 @@ def test_reference_known_answer_tests_on_gpu(eng):
         assert eng.find_score(_model(name), [(rec["query"], rec["target"])]) == [score]
     rec = [r for r in load_set("est2genome") if r["id"] == "kat_est2genome"][0]
     assert eng.find_score(_model("est2genome"), [(rec["query"], rec["target"])]) == [157]
+    # src/model/protein2dna.test.c:34 and protein2genome.test.c:34
+    for name, rid, score in (("protein2dna", "kat_protein2dna", 134), ("protein2genome", "kat_protein2genome", 125)):
+        rec = [r for r in load_set(name) if r["id"] == rid][0]
+        assert eng.find_score(_model(name), [(rec["query"], rec["target"])]) == [score]
+        assert eng.find_path(_model(name), [(rec["query"], rec["target"])])[0].as_dict(rid) == expected(rec)
     rec = [r for r in load_set("affine_local_protein") if r["id"] == "kat_affine"][0]
     aln = eng.find_path(_model("affine_local_protein"), [(rec["query"], rec["target"])])[0]
     assert aln.vulgar("kat_affine").endswith("32 M 8 8 G 1 0 M 4 4") and aln.region == (11, 33, 13, 12)

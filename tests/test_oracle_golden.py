@@ -74,7 +74,8 @@ def test_oracle_span_seam_matches_reference(lib, params, name, mtype, qa, match_
 
 
 def test_reference_known_answer_tests(lib, params):
-    """src/model/affine.test.c:107-110 (-151/18/32/18) and est2genome.test.c:63 (157)."""
+    """src/model/affine.test.c:107-110 (-151/18/32/18), est2genome.test.c:63 (157), protein2dna.test.c:34 (134),
+    protein2genome.test.c:34 (125)."""
     kat = {"affine_global_protein": -151, "affine_bestfit_protein": 18, "affine_local_protein": 32,
            "affine_overlap_protein": 18}
     for name, score in kat.items():
@@ -84,6 +85,11 @@ def test_reference_known_answer_tests(lib, params):
         assert oracle_lib.find_score(model, params, rec["query"].encode(), rec["target"].encode()) == score
     rec = [r for r in load_set("est2genome") if r["id"] == "kat_est2genome"][0]
     assert rec["score"] == 157
+    for name, rid, score in (("protein2dna", "kat_protein2dna", 134), ("protein2genome", "kat_protein2genome", 125)):
+        rec = [r for r in load_set(name) if r["id"] == rid][0]
+        assert rec["score"] == score == rec["path_score"]
+        model = get_model(lib, params, name)
+        assert oracle_lib.find_score(model, params, rec["query"].encode(), rec["target"].encode()) == score
     # vulgar printed by affine.test.c for the local model
     rec = [r for r in load_set("affine_local_protein") if r["id"] == "kat_affine"][0]
     assert rec["vulgar"].endswith("32 M 8 8 G 1 0 M 4 4") and rec["region"] == [11, 33, 13, 12]

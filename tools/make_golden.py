@@ -5,7 +5,8 @@ writes are small, committed, and are what pins the oracle (oracle/c4_oracle.c) a
 
 Inputs are seeded synthetic sequences (generator below, no reference code) plus the hard-coded inputs of
 the reference's own model known-answer tests (src/model/affine.test.c:33-38, est2genome.test.c:24-37,
-protein2dna.test.c) so those KAT scores (-151/18/32/18, 157, 134) are part of the vectors.
+protein2dna.test.c:58-70, protein2genome.test.c:62-75) so those KAT scores (-151/18/32/18, 157, 134, 125) are
+part of the vectors (records kat_affine, kat_est2genome, kat_protein2dna, kat_protein2genome).
 """
 import json, os, random, subprocess, sys, tempfile
 
@@ -148,6 +149,15 @@ KAT_E2G = ("kat_est2genome", "CGATCGATCGNATCGATCGATC" "CATCTATCTAGCGAGCGATCTA",
            "CGATCGATCGATCGATCGATC" "GT" + "N" * 20 + "N" * 47 * 3 + "N" * 27 + "AG" + "CATCTATCTANNNGCGAGCGATCTA")
 
 
+# src/model/protein2dna.test.c:58-70 (score 134) and protein2genome.test.c:62-75 (score 125): inputs only
+KAT_P2D = ("kat_protein2dna", "NNNNNNMADQLTEQIAEFKEAFSLFDKDG" "TVHNC" "X" "WYFSGRW" "DGTITT",
+           "ATGGCTGACCAGCTGACTGAGGAGCAGATT" "GCAGAGTTCNAAGGAGGCCTTCTCCCTCTTT" "GACAAGGATGGA"
+           "NNACTGTCCATAATTGC" "TGGTACTTCAGCGGTCGATGG" "GATGGCACTCTGACCACC")
+KAT_P2G = ("kat_protein2genome", "MADQLTEQIAEFKEAFSLFDKDGDGTITT",
+           "ATGGCTGACCAGCTGACTGAGCAGATT" "GCAGAGTTCAA" "GT" + "N" * 42 + "AG" + "GGAGGCCTTCTCCCTCTTT"
+           "GACAAGGATGGAGATGGCACTATTACCACC")
+
+
 def repeat_pairs(rng, n, kind):
     """Targets holding several diverged copies of the query: successive sub-optimal alignments
     (GAM_Result_exhaustive_create's loop) each find the next copy, or a second path through the same one."""
@@ -219,8 +229,8 @@ def main():
     dna = dna_pairs(rng, 30)
     prot = protein_pairs(rng, 18) + [KAT_AFFINE]
     est = est_pairs(rng, 28) + [KAT_E2G]
-    p2d = p2d_pairs(rng, 24)
-    p2g = p2g_pairs(random.Random(99), 26)
+    p2d = p2d_pairs(rng, 24) + [KAT_P2D]
+    p2g = p2g_pairs(random.Random(99), 26) + [KAT_P2G]
     for scope in ("local", "global", "bestfit", "overlap"):
         # empty sequences are rejected by the reference's Sequence_create for non-local global DP
         d = [c for c in dna if len(c[1]) > 0 and len(c[2]) > 0]
