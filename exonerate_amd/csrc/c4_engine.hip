@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -416,6 +417,11 @@ struct Engine {
     const c4gpu_model *model;
     int family;
     bool local;
+    // The local-scope score / region kernels drop the row-0 validity mask (c4_viterbi_kernel.h, eval_cell):
+    // a phantom candidate there is -987654321 plus one or two calc values and must stay far below every
+    // candidate the reference has.  True while the calc magnitudes are small against 987654321; checked
+    // here, and parameters outside that range get the general kernels (all masks kept) instead.
+    bool local_exact = true;
     DevBuf<KParams> kparams;
     // reusable device buffers
     DevBuf<DevJob> d_jobs;
@@ -461,6 +467,28 @@ struct Engine {
         for (int i = 0; i < m->n_calcs; i++)
             if (m->calcs[i].kind == C4GPU_CALC_MATCH_PROTEIN || m->calcs[i].kind == C4GPU_CALC_MATCH_P2D) protein = true;
         memcpy(kp.submat, protein ? &params->protein_submat[0][0] : &params->dna_submat[0][0], sizeof kp.submat);
+        {
+            // largest magnitude one calc can contribute (the -987654321 sentinel of --forcegtag aside: it is
+            // the same number in the reference)
+            double pmax = 0;
+            for (int i = 0; i < m->n_calcs; i++) pmax = std::max(pmax, std::fabs((double)m->calcs[i].value));
+            for (int i = 0; i < 24 * 24; i++) pmax = std::max(pmax, std::fabs((double)kp.submat[i]));
+            double smax = 0;
+            if (family_has_splice(family))
+                for (int k = 0; k < 4; k++) {
+                    const c4gpu_splice_model &sp = params->splice[k];
+                    double sum = 0;
+                    for (int r = 0; r < sp.model_length && r < C4GPU_SPLICE_MAX_LEN; r++) {
+                        double mx = 0;
+                        for (int c = 0; c < 5; c++) mx = std::max(mx, std::fabs((double)sp.data[r][c]));
+                        sum += mx;
+                    }
+                    smax = std::max(smax, sum + 1.0);
+                }
+            // a real candidate is at least -(states x largest calc); a phantom one at most LOW + 3 calcs
+            local_exact = (pmax + smax) * (m->n_states + 4) < 4.0e8;
+            if (getenv("C4GPU_LOCAL_EXACT") && atoi(getenv("C4GPU_LOCAL_EXACT")) == 0) local_exact = false;   // test hook
+        }
         for (int c = 0; c < 4096; c++) {
             const uint8_t row = params->submat_index[params->aa[params->trans[c]]];
             kp.codon_row[c] = row < 24 ? row : 0;        // '-' (empty mask) never scores: such columns are rejected at upload
@@ -523,10 +551,12 @@ struct Engine {
         const int n = (int)specs.size();
         out.assign(n, JobOut());
         if (!n) return 0;
-        const bool use_local = local && !cont && (mode == MODE_SCORE || mode == MODE_REGION);
+        const bool use_local = local && local_exact && !cont && (mode == MODE_SCORE || mode == MODE_REGION);
         // packed region-start slot: (query_start << tshift) | target_start must fit 31 bits for every job
         auto nbits = [](int v) { int b = 0; while ((1LL << b) <= v) b++; return b; };
-        bool pack = (mode == MODE_REGION);
+        // C4GPU_PACK=0 forces the two-slot form (what targets beyond 2^31 / query-rows columns get): read on
+        // every call so that a test can switch it
+        bool pack = (mode == MODE_REGION) && !(getenv("C4GPU_PACK") && atoi(getenv("C4GPU_PACK")) == 0);
         for (int i = 0; i < n && pack; i++)
             pack = nbits(specs[i].region.query_length) + nbits(specs[i].region.target_length) <= 31;
         static const int wpe_env = getenv("C4GPU_WPE") ? atoi(getenv("C4GPU_WPE")) : 0;

@@ -21,7 +21,23 @@ SETS = {
     "protein2genome_bestfit_D0": ("protein2genome:bestfit", 1, 0),
     "est2genome_forcegtag": ("est2genome", 0, 0), "est2genome_forcegtag_D0": ("est2genome", 0, 0),
     "protein2genome_forcegtag": ("protein2genome", 1, 0),
+    # non-default penalties / intron window / matrices (tools/make_golden.py:ALT_FLAGS, parsed by the reference)
+    "affine_local_dna_altparams": ("affine:local", 0, 0), "affine_local_dna_altparams_D0": ("affine:local", 0, 0),
+    "affine_global_protein_altparams": ("affine:global", 1, 1),
+    "est2genome_altparams": ("est2genome", 0, 0), "est2genome_altparams_D0": ("est2genome", 0, 0),
+    "protein2dna_altparams": ("protein2dna", 1, 0), "protein2dna_altparams_D0": ("protein2dna", 1, 0),
+    "protein2genome_altparams": ("protein2genome", 1, 0), "protein2genome_altparams_D0": ("protein2genome", 1, 0),
 }
+
+
+for _tag, _bases in (("hugegap", ("affine_local_dna", "est2genome", "protein2dna", "protein2genome")),
+                     ("hugeintron", ("est2genome", "protein2dna", "protein2genome")),
+                     ("tightintron", ("est2genome", "protein2genome")),
+                     ("invertedintron", ("est2genome", "protein2genome")),
+                     ("posgap", ("affine_local_dna", "est2genome", "protein2dna", "protein2genome"))):
+    for _b in _bases:
+        SETS["%s_%s" % (_b, _tag)] = SETS[_b]
+        SETS["%s_%s_D0" % (_b, _tag)] = SETS[_b]
 
 
 # sets with the GAM sub-optimal loop (rec["subopt"] = successive alignments, rec["threshold"])
@@ -31,6 +47,7 @@ SUBOPT_SETS = {
     "est2genome_subopt": ("est2genome", 0, 0), "est2genome_subopt_D0": ("est2genome", 0, 0),
     "protein2dna_subopt": ("protein2dna", 1, 0), "protein2dna_subopt_D0": ("protein2dna", 1, 0),
     "protein2genome_subopt": ("protein2genome", 1, 0), "protein2genome_subopt_D0": ("protein2genome", 1, 0),
+    "est2genome_altparams_subopt": ("est2genome", 0, 0),
 }
 
 
@@ -50,12 +67,56 @@ def load_set(name):
         return [json.loads(l) for l in f if l.strip()]
 
 
+# Scoring-parameter variants of the vector sets: the reference's own command-line flags (parsed by its
+# ArgumentSets in refdump: affine.c:24-49, intron.c:24-32, frameshift.c, match.c) that tools/make_golden.py passes
+# when it generates "<set>_<tag>" — and that the tests turn into a c4gpu_params here.  The two non-default
+# matrices travel as data in scoring_data_alt.json (dumped by refdump --cmd data).
+PARAM_VARIANTS = {
+    "altparams": ["--gapopen", "-7", "--gapextend", "-2", "--codongapopen", "-11", "--codongapextend", "-3",
+                  "--intronpenalty", "-14", "--minintron", "36", "--maxintron", "180", "--frameshift", "-13",
+                  "--dnasubmat", "identity", "--proteinsubmat", "pam250"],
+    # magnitudes at which "unset" (-987654321) and real scores are no longer far apart (local models only: a
+    # global model's gap chains would overflow int32 in the reference itself)
+    "hugegap": ["--gapopen", "-350000000", "--gapextend", "-300000000", "--codongapopen", "-350000000",
+                "--codongapextend", "-300000000"],
+    "hugeintron": ["--intronpenalty", "-350000000", "--frameshift", "-300000000"],
+    "tightintron": ["--minintron", "77", "--maxintron", "78", "--intronpenalty", "-1"],
+    "invertedintron": ["--minintron", "500", "--maxintron", "40"],       # every intron is rejected
+    "posgap": ["--gapopen", "3", "--gapextend", "1", "--codongapopen", "4", "--codongapextend", "2",
+               "--frameshift", "2"],                                      # rewards: nonsense the reference accepts
+}
+_FLAG_FIELD = {"--gapopen": "gap_open", "--gapextend": "gap_extend", "--codongapopen": "codon_gap_open",
+               "--codongapextend": "codon_gap_extend", "--intronpenalty": "intron_open_penalty",
+               "--minintron": "min_intron", "--maxintron": "max_intron", "--frameshift": "frameshift_penalty"}
+
+
+def apply_flags(p, flags):
+    for k in range(0, len(flags), 2):
+        flag, val = flags[k], flags[k + 1]
+        if flag in _FLAG_FIELD:
+            setattr(p, _FLAG_FIELD[flag], int(val))
+        elif flag in ("--dnasubmat", "--proteinsubmat"):
+            with open(os.path.join(GOLDEN_DIR, "scoring_data_alt.json")) as f:
+                mat = json.load(f)[flag[2:] + ":" + val]
+            dst = p.dna_submat if flag == "--dnasubmat" else p.protein_submat
+            for i in range(24):
+                for j in range(24):
+                    dst[i][j] = mat[i][j]
+        else:
+            raise ValueError(flag)
+    return p
+
+
 def set_params(lib, name):
-    """Parameters a set was generated with (the defaults, or --forcegtag for the *_forcegtag sets)."""
+    """Parameters a set was generated with: the defaults, --forcegtag for the *_forcegtag sets, and the flags of
+    the PARAM_VARIANTS tag in the set's name."""
     p = _abi.Params()
     lib.c4gpu_params_default(p)
     if "forcegtag" in name:
         lib.c4gpu_params_set_forcegtag(p, 1)
+    for tag, flags in PARAM_VARIANTS.items():
+        if ("_" + tag) in name:
+            apply_flags(p, flags)
     return p
 
 

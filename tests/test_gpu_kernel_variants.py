@@ -1,0 +1,201 @@
+"""Kernel variants the default inputs never select, each held to the same bar as the default ones:
+
+* the UNPACKED FIND_REGION kernels (two region-start slots per state; taken when bits(Q) + bits(T) > 31, e.g.
+  300 aa x 10 Mb) — forced with C4GPU_PACK=0 over the reference's vector sets and seeded pairs, one-wave,
+  4-wave and 8-wave forms;
+* the GENERAL score / region kernels (every Layout validity mask kept) that local models fall back to when the
+  scoring parameters are too large for the local-scope shortcuts (Engine::local_exact) — forced with
+  C4GPU_LOCAL_EXACT=0, and reached for real with penalties of hundreds of millions;
+* BASELINE config 5's shape at its real size: proteins against ONE 10 Mb contig (unpacked kernels by
+  necessity), checked through the window property against the oracle.
+"""
+import random
+import pytest
+
+import exonerate_amd as ex
+from exonerate_amd import _abi, workloads
+import oracle_lib
+from golden_util import SETS, SUBOPT_SETS, PARAM_VARIANTS, apply_flags, load_set, expected, set_params
+
+TABLE = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"
+CODON = {}
+for _i, _a in enumerate("TCAG"):
+    for _j, _b in enumerate("TCAG"):
+        for _k, _c in enumerate("TCAG"):
+            CODON.setdefault(TABLE[_i * 16 + _j * 4 + _k], []).append(_a + _b + _c)
+
+pytestmark = pytest.mark.gpu
+
+# sets whose alignments go through the region pass on small inputs (-D 0), plus the larger default-route one
+_EXTREME = ("hugegap", "hugeintron", "tightintron", "invertedintron", "posgap")
+REGION_SETS = sorted(n for n in SETS if n.endswith("_D0") and not any(t in n for t in _EXTREME)) + ["est2genome_big"]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = ex.Engine(0)
+    yield e
+    e.close()
+
+
+def _model(name):
+    mt, qa, ta = SETS[name] if name in SETS else SUBOPT_SETS[name]
+    return ex.Model(mt, qa, ta, params=set_params(_abi.load(), name))
+
+
+def _check_set(eng, name):
+    model = _model(name)
+    recs = load_set(name)
+    pairs = [(r["query"], r["target"]) for r in recs]
+    assert eng.find_score(model, pairs) == [r["score"] for r in recs]
+    alns = eng.find_path(model, pairs, dpmemory=recs[0]["dpmemory"])
+    for rec, aln in zip(recs, alns):
+        if "path_score" not in rec:
+            assert aln is None, rec["id"]
+        else:
+            assert aln is not None and aln.as_dict(rec["id"]) == expected(rec), rec["id"]
+
+
+@pytest.mark.parametrize("name", REGION_SETS)
+def test_unpacked_region_kernels_match_reference_vectors(eng, monkeypatch, name):
+    monkeypatch.setenv("C4GPU_PACK", "0")
+    _check_set(eng, name)
+
+
+@pytest.mark.parametrize("name", sorted(n for n in SETS if ("local" in n or "est2genome" in n or n.startswith("protein2")
+                                                         or n.startswith("ungapped"))
+                                        and not any(t in n for t in _EXTREME if not t.startswith("huge"))))
+def test_general_kernels_match_reference_vectors(eng, monkeypatch, name):
+    """Local models on the kernels that keep every validity mask (what very large penalties select)."""
+    monkeypatch.setenv("C4GPU_LOCAL_EXACT", "0")
+    _check_set(eng, name)
+
+
+@pytest.mark.parametrize("name", ["est2genome_subopt", "est2genome_subopt_D0", "affine_local_dna_subopt_D0",
+                                  "protein2genome_subopt_D0", "est2genome_altparams_subopt"])
+@pytest.mark.parametrize("switch", ["C4GPU_PACK", "C4GPU_LOCAL_EXACT"])
+def test_blocking_kernels_of_both_variants(eng, monkeypatch, name, switch):
+    """The sub-optimal loop (blocked MATCH cells) through the unpacked / general kernels."""
+    monkeypatch.setenv(switch, "0")
+    model = _model(name)
+    recs = load_set(name)
+    found = eng.find_all_paths(model, [(r["query"], r["target"]) for r in recs], dpmemory=recs[0]["dpmemory"],
+                               threshold=recs[0]["threshold"], max_paths=6)
+    for rec, alns in zip(recs, found):
+        assert [(a.score, list(a.region), [list(o) for o in a.ops], a.vulgar(rec["id"])) for a in alns] == \
+               [(e["path_score"], e["region"], e["ops"], e["vulgar"]) for e in rec["subopt"]], rec["id"]
+
+
+def _rand(rng, n, alpha="ACGT"):
+    return "".join(rng.choice(alpha) for _ in range(n))
+
+
+def _mutate(rng, s, rate, alpha="ACGT"):
+    out = []
+    for ch in s:
+        r = rng.random()
+        if r < rate / 3:
+            out.append(rng.choice(alpha))
+        elif r < 2 * rate / 3:
+            out.append(ch + rng.choice(alpha))
+        elif r >= rate:
+            out.append(ch)
+    return "".join(out)
+
+
+def _seeded_pairs(rng, model_type, qlen, tlen, n):
+    pairs = []
+    for k in range(n):
+        q = _rand(rng, qlen + 3 * k)
+        if model_type == "est2genome":
+            c = qlen // 3
+            t = (_rand(rng, 120) + _mutate(rng, q[:c], 0.03) + "GT" + _rand(rng, tlen // 3) + "AG" +
+                 _mutate(rng, q[c:], 0.03) + _rand(rng, 200))
+        else:
+            t = _rand(rng, 50) + _mutate(rng, q, 0.08) + _rand(rng, max(0, tlen - qlen))
+        pairs.append((q, t))
+    return pairs
+
+
+@pytest.mark.parametrize("switch", ["C4GPU_PACK", "C4GPU_LOCAL_EXACT"])
+@pytest.mark.parametrize("model_type,qlen,tlen,n", [
+    ("est2genome", 300, 3000, 5),       # one strip: one-wave kernels
+    ("est2genome", 1300, 5000, 2),      # > 1 024 rows: cooperating waves + HBM carry rows between super-strips
+    ("affine:local", 900, 1100, 6),     # several strips, many jobs: 4 cooperating waves per job
+    ("affine:local", 2100, 2300, 2),
+])
+def test_seeded_pairs_on_unpacked_and_general_kernels(eng, monkeypatch, switch, model_type, qlen, tlen, n):
+    monkeypatch.setenv(switch, "0")
+    rng = random.Random(qlen * 7 + len(switch))
+    model = ex.Model(model_type)
+    pairs = _seeded_pairs(rng, model_type, qlen, tlen, n)
+    scores = eng.find_score(model, pairs)
+    alns = eng.find_path(model, pairs, dpmemory=1)
+    for (q, t), s_, a in zip(pairs, scores, alns):
+        assert s_ == oracle_lib.find_score(model.c, model.params, q.encode(), t.encode())
+        assert a.as_dict() == oracle_lib.find_path(model.c, model.params, q.encode(), t.encode(), dpmemory=1)
+
+
+@pytest.mark.parametrize("kind", ["hugegap", "hugeintron", "tightintron", "invertedintron", "posgap"])
+@pytest.mark.parametrize("model_type", ["affine:local", "est2genome", "protein2dna", "protein2genome"])
+def test_extreme_parameters_match_oracle(eng, model_type, kind):
+    """User-settable penalties at magnitudes where "unset" (-987654321) and real scores are no longer far apart,
+    degenerate intron windows, rewards instead of penalties — on inputs of several strips (the reference's own
+    small vectors with these flags are part of SETS; the oracle is pinned on them).  The magnitude guard
+    (Engine::local_exact) must route the huge ones to kernels that stay exact."""
+    import zlib
+    rng = random.Random(zlib.crc32(("%s %s" % (model_type, kind)).encode()))
+    params = apply_flags(ex.default_params(), PARAM_VARIANTS[kind])
+    model = ex.Model(model_type, params=params)
+    pairs = []
+    for k in range(4):
+        if model_type.startswith("protein"):
+            aa = "ARNDCQEGHILKMFPSTWYV"
+            q = _rand(rng, rng.choice([20, 90, 150, 320]), aa)
+            coding = "".join(rng.choice(CODON[x]) for x in _mutate(rng, q, 0.06, aa))
+            if "genome" in model_type and len(coding) > 60:
+                c = rng.randint(10, len(coding) - 10)
+                coding = coding[:c] + "GT" + _rand(rng, rng.choice([40, 75, 300])) + "AG" + coding[c:]
+            if k % 2:
+                c = rng.randint(5, len(coding) - 5)
+                coding = coding[:c] + "A" + coding[c:]
+            t = _rand(rng, rng.randint(0, 60)) + coding + _rand(rng, rng.randint(0, 60))
+        else:
+            q = _rand(rng, rng.choice([40, 130, 300, 700]))
+            if model_type == "est2genome":
+                c = len(q) // 2
+                t = _rand(rng, 30) + _mutate(rng, q[:c], 0.04) + "GT" + _rand(rng, rng.choice([40, 74, 400])) + "AG" + \
+                    _mutate(rng, q[c:], 0.04) + _rand(rng, 40)
+            else:
+                t = _rand(rng, rng.randint(0, 30)) + _mutate(rng, q, 0.12) + _rand(rng, rng.randint(0, 30))
+        pairs.append((q, t))
+    scores = eng.find_score(model, pairs)
+    for dpm in (32, 0):
+        alns = eng.find_path(model, pairs, dpmemory=dpm)
+        for (q, t), s_, a in zip(pairs, scores, alns):
+            assert s_ == oracle_lib.find_score(model.c, model.params, q.encode(), t.encode()), (kind, dpm)
+            exp = oracle_lib.find_path(model.c, model.params, q.encode(), t.encode(), dpmemory=dpm)
+            assert (a.as_dict() if a else None) == exp, (kind, dpm)
+
+
+def test_c5_protein2genome_against_a_10mb_contig(eng):
+    """BASELINE config 5's exhaustive shape at full size: proteins vs ONE 10 Mb chromosome.  9 + 24 bits of
+    coordinates do not fit the packed region-start slot: these launches run the unpacked kernels (8 cooperating
+    waves per job for the 16-job launch, 4 for the 272-job one).  Parity through the window property: a local
+    alignment whose path lies inside a window of the contig is the window's alignment shifted by its offset."""
+    proteins, contig, places = workloads.protein_vs_contig(16, 300, 10000000, seed=20260936, introns=True)
+    model = ex.Model("protein2genome")
+    alns = eng.find_path(model, [(p, contig) for p in proteins], dpmemory=32)
+    margin = 1000
+    for p, (g0, g1), a in zip(proteins, places, alns):
+        w0, w1 = max(0, g0 - margin), min(len(contig), g1 + margin)
+        exp = oracle_lib.find_path(model.c, model.params, p, contig[w0:w1], dpmemory=32)
+        assert a is not None and exp is not None
+        assert a.score == exp["score"]
+        assert [list(o) for o in a.ops] == exp["ops"]
+        r = exp["region"]
+        assert list(a.region) == [r[0], r[1] + w0, r[2], r[3]]
+    # the same 16 proteins 17 times over: a launch with more jobs than CUs takes the 4-wave kernels
+    many = eng.find_path(model, [(p, contig) for p in proteins] * 17, dpmemory=32)
+    for k, a in enumerate(many):
+        assert a.as_dict() == alns[k % 16].as_dict(), k

@@ -10,7 +10,7 @@ import pytest
 import exonerate_amd as ex
 from exonerate_amd import _abi
 import oracle_lib
-from golden_util import SETS, SUBOPT_SETS, DERIVED_SETS, SPAN_SETS, load_set, expected
+from golden_util import SETS, SUBOPT_SETS, DERIVED_SETS, SPAN_SETS, load_set, expected, set_params
 
 pytestmark = pytest.mark.gpu
 
@@ -26,11 +26,8 @@ def _model(name):
     if name in DERIVED_SETS:
         mt, qa, ta, (src, dst, ss, es) = DERIVED_SETS[name]
         return ex.Model.derived(mt, src, dst, ss, es, qa, ta)
-    mt, qa, ta = SETS[name]
-    params = ex.default_params()
-    if "forcegtag" in name:
-        _abi.load().c4gpu_params_set_forcegtag(params, 1)
-    return ex.Model(mt, qa, ta, params=params)
+    mt, qa, ta = SETS[name] if name in SETS else SUBOPT_SETS[name]
+    return ex.Model(mt, qa, ta, params=set_params(_abi.load(), name))
 
 
 @pytest.mark.parametrize("name", sorted(SETS) + sorted(DERIVED_SETS))
@@ -179,8 +176,7 @@ def test_raw_viterbi_modes_match_oracle(eng):
 def test_suboptimal_loop_matches_reference_vectors(eng, name):
     """GAM_Result_exhaustive_create's loop with SubOpt blocking on the device (viterbi.c:701-704) against
     the successive alignments the reference itself produced — all pairs of the set in one batch per round."""
-    mt, qa, ta = SUBOPT_SETS[name]
-    model = ex.Model(mt, qa, ta)
+    model = _model(name)
     recs = load_set(name)
     pairs = [(r["query"], r["target"]) for r in recs]
     found = eng.find_all_paths(model, pairs, dpmemory=recs[0]["dpmemory"], threshold=recs[0]["threshold"],

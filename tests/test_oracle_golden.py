@@ -30,6 +30,7 @@ def test_oracle_matches_reference_vectors(lib, params, name):
 def test_oracle_suboptimal_loop_matches_reference(lib, params, name):
     """SubOpt blocking (subopt.c, viterbi.c:701-704): the successive alignments of the GAM loop and the
     blocked point set after each, as the reference produced them."""
+    params = set_params(lib, name)
     model = get_model(lib, params, name)
     for rec in load_set(name):
         q, t = rec["query"].encode(), rec["target"].encode()

@@ -191,6 +191,12 @@ def repeat_pairs(rng, n, kind):
     return cases
 
 
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+from golden_util import PARAM_VARIANTS          # the flag lists live next to the code that mirrors them in the tests
+ALT_FLAGS = PARAM_VARIANTS["altparams"]
+
+
 def run(model, cases, dpmemory, extra=()):
     with tempfile.NamedTemporaryFile("w", suffix=".tsv", delete=False) as f:
         for cid, q, t in cases:
@@ -300,8 +306,43 @@ def main():
     sets.append(("protein2dna_subopt_D0", "protein2dna", sub_p2d, 0, so))
     sets.append(("protein2genome_subopt", "protein2genome", sub_p2g, 32, so))
     sets.append(("protein2genome_subopt_D0", "protein2genome", sub_p2g, 0, so))
+    # non-default scoring parameters, parsed by the reference's own ArgumentSets (affine.c:24-49, intron.c:24-32,
+    # frameshift.c, match.c): penalties, intron length window, pam250 / identity matrices (submat.c:296-307).
+    # The flag lists are tests/golden_util.py:PARAM_VARIANTS; the matrices travel in scoring_data_alt.json.
+    alt = tuple(ALT_FLAGS)
+    sets.append(("affine_local_dna_altparams", "affine:local", d, 32, alt))
+    sets.append(("affine_local_dna_altparams_D0", "affine:local", big, 0, alt))
+    sets.append(("affine_global_protein_altparams", "affine:global:protein", [c for c in prot if len(c[2]) > 0], 32, alt))
+    sets.append(("est2genome_altparams", "est2genome", est, 32, alt + ("--withsplice", "yes")))
+    sets.append(("est2genome_altparams_D0", "est2genome", est, 0, alt))
+    sets.append(("protein2dna_altparams", "protein2dna", [c for c in p2d if len(c[2]) > 0], 32, alt))
+    sets.append(("protein2dna_altparams_D0", "protein2dna", [c for c in p2d if len(c[2]) > 30], 0, alt))
+    sets.append(("protein2genome_altparams", "protein2genome", p2g, 32, alt))
+    sets.append(("protein2genome_altparams_D0", "protein2genome", p2g, 0, alt))
+    sets.append(("est2genome_altparams_subopt", "est2genome", sub_est, 32, alt + so))
+    # extreme magnitudes / degenerate windows on the local-scope models (12 cases each, both routes)
+    base_cases = {"affine_local_dna": ("affine:local", d[:14]), "est2genome": ("est2genome", est[:12] + [KAT_E2G]),
+                  "protein2dna": ("protein2dna", [c for c in p2d if len(c[2]) > 30][:12]),
+                  "protein2genome": ("protein2genome", p2g[:12] + [KAT_P2G])}
+    for tag, bases in (("hugegap", ("affine_local_dna", "est2genome", "protein2dna", "protein2genome")),
+                       ("hugeintron", ("est2genome", "protein2dna", "protein2genome")),
+                       ("tightintron", ("est2genome", "protein2genome")),
+                       ("invertedintron", ("est2genome", "protein2genome")),
+                       ("posgap", ("affine_local_dna", "est2genome", "protein2dna", "protein2genome"))):
+        for b in bases:
+            model, cases = base_cases[b]
+            sets.append(("%s_%s" % (b, tag), model, cases, 32, tuple(PARAM_VARIANTS[tag])))
+            sets.append(("%s_%s_D0" % (b, tag), model, [c for c in cases if len(c[1]) >= 13 and len(c[2]) >= 13], 0,
+                         tuple(PARAM_VARIANTS[tag])))
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])
+    if not only or "scoring_data_alt" in only:
+        out = subprocess.run([REFDUMP, "--cmd", "data"] + ALT_FLAGS, stdout=subprocess.PIPE, check=True).stdout.decode()
+        dd = json.loads(out)
+        # dump_data prints whatever matrices are loaded under fixed key names
+        keep = {"dnasubmat:identity": dd["nucleic"], "proteinsubmat:pam250": dd["blosum62"]}
+        with open(os.path.join(OUT, "scoring_data_alt.json"), "w") as f:
+            json.dump(keep, f, separators=(",", ":"))
     # span models (BSDP): src DP reporting END cells, dst DP starting from them (refdump --cmd span)
     sr = random.Random(909)
     span_cases = []
