@@ -165,6 +165,40 @@ def _pairs(pairs):
     return arr, keep
 
 
+def _viterbi_jobs(jobs):
+    cj = (_abi.ViterbiJob * max(1, len(jobs)))()
+    for i, j in enumerate(jobs):
+        cj[i].pair = j["pair"]
+        cj[i].region = _abi.Region(*j["region"])
+        cont = j.get("continuation")
+        cj[i].use_continuation = 1 if cont else 0
+        if cont:
+            cj[i].continuation.first_state = cont["first_state"]
+            cj[i].continuation.final_state = cont["final_state"]
+            for l, v in enumerate(cont.get("first_cell", [])):
+                cj[i].continuation.first_cell[l] = v
+        cj[i].checkpoint_count = j.get("checkpoints", 0)
+        cj[i].subopt = j["subopt"].h if j.get("subopt") is not None else None
+        # span models: ctypes int32 arrays over the region, [(i * (T+1)) + j][1 + designations]
+        if j.get("start_cells") is not None:
+            cj[i].start_cells = C.cast(j["start_cells"], C.POINTER(C.c_int32))
+        if j.get("end_cells") is not None:
+            cj[i].end_cells = C.cast(j["end_cells"], C.POINTER(C.c_int32))
+    return cj
+
+
+def _viterbi_results(res, n):
+    out = []
+    for i in range(n):
+        r = res[i]
+        out.append({"score": r.score, "query_start": r.query_start, "target_start": r.target_start,
+                    "query_end": r.query_end, "target_end": r.target_end,
+                    "final_cell": list(r.final_cell), "last_srp": r.last_srp,
+                    "ops": [r.ops[k] for k in range(r.n_ops)]})
+        _lib().c4gpu_viterbi_result_clear(r)
+    return out
+
+
 class Engine:
     """One HIP device (c4gpu_ctx).  Raises when there is no gfx950 GPU: nothing here runs on the CPU."""
 
@@ -254,37 +288,12 @@ class Engine:
         """Raw Viterbi_DP_Func level: jobs = list of dict(pair, region, continuation=None, checkpoints=0,
         subopt=None)."""
         arr, keep = _pairs(pairs)
-        cj = (_abi.ViterbiJob * max(1, len(jobs)))()
-        for i, j in enumerate(jobs):
-            cj[i].pair = j["pair"]
-            cj[i].region = _abi.Region(*j["region"])
-            cont = j.get("continuation")
-            cj[i].use_continuation = 1 if cont else 0
-            if cont:
-                cj[i].continuation.first_state = cont["first_state"]
-                cj[i].continuation.final_state = cont["final_state"]
-                for l, v in enumerate(cont.get("first_cell", [])):
-                    cj[i].continuation.first_cell[l] = v
-            cj[i].checkpoint_count = j.get("checkpoints", 0)
-            cj[i].subopt = j["subopt"].h if j.get("subopt") is not None else None
-            # span models: ctypes int32 arrays over the region, [(i * (T+1)) + j][1 + designations]
-            if j.get("start_cells") is not None:
-                cj[i].start_cells = C.cast(j["start_cells"], C.POINTER(C.c_int32))
-            if j.get("end_cells") is not None:
-                cj[i].end_cells = C.cast(j["end_cells"], C.POINTER(C.c_int32))
+        cj = _viterbi_jobs(jobs)
         res = (_abi.ViterbiResult * max(1, len(jobs)))()
         if _lib().c4gpu_viterbi_batch(self.ctx, model.c, model.params, mode, arr, len(pairs), cj, len(jobs),
                                       res) != 0:
             raise _err("c4gpu_viterbi_batch")
-        out = []
-        for i in range(len(jobs)):
-            r = res[i]
-            out.append({"score": r.score, "query_start": r.query_start, "target_start": r.target_start,
-                        "query_end": r.query_end, "target_end": r.target_end,
-                        "final_cell": list(r.final_cell), "last_srp": r.last_srp,
-                        "ops": [r.ops[k] for k in range(r.n_ops)]})
-            _lib().c4gpu_viterbi_result_clear(r)
-        return out
+        return _viterbi_results(res, len(jobs))
 
     def splice_predict(self, params, target):
         t = target if isinstance(target, bytes) else target.encode()
@@ -335,6 +344,19 @@ class ResidentBatch:
         out = Alignment(self.model, a, len(self._keep[i][0]), len(self._keep[i][1])) if a.valid else None
         _lib().c4gpu_alignment_clear(a)
         return out
+
+    def viterbi(self, mode, jobs, model=None):
+        """Viterbi_DP_Func-level jobs on the resident pairs; `model` = another model of the same family (BSDP's
+        derived terminal / join / span models) that shares the batch's sequence arrays."""
+        cj = _viterbi_jobs(jobs)
+        res = (_abi.ViterbiResult * max(1, len(jobs)))()
+        if model is None:
+            rc = _lib().c4gpu_batch_viterbi(self.h, mode, cj, len(jobs), res)
+        else:
+            rc = _lib().c4gpu_batch_viterbi_model(self.h, model.c, mode, cj, len(jobs), res)
+        if rc != 0:
+            raise _err("c4gpu_batch_viterbi")
+        return _viterbi_results(res, len(jobs))
 
     def kernel_stats(self, mode, reset=False):
         ms, n, cells = C.c_double(), C.c_int64(), C.c_int64()

@@ -14,6 +14,7 @@
 #include <numeric>
 #include <string>
 #include <map>
+#include <memory>
 #include <vector>
 
 #include "c4gpu.h"
@@ -1149,6 +1150,10 @@ struct c4gpu_batch {
     std::vector<c4gpu_subopt *> subopts;
     std::vector<uint8_t> in_loop;
     std::vector<c4gpu_score> pair_thresholds;        // c4gpu_batch_set_thresholds; empty = none
+    // engines of further models run on the same resident sequences (c4gpu_batch_viterbi_model): BSDP's derived
+    // terminal / join / span models of the batch's model, keyed by the flattened model's bytes
+    struct ExtraEngine { c4gpu_model model; Engine eng; };
+    std::map<std::string, std::unique_ptr<ExtraEngine>> extra;
     void clear_loop() {
         for (c4gpu_subopt *so : subopts) c4gpu_subopt_destroy(so);
         subopts.clear(); in_loop.clear();
@@ -1283,6 +1288,27 @@ int c4gpu_batch_viterbi(c4gpu_batch *b, int mode, const c4gpu_viterbi_job *jobs,
                         c4gpu_viterbi_result *results) {
     if (hipSetDevice(b->ctx->device) != hipSuccess) return -1;
     return viterbi_jobs(b->eng, b->seqs, mode, jobs, n_jobs, results);
+}
+
+int c4gpu_batch_viterbi_model(c4gpu_batch *b, const c4gpu_model *model, int mode, const c4gpu_viterbi_job *jobs,
+                              int32_t n_jobs, c4gpu_viterbi_result *results) {
+    if (hipSetDevice(b->ctx->device) != hipSuccess) return -1;
+    const std::string key(reinterpret_cast<const char *>(model), sizeof(c4gpu_model));
+    auto it = b->extra.find(key);
+    if (it == b->extra.end()) {
+        std::unique_ptr<c4gpu_batch::ExtraEngine> e(new c4gpu_batch::ExtraEngine);
+        e->model = *model;
+        if (e->eng.init(b->ctx, &e->model, &b->params)) return -1;
+        // the resident arrays were prepared for the batch's own model: the other model must read the same ones
+        if (family_is_p2d(e->eng.family) != family_is_p2d(b->eng.family) ||
+            (family_has_splice(e->eng.family) && !family_has_splice(b->eng.family)) ||
+            (family_has_phase(e->eng.family) && !family_has_phase(b->eng.family))) {
+            c4h::set_error(std::string("model [") + model->name + "] needs sequence arrays this batch was not built with");
+            return -1;
+        }
+        it = b->extra.emplace(key, std::move(e)).first;
+    }
+    return viterbi_jobs(it->second->eng, b->seqs, mode, jobs, n_jobs, results);
 }
 
 void c4gpu_viterbi_result_clear(c4gpu_viterbi_result *r) {

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define C4GPU_ABI_VERSION 2
+#define C4GPU_ABI_VERSION 3
 
 /* src/c4/c4.h:28-30 */
 typedef int32_t c4gpu_score;
@@ -307,6 +307,12 @@ int          c4gpu_batch_set_thresholds(c4gpu_batch *b, const c4gpu_score *per_p
  * many Viterbi_DP_Func calls on the same pair uses to upload it once. */
 int          c4gpu_batch_viterbi(c4gpu_batch *b, int mode, const c4gpu_viterbi_job *jobs, int32_t n_jobs,
                                  c4gpu_viterbi_result *results);
+/* The same for ANOTHER model on the batch's resident pairs: BSDP's derived models (terminal, join, span src / dst;
+ * heuristic.c:242-330,461-472) of the batch's model all read the residue codes and splice arrays the batch already
+ * holds, and a heuristic run asks for all of them on every pair (sar.c:393,697,898).  The model's engine is set up on
+ * first use and kept with the batch.  Fails when `model` needs arrays the batch's own model does not. */
+int          c4gpu_batch_viterbi_model(c4gpu_batch *b, const c4gpu_model *model, int mode,
+                                       const c4gpu_viterbi_job *jobs, int32_t n_jobs, c4gpu_viterbi_result *results);
 /* The sub-optimal loop on the resident batch: after c4gpu_batch_run(b, 2, ...), each call blocks the
  * alignments found so far (SubOpt_add_alignment, gam.c:673) and finds the next best path of every pair
  * that still had one in the previous round; pairs whose score drops below `threshold` leave the loop.

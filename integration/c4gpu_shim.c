@@ -25,6 +25,7 @@
 #include "codegen.h"
 
 #include "c4gpu.h"
+#include "c4gpu_shim.h"
 
 extern gpointer Bootstrapper_lookup_cpu(gchar *name);
 
@@ -55,7 +56,7 @@ Codegen_ArgumentSet *Codegen_ArgumentSet_create(Argument *arg){
     return cas;
     }
 
-static c4gpu_ctx *shim_get_ctx(void){
+c4gpu_ctx *shim_get_ctx(void){
     if(!shim_tried){
         shim_tried = TRUE;
         shim_verbose = (g_getenv("C4GPU_VERBOSE") != NULL);
@@ -73,7 +74,7 @@ static c4gpu_ctx *shim_get_ctx(void){
 
 /* ---- C4_Model (closed) -> c4gpu_model ------------------------------------------------------------- */
 
-static gboolean shim_flatten(C4_Model *m, Ungapped_Data *ud, c4gpu_model *out){
+gboolean shim_flatten_any(C4_Model *m, Ungapped_Data *ud, c4gpu_model *out, gboolean allow_span){
     register guint i, j;
     memset(out, 0, sizeof(*out));
     if((m->state_list->len > C4GPU_MAX_STATES) || (m->transition_list->len > C4GPU_MAX_TRANSITIONS)
@@ -93,8 +94,8 @@ static gboolean shim_flatten(C4_Model *m, Ungapped_Data *ud, c4gpu_model *out){
     out->total_shadow_designations = m->total_shadow_designations;
     out->query_alphabet = (ud->query->alphabet->type == Alphabet_Type_PROTEIN);
     out->target_alphabet = (ud->target->alphabet->type == Alphabet_Type_PROTEIN);
-    if(m->start_state->cell_start_func || m->end_state->cell_end_func)
-        return FALSE;                                /* BSDP span models: not accelerated */
+    if((m->start_state->cell_start_func || m->end_state->cell_end_func) && !allow_span)
+        return FALSE;                                /* BSDP span models: only with their matrices (c4gpu_bsdp.c) */
     for(i = 0; i < m->state_list->len; i++){
         C4_State *s = m->state_list->pdata[i];
         g_strlcpy(out->state_names[i], s->name, C4GPU_NAME_LEN);
@@ -163,8 +164,12 @@ static gboolean shim_flatten(C4_Model *m, Ungapped_Data *ud, c4gpu_model *out){
     return c4gpu_model_is_accelerated(out);
     }
 
+static gboolean shim_flatten(C4_Model *m, Ungapped_Data *ud, c4gpu_model *out){
+    return shim_flatten_any(m, ud, out, FALSE);
+    }
+
 /* the static ArgumentSets + Match tables -> c4gpu_params */
-static void shim_params(Ungapped_Data *ud, c4gpu_params *p){
+void shim_params(Ungapped_Data *ud, c4gpu_params *p){
     register Affine_ArgumentSet *aas = Affine_ArgumentSet_create(NULL);
     register Intron_ArgumentSet *ias = Intron_ArgumentSet_create(NULL);
     register Frameshift_ArgumentSet *fas = Frameshift_ArgumentSet_create(NULL);
@@ -261,29 +266,41 @@ static C4_Score shim_dp(C4_Model *model, Region *region, Viterbi_Data *vd, SubOp
         job.subopt = blocked;
         }
     /* The reference makes many Viterbi calls on one pair (region, checkpoints, every sub-alignment): the
-     * pair stays resident on the device between them.  Identity = content (a freed Sequence's address may
-     * be reused), the model by name and, for calls without a continuation, its scopes. */
+     * pair stays resident on the device between them.  Identity = content: the residues (a freed Sequence's
+     * address may be reused), the whole flattened model (tables, calc values, scopes -- derived models share long
+     * name prefixes) and the scoring parameters in force. */
     {
         static c4gpu_batch *resident = NULL;
         static guint64 resident_key = 0;
-        static gchar resident_model[C4GPU_NAME_LEN];
+        static gboolean resident_failed = FALSE;     /* creation failed for resident_key: do not retry per call */
         static gint resident_scope[2];
         register guint64 key = 1469598103934665603ULL;
         register const guchar *c;
+        register gsize n;
         for(c = (const guchar*)qstr; *c; c++) key = (key ^ *c) * 1099511628211ULL;
         key = (key ^ 0xff) * 1099511628211ULL;
         for(c = (const guchar*)tstr; *c; c++) key = (key ^ *c) * 1099511628211ULL;
         key ^= ((guint64)ud->query->len << 32) ^ (guint64)ud->target->len;
-        if((!resident) || (key != resident_key) || strcmp(resident_model, fm.name)
+        memset(&params, 0, sizeof(params));
+        shim_params(ud, &params);
+        /* a continuation copy differs from its model in the scopes only (viterbi.c:68-76) and the device picks the
+         * CORNER kernels by the call, not by the batch: scopes are compared for the other calls only */
+        {
+            static c4gpu_model keyed;
+            keyed = fm;
+            keyed.start_scope = keyed.end_scope = 0;
+            for(c = (const guchar*)&keyed, n = sizeof(keyed); n; n--, c++) key = (key ^ *c) * 1099511628211ULL;
+        }
+        for(c = (const guchar*)&params, n = sizeof(params); n; n--, c++) key = (key ^ *c) * 1099511628211ULL;
+        if((!resident && !(resident_failed && (key == resident_key))) || (key != resident_key)
         || ((!vd->continuation) && ((resident_scope[0] != fm.start_scope) || (resident_scope[1] != fm.end_scope)))){
             if(resident)
                 c4gpu_batch_destroy(resident);
-            shim_params(ud, &params);
             pair.query = (const uint8_t*)qstr;  pair.query_len = ud->query->len;
             pair.target = (const uint8_t*)tstr; pair.target_len = ud->target->len;
             resident = c4gpu_batch_create(shim_ctx, &fm, &params, &pair, 1);
             resident_key = key;
-            g_strlcpy(resident_model, fm.name, C4GPU_NAME_LEN);
+            resident_failed = (resident == NULL);
             resident_scope[0] = fm.start_scope; resident_scope[1] = fm.end_scope;
             }
         i = resident ? c4gpu_batch_viterbi(resident, mode, &job, 1, &r) : -1;
@@ -291,8 +308,10 @@ static C4_Score shim_dp(C4_Model *model, Region *region, Viterbi_Data *vd, SubOp
     if(blocked)
         c4gpu_subopt_destroy(blocked);
     if(i != 0){
-        g_warning("c4gpu: %s -- using the CPU Viterbi for this call", c4gpu_last_error());
         g_free(qstr); g_free(tstr);
+        if(!cpu_func)
+            g_error("c4gpu shim: %s, and no CPU implementation to fall back to", c4gpu_last_error());
+        g_warning("c4gpu: %s -- using the CPU Viterbi for this call", c4gpu_last_error());
         return cpu_func(model, region, vd, soi, user_data);
         }
     if(shim_verbose)
@@ -435,7 +454,7 @@ static gdouble shim_pending_bytes = 0.0;   /* device footprint of the collected 
 static ShimPending *shim_replay_pair = NULL;
 static gint shim_replay_call = 0;
 
-static gint shim_batch_size(void){
+gint shim_batch_size(void){
     static gint size = -1;
     if(size < 0)
         size = g_getenv("C4GPU_BATCH") ? atoi(g_getenv("C4GPU_BATCH")) : shim_args.batch;
@@ -641,6 +660,8 @@ GAM_Result *GAM_Result_exhaustive_create(GAM *gam, Sequence *query, Sequence *ta
 
 void GAM_report(GAM *gam){        /* analysis.c:1421: after the last pair */
     shim_flush();
+    shim_bsdp_flush();
+    shim_bsdp_report();
     GAM_report_cpu(gam);
     return;
     }
@@ -653,6 +674,8 @@ Alignment *Optimal_find_path(Optimal *optimal, Region *region, gpointer user_dat
     register Region *ar;
     register C4_Model *model = optimal->find_path->model;
     register gint k;
+    if((!sp) && (alignment = shim_bsdp_find_path(optimal, region, subopt)))
+        return alignment;                       /* a terminal / join path of the BSDP batch (c4gpu_bsdp.c) */
     if((!sp) || (shim_replay_call >= sp->round_total)
     || region->query_start || region->target_start
     || (region->query_length != (gint)sp->query->len) || (region->target_length != (gint)sp->target->len)){

@@ -1,0 +1,21 @@
+/* c4gpu_shim.h — what the two files of the exonerate-gpu shim share (c4gpu_shim.c: the Viterbi plug-in table and
+ * the exhaustive batching seam; c4gpu_bsdp.c: the heuristic / BSDP seam). */
+#ifndef INCLUDED_C4GPU_SHIM_H
+#define INCLUDED_C4GPU_SHIM_H
+
+#include "c4.h"
+#include "ungapped.h"
+#include "optimal.h"
+#include "c4gpu.h"
+
+c4gpu_ctx *shim_get_ctx(void);
+gint shim_batch_size(void);
+/* closed C4_Model -> c4gpu_model; allow_span: BSDP's span models (cell_start_func / cell_end_func become matrices) */
+gboolean shim_flatten_any(C4_Model *m, Ungapped_Data *ud, c4gpu_model *out, gboolean allow_span);
+void shim_params(Ungapped_Data *ud, c4gpu_params *p);
+/* c4gpu_bsdp.c */
+void shim_bsdp_flush(void);
+void shim_bsdp_report(void);
+Alignment *shim_bsdp_find_path(Optimal *optimal, Region *region, SubOpt *subopt);
+
+#endif /* INCLUDED_C4GPU_SHIM_H */

@@ -5,6 +5,11 @@ process pinned to its device by --gpudevice.  Query chunks are contiguous byte r
 order, so the chunks' outputs concatenated in chunk order are the single-process output: this launcher prints
 them that way (the "Command line:" / "Hostname:" banner of chunk 1 only, one "-- completed" line at the end).
 
+Exception: --bestn.  The reference then defers all output to GAM_report, which walks its per-query tree in query-id
+(strcmp) order (gam.c:551-553), so a single process prints globally id-sorted blocks while the chunks print
+id-sorted blocks per chunk.  The same alignments are reported (--bestn is per query, hence shard-local); the
+concatenation is byte-identical to the single-process output only when the query file is already sorted by id.
+
     exonerate_multigpu.py --gpus 8 [--devices 0,1,..] [--exe PATH] -- -m est2genome -E yes q.fa t.fa
 
 No data-path collective: alignments of different queries are independent."""

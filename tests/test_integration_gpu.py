@@ -207,3 +207,32 @@ def test_low_complexity_inputs_tie_everywhere(tmp_path, model):
     assert "c4gpu: batch of" in gpu_err
     assert gpu_out == ref_out
     assert ref_out.count("vulgar:") >= 4
+
+
+@pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
+                    reason="reference binaries are built in the build container (make -C integration)")
+def test_c1_protein_heuristic_run_passes_through_untouched(tmp_path):
+    """BASELINE config 1 (plumbing only): `--model affine:local`, 100 protein queries of ~300 aa against one
+    ~10 kaa target, the DEFAULT heuristic mode.  Nothing on this route is ours (seeding, HSPs, SDP/BSDP stay
+    reference code; the small Optimal calls are below the device cut-off): the drop-in must print what the reference
+    prints and must not have touched the device."""
+    rng = random.Random(20260929)
+    aa = "ARNDCQEGHILKMFPSTWYV"
+    queries = ["".join(rng.choice(aa) for _ in range(rng.randint(250, 350))) for _ in range(100)]
+    target = []
+    while sum(len(x) for x in target) < 10000:
+        q = queries[rng.randrange(100)]
+        a = rng.randrange(0, len(q) - 80)
+        piece = q[a:a + rng.randint(60, 150)]
+        target.append("".join((rng.choice(aa) if rng.random() < 0.10 else c) for c in piece))
+        target.append("".join(rng.choice(aa) for _ in range(rng.randint(20, 120))))
+    qf, tf = str(tmp_path / "q.fa"), str(tmp_path / "t.fa")
+    _fasta(qf, [("prot%03d" % k, q) for k, q in enumerate(queries)])
+    _fasta(tf, [("tg", "".join(target)[:10000])])
+    args = ["-m", "affine:local", "--querytype", "protein", "--targettype", "protein", "--showalignment", "yes",
+            "--showvulgar", "yes", "-V", "0", qf, tf]
+    ref_out, _ = _run(CPU_EXE, args)
+    gpu_out, gpu_err = _run(GPU_EXE, args, {"C4GPU_VERBOSE": "1"})
+    assert gpu_out == ref_out
+    assert ref_out.count("vulgar:") >= 20
+    assert "c4gpu:" not in gpu_err, gpu_err[-1500:]
