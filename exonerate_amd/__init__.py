@@ -319,6 +319,14 @@ class ResidentBatch:
         if _lib().c4gpu_batch_run(self.h, what, dpmemory, threshold) != 0:
             raise _err("c4gpu_batch_run")
 
+    def run_regions(self, regions, dpmemory=32, threshold=IMPOSSIBLY_LOW_SCORE, active=None):
+        """Optimal_find_path of every pair over its own region (query_start, target_start, query_length,
+        target_length) of the rectangle: what --refine region asks for (c4gpu_batch_run_regions)."""
+        arr = (_abi.Region * max(1, self.n))(*[_abi.Region(*r) for r in regions])
+        act = None if active is None else (C.c_uint8 * max(1, self.n))(*[1 if a else 0 for a in active])
+        if _lib().c4gpu_batch_run_regions(self.h, arr, act, dpmemory, threshold) != 0:
+            raise _err("c4gpu_batch_run_regions")
+
     def set_thresholds(self, per_pair):
         """Per-pair score thresholds (exonerate's --percent); None switches them off."""
         arr = None if per_pair is None else (C.c_int32 * max(1, self.n))(*per_pair)

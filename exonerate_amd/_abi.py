@@ -157,9 +157,11 @@ PROTOTYPES = [
                                         C.POINTER(Pair), C.c_int32]),
     ("c4gpu_batch_destroy", None, [C.c_void_p]),
     ("c4gpu_batch_run", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int32]),
+    ("c4gpu_batch_run_regions", C.c_int, [C.c_void_p, C.POINTER(Region), C.POINTER(C.c_uint8), C.c_int, C.c_int32]),
     ("c4gpu_batch_set_thresholds", C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     ("c4gpu_batch_viterbi", C.c_int, [C.c_void_p, C.c_int, C.POINTER(ViterbiJob), C.c_int32,
                                       C.POINTER(ViterbiResult)]),
+    ("c4gpu_model_device_family", C.c_int, [C.POINTER(Model)]),
     ("c4gpu_batch_viterbi_model", C.c_int, [C.c_void_p, C.POINTER(Model), C.c_int, C.POINTER(ViterbiJob), C.c_int32,
                                             C.POINTER(ViterbiResult)]),
     ("c4gpu_batch_scores", C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(Region)]),

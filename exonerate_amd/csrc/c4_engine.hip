@@ -846,9 +846,12 @@ int sequential_reduced_path(Engine &eng, const ResidentSeqs &seqs, int pair, int
 
 // subs (may be NULL): per-pair SubOpt, the `subopt` argument the reference hands to every Viterbi_calculate of
 // the path (optimal.c:368-413); active (may be NULL): pairs to run, the others get no alignment.
+// initial (may be NULL): the `region` argument of each pair's Optimal_find_path (default: the whole rectangle) — what
+// GAM_Result_refine_alignment passes for --refine region (gam.c:618-640).
 int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gpu_score threshold,
                     c4gpu_alignment *alignments, const std::vector<const c4gpu_subopt *> *subs = nullptr,
-                    const uint8_t *active = nullptr, const std::vector<c4gpu_score> *pair_thresholds = nullptr) {
+                    const uint8_t *active = nullptr, const std::vector<c4gpu_score> *pair_thresholds = nullptr,
+                    const c4gpu_region *initial = nullptr) {
     const c4gpu_model *m = eng.model;
     const int n = seqs.n_pairs;
     // per-pair thresholds (GAM_get_query_threshold with --percent, gam.c:677-705): never below `threshold`
@@ -876,7 +879,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
     // -- step 1: where the whole rectangle is too large for a traceback, find the region first
     std::vector<int> region_pairs;
     for (int i = 0; i < n; i++) {
-        plan[i].ar = c4gpu_region{0, 0, seqs.qlen[i], seqs.tlen[i]};
+        plan[i].ar = initial ? initial[i] : c4gpu_region{0, 0, seqs.qlen[i], seqs.tlen[i]};
         plan[i].active = !active || active[i];
         if (!plan[i].active) continue;
         if (c4h::use_reduced_space(m, &plan[i].ar, dpmemory_mb)) {
@@ -936,9 +939,9 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
         const DevResult &r = outs[x].res;
         if (r.score < thr(region_pairs[x])) { p.active = false; continue; }
         p.region_score = r.score;
-        // Viterbi_Data_finalise, viterbi.c:633-653
-        if (m->start_scope != C4GPU_SCOPE_QUERY) p.ar.query_start = r.qs;
-        if (m->start_scope != C4GPU_SCOPE_TARGET) p.ar.target_start = r.ts;
+        // Viterbi_Data_finalise, viterbi.c:633-653 (curr_*_start are relative to the region the pass ran over)
+        if (m->start_scope != C4GPU_SCOPE_QUERY) p.ar.query_start += r.qs;
+        if (m->start_scope != C4GPU_SCOPE_TARGET) p.ar.target_start += r.ts;
         p.ar.query_length = r.qe - (m->start_scope != C4GPU_SCOPE_QUERY ? r.qs : 0);
         p.ar.target_length = r.te - (m->start_scope != C4GPU_SCOPE_TARGET ? r.ts : 0);
     }
@@ -1190,6 +1193,8 @@ c4gpu_ctx *c4gpu_ctx_create(int device_ordinal) {
     return ctx;
 }
 
+int c4gpu_model_device_family(const c4gpu_model *model) { return model_family(*model); }
+
 void c4gpu_ctx_destroy(c4gpu_ctx *ctx) {
     if (!ctx) return;
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -1399,6 +1404,29 @@ int c4gpu_batch_run(c4gpu_batch *b, int what, int dpmemory_mb, c4gpu_score thres
     b->clear_loop();
     if (find_path_batch(b->eng, b->seqs, dpmemory_mb, threshold, b->alignments.data(), nullptr, nullptr,
                         b->pair_thresholds.empty() ? nullptr : &b->pair_thresholds)) return -1;
+    b->scores.resize(n); b->regions.resize(n);
+    for (int i = 0; i < n; i++) { b->scores[i] = b->alignments[i].score; b->regions[i] = b->alignments[i].region; }
+    return 0;
+}
+
+int c4gpu_batch_run_regions(c4gpu_batch *b, const c4gpu_region *regions, const uint8_t *active, int dpmemory_mb,
+                            c4gpu_score threshold) {
+    if (hipSetDevice(b->ctx->device) != hipSuccess) return -1;
+    const int n = b->seqs.n_pairs;
+    for (int i = 0; i < n; i++) {
+        if (active && !active[i]) continue;
+        const c4gpu_region &r = regions[i];
+        if (r.query_start < 0 || r.target_start < 0 || r.query_length < 0 || r.target_length < 0 ||
+            r.query_start + r.query_length > b->seqs.qlen[i] || r.target_start + r.target_length > b->seqs.tlen[i]) {
+            c4h::set_error("c4gpu_batch_run_regions: a region lies outside its pair");
+            return -1;
+        }
+    }
+    for (auto &a : b->alignments) c4gpu_alignment_clear(&a);
+    b->alignments.assign(n, c4gpu_alignment{});
+    b->clear_loop();
+    if (find_path_batch(b->eng, b->seqs, dpmemory_mb, threshold, b->alignments.data(), nullptr, active, nullptr, regions))
+        return -1;
     b->scores.resize(n); b->regions.resize(n);
     for (int i = 0; i < n; i++) { b->scores[i] = b->alignments[i].score; b->regions[i] = b->alignments[i].region; }
     return 0;

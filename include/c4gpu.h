@@ -238,6 +238,10 @@ int         c4gpu_model_plugin_name(const c4gpu_model *model, int mode, int use_
 /* 1 when every calc kind / shadow of `model` is implemented by the device engine. */
 int         c4gpu_model_is_accelerated(const c4gpu_model *model);
 
+/* Index of the compiled device family whose closed tables equal `model`'s (the device-side counterpart of
+ * Bootstrapper_lookup finding a compiled function, bootstrapper.c:85-90), or -1.  Host-only: needs no device. */
+int         c4gpu_model_device_family(const c4gpu_model *model);
+
 /* Viterbi_use_reduced_space (viterbi.c:128-150) and Viterbi_checkpoint_rows (viterbi.c:207-218):
  * identical decisions to the reference for a given --dpmemory (Mb). */
 int         c4gpu_use_reduced_space(const c4gpu_model *model, const c4gpu_region *region, int dpmemory_mb);
@@ -299,6 +303,12 @@ void         c4gpu_batch_destroy(c4gpu_batch *b);
 /* One pass of the hot path over the resident batch. `what`: 0 = score pass only (FIND_SCORE),
  * 1 = region pass only, 2 = full Optimal_find_path.  Results stay on the object. */
 int          c4gpu_batch_run(c4gpu_batch *b, int what, int dpmemory_mb, c4gpu_score threshold);
+/* Optimal_find_path (optimal.c:368) of every pair with active[i] != 0 (NULL = all) over ITS OWN region of the pair's
+ * rectangle instead of the whole of it: the call GAM_Result_refine_alignment makes under --refine region (the
+ * heuristic alignment's bounding box grown by --refineboundary, gam.c:618-640).  Results as after
+ * c4gpu_batch_run(b, 2, ...): c4gpu_batch_alignment; alignment regions are in sequence coordinates. */
+int          c4gpu_batch_run_regions(c4gpu_batch *b, const c4gpu_region *regions, const uint8_t *active,
+                                     int dpmemory_mb, c4gpu_score threshold);
 /* Per-pair score thresholds for the full runs (what = 2) and c4gpu_batch_next_paths: what
  * GAM_get_query_threshold gives a query under --percent (gam.c:466-487,677-705; never below --score).  A pair
  * is held to max(threshold argument, per_pair[i]).  NULL switches them off. */

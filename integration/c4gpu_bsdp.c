@@ -47,10 +47,13 @@ extern gint BSDP_add_node_cpu(BSDP *bsdp, gpointer node_data, C4_Score node_scor
                               gboolean is_valid_end, C4_Score start_bound, C4_Score end_bound);
 extern void BSDP_add_edge_cpu(BSDP *bsdp, gpointer edge_data, gint src_node_id, gint dst_node_id, C4_Score bound_score);
 extern void BSDP_initialise_cpu(BSDP *bsdp, C4_Score threshold);
+extern BSDP_Path *BSDP_next_path_cpu(BSDP *bsdp, C4_Score threshold);
 extern C4_Score SAR_Terminal_find_score_cpu(SAR_Terminal *sar_terminal, Optimal *optimal, HPair *hpair);
 extern C4_Score SAR_Join_find_score_cpu(SAR_Join *sar_join, HPair *hpair);
 extern C4_Score SAR_Span_find_score_cpu(SAR_Span *sar_span, HPair *hpair);
 extern GAM_Result *GAM_Result_heuristic_create_cpu(GAM *gam, Comparison *comparison);
+extern Alignment *Optimal_find_path_cpu(Optimal *optimal, Region *region, gpointer user_data,
+                                        C4_Score threshold, SubOpt *subopt);
 
 /* hpair.c:22-27,60-63: the node / edge payloads HPair hands to BSDP (file-local types there) */
 typedef struct { Heuristic_Match *match; gint hsp_id; SAR_Terminal *sar_start; SAR_Terminal *sar_end; } ShimNodeData;
@@ -73,14 +76,19 @@ typedef struct {
     Comparison *comparison;
     GArray *sars;                  /* ShimSar, in creation order */
     GHashTable *index;             /* (optimal, regions) -> ShimSar* */
+    /* --refine: the pair's FIRST refinement (GAM_Result_refine_alignment, gam.c:605-655) is part of a batch too */
+    gboolean refine_seen, refine_have, refine_used;
+    gint refine_region[4];
+    c4gpu_alignment refined;
 } ShimHPending;
 
-enum { BSDP_OFF = 0, BSDP_COLLECT, BSDP_REPLAY };
+enum { BSDP_OFF = 0, BSDP_COLLECT, BSDP_REFINE_COLLECT, BSDP_REPLAY };
 static gint bsdp_mode = BSDP_OFF;
 static ShimHPending *bsdp_cur = NULL;
 static GPtrArray *bsdp_pending = NULL;
-static struct { long pairs, candidates, spans, score_calls, score_served, path_calls, path_served, flushes;
-                double device_ms, dry_ms, replay_ms; } st;
+static struct { long pairs, candidates, spans, score_calls, score_served, path_calls, path_served, flushes,
+                     refine_calls, refine_served;
+                double device_ms, dry_ms, replay_ms, refine_ms; } st;
 
 static guint sar_hash(gconstpointer p){
     const ShimSar *s = p;
@@ -107,6 +115,35 @@ static void bsdp_record(Optimal *optimal, Heuristic_Span *span, Region *r1, Regi
     s.span = span;
     s.raw = C4_IMPOSSIBLY_LOW_SCORE;
     g_array_append_val(bsdp_cur->sars, s);
+    }
+
+/* a path-only entry (the src traceback of a span: its region is only known once the dst path is) */
+static void bsdp_record_path(ShimHPending *hp, Optimal *optimal, Region *region, C4_Score score, gint n_ops,
+                             const gint *ops, gint qs, gint ts, gint ql, gint tl){
+    ShimSar s;
+    sar_key(&s, optimal, region, NULL);
+    s.raw = score;
+    s.n_ops = n_ops;
+    s.ops = g_new(gint, n_ops + 1);
+    memcpy(s.ops, ops, sizeof(gint) * n_ops);
+    s.path_region[0] = qs; s.path_region[1] = ts; s.path_region[2] = ql; s.path_region[3] = tl;
+    s.have_path = TRUE;
+    g_array_append_val(hp->sars, s);
+    }
+
+static gint *bsdp_alignment_ops(Alignment *a, gint *n_ops){
+    register guint o;
+    register gint l, total = 0, *ops;
+    for(o = 0; o < a->operation_list->len; o++)
+        total += ((AlignmentOperation*)a->operation_list->pdata[o])->length;
+    ops = g_new(gint, total + 1);
+    *n_ops = 0;
+    for(o = 0; o < a->operation_list->len; o++){
+        register AlignmentOperation *ao = a->operation_list->pdata[o];
+        for(l = 0; l < ao->length; l++)
+            ops[(*n_ops)++] = ao->transition->id;
+        }
+    return ops;
     }
 
 /* ---- fronts seen by hpair.o ---------------------------------------------------------------------------------- */
@@ -142,6 +179,13 @@ void BSDP_initialise(BSDP *bsdp, C4_Score threshold){
     return;
     }
 
+BSDP_Path *BSDP_next_path(BSDP *bsdp, C4_Score threshold){
+    /* the refinement dry run only wants the first alignment's refinement request (see shim_bsdp_find_path) */
+    if((bsdp_mode == BSDP_REFINE_COLLECT) && bsdp_cur && bsdp_cur->refine_seen)
+        return NULL;
+    return BSDP_next_path_cpu(bsdp, threshold);
+    }
+
 /* Viterbi_calculate builds its SubOpt_Index from (subopt, region) and runs the plain DP when that is NULL
  * (viterbi.c:846-865, subopt.c:250-266): exactly then a score computed without blocked cells is the call's result */
 static gboolean bsdp_region_unblocked(SubOpt *subopt, Region *region){
@@ -157,7 +201,7 @@ static gboolean bsdp_region_unblocked(SubOpt *subopt, Region *region){
 
 static ShimSar *bsdp_lookup(Optimal *optimal, Region *r1, Region *r2){
     ShimSar k;
-    if((bsdp_mode != BSDP_REPLAY) || (!bsdp_cur) || (!bsdp_cur->index))
+    if(((bsdp_mode != BSDP_REPLAY) && (bsdp_mode != BSDP_REFINE_COLLECT)) || (!bsdp_cur) || (!bsdp_cur->index))
         return NULL;
     sar_key(&k, optimal, r1, r2);
     return g_hash_table_lookup(bsdp_cur->index, &k);
@@ -165,9 +209,9 @@ static ShimSar *bsdp_lookup(Optimal *optimal, Region *r1, Region *r2){
 
 C4_Score SAR_Terminal_find_score(SAR_Terminal *sar_terminal, Optimal *optimal, HPair *hpair){
     register ShimSar *s = bsdp_lookup(optimal, sar_terminal->region, NULL);
-    st.score_calls++;
+    st.score_calls += (bsdp_mode == BSDP_REPLAY);
     if(s && bsdp_region_unblocked(hpair->subopt, sar_terminal->region)){
-        st.score_served++;
+        st.score_served += (bsdp_mode == BSDP_REPLAY);
         return s->raw - sar_terminal->component;                                  /* sar.c:393-398 */
         }
     return SAR_Terminal_find_score_cpu(sar_terminal, optimal, hpair);
@@ -175,9 +219,9 @@ C4_Score SAR_Terminal_find_score(SAR_Terminal *sar_terminal, Optimal *optimal, H
 
 C4_Score SAR_Join_find_score(SAR_Join *sar_join, HPair *hpair){
     register ShimSar *s = bsdp_lookup(sar_join->pair->join->optimal, sar_join->region, NULL);
-    st.score_calls++;
+    st.score_calls += (bsdp_mode == BSDP_REPLAY);
     if(s && bsdp_region_unblocked(hpair->subopt, sar_join->region)){
-        st.score_served++;
+        st.score_served += (bsdp_mode == BSDP_REPLAY);
         return s->raw - (sar_join->src_component + sar_join->dst_component);     /* sar.c:697-702 */
         }
     return SAR_Join_find_score_cpu(sar_join, hpair);
@@ -185,10 +229,10 @@ C4_Score SAR_Join_find_score(SAR_Join *sar_join, HPair *hpair){
 
 C4_Score SAR_Span_find_score(SAR_Span *sar_span, HPair *hpair){
     register ShimSar *s = bsdp_lookup(sar_span->span->dst_optimal, sar_span->src_region, sar_span->dst_region);
-    st.score_calls++;
+    st.score_calls += (bsdp_mode == BSDP_REPLAY);
     if(s && bsdp_region_unblocked(hpair->subopt, sar_span->src_region)
          && bsdp_region_unblocked(hpair->subopt, sar_span->dst_region)){
-        st.score_served++;
+        st.score_served += (bsdp_mode == BSDP_REPLAY);
         return s->raw - (sar_span->src_component + sar_span->dst_component);     /* sar.c:898-918 */
         }
     return SAR_Span_find_score_cpu(sar_span, hpair);
@@ -202,13 +246,59 @@ Alignment *shim_bsdp_find_path(Optimal *optimal, Region *region, SubOpt *subopt)
     register Region *ar;
     register C4_Model *model;
     register gint k, run;
-    if(bsdp_mode != BSDP_REPLAY)
+    if((bsdp_mode != BSDP_REPLAY) && (bsdp_mode != BSDP_REFINE_COLLECT))
         return NULL;
-    st.path_calls++;
+    if(bsdp_cur && (optimal == bsdp_cur->gam->optimal)){
+        /* GAM_Result_refine_alignment's call (gam.c:618-640).  Dry run: write the first one down and hand back an
+         * alignment that loses against the unrefined one (gam.c:664-669), then BSDP_next_path ends the run.  Replay:
+         * the first request, with nothing blocked yet, is answered from the refinement batch. */
+        if(bsdp_mode == BSDP_REFINE_COLLECT){
+            if(!bsdp_cur->refine_seen){
+                bsdp_cur->refine_seen = TRUE;
+                bsdp_cur->refine_region[0] = region->query_start;  bsdp_cur->refine_region[1] = region->target_start;
+                bsdp_cur->refine_region[2] = region->query_length; bsdp_cur->refine_region[3] = region->target_length;
+                }
+            return Alignment_create(optimal->find_path->model, region, C4_IMPOSSIBLY_LOW_SCORE);
+            }
+        st.refine_calls++;
+        if(bsdp_cur->refine_have && (!bsdp_cur->refine_used)
+        && (bsdp_cur->refine_region[0] == region->query_start) && (bsdp_cur->refine_region[1] == region->target_start)
+        && (bsdp_cur->refine_region[2] == region->query_length) && (bsdp_cur->refine_region[3] == region->target_length)
+        && bsdp_region_unblocked(subopt, region) && bsdp_cur->refined.valid){
+            register c4gpu_alignment *a = &bsdp_cur->refined;
+            bsdp_cur->refine_used = TRUE;
+            st.refine_served++;
+            model = optimal->find_path->model;
+            ar = Region_create(a->region.query_start, a->region.target_start, a->region.query_length, a->region.target_length);
+            alignment = Alignment_create(model, ar, a->score);
+            Region_destroy(ar);
+            for(k = 0; k < a->n_ops; k++)
+                Alignment_add(alignment, model->transition_list->pdata[a->op_transition[k]], a->op_length[k]);
+            return alignment;
+            }
+        return NULL;
+        }
+    st.path_calls += (bsdp_mode == BSDP_REPLAY);
     s = bsdp_lookup(optimal, region, NULL);
+    if((!s) && bsdp_cur && bsdp_cur->index){
+        /* the dst path of a span (SAR_Alignment_add_SAR_Span, sar.c:1042-1062): its START cells came from the span's
+         * src region, registered with the span just before this call */
+        register guint x;
+        for(x = 0; x < bsdp_cur->sars->len; x++){
+            register ShimSar *c = &g_array_index(bsdp_cur->sars, ShimSar, x);
+            if(c->span && (c->span->dst_optimal == optimal)){
+                register Region *src = c->span->curr_src_region, *dst = c->span->curr_dst_region;
+                if(src && dst && (dst->query_start == region->query_start) && (dst->target_start == region->target_start)
+                && (dst->query_length == region->query_length) && (dst->target_length == region->target_length)
+                && bsdp_region_unblocked(subopt, src))
+                    s = bsdp_lookup(optimal, src, region);
+                break;
+                }
+            }
+        }
     if((!s) || (!s->have_path) || (!bsdp_region_unblocked(subopt, region)))
         return NULL;
-    st.path_served++;
+    st.path_served += (bsdp_mode == BSDP_REPLAY);
     model = optimal->find_path->model;
     ar = Region_create(s->path_region[0], s->path_region[1], s->path_region[2], s->path_region[3]);
     alignment = Alignment_create(model, ar, s->raw);
@@ -244,13 +334,14 @@ static ShimGroup *bsdp_group(GPtrArray *groups, Optimal *optimal, Ungapped_Data 
 /* step 3 without a device (C4GPU_BSDP_HOST=1, the CPU test of steps 1, 2 and 4): the reference's own DPs */
 static void bsdp_host_scores(ShimHPending *hp){
     register guint i;
-    register gpointer ud = Model_Type_create_data(hp->gam->gas->type, hp->comparison->query, hp->comparison->target);
+    gpointer ud = Model_Type_create_data(hp->gam->gas->type, hp->comparison->query, hp->comparison->target);
     register SubOpt *empty = SubOpt_create(hp->comparison->query->len, hp->comparison->target->len);
     HPair fake;
     memset(&fake, 0, sizeof(fake));
     fake.user_data = ud;
     fake.subopt = empty;
-    for(i = 0; i < hp->sars->len; i++){
+    register guint n_cand = hp->sars->len;            /* src traceback entries are appended behind the candidates */
+    for(i = 0; i < n_cand; i++){
         register ShimSar *s = &g_array_index(hp->sars, ShimSar, i);
         Region *r1 = Region_create(s->r[0], s->r[1], s->r[2], s->r[3]);      /* the span keeps a share */
         if(s->span){
@@ -258,11 +349,78 @@ static void bsdp_host_scores(ShimHPending *hp){
             Region *r2 = Region_create(s->r[4], s->r[5], s->r[6], s->r[7]);
             tmp.src_region = r1; tmp.dst_region = r2; tmp.src_component = tmp.dst_component = 0; tmp.span = s->span;
             s->raw = SAR_Span_find_score_cpu(&tmp, &fake);
+            {   /* the two paths of the span, in SAR_Alignment_add_SAR_Span's order (sar.c:1042-1085) */
+                register Heuristic_Data *hd = ud;
+                register Alignment *da, *sa;
+                hd->heuristic_span = s->span;
+                Heuristic_Span_register(s->span, r1, r2);
+                Optimal_find_score(s->span->src_optimal, r1, ud, empty);
+                Heuristic_Span_integrate(s->span, r1, r2);
+                da = Optimal_find_path_cpu(s->span->dst_optimal, r2, ud, C4_IMPOSSIBLY_LOW_SCORE, empty);
+                if(da){
+                    register gint qe = da->region->query_start - r2->query_start,
+                                  te = da->region->target_start - r2->target_start;
+                    register Heuristic_Span_Cell *sc = &s->span->dst_integration_matrix[qe][te];
+                    s->ops = bsdp_alignment_ops(da, &s->n_ops);
+                    s->path_region[0] = da->region->query_start;  s->path_region[1] = da->region->target_start;
+                    s->path_region[2] = da->region->query_length; s->path_region[3] = da->region->target_length;
+                    s->have_path = (da->score == s->raw);
+                    if((sc->query_pos != -1) && (sc->target_pos != -1)){
+                        Region *tr = Region_create(r1->query_start, r1->target_start, sc->query_pos - r1->query_start,
+                                                   sc->target_pos - r1->target_start);
+                        sa = Optimal_find_path_cpu(s->span->src_traceback_optimal, tr, ud, C4_IMPOSSIBLY_LOW_SCORE, empty);
+                        if(sa){
+                            gint n_ops, *ops = bsdp_alignment_ops(sa, &n_ops);
+                            register Optimal *tbo = s->span->src_traceback_optimal;
+                            bsdp_record_path(hp, tbo, tr, sa->score, n_ops, ops, sa->region->query_start,
+                                             sa->region->target_start, sa->region->query_length, sa->region->target_length);
+                            s = &g_array_index(hp->sars, ShimSar, i);        /* the array may have moved */
+                            g_free(ops);
+                            Alignment_destroy(sa);
+                            }
+                        Region_destroy(tr);
+                        }
+                    Alignment_destroy(da);
+                    }
+                hd->heuristic_span = NULL;
+            }
             Region_destroy(r2);
         } else {
+            register Alignment *a;
             s->raw = Optimal_find_score(s->optimal, r1, ud, empty);
+            /* ... and the path, as the device's path pass would deliver it */
+            if((s->optimal->type & Optimal_Type_PATH)
+            && (a = Optimal_find_path_cpu(s->optimal, r1, ud, C4_IMPOSSIBLY_LOW_SCORE, empty))){
+                s->ops = bsdp_alignment_ops(a, &s->n_ops);
+                s->path_region[0] = a->region->query_start;  s->path_region[1] = a->region->target_start;
+                s->path_region[2] = a->region->query_length; s->path_region[3] = a->region->target_length;
+                s->have_path = (a->score == s->raw);
+                Alignment_destroy(a);
+                }
             }
         Region_destroy(r1);
+        }
+    /* what the device route would need of these models: every one flattens and has a compiled family */
+    for(i = 0; i < n_cand; i++){
+        register ShimSar *s = &g_array_index(hp->sars, ShimSar, i);
+        Optimal *opts[4];
+        register gint o, no = 0;
+        static GHashTable *seen = NULL;
+        c4gpu_model fm;
+        if(!seen)
+            seen = g_hash_table_new(g_direct_hash, g_direct_equal);
+        if(s->span){ opts[no++] = s->span->src_optimal; opts[no++] = s->span->dst_optimal; opts[no++] = s->span->src_traceback_optimal; }
+        else opts[no++] = s->optimal;
+        for(o = 0; o < no; o++){
+            register C4_Model *m = opts[o]->find_score ? opts[o]->find_score->model : opts[o]->find_path->model;
+            if(g_hash_table_lookup(seen, opts[o]))
+                continue;
+            g_hash_table_insert(seen, opts[o], opts[o]);
+            if((!shim_flatten_any(m, ud, &fm, TRUE)) || (c4gpu_model_device_family(&fm) < 0))
+                g_warning("c4gpu bsdp: model [%s] has no device family", m->name);
+            else if(g_getenv("C4GPU_VERBOSE"))
+                g_message("c4gpu bsdp: model [%s] -> device family %d", m->name, c4gpu_model_device_family(&fm));
+            }
         }
     SubOpt_destroy(empty);
     Model_Type_destroy_data(hp->gam->gas->type, ud);
@@ -284,7 +442,7 @@ static void bsdp_span_start_cells(Heuristic_Span *span, Region *src, Region *dst
     return;
     }
 
-static gboolean bsdp_device_scores(GPtrArray *todo){
+static gboolean bsdp_device_scores(GPtrArray *todo, c4gpu_batch **batch_out){
     register guint i, k, n = todo->len;
     register ShimHPending *hp = todo->pdata[0];
     register GAM *gam = hp->gam;
@@ -402,6 +560,7 @@ static gboolean bsdp_device_scores(GPtrArray *todo){
             c4gpu_viterbi_job *djob = g_new0(c4gpu_viterbi_job, cnt);
             c4gpu_viterbi_result *dres = g_new0(c4gpu_viterbi_result, cnt);
             c4gpu_score **dmat = g_new0(c4gpu_score*, cnt);
+            gint **dpos = g_new0(gint*, cnt);          /* per candidate: dst_integration_matrix (query_pos, target_pos) */
             for(k = 0; k < cnt; k++){
                 register ShimMember *m = &g_array_index(g->members, ShimMember, k);
                 register ShimHPending *h = todo->pdata[m->pair];
@@ -417,6 +576,12 @@ static gboolean bsdp_device_scores(GPtrArray *todo){
                 Heuristic_Span_integrate(s->span, src, dst);
                 dmat[k] = g_new(c4gpu_score, (gsize)(s->r[6] + 1) * (s->r[7] + 1) * cs);
                 bsdp_span_start_cells(s->span, src, dst, cs, dmat[k]);
+                dpos[k] = g_new(gint, (gsize)(s->r[6] + 1) * (s->r[7] + 1) * 2);
+                for(a = 0; a <= s->r[6]; a++)
+                    for(b = 0; b <= s->r[7]; b++){
+                        dpos[k][((gsize)a * (s->r[7] + 1) + b) * 2] = s->span->dst_integration_matrix[a][b].query_pos;
+                        dpos[k][((gsize)a * (s->r[7] + 1) + b) * 2 + 1] = s->span->dst_integration_matrix[a][b].target_pos;
+                        }
                 djob[k].pair = m->pair;
                 djob[k].region.query_start = s->r[4];  djob[k].region.target_start = s->r[5];
                 djob[k].region.query_length = s->r[6]; djob[k].region.target_length = s->r[7];
@@ -424,18 +589,63 @@ static gboolean bsdp_device_scores(GPtrArray *todo){
                 Region_destroy(src);
                 Region_destroy(dst);
                 }
-            if((!gd->ok) || (c4gpu_batch_viterbi_model(batch, &gd->fm, C4GPU_MODE_FIND_SCORE, djob, cnt, dres) != 0))
+            /* the path pass: score and dst path (SAR_Alignment_add_SAR_Span, sar.c:1052-1056) in one */
+            if((!gd->ok) || (c4gpu_batch_viterbi_model(batch, &gd->fm, C4GPU_MODE_FIND_PATH, djob, cnt, dres) != 0))
                 ok = FALSE;
-            for(k = 0; ok && (k < cnt); k++){
-                register ShimMember *m = &g_array_index(g->members, ShimMember, k);
-                register ShimHPending *h = todo->pdata[m->pair];
-                g_array_index(h->sars, ShimSar, m->sar).raw = dres[k].score;
+            if(ok){
+                /* pass 3: the src traceback of each span (CORNER to CORNER, from the src region's corner to the cell the
+                 * dst path started from, sar.c:1057-1075) */
+                register ShimGroup *gt = bsdp_group(groups, span->src_traceback_optimal, ud);
+                c4gpu_viterbi_job *tjob = g_new0(c4gpu_viterbi_job, cnt);
+                c4gpu_viterbi_result *tres = g_new0(c4gpu_viterbi_result, cnt);
+                gint *towner = g_new(gint, cnt), nt = 0;
+                for(k = 0; k < cnt; k++){
+                    register ShimMember *m = &g_array_index(g->members, ShimMember, k);
+                    register ShimHPending *h = todo->pdata[m->pair];
+                    register ShimSar *s = &g_array_index(h->sars, ShimSar, m->sar);
+                    s->raw = dres[k].score;
+                    if(dres[k].n_ops > 0){
+                        register gsize at = ((gsize)dres[k].query_start * (s->r[7] + 1) + dres[k].target_start) * 2;
+                        register gint qp = dpos[k][at], tp = dpos[k][at + 1];
+                        s->n_ops = dres[k].n_ops;
+                        s->ops = g_new(gint, dres[k].n_ops + 1);
+                        memcpy(s->ops, dres[k].ops, sizeof(gint) * dres[k].n_ops);
+                        s->path_region[0] = s->r[4] + dres[k].query_start;  s->path_region[1] = s->r[5] + dres[k].target_start;
+                        s->path_region[2] = dres[k].query_end - dres[k].query_start;
+                        s->path_region[3] = dres[k].target_end - dres[k].target_start;
+                        s->have_path = TRUE;
+                        if((qp != -1) && (tp != -1) && gt->ok){
+                            tjob[nt].pair = m->pair;
+                            tjob[nt].region.query_start = s->r[0];       tjob[nt].region.target_start = s->r[1];
+                            tjob[nt].region.query_length = qp - s->r[0]; tjob[nt].region.target_length = tp - s->r[1];
+                            towner[nt++] = k;
+                            }
+                        }
+                    }
+                if(nt && (c4gpu_batch_viterbi_model(batch, &gt->fm, C4GPU_MODE_FIND_PATH, tjob, nt, tres) == 0)){
+                    for(k = 0; k < (guint)nt; k++){
+                        register ShimMember *m = &g_array_index(g->members, ShimMember, towner[k]);
+                        register ShimHPending *h = todo->pdata[m->pair];
+                        Region tr;
+                        if(tres[k].n_ops <= 0)
+                            continue;
+                        Region_init_static(&tr, tjob[k].region.query_start, tjob[k].region.target_start,
+                                           tjob[k].region.query_length, tjob[k].region.target_length);
+                        bsdp_record_path(h, span->src_traceback_optimal, &tr, tres[k].score, tres[k].n_ops, tres[k].ops,
+                                         tr.query_start + tres[k].query_start, tr.target_start + tres[k].target_start,
+                                         tres[k].query_end - tres[k].query_start, tres[k].target_end - tres[k].target_start);
+                        }
+                    for(k = 0; k < (guint)nt; k++)
+                        c4gpu_viterbi_result_clear(&tres[k]);
+                    }
+                g_free(tjob); g_free(tres); g_free(towner);
                 }
             for(k = 0; k < cnt; k++){
                 c4gpu_viterbi_result_clear(&dres[k]);
                 g_free(dmat[k]);
+                g_free(dpos[k]);
                 }
-            g_free(djob); g_free(dres); g_free(dmat);
+            g_free(djob); g_free(dres); g_free(dmat); g_free(dpos);
             }
         for(k = 0; k < cnt; k++){
             c4gpu_viterbi_result_clear(&res[k]);
@@ -446,7 +656,9 @@ static gboolean bsdp_device_scores(GPtrArray *todo){
         }
     Model_Type_destroy_data(gam->gas->type, ud);
 done:
-    if(batch)
+    if(batch && ok)
+        *batch_out = batch;                     /* the refinement batch runs on the same resident pairs */
+    else if(batch)
         c4gpu_batch_destroy(batch);
     for(i = 0; i < groups->len; i++){
         register ShimGroup *g = groups->pdata[i];
@@ -462,13 +674,93 @@ done:
     return ok;
     }
 
+/* ---- the first refinement of every pair (--refine region | full), one batch ------------------------------------------ */
+
+static void bsdp_refine(GPtrArray *todo, c4gpu_batch *batch){
+    register guint i, n = todo->len;
+    register ShimHPending *hp = todo->pdata[0];
+    register GAM *gam = hp->gam;
+    register gint dpmemory = gam->optimal->find_path->vas->traceback_memory_limit;
+    c4gpu_region *regions = g_new0(c4gpu_region, n);
+    uint8_t *active = g_new0(uint8_t, n);
+    register guint wanted = 0;
+    /* dry runs with the sub-DP scores at hand: each stops at its first Optimal_find_path on the whole model */
+    for(i = 0; i < n; i++){
+        register GAM_Result *none;
+        hp = todo->pdata[i];
+        bsdp_mode = BSDP_REFINE_COLLECT;
+        bsdp_cur = hp;
+        none = GAM_Result_heuristic_create_cpu(hp->gam, hp->comparison);
+        bsdp_cur = NULL;
+        bsdp_mode = BSDP_OFF;
+        if(none)
+            GAM_Result_destroy(none);              /* never submitted */
+        if(hp->refine_seen){
+            regions[i].query_start = hp->refine_region[0];  regions[i].target_start = hp->refine_region[1];
+            regions[i].query_length = hp->refine_region[2]; regions[i].target_length = hp->refine_region[3];
+            active[i] = 1;
+            wanted++;
+            }
+        }
+    if(wanted && batch){
+        /* GAM_Result_refine_alignment's threshold is 0 (gam.c:626,645) */
+        if(c4gpu_batch_run_regions(batch, regions, active, dpmemory, 0) == 0){
+            for(i = 0; i < n; i++){
+                hp = todo->pdata[i];
+                if(active[i] && (c4gpu_batch_alignment(batch, i, &hp->refined) == 0))
+                    hp->refine_have = TRUE;
+                }
+        } else {
+            g_warning("c4gpu: %s -- refinements stay one call at a time", c4gpu_last_error());
+            }
+    } else if(wanted){                              /* C4GPU_BSDP_HOST: the reference's own Optimal_find_path */
+        for(i = 0; i < n; i++){
+            register gpointer ud;
+            register SubOpt *empty;
+            register Alignment *a;
+            Region *r;
+            hp = todo->pdata[i];
+            if(!active[i])
+                continue;
+            ud = Model_Type_create_data(gam->gas->type, hp->comparison->query, hp->comparison->target);
+            empty = SubOpt_create(hp->comparison->query->len, hp->comparison->target->len);
+            r = Region_create(regions[i].query_start, regions[i].target_start, regions[i].query_length, regions[i].target_length);
+            a = Optimal_find_path_cpu(gam->optimal, r, ud, 0, empty);
+            if(a){
+                register guint o;
+                hp->refined.score = a->score;
+                hp->refined.region.query_start = a->region->query_start;   hp->refined.region.target_start = a->region->target_start;
+                hp->refined.region.query_length = a->region->query_length; hp->refined.region.target_length = a->region->target_length;
+                hp->refined.n_ops = a->operation_list->len;
+                hp->refined.op_transition = malloc(sizeof(int32_t) * (a->operation_list->len + 1));
+                hp->refined.op_length = malloc(sizeof(int32_t) * (a->operation_list->len + 1));
+                for(o = 0; o < a->operation_list->len; o++){
+                    register AlignmentOperation *ao = a->operation_list->pdata[o];
+                    hp->refined.op_transition[o] = ao->transition->id;
+                    hp->refined.op_length[o] = ao->length;
+                    }
+                hp->refined.valid = 1;
+                hp->refine_have = TRUE;
+                Alignment_destroy(a);
+                }
+            Region_destroy(r);
+            SubOpt_destroy(empty);
+            Model_Type_destroy_data(gam->gas->type, ud);
+            }
+        }
+    g_free(regions);
+    g_free(active);
+    return;
+    }
+
 /* ---- collect / flush ---------------------------------------------------------------------------------------------- */
 
 void shim_bsdp_flush(void){
     register guint i, k;
     register GPtrArray *todo = bsdp_pending;
     register gboolean have_scores;
-    gint64 t0 = g_get_monotonic_time(), t1, t2;
+    c4gpu_batch *batch = NULL;
+    gint64 t0 = g_get_monotonic_time(), t1, t2, t3;
     if((!todo) || (!todo->len))
         return;
     bsdp_pending = NULL;
@@ -492,24 +784,32 @@ void shim_bsdp_flush(void){
             bsdp_host_scores(todo->pdata[i]);
         have_scores = TRUE;
     } else {
-        have_scores = bsdp_device_scores(todo);
+        have_scores = bsdp_device_scores(todo, &batch);
         if(!have_scores)
             g_warning("c4gpu: %s -- BSDP sub-DPs stay on the CPU for this batch", c4gpu_last_error());
         }
     t2 = g_get_monotonic_time();
+    for(i = 0; have_scores && (i < todo->len); i++){
+        register ShimHPending *hp = todo->pdata[i];
+        hp->index = g_hash_table_new(sar_hash, sar_equal);
+        for(k = 0; k < hp->sars->len; k++){
+            register ShimSar *s = &g_array_index(hp->sars, ShimSar, k);
+            if(s->span)
+                st.spans++;
+            g_hash_table_insert(hp->index, s, s);
+            }
+        }
+    /* 3b. --refine: the first refinement of every pair as one more batch on the same resident pairs */
+    if(have_scores && (((ShimHPending*)todo->pdata[0])->gam->gas->refinement != GAM_Refinement_NONE)
+    && ((ShimHPending*)todo->pdata[0])->gam->optimal && (!g_getenv("C4GPU_REFINE_BATCH_OFF")))
+        bsdp_refine(todo, batch);
+    if(batch)
+        c4gpu_batch_destroy(batch);
+    t3 = g_get_monotonic_time();
     /* 4. replay in submission order */
     for(i = 0; i < todo->len; i++){
         register ShimHPending *hp = todo->pdata[i];
         register GAM_Result *gam_result;
-        if(have_scores){
-            hp->index = g_hash_table_new(sar_hash, sar_equal);
-            for(k = 0; k < hp->sars->len; k++){
-                register ShimSar *s = &g_array_index(hp->sars, ShimSar, k);
-                if(s->span)
-                    st.spans++;
-                g_hash_table_insert(hp->index, s, s);
-                }
-            }
         bsdp_mode = BSDP_REPLAY;
         bsdp_cur = hp;
         gam_result = GAM_Result_heuristic_create_cpu(hp->gam, hp->comparison);
@@ -524,13 +824,16 @@ void shim_bsdp_flush(void){
         for(k = 0; k < hp->sars->len; k++)
             g_free(g_array_index(hp->sars, ShimSar, k).ops);
         g_array_free(hp->sars, TRUE);
+        if(hp->refine_have)
+            c4gpu_alignment_clear(&hp->refined);
         Comparison_destroy(hp->comparison);
         GAM_destroy(hp->gam);
         g_free(hp);
         st.pairs++;
         }
     g_ptr_array_free(todo, TRUE);
-    st.dry_ms += (t1 - t0) / 1e3; st.device_ms += (t2 - t1) / 1e3; st.replay_ms += (g_get_monotonic_time() - t2) / 1e3;
+    st.dry_ms += (t1 - t0) / 1e3; st.device_ms += (t2 - t1) / 1e3; st.refine_ms += (t3 - t2) / 1e3;
+    st.replay_ms += (g_get_monotonic_time() - t3) / 1e3;
     return;
     }
 
@@ -563,8 +866,9 @@ GAM_Result *GAM_Result_heuristic_create(GAM *gam, Comparison *comparison){
 void shim_bsdp_report(void){
     if(g_getenv("C4GPU_VERBOSE") && st.pairs)
         g_message("c4gpu bsdp: %ld pairs in %ld flush(es): %ld candidate sub-DPs (%ld spans) in device batches; "
-                  "%ld of %ld score calls and %ld of %ld path calls served from them; dry runs %.0f ms, "
-                  "device %.0f ms, replay %.0f ms", st.pairs, st.flushes, st.candidates, st.spans, st.score_served,
-                  st.score_calls, st.path_served, st.path_calls, st.dry_ms, st.device_ms, st.replay_ms);
+                  "%ld of %ld score calls and %ld of %ld path calls served from them; %ld of %ld refinements from "
+                  "refinement batches; dry runs %.0f ms, device %.0f ms, refinement %.0f ms, replay %.0f ms", st.pairs,
+                  st.flushes, st.candidates, st.spans, st.score_served, st.score_calls, st.path_served, st.path_calls,
+                  st.refine_served, st.refine_calls, st.dry_ms, st.device_ms, st.refine_ms, st.replay_ms);
     return;
     }

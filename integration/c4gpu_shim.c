@@ -410,6 +410,10 @@ gpointer Bootstrapper_lookup(gchar *name){
     /* only the Optimal (full Viterbi) functions are ours: "optimal_58_<model>_32_find_32_<mode>" */
     if((mode < 0) || strncmp(name, "optimal_58_", 11) || g_getenv("C4GPU_DISABLE") || (!shim_args.use_gpu))
         return (gpointer)cpu;
+    /* no compiled CPU function of this name (the archive was built without the model) and no device either: leave
+     * the slot empty, Viterbi_calculate then runs the reference's interpreted loop (viterbi.c:855-859) */
+    if((!cpu) && (!shim_get_ctx()))
+        return NULL;
     for(i = 0; i < shim_slot_count; i++)
         if(!strcmp(shim_slot[i].name, name))
             return (gpointer)shim_funcs[i];

@@ -965,8 +965,18 @@ int oracle_find_path_subopt(const c4gpu_model *model, const c4gpu_params *params
                      const uint8_t *query, int32_t qlen, const uint8_t *target, int32_t tlen,
                      int dpmemory_mb, c4gpu_score threshold, const oracle_subopt *subopt,
                      c4gpu_alignment *out){
-    octx cx = {model, params, query, target, qlen, tlen, dpmemory_mb, subopt};
     c4gpu_region region = {0, 0, qlen, tlen};
+    return oracle_find_path_region(model, params, query, qlen, target, tlen, &region, dpmemory_mb, threshold, subopt, out);
+    }
+
+/* Optimal_find_path (optimal.c:368-413) with its `region` argument: GAM_Result_refine_alignment's call under
+ * --refine region (gam.c:618-640) */
+int oracle_find_path_region(const c4gpu_model *model, const c4gpu_params *params,
+                     const uint8_t *query, int32_t qlen, const uint8_t *target, int32_t tlen,
+                     const c4gpu_region *region_in, int dpmemory_mb, c4gpu_score threshold,
+                     const oracle_subopt *subopt, c4gpu_alignment *out){
+    octx cx = {model, params, query, target, qlen, tlen, dpmemory_mb, subopt};
+    c4gpu_region region = *region_in;
     memset(out, 0, sizeof(*out));
     if(oracle_use_reduced_space(model, &region, dpmemory_mb)){
         c4gpu_region ar = region;

@@ -46,6 +46,11 @@ int  oracle_find_path_subopt(const c4gpu_model *model, const c4gpu_params *param
                       const uint8_t *query, int32_t qlen, const uint8_t *target, int32_t tlen,
                       int dpmemory_mb, c4gpu_score threshold, const oracle_subopt *subopt,
                       c4gpu_alignment *out);
+/* the same over a region of the rectangle (Optimal_find_path's `region` argument; --refine region, gam.c:618-640) */
+int  oracle_find_path_region(const c4gpu_model *model, const c4gpu_params *params,
+                      const uint8_t *query, int32_t qlen, const uint8_t *target, int32_t tlen,
+                      const c4gpu_region *region, int dpmemory_mb, c4gpu_score threshold,
+                      const oracle_subopt *subopt, c4gpu_alignment *out);
 
 /* one raw Viterbi call in any mode (Viterbi_interpreted, src/c4/viterbi.c:655-837); used by the parity
  * tests of c4gpu_viterbi_batch.  checkpoints (may be NULL) receives

@@ -59,6 +59,10 @@ def load():
         lib.oracle_find_path_subopt.argtypes = [C.POINTER(_abi.Model), C.POINTER(_abi.Params), C.c_char_p,
                                                 C.c_int32, C.c_char_p, C.c_int32, C.c_int, C.c_int32,
                                                 C.c_void_p, C.POINTER(_abi.Alignment)]
+        lib.oracle_find_path_region.restype = C.c_int
+        lib.oracle_find_path_region.argtypes = [C.POINTER(_abi.Model), C.POINTER(_abi.Params), C.c_char_p,
+                                                C.c_int32, C.c_char_p, C.c_int32, C.POINTER(_abi.Region), C.c_int,
+                                                C.c_int32, C.c_void_p, C.POINTER(_abi.Alignment)]
         lib.oracle_viterbi_subopt.argtypes = [C.POINTER(_abi.Model), C.POINTER(_abi.Params), C.c_int,
                                               C.c_char_p, C.c_int32, C.c_char_p, C.c_int32,
                                               C.POINTER(_abi.Region), C.POINTER(_abi.Continuation), C.c_int,
@@ -88,6 +92,19 @@ def find_path(model, params, q, t, dpmemory=32, threshold=_abi.IMPOSSIBLY_LOW_SC
     lib = load()
     a = _abi.Alignment()
     ok = lib.oracle_find_path(model, params, q, len(q), t, len(t), dpmemory, threshold, a)
+    if not ok:
+        return None
+    d = alignment_to_dict(model, a, lib.oracle_alignment_format, qid, len(q), len(t))
+    lib.oracle_alignment_clear(a)
+    return d
+
+
+def find_path_region(model, params, q, t, region, dpmemory=32, threshold=_abi.IMPOSSIBLY_LOW_SCORE, qid="qy"):
+    """Optimal_find_path over a region of the rectangle (--refine region's call)."""
+    lib = load()
+    a = _abi.Alignment()
+    ok = lib.oracle_find_path_region(model, params, q, len(q), t, len(t), _abi.Region(*region), dpmemory, threshold,
+                                     None, a)
     if not ok:
         return None
     d = alignment_to_dict(model, a, lib.oracle_alignment_format, qid, len(q), len(t))

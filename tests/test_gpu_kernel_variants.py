@@ -199,3 +199,39 @@ def test_c5_protein2genome_against_a_10mb_contig(eng):
     many = eng.find_path(model, [(p, contig) for p in proteins] * 17, dpmemory=32)
     for k, a in enumerate(many):
         assert a.as_dict() == alns[k % 16].as_dict(), k
+
+
+@pytest.mark.parametrize("model_type,dpm", [("est2genome", 32), ("est2genome", 0), ("affine:local", 1), ("protein2genome", 32)])
+def test_find_path_over_regions_of_resident_pairs(eng, model_type, dpm):
+    """c4gpu_batch_run_regions: Optimal_find_path with a region argument (what --refine region asks for: the heuristic
+    alignment's box grown by 32) for every pair of a resident batch in one go, against the oracle's region form."""
+    import zlib
+    rng = random.Random(zlib.crc32(model_type.encode()) + dpm)
+    model = ex.Model(model_type)
+    pairs = []
+    for k in range(6):
+        if model_type.startswith("protein"):
+            aa = "ARNDCQEGHILKMFPSTWYV"
+            q = _rand(rng, 150 + 20 * k, aa)
+            coding = "".join(rng.choice(CODON[x]) for x in _mutate(rng, q, 0.05, aa))
+            c = len(coding) // 2
+            t = _rand(rng, 900) + coding[:c] + "GT" + _rand(rng, 300) + "AG" + coding[c:] + _rand(rng, 700)
+        else:
+            pairs_k = _seeded_pairs(rng, model_type, 500 + 40 * k, 6000, 1)[0]
+            q, t = pairs_k
+        pairs.append((q, t))
+    full = eng.find_path(model, pairs, dpmemory=dpm)
+    regions = []
+    for (q, t), a in zip(pairs, full):
+        qs, ts, ql, tl = a.region
+        r0, r1 = max(0, qs - 32), max(0, ts - 32)
+        regions.append((r0, r1, min(len(q), qs + ql + 32) - r0, min(len(t), ts + tl + 32) - r1))
+    regions[1] = (0, 0, len(pairs[1][0]), len(pairs[1][1]) // 3)           # a region that cuts the gene
+    batch = ex.ResidentBatch(eng, model, pairs)
+    batch.run_regions(regions, dpmemory=dpm, threshold=0)
+    got = [batch.alignment(i) for i in range(len(pairs))]
+    batch.close()
+    for (q, t), r, a in zip(pairs, regions, got):
+        exp = oracle_lib.find_path_region(model.c, model.params, q.encode(), t.encode(), r, dpmemory=dpm, threshold=0)
+        assert (a.as_dict() if a else None) == exp, r
+    assert got[0].as_dict() == full[0].as_dict()                           # the box holds the whole alignment

@@ -236,3 +236,57 @@ def test_c1_protein_heuristic_run_passes_through_untouched(tmp_path):
     assert gpu_out == ref_out
     assert ref_out.count("vulgar:") >= 20
     assert "c4gpu:" not in gpu_err, gpu_err[-1500:]
+
+
+@pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
+                    reason="reference binaries are built in the build container (make -C integration)")
+@pytest.mark.parametrize("model,extra,batch", [
+    ("est2genome", [], "4096"), ("est2genome", ["-S", "no"], "4096"), ("est2genome", ["--refine", "region"], "4096"),
+    ("est2genome", ["--refine", "region", "-S", "no"], "3"), ("est2genome", ["--refine", "full", "--bestn", "1"], "4096"),
+    ("affine:local", [], "4096"), ("protein2dna", ["-S", "no"], "4096"), ("protein2genome", ["--refine", "region"], "4096"),
+    ("est2genome", ["--percent", "50"], "2"),
+])
+def test_heuristic_bsdp_mode_runs_its_sub_dps_in_device_batches(tmp_path, model, extra, batch):
+    """The default heuristic mode with --gappedextension no (BSDP): every collected pair's candidate sub-alignment
+    regions (terminals, joins, span sources and destinations, their paths) go to the MI355X in a few launches per flush
+    (integration/c4gpu_bsdp.c) and, with --refine, so does each pair's first refinement; the reference's own BSDP then
+    confirms against those results.  Byte-identical output, and the share of its DP calls that the batches answered."""
+    import re
+    import test_integration_bsdp_host as hb
+    ref, gpu, err = hb.run_pair(tmp_path, model, extra, {"C4GPU_BATCH": batch}, n=8, seed=11)
+    assert gpu == ref
+    assert ref.count(b"vulgar:") >= 4
+    assert "stay on the CPU" not in err and "stay one call at a time" not in err, err[-1500:]
+    s_ok, s_all, p_ok, p_all = hb.served(err)
+    assert s_all > 20 and p_all > 10
+    if "-S" in extra:                                     # nothing is ever blocked: every call comes from a batch
+        assert (s_ok, p_ok) == (s_all, p_all), err[-600:]
+    else:
+        assert s_ok + p_ok >= 0.7 * (s_all + p_all), err[-600:]
+    if "--refine" in extra:
+        m = re.search(r"(\d+) of (\d+) refinements from refinement batches", err)
+        assert m and int(m.group(2)) >= 4 and int(m.group(1)) >= int(m.group(2)) - 3, err[-800:]
+
+
+@pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
+                    reason="reference binaries are built in the build container (make -C integration)")
+def test_heuristic_bsdp_on_north_star_shaped_input(tmp_path):
+    """C4-shaped input (1 kb cDNAs against 100 kb genomic windows, all against all, both strands) through the heuristic
+    BSDP mode with --refine region: byte-identical, >= 95 % of the sub-DP calls of a run without sub-optimal rounds
+    answered by device batches."""
+    import re
+    import test_integration_bsdp_host as hb
+    from exonerate_amd import workloads
+    pairs = workloads.est2genome_pairs(6, 1000, 100000)
+    qf, tf = str(tmp_path / "q.fa"), str(tmp_path / "t.fa")
+    _fasta(qf, [("q%d" % k, q.decode()) for k, (q, t) in enumerate(pairs)])
+    _fasta(tf, [("t%d" % k, t.decode()) for k, (q, t) in enumerate(pairs)])
+    args = ["-m", "est2genome", "--gappedextension", "no", "--refine", "region", "-S", "no", "--showalignment", "yes",
+            "--showvulgar", "yes", "-V", "0", qf, tf]
+    ref_out, _ = _run(CPU_EXE, args)
+    gpu_out, gpu_err = _run(GPU_EXE, args, {"C4GPU_VERBOSE": "1"})
+    assert gpu_out == ref_out and ref_out.count("vulgar:") >= 6
+    s_ok, s_all, p_ok, p_all = hb.served(gpu_err)
+    assert s_ok + p_ok >= 0.95 * (s_all + p_all), gpu_err[-800:]
+    m = re.search(r"(\d+) of (\d+) refinements from refinement batches", gpu_err)
+    assert m and int(m.group(1)) == int(m.group(2)) >= 6, gpu_err[-800:]
