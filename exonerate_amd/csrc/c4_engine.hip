@@ -413,6 +413,14 @@ struct JobOut {
     std::vector<int> checkpoints; // CKPT + dump_checkpoints
 };
 
+// The windowed region pass (c4_viterbi_kernel.h, SEED): what a launch needs to know about the column dumps.
+struct SeedPlan {
+    int mode = 0;                  // 1: the score pass writes dumps; 2: the region windows start from them
+    int kshift = 11;               // a dump every 1 << kshift columns
+    std::vector<long long> off;    // per spec: mode 1 (out) start of the job's dumps; mode 2 (in) the dump to start from, -1 = none
+    std::vector<int> rows;         // per spec, mode 2: rows of a dumped column (Q + 1 of the score pass)
+};
+
 struct Engine {
     c4gpu_ctx *ctx;
     const c4gpu_model *model;
@@ -433,7 +441,7 @@ struct Engine {
     DevBuf<uint8_t> d_ops;
     DevBuf<int> d_bnd, d_ckpt, d_ckpt_dump, d_queue;
     DevBuf<uint32_t> d_tb;
-    DevBuf<int> d_sub_t, d_sub_q, d_sub_colptr, d_span;
+    DevBuf<int> d_sub_t, d_sub_q, d_sub_colptr, d_span, d_seed;
     // reusable host staging of run_impl (a sub-alignment launch lists ~10^5 jobs: fresh vectors of that size
     // are page-faulted in on every call)
     std::vector<int> h_order;
@@ -500,8 +508,10 @@ struct Engine {
     // Runs `specs` in `mode`; out[i] corresponds to specs[i].  Calls whose region holds blocked cells
     // (SubOpt_Index_create returns an index, subopt.c:250-266) go to the kernels compiled with blocking, the
     // others (it returns NULL) to the plain ones.
-    int run(const ResidentSeqs &seqs, int mode, bool cont, const std::vector<JobSpec> &specs, std::vector<JobOut> &out) {
+    int run(const ResidentSeqs &seqs, int mode, bool cont, const std::vector<JobSpec> &specs, std::vector<JobOut> &out,
+            SeedPlan *seed = nullptr) {
         const int n = (int)specs.size();
+        if (seed) return run_impl(seqs, mode, cont, specs, out, nullptr, seed);
         for (int i = 0; i < n; i++)
             if (specs[i].span_in || specs[i].span_out) return run_impl(seqs, mode, cont, specs, out, nullptr);
         std::vector<int> plain, blocked;
@@ -535,7 +545,7 @@ struct Engine {
     }
 
     int run_impl(const ResidentSeqs &seqs, int mode, bool cont, const std::vector<JobSpec> &specs,
-                 std::vector<JobOut> &out, const std::vector<RegionPoints> *pts) {
+                 std::vector<JobOut> &out, const std::vector<RegionPoints> *pts, SeedPlan *seed = nullptr) {
         static const bool trace = getenv("C4GPU_TRACE") != nullptr;
         const auto t_begin = std::chrono::steady_clock::now();
         struct Trace {
@@ -573,7 +583,10 @@ struct Engine {
         // whole-rectangle passes whose query spans several 64*R-row strips run on 4 cooperating waves per
         // job (strip carry rows stay in LDS instead of HBM); C4GPU_MW=0 forces the one-wave kernels
         static const int mw_env = getenv("C4GPU_MW") ? atoi(getenv("C4GPU_MW")) : 1;
-        if (mw_env && !cont && (mode == MODE_SCORE || mode == MODE_REGION)) {
+        if (seed) {
+            ki = get_kernel_mw(family, mode, true, mode == MODE_REGION, 4, false, seed->mode);
+            if (!ki || !use_local || (mode == MODE_REGION && !pack)) { c4h::set_error("no seeded kernel for this launch"); return -1; }
+        } else if (mw_env && !cont && (mode == MODE_SCORE || mode == MODE_REGION)) {
             const KernelInfo *kmw = get_kernel_mw(family, mode, use_local, pack, 4, pts != nullptr);
             if (kmw) {
                 long long strips = 0;
@@ -603,7 +616,8 @@ struct Engine {
         std::vector<DevJob> &jobs = h_jobs;
         jobs.resize(n);
         long long ops_total = 0, vsa_total = 0, dump_total = 0, max_T = 0, max_tb = 0, max_ckpt = 0, total_cells = 0;
-        long long max_runs = 0, sub_cols = 0, span_total = 0;
+        long long max_runs = 0, sub_cols = 0, span_total = 0, seed_total = 0;
+        if (seed && seed->mode == 1) seed->off.assign(n, -1);
         std::vector<int> sub_t, sub_q;
         for (int x = 0; x < n; x++) {
             const JobSpec &s = specs[order[x]];
@@ -618,6 +632,18 @@ struct Engine {
                 j.sub_off = sub_cols; j.sub_pt_off = (int)sub_t.size(); j.sub_pt_n = (int)rp.size();
                 sub_cols += s.region.target_length + 2;
                 for (const auto &p : rp) { sub_t.push_back(p.first); sub_q.push_back(p.second); }
+            }
+            j.seed_off = -1;
+            if (seed) {
+                j.seed_kshift = seed->kshift;
+                if (seed->mode == 1) {            // dumps d = 1 .. T >> kshift, two columns of Q + 1 rows each
+                    j.seed_off = seed_total; j.seed_rows = s.region.query_length + 1;
+                    seed->off[order[x]] = seed_total;
+                    seed_total += (long long)(s.region.target_length >> seed->kshift) * 2 * (s.region.query_length + 1) *
+                                  ki->n_states * (ki->cs_dump);
+                } else {
+                    j.seed_off = seed->off[order[x]]; j.seed_rows = seed->rows[order[x]];
+                }
             }
             j.pair = s.pair; j.q0 = s.region.query_start; j.t0 = s.region.target_start;
             j.Q = s.region.query_length; j.T = s.region.target_length;
@@ -698,6 +724,11 @@ struct Engine {
                                    d_sub_t.p, d_sub_q.p, d_sub_colptr.p);
                 HIP_OK(hipGetLastError());
                 a.seqs.sub_colptr = d_sub_colptr.p; a.seqs.sub_rows = d_sub_q.p;
+            }
+            a.seqs.seed = nullptr;
+            if (seed) {
+                if (seed->mode == 1 && d_seed.alloc((size_t)std::max<long long>(seed_total, 1))) return -1;
+                a.seqs.seed = d_seed.p;
             }
             a.vsas = d_vsa.p; a.ops = nullptr; a.queue = d_queue.p; a.grid = (int)grid; a.stream = s;
             a.scratch.bnd = d_bnd.p; a.scratch.bnd_stride = bnd_per_wave; a.scratch.carry = carry_T ? 1 : 0;
@@ -844,6 +875,79 @@ int sequential_reduced_path(Engine &eng, const ResidentSeqs &seqs, int pair, int
     return 0;
 }
 
+// FIND_REGION of whole rectangles in two passes (c4_viterbi_kernel.h, SEED): a score pass that also dumps the DP state
+// every K columns, then region-start payload passes over windows of one dump interval each, walking left from the end
+// cell until the payload is a real start.  Scores, end cells and starts are those of the one-pass kernel (every
+// window cell is computed from the whole-rectangle pass's own values); the payload work shrinks from the whole target
+// to the alignment's extent.  out[x] for pairs[x]: score, qe, te always; qs, ts where the score reaches thr(pair).
+template <class Thr>
+int windowed_region_pass(Engine &eng, const ResidentSeqs &seqs, const std::vector<int> &pairs,
+                         const std::vector<PairPlan> &plan, Thr thr, int kshift, std::vector<DevResult> &out) {
+    const int n = (int)pairs.size();
+    const KernelInfo *kw = get_kernel_mw(eng.family, MODE_REGION, true, true, 4, false, 2);
+    const long long seedw = (long long)kw->n_states * kw->cs_dump;
+    auto nbits = [](int v) { int b = 0; while ((1LL << b) <= v) b++; return b; };
+    std::vector<JobSpec> specs(n);
+    std::vector<JobOut> outs;
+    for (int x = 0; x < n; x++) { specs[x].pair = pairs[x]; specs[x].region = plan[pairs[x]].ar; }
+    SeedPlan sp1;
+    sp1.mode = 1; sp1.kshift = kshift;
+    if (eng.run(seqs, MODE_SCORE, false, specs, outs, &sp1)) return -1;
+    out.assign(n, DevResult());
+    struct Hop { int x, rows, endcol, fstate, d; };
+    std::vector<Hop> hops;
+    for (int x = 0; x < n; x++) {
+        out[x] = outs[x].res;
+        out[x].qs = out[x].ts = 0;
+        if (!outs[x].res.end_set || outs[x].res.score < thr(pairs[x])) continue;
+        hops.push_back(Hop{x, outs[x].res.qe, outs[x].res.te, eng.model->end_state, (outs[x].res.te - 1) >> kshift});
+    }
+    int round = 0;
+    while (!hops.empty()) {
+        std::vector<JobSpec> hs(hops.size());
+        SeedPlan sp2;
+        sp2.mode = 2; sp2.kshift = kshift;
+        sp2.off.resize(hops.size()); sp2.rows.resize(hops.size());
+        std::vector<int> t0w(hops.size());
+        for (size_t h = 0; h < hops.size(); h++) {
+            const Hop &hp = hops[h];
+            const c4gpu_region &ar = plan[pairs[hp.x]].ar;
+            t0w[h] = hp.d >= 1 ? (hp.d << kshift) - 1 : 0;              // window column 0 = lattice column t0w
+            hs[h].pair = pairs[hp.x];
+            hs[h].region = c4gpu_region{ar.query_start, ar.target_start + t0w[h], hp.rows, hp.endcol - t0w[h]};
+            hs[h].final_state = hp.fstate;
+            sp2.rows[h] = ar.query_length + 1;
+            sp2.off[h] = hp.d >= 1 ? sp1.off[hp.x] + (long long)(hp.d - 1) * 2 * (ar.query_length + 1) * seedw : -1;
+        }
+        if (eng.run(seqs, MODE_REGION, false, hs, outs, &sp2)) return -1;
+        std::vector<Hop> next;
+        for (size_t h = 0; h < hops.size(); h++) {
+            const Hop &hp = hops[h];
+            const DevResult &r = outs[h].res;
+            if (!r.end_set || (round == 0 && r.score != out[hp.x].score)) {
+                c4h::set_error("windowed region pass: a window's corner cell differs from the score pass");
+                return -1;
+            }
+            const int payload = r.pad;
+            if (payload >= 0) {
+                const int tshift = nbits(hs[h].region.target_length);
+                out[hp.x].qs = payload >> tshift;
+                out[hp.x].ts = (payload & ((1 << tshift) - 1)) + t0w[h];
+            } else {                                                    // entered through the dump: identity of the cell
+                if (hp.d < 1) { c4h::set_error("windowed region pass: dump identity without a dump"); return -1; }
+                const int v = -payload - 1, jc = v & 1, rest = v >> 1;
+                next.push_back(Hop{hp.x, rest / kw->n_states, t0w[h] + jc, rest % kw->n_states, hp.d - 1});
+            }
+        }
+        hops.swap(next);
+        round++;
+    }
+    if (getenv("C4GPU_TRACE"))
+        fprintf(stderr, "c4gpu trace: windowed region pass: %d pairs, dumps every %d columns, %d window launches\n", n,
+                1 << kshift, round);
+    return 0;
+}
+
 // subs (may be NULL): per-pair SubOpt, the `subopt` argument the reference hands to every Viterbi_calculate of
 // the path (optimal.c:368-413); active (may be NULL): pairs to run, the others get no alignment.
 // initial (may be NULL): the `region` argument of each pair's Optimal_find_path (default: the whole rectangle) — what
@@ -889,6 +993,30 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
     }
     const size_t step1_total = region_pairs.size();
     double &hit_rate = eng.ctx->hit_rate[subs ? 1 : 0];
+    // long targets under a local model, nothing blocked: the two-pass (windowed) form of the region pass
+    std::vector<std::pair<int, DevResult>> region_done;
+    {
+        static const int kshift_env = getenv("C4GPU_SEED_KSHIFT") ? atoi(getenv("C4GPU_SEED_KSHIFT")) : 11;
+        const int kshift = std::max(2, std::min(kshift_env, 20));
+        const bool off = getenv("C4GPU_WINDOWED") && atoi(getenv("C4GPU_WINDOWED")) == 0;
+        const KernelInfo *k1 = get_kernel_mw(eng.family, MODE_SCORE, true, false, 4, false, 1);
+        const KernelInfo *k2 = get_kernel_mw(eng.family, MODE_REGION, true, true, 4, false, 2);
+        if (!off && !subs && eng.local && eng.local_exact && k1 && k2 && !(getenv("C4GPU_PACK") && atoi(getenv("C4GPU_PACK")) == 0)) {
+            std::vector<int> win_pairs, rest;
+            for (int i : region_pairs) {
+                const c4gpu_region &ar = plan[i].ar;
+                const bool rows_ok = ar.query_length + 1 > 2 * 64 * k2->R;       // the cooperating-wave kernels' domain
+                if (rows_ok && ar.target_length >= (4 << kshift) && ar.query_length < (1 << 20)) win_pairs.push_back(i);
+                else rest.push_back(i);
+            }
+            if (!win_pairs.empty()) {
+                std::vector<DevResult> wres;
+                if (windowed_region_pass(eng, seqs, win_pairs, plan, thr, kshift, wres)) return -1;
+                for (size_t x = 0; x < win_pairs.size(); x++) region_done.emplace_back(win_pairs[x], wres[x]);
+                region_pairs.swap(rest);
+            }
+        }
+    }
     // A pair whose best score is below the threshold ends here (optimal.c:144-145).  The score alone costs
     // 0.64 of a region pass (no region-start payload), so where few pairs reach the threshold — all-vs-all
     // runs, the last round of the sub-optimal loop — a FIND_SCORE pass goes first and only the survivors get
@@ -934,10 +1062,11 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
     specs.clear();
     for (int i : region_pairs) { JobSpec s; s.pair = i; s.region = plan[i].ar; specs.push_back(s); }
     if (eng.run(seqs, MODE_REGION, false, specs, outs)) return -1;
-    for (size_t x = 0; x < region_pairs.size(); x++) {
-        PairPlan &p = plan[region_pairs[x]];
-        const DevResult &r = outs[x].res;
-        if (r.score < thr(region_pairs[x])) { p.active = false; continue; }
+    for (size_t x = 0; x < region_pairs.size(); x++) region_done.emplace_back(region_pairs[x], outs[x].res);
+    for (const auto &pr : region_done) {
+        PairPlan &p = plan[pr.first];
+        const DevResult &r = pr.second;
+        if (r.score < thr(pr.first)) { p.active = false; continue; }
         p.region_score = r.score;
         // Viterbi_Data_finalise, viterbi.c:633-653 (curr_*_start are relative to the region the pass ran over)
         if (m->start_scope != C4GPU_SCOPE_QUERY) p.ar.query_start += r.qs;
@@ -947,7 +1076,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
     }
     if (step1_total >= 64 && threshold > C4GPU_IMPOSSIBLY_LOW_SCORE) {
         size_t hits = 0;
-        for (int i : region_pairs) hits += plan[i].active ? 1 : 0;
+        for (const auto &pr : region_done) hits += plan[pr.first].active ? 1 : 0;
         const double rate = (double)hits / (double)step1_total;
         hit_rate = hit_rate < 0 ? rate : 0.5 * hit_rate + 0.5 * rate;
     }

@@ -44,6 +44,7 @@ struct KernelInfo {
     int bnd;                  // ints per column of the strip carry row
     int n_states, max_at;
     int waves;                // waves per job (workgroup = 64 * waves threads)
+    int cs_dump;              // ints per state in a dumped column (score + shadow-like slots), SEED kernels
 };
 
 // family x mode x continuation x local-scope specialisation; NULL launch = not compiled
@@ -53,7 +54,9 @@ const KernelInfo *get_kernel(int family, int mode, bool cont, bool local, bool p
                              int span = 0);
 // multi-wave kernels (`waves` = 4 or 8 cooperating waves per job) for FIND_SCORE / FIND_REGION without
 // continuation
-const KernelInfo *get_kernel_mw(int family, int mode, bool local, bool pack, int waves = 4, bool sub = false);
+// seed: 0, or the two halves of the windowed region pass (1 = score pass that dumps columns, 2 = region pass that
+// starts from a dump and reports its corner cell); local, 4 waves only
+const KernelInfo *get_kernel_mw(int family, int mode, bool local, bool pack, int waves = 4, bool sub = false, int seed = 0);
 
 #define C4K_DEFINE_KERNEL_SPAN(SYMBOL, M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV, SPANV)                                          \
     static hipError_t SYMBOL##_launch(const LaunchArgs &a) {                                               \
@@ -71,30 +74,33 @@ const KernelInfo *get_kernel_mw(int family, int mode, bool local, bool pack, int
                                       WaveDP<M, RVAL, MODE, CONT, LOCAL, PACK>::BND,                             \
                                       M::NS,                                                               \
                                       M::MAXAT,                                                            \
-                                      1};                                                           \
+                                      1, 0};                                                        \
         return &ki;                                                                                        \
     }
 
 #define C4K_DEFINE_KERNEL(SYMBOL, M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV) \
     C4K_DEFINE_KERNEL_SPAN(SYMBOL, M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV, 0)
 
-#define C4K_DEFINE_KERNEL_MW(SYMBOL, M, RVAL, MODE, LOCAL, PACK, NWV, WPE, SUBV)                                 \
+#define C4K_DEFINE_KERNEL_MW(SYMBOL, M, RVAL, MODE, LOCAL, PACK, NWV, WPE, SUBV) \
+    C4K_DEFINE_KERNEL_MW_SEED(SYMBOL, M, RVAL, MODE, LOCAL, PACK, NWV, WPE, SUBV, 0)
+
+#define C4K_DEFINE_KERNEL_MW_SEED(SYMBOL, M, RVAL, MODE, LOCAL, PACK, NWV, WPE, SUBV, SEEDV)                     \
     static hipError_t SYMBOL##_launch(const LaunchArgs &a) {                                               \
-        hipLaunchKernelGGL((viterbi_kernel_mw<M, RVAL, MODE, LOCAL, PACK, NWV, WPE, SUBV>), dim3(a.grid),          \
+        hipLaunchKernelGGL((viterbi_kernel_mw<M, RVAL, MODE, LOCAL, PACK, NWV, WPE, SUBV, SEEDV>), dim3(a.grid),   \
                            dim3(64 * NWV), 0, a.stream, a.kp, a.seqs, a.jobs, a.n_jobs, a.results,          \
                            a.scratch, a.queue);                                                            \
         return hipGetLastError();                                                                          \
     }                                                                                                      \
     const KernelInfo *SYMBOL() {                                                                           \
         static const KernelInfo ki = {SYMBOL##_launch,                                                     \
-                                      (const void *)viterbi_kernel_mw<M, RVAL, MODE, LOCAL, PACK, NWV, WPE, SUBV>, \
+                                      (const void *)viterbi_kernel_mw<M, RVAL, MODE, LOCAL, PACK, NWV, WPE, SUBV, SEEDV>, \
                                       #SYMBOL,                                                             \
                                       RVAL,                                                                \
                                       WaveDP<M, RVAL, MODE, false, LOCAL, PACK>::CS,                       \
                                       WaveDP<M, RVAL, MODE, false, LOCAL, PACK>::BND,                      \
                                       M::NS,                                                               \
                                       M::MAXAT,                                                            \
-                                      NWV};                                                                \
+                                      NWV, 1 + WaveDP<M, RVAL, MODE, false, LOCAL, PACK>::XD};             \
         return &ki;                                                                                        \
     }
 

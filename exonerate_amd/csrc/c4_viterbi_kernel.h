@@ -65,6 +65,8 @@ struct DevSeqs {
     // span models: start cells in / END cells out, [(i * (T+1)) + j][1 + designations] per job (DevJob::span_off)
     const int *span_in;
     int *span_out;
+    // SEED kernels: column dumps of the score pass, read back by the windowed region pass (see WaveDP)
+    int *seed;
 };
 struct DevJob {
     int pair, q0, t0, Q, T;
@@ -77,6 +79,8 @@ struct DevJob {
     long long sub_off;                   // SUB kernels: this job's column pointers start at sub_colptr + sub_off
     int sub_pt_off, sub_pt_n;            // its points in the launch's point arrays (colptr construction)
     long long span_off;                  // SPAN kernels: this job's matrix starts at span_in/span_out + span_off
+    long long seed_off;                  // SEED 1: this job's dumps start at seed + seed_off; SEED 2: the dump to start from (-1: none)
+    int seed_kshift, seed_rows;          // dump spacing = 1 << seed_kshift columns; rows per dumped column (Q + 1 of the score pass)
 };
 struct DevResult {
     int score, qs, ts, qe, te, end_set, last_srp, n_ops, flags, n_vsa, cell_size, pad;
@@ -176,7 +180,16 @@ __device__ __forceinline__ bool scope_ok(int scope, bool at_q, bool at_t) {
 // SPAN: BSDP's span models exchange cells with the host through the model's cell_start_func / cell_end_func
 // (viterbi.c:728-741,793-799): 1 = transitions out of START read the start cell of their position from a
 // matrix (score and shadow slots), 2 = every cell that reaches END is copied out to a matrix.
-template <class M, int R, int MODE, bool CONT, bool LOCAL, bool PACK = false, bool SUB = false, int SPAN = 0>
+// SEED: FIND_REGION in two passes for long targets.  The payload that makes FIND_REGION dearer than FIND_SCORE (the
+// region start carried beside every score) only matters along the one path that ends in the best cell, which spans a
+// small part of a long target.  SEED = 1 (FIND_SCORE): besides the score and the end cell, every lane copies out the
+// cells of its rows at columns d*K - 1 and d*K (d = 1, 2, ..): the complete DP state at those columns.  SEED = 2
+// (FIND_REGION): the pass starts from such a dump instead of from column 0 — cells of the first two columns are
+// loaded, not computed, so every later cell, winner and tie-break is that of the whole-rectangle pass — and ends in
+// the corner cell, whose region-start payload is reported.  A payload that entered through the dump carries the
+// identity of its entry cell (row, state, column) instead of a start: the host then walks one dump further left
+// (find_path_batch), so the payload work is done over the alignment's own extent only.
+template <class M, int R, int MODE, bool CONT, bool LOCAL, bool PACK = false, bool SUB = false, int SPAN = 0, int SEED = 0>
 struct WaveDP {
     using F = Facts<M>;
     static constexpr int NDES = M::NDES;
@@ -197,6 +210,11 @@ struct WaveDP {
     // sub-optimal blocking in the local score / region passes: see eval_cell
     static constexpr bool BLOCK_AS_LOW = LOCAL && (MODE == MODE_SCORE || MODE == MODE_REGION) && F::match_states_have_start();
     static constexpr int BND = NEXP * (1 + XS);         // ints per column in the strip carry row
+    static constexpr int XD = NDES + NAUX;              // shadow-like slots of a dumped cell
+    static constexpr int SEEDW = M::NS * (1 + XD);      // ints per row of a dumped column
+    static_assert(SEED == 0 || (SEED == 1 && MODE == MODE_SCORE) || (SEED == 2 && MODE == MODE_REGION && PACK),
+                  "dumps are written by the score pass and read by the packed region pass");
+    static_assert(SEED == 0 || (!CONT && !SUB && SPAN == 0), "seeded passes: plain whole-rectangle kernels only");
     using C = Cell<M, X>;
 
     // Is slot e of state s ever read?  A designation slot only matters while a path to a consuming
@@ -442,6 +460,28 @@ struct WaveDP {
         // whether this cell can be the end cell (viterbi.c:778-791): the comparison with the best so far is
         // done once per step over the lane's R cells (step, below)
         end_ok = active & set[M::END];
+        // SEED 2: the cells of the window's first two columns are the whole-rectangle pass's, read from its dump; their
+        // region-start payload is the cell's own identity.  Only in the steps that hold those columns (wave-uniform branch).
+        if constexpr (SEED == 2 && !JINT) {
+            const bool sd = seeded & active & (j >= 0) & (j <= 1);
+            if (__builtin_amdgcn_ballot_w64(sd)) {
+                const int ic = i < 0 ? 0 : (i > Q ? Q : i), jc = j < 0 ? 0 : (j > 1 ? 1 : j);
+                const int *p = seed_rd + ((long long)jc * seed_rows + ic) * SEEDW;
+                static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                    const int v = p[S * (1 + XD)], old_sc = c.sc[S];
+                    c.sc[S] = sd ? v : old_sc;
+                    static_for<XD>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
+                        if constexpr (slot_live(S, E)) {
+                            const int ve = p[S * (1 + XD) + 1 + E], old_ex = c.ex[S][E];
+                            c.ex[S][E] = sd ? ve : old_ex;
+                        }
+                    });
+                    const int ident = -(1 + (((ic * M::NS) + S) * 2 + jc)), old_rs = c.ex[S][RSQ];
+                    c.ex[S][RSQ] = sd ? ident : old_rs;
+                });
+                end_ok = end_ok & !sd;
+            }
+        }
     }
 
     // ---- cross-lane / cross-strip exchange ----------------------------------------------------------------
@@ -502,6 +542,10 @@ struct WaveDP {
     // models, the splice-site scores at the column the (0,2) transitions leave from.  Requested one step
     // ahead from clamped (always valid) addresses; a lane outside the rectangle gets values it never
     // uses, because every transition that would read them is masked invalid.
+    int *seed_wr;               // SEED 1: this job's dumps
+    const int *seed_rd;         // SEED 2: the two dumped columns this job starts from
+    bool seeded;
+    int seed_rows, seed_kshift, seed_next;      // seed_next: the next column d*K - 1 this lane will cross
     int nx_tcode, nx_sp[4], nx_tn4, tlast;
     const uint16_t *tn4p;
     const int *span_in_p;               // SPAN == 1: this job's start cells
@@ -697,6 +741,44 @@ struct WaveDP {
                 });
             }
         }
+        // SEED 1: columns d*K - 1 and d*K of our rows go to the job's dumps (each lane at its own step: rare, divergent)
+        if constexpr (SEED == 1) {
+            const bool hit_b = jact & (j == seed_next), hit_a = jact & (j == seed_next + 1);
+            if (hit_a | hit_b) {
+                const int d = (j + (hit_b ? 1 : 0)) >> seed_kshift;              // 1-based dump index
+                if ((d << seed_kshift) <= T) {
+                    static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                        const int i = i0 + RR;
+                        if (i <= Q) {
+                            int *p = seed_wr + (((long long)(d - 1) * 2 + (hit_a ? 1 : 0)) * seed_rows + i) * SEEDW;
+                            static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                                p[S * (1 + XD)] = col[PH][RR].sc[S];
+                                static_for<XD>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
+                                    p[S * (1 + XD) + 1 + E] = slot_live(S, E) ? col[PH][RR].ex[S][E] : 0;
+                                });
+                            });
+                        }
+                    });
+                }
+                if (hit_a) seed_next += 1 << seed_kshift;
+            }
+        }
+        // SEED 2: the corner cell (Q, T) of the window: score and region-start payload of the requested state
+        if constexpr (SEED == 2) {
+            if (jact && j == T) {
+                static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                    if (i0 + RR == Q) {
+                        static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                            if (final_state == S) {
+                                corner[0] = col[PH][RR].sc[S];
+                                corner[1] = col[PH][RR].ex[S][RSQ];
+                                corner_set = true;
+                            }
+                        });
+                    }
+                });
+            }
+        }
         // (7) checkpoint rows (Viterbi_Checkpoint_process, viterbi.c:605-631).  At checkpoint column c the
         // reference copies rows c, c-1, .. c-(MAXAT-1) and then stamps their SRP slots.  A column never
         // changes after it has been computed, so each of those rows is copied out at the step that
@@ -849,8 +931,11 @@ struct WaveDP {
             }
         }
         if constexpr (SUB) { sub_cp = seqs.sub_colptr + 2 * job.sub_off; sub_rows = seqs.sub_rows; }
-        first_state = job.first_state; final_state = M::END;
+        first_state = job.first_state; final_state = (SEED == 2) ? job.final_state : M::END;
         first_cell = job.first_cell;
+        seeded = false; seed_rows = job.seed_rows; seed_kshift = job.seed_kshift; seed_next = 0x7fffffff;
+        if constexpr (SEED == 1) seed_wr = seqs.seed + job.seed_off;
+        if constexpr (SEED == 2) { seeded = job.seed_off >= 0; seed_rd = seqs.seed + (seeded ? job.seed_off : 0); }
         min_intron = kp->min_intron; max_intron = kp->max_intron;
         intron_span = (unsigned)(max_intron - min_intron);
         start_scope = kp->start_scope; end_scope = kp->end_scope;
@@ -887,6 +972,7 @@ struct WaveDP {
                 });
             });
             strip_begin();
+            if constexpr (SEED == 1) seed_next = (1 << seed_kshift) - 1;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             carry_cols = carry_ok & (sb > 0);
             const int *bnd_in = (sb == 0) ? bnd : bnd + BND + (carry_ok ? (long long)((sb + 1) & 1) * (T + 1) * BND : 0);
@@ -1159,11 +1245,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
 // -------------------------------------------------------------------------------------------------------------
 // Kernel: NW cooperating waves per job (FIND_SCORE / FIND_REGION over whole rectangles).
 // -------------------------------------------------------------------------------------------------------------
-template <class M, int R, int MODE, bool LOCAL, bool PACK, int NW, int WPE, bool SUB = false>
+template <class M, int R, int MODE, bool LOCAL, bool PACK, int NW, int WPE, bool SUB = false, int SEED = 0>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
 void viterbi_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, int n_jobs, DevResult *results,
                        DevScratch scratch, int *queue) {
-    using DP = WaveDP<M, R, MODE, false, LOCAL, PACK, SUB>;
+    using DP = WaveDP<M, R, MODE, false, LOCAL, PACK, SUB, 0, SEED>;
+    __shared__ int corner_lds[3];
     __shared__ KParams kp_lds;
     __shared__ int next_job;
     __shared__ int rings[(NW > 1 ? NW - 1 : 1) * DP::RING * DP::BND];
@@ -1190,7 +1277,14 @@ void viterbi_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *jobs,
         dp.kp = &kp_lds;
         dp.lane = threadIdx.x & 63;
         dp.carry_ok = scratch.carry != 0;
+        if constexpr (SEED == 2) {
+            if (threadIdx.x == 0) corner_lds[2] = 0;
+            __syncthreads();
+        }
         dp.template run_mw<NW>(job, seqs, bnd, (typename DP::lds_int *)rings, wid);
+        if constexpr (SEED == 2) {
+            if (dp.corner_set) { corner_lds[0] = dp.corner[0]; corner_lds[1] = dp.corner[1]; corner_lds[2] = 1; }
+        }
         dp.reduce_best();
         if (dp.lane == 0) {
             wave_best[wid][0] = dp.best; wave_best[wid][1] = dp.best_i; wave_best[wid][2] = dp.best_j;
@@ -1214,6 +1308,11 @@ void viterbi_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *jobs,
             if constexpr (MODE == MODE_REGION) {
                 if constexpr (PACK) { res.qs = bqs >> job.tshift; res.ts = bqs & ((1 << job.tshift) - 1); }
                 else { res.qs = bqs; res.ts = bts; }
+            }
+            if constexpr (SEED == 2) {          // the window's corner cell: score, raw payload (start or entry-cell identity)
+                res.end_set = corner_lds[2]; res.score = corner_lds[0]; res.pad = corner_lds[1];
+                res.qe = job.Q; res.te = job.T;
+                res.flags = corner_lds[2] ? 0 : FLAG_NO_END;
             }
             results[jid] = res;
         }

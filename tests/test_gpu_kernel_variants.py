@@ -235,3 +235,53 @@ def test_find_path_over_regions_of_resident_pairs(eng, model_type, dpm):
         exp = oracle_lib.find_path_region(model.c, model.params, q.encode(), t.encode(), r, dpmemory=dpm, threshold=0)
         assert (a.as_dict() if a else None) == exp, r
     assert got[0].as_dict() == full[0].as_dict()                           # the box holds the whole alignment
+
+
+@pytest.mark.parametrize("kshift", ["3", "5", "7"])
+@pytest.mark.parametrize("model_type,qlen,tlen,dpm", [
+    ("est2genome", 600, 6000, 32), ("est2genome", 1300, 5000, 1), ("affine:local", 700, 2500, 1),
+    ("affine:local", 2100, 2300, 32), ("protein2dna", 300, 3000, 32), ("protein2genome", 330, 5000, 32),
+])
+def test_windowed_region_pass_matches_oracle(eng, monkeypatch, capfd, model_type, qlen, tlen, dpm, kshift):
+    """FIND_REGION in two passes (score pass that dumps the DP state every 2^kshift columns, region-start payload
+    passes over one dump interval at a time, walking left from the end cell): same scores, end cells and region starts
+    as the one-pass kernel — checked through the alignments, against the oracle, with tiny dump intervals so that a
+    path crosses many of them (and introns jump over dumped columns)."""
+    monkeypatch.setenv("C4GPU_SEED_KSHIFT", kshift)
+    monkeypatch.setenv("C4GPU_TRACE", "1")
+    import zlib
+    rng = random.Random(zlib.crc32(("%s %d %s" % (model_type, qlen, kshift)).encode()))
+    model = ex.Model(model_type)
+    pairs = []
+    for k in range(4):
+        if model_type.startswith("protein"):
+            aa = "ARNDCQEGHILKMFPSTWYV"
+            q = _rand(rng, qlen + 7 * k, aa)
+            coding = "".join(rng.choice(CODON[x]) for x in _mutate(rng, q, 0.05, aa))
+            if "genome" in model_type:
+                c1, c2 = len(coding) // 3, 2 * len(coding) // 3 + 1
+                coding = coding[:c1] + "GT" + _rand(rng, 150 + 40 * k) + "AG" + coding[c1:c2] + "GT" + _rand(rng, 700) + "AG" + coding[c2:]
+            t = _rand(rng, tlen // 3) + coding + _rand(rng, tlen // 2)
+        else:
+            q, t = _seeded_pairs(rng, model_type, qlen + 11 * k, tlen, 1)[0]
+        pairs.append((q, t))
+    pairs.append((pairs[0][0], _rand(rng, tlen)))                       # unrelated: a short alignment anywhere
+    alns = eng.find_path(model, pairs, dpmemory=dpm, threshold=20)
+    err = capfd.readouterr().err
+    assert "windowed region pass" in err, "these inputs no longer take the two-pass route:\n" + err[-800:]
+    for (q, t), a in zip(pairs, alns):
+        exp = oracle_lib.find_path(model.c, model.params, q.encode(), t.encode(), dpmemory=dpm, threshold=20)
+        assert (a.as_dict() if a else None) == exp
+
+
+def test_windowed_and_one_pass_region_agree_at_full_size(eng, monkeypatch):
+    """1 kb x 100 kb est2genome pairs of the north-star batch: the two-pass route (default) and the one-pass kernel
+    (C4GPU_WINDOWED=0) give identical alignments; pair 0 also against the oracle."""
+    model = ex.Model("est2genome")
+    pairs = workloads.est2genome_pairs(24, 1000, 100000, first=100)
+    two = eng.find_path(model, pairs, dpmemory=32)
+    monkeypatch.setenv("C4GPU_WINDOWED", "0")
+    one = eng.find_path(model, pairs, dpmemory=32)
+    assert [a.as_dict() for a in two] == [a.as_dict() for a in one]
+    q, t = pairs[0]
+    assert two[0].as_dict() == oracle_lib.find_path(model.c, model.params, q, t, dpmemory=32)

@@ -8,6 +8,7 @@ import pytest
 
 import exonerate_amd as ex
 import oracle_lib
+from golden_util import PARAM_VARIANTS, apply_flags
 
 pytestmark = pytest.mark.gpu
 
@@ -67,11 +68,17 @@ def _pairs(rng, mt):
 
 # C4_FUZZ_SEED / C4_FUZZ_REPS: longer one-off campaigns with other seeds (default: the 12 committed seeds)
 @pytest.mark.parametrize("seed", range(int(os.environ.get("C4_FUZZ_REPS", "3")) * 4))
-def test_library_fuzz(eng, seed):
+def test_library_fuzz(eng, seed, monkeypatch):
     rng = random.Random(int(os.environ.get("C4_FUZZ_SEED", "9000")) + seed)
+    if seed % 2:                    # every other seed: the two-pass region route with small dump intervals
+        monkeypatch.setenv("C4GPU_SEED_KSHIFT", str(3 + seed % 5))
     for _ in range(3):
         mt = rng.choice(MODELS)
-        model = ex.Model(mt)
+        # scoring parameters: the defaults, or one of the non-default sets the reference vectors were generated with
+        # (penalties, intron window, pam250 / identity matrices, rewards instead of penalties)
+        variant = rng.choice([None, None, "altparams", "tightintron", "invertedintron", "posgap"])
+        params = ex.default_params() if variant is None else apply_flags(ex.default_params(), PARAM_VARIANTS[variant])
+        model = ex.Model(mt, params=params)
         pairs = _pairs(rng, mt)
         dpm = rng.choice([0, 1, 32])
         thr = rng.choice([-987654321, 50, 200])
@@ -87,4 +94,4 @@ def test_library_fuzz(eng, seed):
             else:
                 exp = [d for d, _ in oracle_lib.find_paths_subopt(model.c, model.params, q.encode(), t.encode(),
                                                                   dpm, max(thr, 40), rounds)]
-            assert [a.as_dict() for a in alns] == exp, (mt, len(q), len(t), dpm, thr, rounds)
+            assert [a.as_dict() for a in alns] == exp, (mt, variant, len(q), len(t), dpm, thr, rounds)
