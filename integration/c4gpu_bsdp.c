@@ -1,6 +1,6 @@
 /* c4gpu_bsdp.c — the heuristic (BSDP) seam of the drop-in: speculative batch-confirm of the sub-alignment regions'
  * small DPs of MANY pairs in a few device launches.  Part of the exonerate-gpu shim (integration/Makefile), written
- * against the reference's own headers; INTEGRATION.md section 4.
+ * against the reference's own headers; INTEGRATION.md section 3.
  *
  * What the reference does (src/hub/gam.c:797-850, src/bsdp/{hpair,bsdp,sar}.c): per comparison it builds an HPair —
  * one BSDP node per HSP with a start and an end terminal region (SAR_Terminal), one edge per joinable HSP pair with a
