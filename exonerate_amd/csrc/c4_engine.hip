@@ -50,6 +50,9 @@ struct c4gpu_ctx {
     // (-1: not known yet): decides whether a score-only pass goes first (find_path_batch, step 1);
     // kept apart for first alignments [0] and the later rounds of the sub-optimal loop [1], which mostly fail
     double hit_rate[2] = {-1.0, -1.0};
+    // share of pairs whose region start the windowed region pass found within its hop budget in recent batches
+    // (-1: not known yet): alignments that span most of their target make the two-pass form the dearer one
+    double window_rate = -1.0;
 };
 
 namespace {
@@ -639,7 +642,7 @@ struct Engine {
                 if (seed->mode == 1) {            // dumps d = 1 .. T >> kshift, two columns of Q + 1 rows each
                     j.seed_off = seed_total; j.seed_rows = s.region.query_length + 1;
                     seed->off[order[x]] = seed_total;
-                    seed_total += (long long)(s.region.target_length >> seed->kshift) * 2 * (s.region.query_length + 1) *
+                    seed_total += (long long)(s.region.target_length >> seed->kshift) * ki->max_at * (s.region.query_length + 1) *
                                   ki->n_states * (ki->cs_dump);
                 } else {
                     j.seed_off = seed->off[order[x]]; j.seed_rows = seed->rows[order[x]];
@@ -886,6 +889,7 @@ int windowed_region_pass(Engine &eng, const ResidentSeqs &seqs, const std::vecto
     const int n = (int)pairs.size();
     const KernelInfo *kw = get_kernel_mw(eng.family, MODE_REGION, true, true, 4, false, 2);
     const long long seedw = (long long)kw->n_states * kw->cs_dump;
+    const int dc = kw->max_at;                           // dumped columns per dump (d*K - (dc - 1) .. d*K)
     auto nbits = [](int v) { int b = 0; while ((1LL << b) <= v) b++; return b; };
     std::vector<JobSpec> specs(n);
     std::vector<JobOut> outs;
@@ -903,7 +907,26 @@ int windowed_region_pass(Engine &eng, const ResidentSeqs &seqs, const std::vecto
         hops.push_back(Hop{x, outs[x].res.qe, outs[x].res.te, eng.model->end_state, (outs[x].res.te - 1) >> kshift});
     }
     int round = 0;
+    const size_t wanted = hops.size();
+    const int max_hops = getenv("C4GPU_WINDOW_HOPS") ? atoi(getenv("C4GPU_WINDOW_HOPS")) : 12;
     while (!hops.empty()) {
+        if (round >= max_hops) {
+            // the paths still open run back further than the hop budget: the one-pass kernel over their whole
+            // rectangles finishes them (same result: it is what the windows reproduce piece by piece)
+            std::vector<JobSpec> fs(hops.size());
+            for (size_t h = 0; h < hops.size(); h++) { fs[h].pair = pairs[hops[h].x]; fs[h].region = plan[pairs[hops[h].x]].ar; }
+            if (eng.run(seqs, MODE_REGION, false, fs, outs)) return -1;
+            for (size_t h = 0; h < hops.size(); h++) {
+                const DevResult &r = outs[h].res;
+                DevResult &o = out[hops[h].x];
+                if (r.score != o.score || r.qe != o.qe || r.te != o.te) {
+                    c4h::set_error("windowed region pass: the one-pass kernel disagrees with the score pass");
+                    return -1;
+                }
+                o.qs = r.qs; o.ts = r.ts;
+            }
+            break;
+        }
         std::vector<JobSpec> hs(hops.size());
         SeedPlan sp2;
         sp2.mode = 2; sp2.kshift = kshift;
@@ -912,12 +935,12 @@ int windowed_region_pass(Engine &eng, const ResidentSeqs &seqs, const std::vecto
         for (size_t h = 0; h < hops.size(); h++) {
             const Hop &hp = hops[h];
             const c4gpu_region &ar = plan[pairs[hp.x]].ar;
-            t0w[h] = hp.d >= 1 ? (hp.d << kshift) - 1 : 0;              // window column 0 = lattice column t0w
+            t0w[h] = hp.d >= 1 ? (hp.d << kshift) - (dc - 1) : 0;       // window column 0 = lattice column t0w
             hs[h].pair = pairs[hp.x];
             hs[h].region = c4gpu_region{ar.query_start, ar.target_start + t0w[h], hp.rows, hp.endcol - t0w[h]};
             hs[h].final_state = hp.fstate;
             sp2.rows[h] = ar.query_length + 1;
-            sp2.off[h] = hp.d >= 1 ? sp1.off[hp.x] + (long long)(hp.d - 1) * 2 * (ar.query_length + 1) * seedw : -1;
+            sp2.off[h] = hp.d >= 1 ? sp1.off[hp.x] + (long long)(hp.d - 1) * dc * (ar.query_length + 1) * seedw : -1;
         }
         if (eng.run(seqs, MODE_REGION, false, hs, outs, &sp2)) return -1;
         std::vector<Hop> next;
@@ -935,16 +958,20 @@ int windowed_region_pass(Engine &eng, const ResidentSeqs &seqs, const std::vecto
                 out[hp.x].ts = (payload & ((1 << tshift) - 1)) + t0w[h];
             } else {                                                    // entered through the dump: identity of the cell
                 if (hp.d < 1) { c4h::set_error("windowed region pass: dump identity without a dump"); return -1; }
-                const int v = -payload - 1, jc = v & 1, rest = v >> 1;
+                const int v = -payload - 1, jc = v % dc, rest = v / dc;
                 next.push_back(Hop{hp.x, rest / kw->n_states, t0w[h] + jc, rest % kw->n_states, hp.d - 1});
             }
         }
         hops.swap(next);
         round++;
     }
+    if (wanted >= 64) {
+        const double rate = 1.0 - (double)hops.size() / (double)wanted;
+        eng.ctx->window_rate = eng.ctx->window_rate < 0 ? rate : 0.5 * eng.ctx->window_rate + 0.5 * rate;
+    }
     if (getenv("C4GPU_TRACE"))
-        fprintf(stderr, "c4gpu trace: windowed region pass: %d pairs, dumps every %d columns, %d window launches\n", n,
-                1 << kshift, round);
+        fprintf(stderr, "c4gpu trace: windowed region pass: %d pairs, dumps every %d columns, %d window launches, %zu of %zu "
+                "paths left to the one-pass kernel\n", n, 1 << kshift, round, hops.size(), wanted);
     return 0;
 }
 
@@ -996,12 +1023,15 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
     // long targets under a local model, nothing blocked: the two-pass (windowed) form of the region pass
     std::vector<std::pair<int, DevResult>> region_done;
     {
-        static const int kshift_env = getenv("C4GPU_SEED_KSHIFT") ? atoi(getenv("C4GPU_SEED_KSHIFT")) : 11;
+        const int kshift_env = getenv("C4GPU_SEED_KSHIFT") ? atoi(getenv("C4GPU_SEED_KSHIFT")) : 12;
         const int kshift = std::max(2, std::min(kshift_env, 20));
         const bool off = getenv("C4GPU_WINDOWED") && atoi(getenv("C4GPU_WINDOWED")) == 0;
         const KernelInfo *k1 = get_kernel_mw(eng.family, MODE_SCORE, true, false, 4, false, 1);
         const KernelInfo *k2 = get_kernel_mw(eng.family, MODE_REGION, true, true, 4, false, 2);
-        if (!off && !subs && eng.local && eng.local_exact && k1 && k2 && !(getenv("C4GPU_PACK") && atoi(getenv("C4GPU_PACK")) == 0)) {
+        // where most alignments ran past the hop budget in the earlier batches of this context (chance alignments across
+        // whole windows: all-against-all without a threshold), the one-pass kernel is the cheaper form
+        const bool pays = eng.ctx->window_rate < 0 || eng.ctx->window_rate >= 0.5 || getenv("C4GPU_SEED_KSHIFT");
+        if (!off && pays && !subs && eng.local && eng.local_exact && k1 && k2 && !(getenv("C4GPU_PACK") && atoi(getenv("C4GPU_PACK")) == 0)) {
             std::vector<int> win_pairs, rest;
             for (int i : region_pairs) {
                 const c4gpu_region &ar = plan[i].ar;

@@ -183,8 +183,8 @@ __device__ __forceinline__ bool scope_ok(int scope, bool at_q, bool at_t) {
 // SEED: FIND_REGION in two passes for long targets.  The payload that makes FIND_REGION dearer than FIND_SCORE (the
 // region start carried beside every score) only matters along the one path that ends in the best cell, which spans a
 // small part of a long target.  SEED = 1 (FIND_SCORE): besides the score and the end cell, every lane copies out the
-// cells of its rows at columns d*K - 1 and d*K (d = 1, 2, ..): the complete DP state at those columns.  SEED = 2
-// (FIND_REGION): the pass starts from such a dump instead of from column 0 — cells of the first two columns are
+// cells of its rows at the max_target_advance columns that end in d*K (d = 1, 2, ..): all a later column can read.  SEED = 2
+// (FIND_REGION): the pass starts from such a dump instead of from column 0 — cells of those first columns are
 // loaded, not computed, so every later cell, winner and tie-break is that of the whole-rectangle pass — and ends in
 // the corner cell, whose region-start payload is reported.  A payload that entered through the dump carries the
 // identity of its entry cell (row, state, column) instead of a start: the host then walks one dump further left
@@ -212,6 +212,7 @@ struct WaveDP {
     static constexpr int BND = NEXP * (1 + XS);         // ints per column in the strip carry row
     static constexpr int XD = NDES + NAUX;              // shadow-like slots of a dumped cell
     static constexpr int SEEDW = M::NS * (1 + XD);      // ints per row of a dumped column
+    static constexpr int DC = M::MAXAT;                 // columns per dump: d*K - (DC - 1) .. d*K
     static_assert(SEED == 0 || (SEED == 1 && MODE == MODE_SCORE) || (SEED == 2 && MODE == MODE_REGION && PACK),
                   "dumps are written by the score pass and read by the packed region pass");
     static_assert(SEED == 0 || (!CONT && !SUB && SPAN == 0), "seeded passes: plain whole-rectangle kernels only");
@@ -463,9 +464,9 @@ struct WaveDP {
         // SEED 2: the cells of the window's first two columns are the whole-rectangle pass's, read from its dump; their
         // region-start payload is the cell's own identity.  Only in the steps that hold those columns (wave-uniform branch).
         if constexpr (SEED == 2 && !JINT) {
-            const bool sd = seeded & active & (j >= 0) & (j <= 1);
+            const bool sd = seeded & active & ((unsigned)j < (unsigned)DC);
             if (__builtin_amdgcn_ballot_w64(sd)) {
-                const int ic = i < 0 ? 0 : (i > Q ? Q : i), jc = j < 0 ? 0 : (j > 1 ? 1 : j);
+                const int ic = i < 0 ? 0 : (i > Q ? Q : i), jc = j < 0 ? 0 : (j > DC - 1 ? DC - 1 : j);
                 const int *p = seed_rd + ((long long)jc * seed_rows + ic) * SEEDW;
                 static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
                     const int v = p[S * (1 + XD)], old_sc = c.sc[S];
@@ -476,7 +477,7 @@ struct WaveDP {
                             c.ex[S][E] = sd ? ve : old_ex;
                         }
                     });
-                    const int ident = -(1 + (((ic * M::NS) + S) * 2 + jc)), old_rs = c.ex[S][RSQ];
+                    const int ident = -(1 + (((ic * M::NS) + S) * DC + jc)), old_rs = c.ex[S][RSQ];
                     c.ex[S][RSQ] = sd ? ident : old_rs;
                 });
                 end_ok = end_ok & !sd;
@@ -545,7 +546,7 @@ struct WaveDP {
     int *seed_wr;               // SEED 1: this job's dumps
     const int *seed_rd;         // SEED 2: the two dumped columns this job starts from
     bool seeded;
-    int seed_rows, seed_kshift, seed_next;      // seed_next: the next column d*K - 1 this lane will cross
+    int seed_rows, seed_kshift, seed_next;      // seed_next: first column of the next dump this lane will cross
     int nx_tcode, nx_sp[4], nx_tn4, tlast;
     const uint16_t *tn4p;
     const int *span_in_p;               // SPAN == 1: this job's start cells
@@ -741,16 +742,16 @@ struct WaveDP {
                 });
             }
         }
-        // SEED 1: columns d*K - 1 and d*K of our rows go to the job's dumps (each lane at its own step: rare, divergent)
+        // SEED 1: the DC columns that end in d*K go to the job's dumps (each lane at its own step: rare, divergent)
         if constexpr (SEED == 1) {
-            const bool hit_b = jact & (j == seed_next), hit_a = jact & (j == seed_next + 1);
-            if (hit_a | hit_b) {
-                const int d = (j + (hit_b ? 1 : 0)) >> seed_kshift;              // 1-based dump index
+            const unsigned which = (unsigned)(j - seed_next);                    // seed_next = d*K - (DC - 1)
+            if (jact & (which < (unsigned)DC)) {
+                const int d = (seed_next + DC - 1) >> seed_kshift;              // 1-based dump index
                 if ((d << seed_kshift) <= T) {
                     static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
                         const int i = i0 + RR;
                         if (i <= Q) {
-                            int *p = seed_wr + (((long long)(d - 1) * 2 + (hit_a ? 1 : 0)) * seed_rows + i) * SEEDW;
+                            int *p = seed_wr + (((long long)(d - 1) * DC + which) * seed_rows + i) * SEEDW;
                             static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
                                 p[S * (1 + XD)] = col[PH][RR].sc[S];
                                 static_for<XD>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
@@ -760,7 +761,7 @@ struct WaveDP {
                         }
                     });
                 }
-                if (hit_a) seed_next += 1 << seed_kshift;
+                if (which == (unsigned)(DC - 1)) seed_next += 1 << seed_kshift;
             }
         }
         // SEED 2: the corner cell (Q, T) of the window: score and region-start payload of the requested state
@@ -972,7 +973,7 @@ struct WaveDP {
                 });
             });
             strip_begin();
-            if constexpr (SEED == 1) seed_next = (1 << seed_kshift) - 1;
+            if constexpr (SEED == 1) seed_next = (1 << seed_kshift) - (DC - 1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             carry_cols = carry_ok & (sb > 0);
             const int *bnd_in = (sb == 0) ? bnd : bnd + BND + (carry_ok ? (long long)((sb + 1) & 1) * (T + 1) * BND : 0);
