@@ -284,18 +284,23 @@ def main():
     if rank == 0:
         total_cells = first_pass_cells * world * args.steps
         value = total_cells / elapsed
-        reg = stats[MODE_REGION]
-        # algorithmic bytes of one region-pass launch: per pair Q + T residue bytes,
+        # the dominant kernel of the step: the whole-rectangle pass (FIND_REGION in one pass, or the FIND_SCORE pass of
+        # the two-pass form: DESIGN.md section 4), whichever mode took the most device time
+        dom_mode = max((0, 2), key=lambda m_: stats[m_]["ms"])
+        reg = stats[dom_mode]
+        # algorithmic bytes of one whole-rectangle launch: per pair Q + T residue bytes,
         # 4 splice arrays x 4 B x T, 32 B of result
         algo_bytes = sum(len(q) + len(t) + 16 * len(t) + 32 for q, t in pairs)
         avg_ms = reg["ms"] / max(1, reg["launches"])
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM bytes per launch of the same kernel from the PMC passes committed under profiles/ (bench.py
         # itself cannot read PMCs); only quoted when the run has the configuration that was profiled
-        traffic, kname, valu_pmc = None, "viterbi_kernel_mw<Est2GenomeDesc, MODE_REGION>", None
+        traffic, valu_pmc = None, None
+        kname = "viterbi_kernel_mw<Est2GenomeDesc, %s>" % ("MODE_SCORE + column dumps" if dom_mode == 0 else "MODE_REGION")
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-            if tj["config"] == {"pairs_per_gpu": args.pairs, "query_len": args.qlen, "target_len": args.tlen}:
+            if tj["config"] == {"pairs_per_gpu": args.pairs, "query_len": args.qlen, "target_len": args.tlen} \
+                    and tj.get("mode", 2) == dom_mode:
                 traffic, kname, valu_pmc = tj["bytes_per_launch"], tj["kernel"], tj.get("valu")
         except (OSError, ValueError, KeyError):
             pass
@@ -340,7 +345,7 @@ def main():
                                  "~17 B per target column, so the HBM fraction is ~0 by construction; `valu` is the "
                                  "binding roof: measured issue rate of the kernel's instruction mix x 1024 SIMDs "
                                  "(DESIGN.md section 5)"},
-            "kernel_ms": {"region": stats[2]["ms"], "checkpoint": stats[3]["ms"], "path": stats[1]["ms"]},
+            "kernel_ms": {"score": stats[0]["ms"], "region": stats[2]["ms"], "checkpoint": stats[3]["ms"], "path": stats[1]["ms"]},
         }
         if rc:
             out["revcomp"] = rc

@@ -4,15 +4,15 @@
 #   2. three separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ activity) as the microarch guide prescribes
 # Everything lands under gpurun_out/prof_<tag>/; tools/summarise_profile.py turns it into profiles/.
 set -u
-TAG=${1:-r01_c}
+TAG=${1:-r02_a}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-revcomp"
 cd /tmp
 python $ROOT/bench.py --steps 2 --warmup 1 > "$OUT/bench.json" 2> "$OUT/bench.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python $ROOT/bench.py > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python $ROOT/bench.py --no-revcomp > "$OUT/trace.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-24)
   timeout 900 rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$N" -- $BENCH > "$OUT/pmc_$N.log" 2>&1

@@ -7,7 +7,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01_c"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
-LAUNCHES_IN_PMC_RUN = 2          # bench.py --steps 1 --warmup 1
+LAUNCHES_IN_PMC_RUN = 2          # bench.py --steps 1 --warmup 1 (fallback when the dispatch count is not in the CSV)
 
 shutil.copy(glob.glob(src + "/trace/*/*_kernel_stats.csv")[0], f"{dst}/{tag}_kernel_stats.csv")
 shutil.copy(src + "/bench.json", f"{dst}/{tag}_bench.json")
@@ -37,16 +37,24 @@ with open(f"{dst}/{tag}_pmc.csv", "w") as o:
 
 bench = json.loads(open(src + "/bench.json").read().strip().splitlines()[-1])
 cfg = bench["config"]
-reg = next(k for k in agg if ", 2, true, true" in k)
-v = agg[reg]
-n = LAUNCHES_IN_PMC_RUN
 stats = {r["Name"]: r for r in csv.DictReader(open(f"{dst}/{tag}_kernel_stats.csv"))}
-avg_ns = next(float(r["AverageNs"]) for name, r in stats.items() if short(name) == reg)
+# the dominant kernel of the step: largest total time among the Viterbi kernels
+dom = max((r for name, r in stats.items() if "viterbi_kernel" in name), key=lambda r: float(r["TotalDurationNs"]))
+reg = short(dom["Name"])
+v = agg[reg]
+n = int(v.get("dispatches:SQ_WAVES", v.get("dispatches:FETCH_SIZE", LAUNCHES_IN_PMC_RUN)))
+avg_ns = float(dom["AverageNs"])
 waves = v["SQ_WAVES"] / n
+# template arguments: viterbi_kernel_mw<Model, R, MODE, ...>
+mode = int(reg.split("<")[1].split(",")[2])
+vj = json.load(open(f"{dst}/valu_issue_latest.json"))
+wave_cycles = 4.0 * v["SQ_WAVE_CYCLES"] / max(v["SQ_WAVES"], 1)          # shader cycles one wave lives (quad-cycle counter)
+waves_per_simd = waves / vj["simds"]
+ipc = (v["SQ_INSTS_VALU"] / max(v["SQ_WAVES"], 1)) / wave_cycles * waves_per_simd
 out = {
     "source": f"profiles/{tag}_pmc.csv, profiles/{tag}_kernel_stats.csv (tools/profile_round.sh, tools/summarise_profile.py)",
     "config": {"pairs_per_gpu": cfg["pairs_per_gpu"], "query_len": cfg["query_len"], "target_len": cfg["target_len"]},
-    "kernel": reg,
+    "kernel": reg, "mode": mode, "dispatches_in_pmc_run": n,
     "fetch_kib": v["FETCH_SIZE"] / n, "write_kib": v["WRITE_SIZE"] / n,
     "fetch_correction": 2.0,
     "bytes_per_launch": (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 / n,
@@ -58,14 +66,19 @@ out = {
         "wait_frac_of_wave_cycles": v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"],
         "waves_per_launch": waves,
         "simd_issue_utilisation": (v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"]) * waves / 1024.0,
-        # VALU issue roofline: a wave64 VALU instruction occupies its SIMD for 4 cycles; 1024 SIMDs at 2.4 GHz
-        "issue_roofline_frac": (v["SQ_INSTS_VALU"] / n) * 4.0 / (1024.0 * (avg_ns * 1e-9) * 2.4e9),
+        # measured against the issue rates of profiles/valu_issue_latest.json (tools/valu_issue_microbench.hip):
+        # wave-instructions per shader cycle per SIMD from the counters alone (SQ_WAVE_CYCLES gives the cycles)
+        "waves_per_simd": waves_per_simd,
+        "cycles_per_inst_per_wave": wave_cycles / (v["SQ_INSTS_VALU"] / max(v["SQ_WAVES"], 1)),
+        "wave_inst_per_clk_per_simd": ipc,
+        "effective_clock_ghz": wave_cycles / (avg_ns * 1e-9) / 1e9,
+        "frac_of_mix_rate_at_this_occupancy": ipc / vj["wave_inst_per_clk_per_simd_by_waves"].get(str(int(round(waves_per_simd))), vj["peak_wave_inst_per_clk_per_simd"]),
+        "frac_of_mix_peak_8_waves": ipc / vj["peak_wave_inst_per_clk_per_simd"],
     },
-    "note": "fetch_kib / write_kib are the raw counters; bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE: the gfx950 "
-            "FETCH_SIZE under-count of MI355X_MICROARCH.md (HBM section), calibrated on this access pattern as the guide "
-            "asks: every input byte (Q + T + 16 T per pair = 6.97 GB per launch) has to be fetched at least once, and the raw "
-            "counter reads 3.5 GB, i.e. one half. SQ_* are per-wave quad-cycles; "
-            "simd_issue_utilisation = VALU-active share of a wave's cycles x resident waves per SIMD (1024 SIMDs).",
+    "note": "fetch_kib / write_kib are the raw counters; bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE: FETCH_SIZE reads "
+            "exactly one half of the bytes fetched at 1, 2, 4 and 16 B per lane, streaming and sliding alike, and WRITE_SIZE "
+            "is exact (profiles/r02_fetch_calibration.md: known-size reads in this kernel's own access widths). SQ_* are "
+            "per-wave quad-cycles; simd_issue_utilisation = VALU-active share of a wave's cycles x resident waves per SIMD.",
 }
 json.dump(out, open(f"{dst}/traffic_latest.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
