@@ -643,7 +643,7 @@ struct Engine {
                     j.seed_off = seed_total; j.seed_rows = s.region.query_length + 1;
                     seed->off[order[x]] = seed_total;
                     seed_total += (long long)(s.region.target_length >> seed->kshift) * ki->max_at * (s.region.query_length + 1) *
-                                  ki->n_states * (ki->cs_dump);
+                                  ki->seedw;
                 } else {
                     j.seed_off = seed->off[order[x]]; j.seed_rows = seed->rows[order[x]];
                 }
@@ -888,7 +888,7 @@ int windowed_region_pass(Engine &eng, const ResidentSeqs &seqs, const std::vecto
                          const std::vector<PairPlan> &plan, Thr thr, int kshift, std::vector<DevResult> &out) {
     const int n = (int)pairs.size();
     const KernelInfo *kw = get_kernel_mw(eng.family, MODE_REGION, true, true, 4, false, 2);
-    const long long seedw = (long long)kw->n_states * kw->cs_dump;
+    const long long seedw = kw->seedw;
     const int dc = kw->max_at;                           // dumped columns per dump (d*K - (dc - 1) .. d*K)
     auto nbits = [](int v) { int b = 0; while ((1LL << b) <= v) b++; return b; };
     std::vector<JobSpec> specs(n);

@@ -44,7 +44,7 @@ struct KernelInfo {
     int bnd;                  // ints per column of the strip carry row
     int n_states, max_at;
     int waves;                // waves per job (workgroup = 64 * waves threads)
-    int cs_dump;              // ints per state in a dumped column (score + shadow-like slots), SEED kernels
+    int seedw;                // ints per row of a dumped column (SEED kernels)
 };
 
 // family x mode x continuation x local-scope specialisation; NULL launch = not compiled
@@ -100,7 +100,7 @@ const KernelInfo *get_kernel_mw(int family, int mode, bool local, bool pack, int
                                       WaveDP<M, RVAL, MODE, false, LOCAL, PACK>::BND,                      \
                                       M::NS,                                                               \
                                       M::MAXAT,                                                            \
-                                      NWV, 1 + WaveDP<M, RVAL, MODE, false, LOCAL, PACK>::XD};             \
+                                      NWV, WaveDP<M, RVAL, MODE, false, LOCAL, PACK>::SEEDW};              \
         return &ki;                                                                                        \
     }
 

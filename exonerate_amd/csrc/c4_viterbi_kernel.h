@@ -211,7 +211,6 @@ struct WaveDP {
     static constexpr bool BLOCK_AS_LOW = LOCAL && (MODE == MODE_SCORE || MODE == MODE_REGION) && F::match_states_have_start();
     static constexpr int BND = NEXP * (1 + XS);         // ints per column in the strip carry row
     static constexpr int XD = NDES + NAUX;              // shadow-like slots of a dumped cell
-    static constexpr int SEEDW = M::NS * (1 + XD);      // ints per row of a dumped column
     static constexpr int DC = M::MAXAT;                 // columns per dump: d*K - (DC - 1) .. d*K
     static_assert(SEED == 0 || (SEED == 1 && MODE == MODE_SCORE) || (SEED == 2 && MODE == MODE_REGION && PACK),
                   "dumps are written by the score pass and read by the packed region pass");
@@ -235,6 +234,18 @@ struct WaveDP {
             }
         return live[s];
     }
+
+    // a dumped cell row: the NS scores, then the shadow-like slots something can still read (slot_live), in (state, slot) order
+    static constexpr int dump_pos(int s_, int e_) {
+        int n = M::NS;
+        for (int s = 0; s < M::NS; s++)
+            for (int e = 0; e < NDES + NAUX; e++) {
+                if (s == s_ && e == e_) return n;
+                if (slot_live(s, e)) n++;
+            }
+        return n;
+    }
+    static constexpr int SEEDW = dump_pos(M::NS, 0);    // ints per row of a dumped column
 
     // job / launch constants
     const KParams *kp;      // in LDS
@@ -263,8 +274,8 @@ struct WaveDP {
     }
 
     // cell slots in the reference layout (for cells that leave the kernel)
-    template <int S>
-    __device__ __forceinline__ void export_cell(const C &c, int *out) const {
+    template <int S, class P = int *>
+    __device__ __forceinline__ void export_cell(const C &c, P out) const {
         out[0] = c.sc[S];
         static_for<NDES>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
             out[1 + E] = slot_live(S, E) ? c.ex[S][E] : 0;
@@ -469,11 +480,11 @@ struct WaveDP {
                 const int ic = i < 0 ? 0 : (i > Q ? Q : i), jc = j < 0 ? 0 : (j > DC - 1 ? DC - 1 : j);
                 const int *p = seed_rd + ((long long)jc * seed_rows + ic) * SEEDW;
                 static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
-                    const int v = p[S * (1 + XD)], old_sc = c.sc[S];
+                    const int v = p[S], old_sc = c.sc[S];
                     c.sc[S] = sd ? v : old_sc;
                     static_for<XD>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
                         if constexpr (slot_live(S, E)) {
-                            const int ve = p[S * (1 + XD) + 1 + E], old_ex = c.ex[S][E];
+                            const int ve = p[dump_pos(S, E)], old_ex = c.ex[S][E];
                             c.ex[S][E] = sd ? ve : old_ex;
                         }
                     });
@@ -546,7 +557,7 @@ struct WaveDP {
     int *seed_wr;               // SEED 1: this job's dumps
     const int *seed_rd;         // SEED 2: the two dumped columns this job starts from
     bool seeded;
-    int seed_rows, seed_kshift, seed_next;      // seed_next: first column of the next dump this lane will cross
+    int seed_rows, seed_kshift;
     int nx_tcode, nx_sp[4], nx_tn4, tlast;
     const uint16_t *tn4p;
     const int *span_in_p;               // SPAN == 1: this job's start cells
@@ -742,42 +753,47 @@ struct WaveDP {
                 });
             }
         }
-        // SEED 1: the DC columns that end in d*K go to the job's dumps (each lane at its own step: rare, divergent)
+        // SEED 1: the DC columns that end in d*K go to the job's dumps.  Lane l is at column s - l, so only the steps
+        // with (s + DC - 1) mod K <= DC + 62 can hold such a column: a scalar test keeps every other step free of it.
         if constexpr (SEED == 1) {
-            const unsigned which = (unsigned)(j - seed_next);                    // seed_next = d*K - (DC - 1)
-            if (jact & (which < (unsigned)DC)) {
-                const int d = (seed_next + DC - 1) >> seed_kshift;              // 1-based dump index
-                if ((d << seed_kshift) <= T) {
+            if (((unsigned)(s + DC - 1) & (unsigned)((1 << seed_kshift) - 1)) <= (unsigned)(DC + 62)) {
+                const int d = (j + DC - 1) >> seed_kshift;                       // 1-based dump index of column j
+                const unsigned which = (unsigned)(j - ((d << seed_kshift) - (DC - 1)));
+                if (jact & (d >= 1) & (which < (unsigned)DC) & ((d << seed_kshift) <= T)) {
                     static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
                         const int i = i0 + RR;
                         if (i <= Q) {
-                            int *p = seed_wr + (((long long)(d - 1) * DC + which) * seed_rows + i) * SEEDW;
+                            // one dword per store (volatile: not merged into x3 / x4 stores, which would need the
+                            // values in consecutive registers and cost the hot loop a third of its register budget)
+                            volatile int *p = seed_wr + (((long long)(d - 1) * DC + which) * seed_rows + i) * SEEDW;
                             static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
-                                p[S * (1 + XD)] = col[PH][RR].sc[S];
+                                p[S] = col[PH][RR].sc[S];
                                 static_for<XD>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
-                                    p[S * (1 + XD) + 1 + E] = slot_live(S, E) ? col[PH][RR].ex[S][E] : 0;
+                                    if constexpr (slot_live(S, E)) p[dump_pos(S, E)] = col[PH][RR].ex[S][E];
                                 });
                             });
                         }
                     });
                 }
-                if (which == (unsigned)(DC - 1)) seed_next += 1 << seed_kshift;
             }
         }
-        // SEED 2: the corner cell (Q, T) of the window: score and region-start payload of the requested state
+        // SEED 2: the corner cell (Q, T) of the window: score and region-start payload of the requested state (lane l
+        // reaches column T at step T + l: a scalar test skips the steps before)
         if constexpr (SEED == 2) {
-            if (jact && j == T) {
-                static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
-                    if (i0 + RR == Q) {
-                        static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
-                            if (final_state == S) {
-                                corner[0] = col[PH][RR].sc[S];
-                                corner[1] = col[PH][RR].ex[S][RSQ];
-                                corner_set = true;
-                            }
-                        });
-                    }
-                });
+            if (s >= T) {
+                if (jact && j == T) {
+                    static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                        if (i0 + RR == Q) {
+                            static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                                if (final_state == S) {
+                                    corner[0] = col[PH][RR].sc[S];
+                                    corner[1] = col[PH][RR].ex[S][RSQ];
+                                    corner_set = true;
+                                }
+                            });
+                        }
+                    });
+                }
             }
         }
         // (7) checkpoint rows (Viterbi_Checkpoint_process, viterbi.c:605-631).  At checkpoint column c the
@@ -793,9 +809,11 @@ struct WaveDP {
                     static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
                         const int i = i0 + RR;
                         if (i <= Q) {
-                            int *p = ckpt + ((((long long)cp_next_i * M::MAXAT + ROW) * (Q + 1) + i) * M::NS) * CS;
+                            // one dword per store (volatile: merged x4 stores want their values in consecutive
+                            // registers, ~45 moves and as many more live registers per row copied out)
+                            volatile int *p = ckpt + ((((long long)cp_next_i * M::MAXAT + ROW) * (Q + 1) + i) * M::NS) * CS;
                             static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
-                                export_cell<S>(col[PH][RR], p + S * CS);
+                                export_cell<S, volatile int *>(col[PH][RR], p + S * CS);
                             });
                         }
                     });
@@ -934,7 +952,7 @@ struct WaveDP {
         if constexpr (SUB) { sub_cp = seqs.sub_colptr + 2 * job.sub_off; sub_rows = seqs.sub_rows; }
         first_state = job.first_state; final_state = (SEED == 2) ? job.final_state : M::END;
         first_cell = job.first_cell;
-        seeded = false; seed_rows = job.seed_rows; seed_kshift = job.seed_kshift; seed_next = 0x7fffffff;
+        seeded = false; seed_rows = job.seed_rows; seed_kshift = job.seed_kshift;
         if constexpr (SEED == 1) seed_wr = seqs.seed + job.seed_off;
         if constexpr (SEED == 2) { seeded = job.seed_off >= 0; seed_rd = seqs.seed + (seeded ? job.seed_off : 0); }
         min_intron = kp->min_intron; max_intron = kp->max_intron;
@@ -973,7 +991,6 @@ struct WaveDP {
                 });
             });
             strip_begin();
-            if constexpr (SEED == 1) seed_next = (1 << seed_kshift) - (DC - 1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             carry_cols = carry_ok & (sb > 0);
             const int *bnd_in = (sb == 0) ? bnd : bnd + BND + (carry_ok ? (long long)((sb + 1) & 1) * (T + 1) * BND : 0);
