@@ -160,6 +160,14 @@ __device__ __forceinline__ int dpp_shr1(int old, int v) {      // lane l <- lane
     return __builtin_amdgcn_update_dpp(old, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
 
+// one global_store_dword at base + OFF bytes (an immediate): the compiler neither merges it with its neighbours nor
+// waits for it; for data no later instruction of the kernel reads
+template <int OFF>
+__device__ __forceinline__ void store_dword(int *base, int v) {
+    static_assert(OFF >= 0 && OFF < 4096, "global_store immediate offset");
+    asm volatile("global_store_dword %0, %1, off offset:%2" : : "v"(base), "v"(v), "n"(OFF) : "memory");
+}
+
 __device__ __forceinline__ bool scope_ok(int scope, bool at_q, bool at_t) {
     switch (scope) {
         case SCOPE_ANYWHERE: return true;
@@ -274,8 +282,8 @@ struct WaveDP {
     }
 
     // cell slots in the reference layout (for cells that leave the kernel)
-    template <int S, class P = int *>
-    __device__ __forceinline__ void export_cell(const C &c, P out) const {
+    template <int S>
+    __device__ __forceinline__ void export_cell(const C &c, int *out) const {
         out[0] = c.sc[S];
         static_for<NDES>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
             out[1 + E] = slot_live(S, E) ? c.ex[S][E] : 0;
@@ -763,13 +771,14 @@ struct WaveDP {
                     static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
                         const int i = i0 + RR;
                         if (i <= Q) {
-                            // one dword per store (volatile: not merged into x3 / x4 stores, which would need the
-                            // values in consecutive registers and cost the hot loop a third of its register budget)
-                            volatile int *p = seed_wr + (((long long)(d - 1) * DC + which) * seed_rows + i) * SEEDW;
+                            // one dword per store, issued as such: merged x3 / x4 stores would want their values in
+                            // consecutive registers and cost the hot loop a third of its register budget (a volatile
+                            // store does not merge either, but waits for each one).  Nothing in the kernel reads the dumps.
+                            int *p = seed_wr + (((long long)(d - 1) * DC + which) * seed_rows + i) * SEEDW;
                             static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
-                                p[S] = col[PH][RR].sc[S];
+                                store_dword<S * 4>(p, col[PH][RR].sc[S]);
                                 static_for<XD>([&](auto E_) __attribute__((always_inline)) { constexpr int E = E_;
-                                    if constexpr (slot_live(S, E)) p[dump_pos(S, E)] = col[PH][RR].ex[S][E];
+                                    if constexpr (slot_live(S, E)) store_dword<dump_pos(S, E) * 4>(p, col[PH][RR].ex[S][E]);
                                 });
                             });
                         }
@@ -809,11 +818,9 @@ struct WaveDP {
                     static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
                         const int i = i0 + RR;
                         if (i <= Q) {
-                            // one dword per store (volatile: merged x4 stores want their values in consecutive
-                            // registers, ~45 moves and as many more live registers per row copied out)
-                            volatile int *p = ckpt + ((((long long)cp_next_i * M::MAXAT + ROW) * (Q + 1) + i) * M::NS) * CS;
+                            int *p = ckpt + ((((long long)cp_next_i * M::MAXAT + ROW) * (Q + 1) + i) * M::NS) * CS;
                             static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
-                                export_cell<S, volatile int *>(col[PH][RR], p + S * CS);
+                                export_cell<S>(col[PH][RR], p + S * CS);
                             });
                         }
                     });
