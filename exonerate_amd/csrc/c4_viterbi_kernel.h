@@ -818,6 +818,8 @@ struct WaveDP {
                     static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
                         const int i = i0 + RR;
                         if (i <= Q) {
+                            // (measured: unmerged dword stores here cut 9 % of the kernel's instructions and most of
+                            // its spills, and cost 20 % in time: 90 store issues per row instead of 23)
                             int *p = ckpt + ((((long long)cp_next_i * M::MAXAT + ROW) * (Q + 1) + i) * M::NS) * CS;
                             static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
                                 export_cell<S>(col[PH][RR], p + S * CS);
