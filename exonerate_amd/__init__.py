@@ -295,6 +295,20 @@ class Engine:
             raise _err("c4gpu_viterbi_batch")
         return _viterbi_results(res, len(jobs))
 
+    def hsp_extend(self, params, match, pairs, seedlen, dropoff, seeds):
+        """HSPset_seed_hsp's ungapped X-drop extension (hspset.c:933) of every seed (pair index, query_start,
+        target_start) in one launch: [query_start, target_start, length, score, cobs] per seed.  `match`:
+        "dna2dna" | "protein2protein" | "protein2dna"."""
+        arr, keep = _pairs(pairs)
+        kind = {"dna2dna": _abi.MATCH_DNA2DNA, "protein2protein": _abi.MATCH_PROTEIN2PROTEIN,
+                "protein2dna": _abi.MATCH_PROTEIN2DNA}[match]
+        n = len(seeds)
+        cs = (_abi.HspSeed * max(1, n))(*[_abi.HspSeed(*s) for s in seeds])
+        out = (_abi.Hsp * max(1, n))()
+        if _lib().c4gpu_hsp_extend_batch(self.ctx, params, kind, arr, len(pairs), seedlen, dropoff, cs, n, out) != 0:
+            raise _err("c4gpu_hsp_extend_batch")
+        return [out[i].aslist() for i in range(n)]
+
     def splice_predict(self, params, target):
         t = target if isinstance(target, bytes) else target.encode()
         bufs = [(C.c_int32 * max(1, len(t)))() for _ in range(4)]

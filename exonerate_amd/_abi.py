@@ -92,6 +92,21 @@ class Alignment(C.Structure):
                 ("valid", C.c_int32)]
 
 
+class HspSeed(C.Structure):
+    _fields_ = [("pair", C.c_int32), ("query_start", C.c_int32), ("target_start", C.c_int32)]
+
+
+class Hsp(C.Structure):
+    _fields_ = [("query_start", C.c_int32), ("target_start", C.c_int32), ("length", C.c_int32),
+                ("score", C.c_int32), ("cobs", C.c_int32)]
+
+    def aslist(self):
+        return [self.query_start, self.target_start, self.length, self.score, self.cobs]
+
+
+MATCH_DNA2DNA, MATCH_PROTEIN2PROTEIN, MATCH_PROTEIN2DNA = 0, 1, 2
+
+
 class Continuation(C.Structure):
     _fields_ = [("first_state", C.c_int32), ("final_state", C.c_int32),
                 ("first_cell", C.c_int32 * CELL_MAX)]
@@ -162,6 +177,8 @@ PROTOTYPES = [
     ("c4gpu_batch_viterbi", C.c_int, [C.c_void_p, C.c_int, C.POINTER(ViterbiJob), C.c_int32,
                                       C.POINTER(ViterbiResult)]),
     ("c4gpu_model_device_family", C.c_int, [C.POINTER(Model)]),
+    ("c4gpu_hsp_extend_batch", C.c_int, [C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(Pair), C.c_int32, C.c_int32,
+                                         C.c_int32, C.POINTER(HspSeed), C.c_int32, C.POINTER(Hsp)]),
     ("c4gpu_batch_viterbi_model", C.c_int, [C.c_void_p, C.POINTER(Model), C.c_int, C.POINTER(ViterbiJob), C.c_int32,
                                             C.POINTER(ViterbiResult)]),
     ("c4gpu_batch_scores", C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(Region)]),

@@ -248,6 +248,64 @@ __global__ void splice_kernel(const uint8_t *__restrict__ seq, const long long *
   }
 }
 
+// ---- HSP seeding: the ungapped X-drop extension of HSPset_seed_hsp (src/comparison/hspset.c:933-997) ----------------
+// One lane per seed: HSP_trim_ends (:837-870), HSP_init (:722-741), HSP_extend without masking (:743-812: left, then
+// right, best extension so far, stop below zero or `dropoff` under the best) and HSP_find_cobs (:426-441).  Residues
+// are read through the batch's coded arrays (qcode / tcode = substitution matrix rows; for PROTEIN2DNA tcode holds the
+// row of the codon starting at each position), the matrix sits in LDS.  Seeds of one diagonal neighbourhood read the
+// same cache lines; the work per seed is a few hundred bytes, so the kernel is latency- and not bandwidth-bound.
+struct HspJob { long long qoff, toff; int qlen, tlen; };
+__global__ void hsp_extend_kernel(const uint8_t *__restrict__ qcode, const uint8_t *__restrict__ tcode,
+                                  const HspJob *__restrict__ jobs, const c4gpu_hsp_seed *__restrict__ seeds, int n_seeds,
+                                  const int *__restrict__ submat, int aq, int at, int seedlen, int dropoff,
+                                  c4gpu_hsp *__restrict__ out) {
+    __shared__ int sm[24 * 24];
+    for (int x = threadIdx.x; x < 24 * 24; x += blockDim.x) sm[x] = submat[x];
+    __syncthreads();
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_seeds; k += gridDim.x * blockDim.x) {
+        const HspJob jb = jobs[seeds[k].pair];
+        const uint8_t *q = qcode + jb.qoff, *t = tcode + jb.toff;
+        auto sc = [&](int qp, int tp) { return sm[q[qp] * 24 + t[tp]]; };
+        int qs = seeds[k].query_start, ts = seeds[k].target_start, length = seedlen, i;
+        for (i = 0; i < length; i++) {                                   // HSP_trim_ends
+            if (sc(qs, ts) > 0) break;
+            qs += aq; ts += at;
+        }
+        length -= i;
+        int qp = qs + length * aq - aq, tp = ts + length * at - at;
+        while (length > 0) {
+            if (sc(qp, tp) > 0) break;
+            length--; qp -= aq; tp -= at;
+        }
+        int score = 0;                                                   // HSP_init
+        for (i = 0, qp = qs, tp = ts; i < length; i++, qp += aq, tp += at) score += sc(qp, tp);
+        int maxscore = score, extend, maxext;                            // HSP_extend: left
+        qp = qs - aq; tp = ts - at;
+        for (extend = 1, maxext = 0; qp >= 0 && tp >= 0; extend++) {
+            score += sc(qp, tp);
+            if (maxscore <= score) { maxscore = score; maxext = extend; }
+            else { if (score < 0) break; if (maxscore - score >= dropoff) break; }
+            qp -= aq; tp -= at;
+        }
+        qp = qs + length * aq; tp = ts + length * at;
+        qs -= maxext * aq; ts -= maxext * at; length += maxext;
+        score = maxscore;
+        for (extend = 1, maxext = 0; qp + aq <= jb.qlen && tp + at <= jb.tlen; extend++) {     // right
+            score += sc(qp, tp);
+            if (maxscore <= score) { maxscore = score; maxext = extend; }
+            else { if (score < 0) break; if (maxscore - score >= dropoff) break; }
+            qp += aq; tp += at;
+        }
+        length += maxext;
+        score = 0;                                                       // HSP_find_cobs
+        for (i = 0, qp = qs, tp = ts; i < length; i++, qp += aq, tp += at) {
+            score += sc(qp, tp);
+            if (score >= (maxscore >> 1)) break;
+        }
+        out[k] = c4gpu_hsp{qs, ts, length, maxscore, i};
+    }
+}
+
 // ---- resident sequences of a batch --------------------------------------------------------------------------
 // Column entries of the blocked-cell lists (the device form of SubOpt_Index's rows, subopt.c:250-333): for
 // every job and every column 0..T+1 two ints: the first blocked row of the column (or SUB_NONE), and twice
@@ -1385,6 +1443,44 @@ int c4gpu_splice_predict(c4gpu_ctx *ctx, const c4gpu_params *params, const uint8
 }
 
 }  // extern "C"
+
+extern "C" int c4gpu_hsp_extend_batch(c4gpu_ctx *ctx, const c4gpu_params *params, int match_type, const c4gpu_pair *pairs,
+                                      int32_t n_pairs, int32_t seedlen, int32_t dropoff, const c4gpu_hsp_seed *seeds,
+                                      int32_t n_seeds, c4gpu_hsp *out) {
+    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+    if (match_type < C4GPU_MATCH_DNA2DNA || match_type > C4GPU_MATCH_PROTEIN2DNA) { c4h::set_error("unknown match type"); return -1; }
+    if (!n_seeds) return 0;
+    const int aq = 1, at = match_type == C4GPU_MATCH_PROTEIN2DNA ? 3 : 1;
+    for (int k = 0; k < n_seeds; k++) {
+        const c4gpu_hsp_seed &sd = seeds[k];
+        if (sd.pair < 0 || sd.pair >= n_pairs || sd.query_start < 0 || sd.target_start < 0 ||
+            sd.query_start + seedlen * aq > pairs[sd.pair].query_len || sd.target_start + seedlen * at > pairs[sd.pair].target_len) {
+            c4h::set_error("an HSP seed lies outside its pair");
+            return -1;
+        }
+    }
+    // the coded arrays of a protein2dna batch are exactly what PROTEIN2DNA scoring reads (row of the codon at each
+    // target position); the 1:1 matches use the plain residue rows
+    ResidentSeqs seqs;
+    if (seqs.build(ctx, match_type == C4GPU_MATCH_PROTEIN2DNA ? FAM_UNGAPPED_P2D : FAM_UNGAPPED, params, pairs, n_pairs)) return -1;
+    std::vector<HspJob> jobs(n_pairs);
+    for (int i = 0; i < n_pairs; i++) jobs[i] = HspJob{seqs.qoff[i], seqs.toff[i], seqs.qlen[i], seqs.tlen[i]};
+    DevBuf<HspJob> d_jobs;
+    DevBuf<c4gpu_hsp_seed> d_seeds;
+    DevBuf<c4gpu_hsp> d_out;
+    DevBuf<int> d_submat;
+    const int32_t *mat = match_type == C4GPU_MATCH_DNA2DNA ? &params->dna_submat[0][0] : &params->protein_submat[0][0];
+    hipStream_t s = ctx->stream;
+    if (d_jobs.upload(jobs.data(), n_pairs, s) || d_seeds.upload(seeds, n_seeds, s) || d_out.alloc(n_seeds) ||
+        d_submat.upload(mat, 24 * 24, s)) return -1;
+    const int block = 64, grid = std::min((n_seeds + block - 1) / block, 65535);
+    hipLaunchKernelGGL(hsp_extend_kernel, dim3(grid), dim3(block), 0, s, seqs.qcode.p, seqs.tcode.p, d_jobs.p, d_seeds.p,
+                       n_seeds, d_submat.p, aq, at, seedlen, dropoff, d_out.p);
+    HIP_OK(hipGetLastError());
+    if (d_out.download(out, n_seeds, s)) return -1;
+    HIP_OK(hipStreamSynchronize(s));
+    return 0;
+}
 
 static int viterbi_jobs(Engine &eng, const ResidentSeqs &seqs, int mode, const c4gpu_viterbi_job *jobs,
                         int32_t n_jobs, c4gpu_viterbi_result *results) {

@@ -337,6 +337,25 @@ int          c4gpu_batch_alignment(c4gpu_batch *b, int32_t i, c4gpu_alignment *o
 int          c4gpu_batch_kernel_stats(c4gpu_batch *b, int mode, int reset, double *ms, int64_t *launches,
                                       int64_t *cells);
 
+/* ---- HSP seeding (src/comparison/hspset.c) ------------------------------------------------------------------------ */
+
+/* Match_Type of an HSPset (src/comparison/match.h:45-51): what one HSP position scores.  DNA2DNA: dna submat[q][t];
+ * PROTEIN2PROTEIN: protein submat[q][t]; PROTEIN2DNA: protein submat[q][aa(t, t+1, t+2)], target advance 3. */
+enum { C4GPU_MATCH_DNA2DNA = 0, C4GPU_MATCH_PROTEIN2PROTEIN = 1, C4GPU_MATCH_PROTEIN2DNA = 2 };
+
+/* one word hit handed to HSPset_seed_hsp (hspset.c:933): positions in pair `pair` */
+typedef struct { int32_t pair, query_start, target_start; } c4gpu_hsp_seed;
+/* the HSP that seed grows into: HSP_trim_ends, HSP_init and HSP_extend without masking (hspset.c:737-812,837-870);
+ * length in match-state visits, cobs = HSP_find_cobs (hspset.c:426-441) */
+typedef struct { int32_t query_start, target_start, length, score, cobs; } c4gpu_hsp;
+
+/* The ungapped X-drop extension of every seed, on the device: what HSPset_seed_hsp computes for a seed its horizon lets
+ * through (the horizon, the threshold and the store order stay with the caller: they need the HSPs in seed order).
+ * seedlen / dropoff: HSP_Param.seedlen / .dropoff.  Fails (-1) on residues outside the submat alphabet. */
+int         c4gpu_hsp_extend_batch(c4gpu_ctx *ctx, const c4gpu_params *params, int match_type,
+                                   const c4gpu_pair *pairs, int32_t n_pairs, int32_t seedlen, int32_t dropoff,
+                                   const c4gpu_hsp_seed *seeds, int32_t n_seeds, c4gpu_hsp *out);
+
 /* Alignment_print_{sugar,cigar,vulgar}_block (alignment.c:1622-1779); coordinates are region
  * coordinates on the given strands ('+', '-', '.'), flipped to the forward strand when
  * forward_coords != 0 as --forwardcoordinates does (alignment.c:177-205).  `what`: 0 sugar, 1 cigar,

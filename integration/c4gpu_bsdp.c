@@ -849,6 +849,8 @@ GAM_Result *GAM_Result_heuristic_create(GAM *gam, Comparison *comparison){
             shim_bsdp_flush();                    /* keep the output order */
         return GAM_Result_heuristic_create_cpu(gam, comparison);
         }
+    if(!Comparison_has_hsps(comparison))          /* gam.c:1122 (a comparison whose word hits grew no HSP: c4gpu_hsp.c) */
+        return NULL;
     if(bsdp_pending && bsdp_pending->len && (((ShimHPending*)bsdp_pending->pdata[0])->gam != gam))
         shim_bsdp_flush();
     if(!bsdp_pending)

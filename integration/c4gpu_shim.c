@@ -213,6 +213,25 @@ void shim_params(Ungapped_Data *ud, c4gpu_params *p){
         }
     }
 
+void shim_hsp_params(c4gpu_params *p){
+    register Match_ArgumentSet *mas = Match_ArgumentSet_create(NULL);
+    register gint i, j;
+    memset(p, 0, sizeof(*p));
+    c4gpu_params_default(p);
+    for(i = 0; i < SUBMAT_ALPHABETSIZE; i++)
+        for(j = 0; j < SUBMAT_ALPHABETSIZE; j++){
+            p->dna_submat[i][j] = mas->dna_submat->matrix[i][j];
+            p->protein_submat[i][j] = mas->protein_submat->matrix[i][j];
+            }
+    memcpy(p->submat_index, mas->dna_submat->index, 256);
+    if(mas->translate){
+        memcpy(p->nt2d, mas->translate->nt2d, 256);
+        memcpy(p->trans, mas->translate->trans, 4096);
+        memcpy(p->aa, mas->translate->aa, 40);
+        }
+    return;
+    }
+
 /* ---- one Viterbi call ----------------------------------------------------------------------------------- */
 
 static C4_Score shim_dp(C4_Model *model, Region *region, Viterbi_Data *vd, SubOpt_Index *soi,
@@ -666,6 +685,7 @@ void GAM_report(GAM *gam){        /* analysis.c:1421: after the last pair */
     shim_flush();
     shim_bsdp_flush();
     shim_bsdp_report();
+    shim_hsp_report();
     GAM_report_cpu(gam);
     return;
     }

@@ -13,6 +13,10 @@ gint shim_batch_size(void);
 /* closed C4_Model -> c4gpu_model; allow_span: BSDP's span models (cell_start_func / cell_end_func become matrices) */
 gboolean shim_flatten_any(C4_Model *m, Ungapped_Data *ud, c4gpu_model *out, gboolean allow_span);
 void shim_params(Ungapped_Data *ud, c4gpu_params *p);
+/* scoring data for calls that have no model at hand (HSP seeding): Match_ArgumentSet's matrices and translation */
+void shim_hsp_params(c4gpu_params *p);
+/* c4gpu_hsp.c */
+void shim_hsp_report(void);
 /* c4gpu_bsdp.c */
 void shim_bsdp_flush(void);
 void shim_bsdp_report(void);

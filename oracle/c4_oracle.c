@@ -1109,3 +1109,95 @@ int oracle_alignment_format(const c4gpu_model *m, const c4gpu_alignment *a, int 
         return b.overflow ? -1 : (int)b.pos;
         }
     }
+
+
+/* ---- HSP seeding (src/comparison/hspset.c) ------------------------------------------------------------------------------ */
+
+typedef struct { const c4gpu_params *p; int type; const uint8_t *q, *t; int qlen, tlen, aq, at; } hsp_ctx;
+
+static int hsp_score(const hsp_ctx *h, int qpos, int tpos){            /* HSP_get_score -> match->score_func */
+    const c4gpu_params *p = h->p;
+    if(h->type == C4GPU_MATCH_DNA2DNA)                                 /* Match_1_1_dna_score_func, match.c:271 */
+        return p->dna_submat[p->submat_index[h->q[qpos]]][p->submat_index[h->t[tpos]]];
+    if(h->type == C4GPU_MATCH_PROTEIN2PROTEIN)                         /* match.c:287 */
+        return p->protein_submat[p->submat_index[h->q[qpos]]][p->submat_index[h->t[tpos]]];
+    {                                                                  /* Match_1_3_score_func, match.c:347 */
+        uint8_t aa = p->aa[p->trans[ p->nt2d[h->t[tpos]] | (p->nt2d[h->t[tpos+1]] << 4) | (p->nt2d[h->t[tpos+2]] << 8)]];
+        return p->protein_submat[p->submat_index[h->q[qpos]]][p->submat_index[aa]];
+    }
+    }
+
+static void hsp_grow(const hsp_ctx *h, int seedlen, int dropoff, int qs, int ts, c4gpu_hsp *o){
+    int length = seedlen, i, score, maxscore, extend, maxext, qpos, tpos;
+    /* HSP_trim_ends, hspset.c:837-870 */
+    for(i = 0; i < length; i++){
+        if(hsp_score(h, qs, ts) > 0) break;
+        qs += h->aq; ts += h->at;
+        }
+    length -= i;
+    qpos = qs + length * h->aq - h->aq; tpos = ts + length * h->at - h->at;
+    while(length > 0){
+        if(hsp_score(h, qpos, tpos) > 0) break;
+        length--; qpos -= h->aq; tpos -= h->at;
+        }
+    /* HSP_init, hspset.c:722-741 */
+    score = 0;
+    for(i = 0, qpos = qs, tpos = ts; i < length; i++, qpos += h->aq, tpos += h->at)
+        score += hsp_score(h, qpos, tpos);
+    /* HSP_extend(forbid_masked = FALSE), hspset.c:743-812: left ... */
+    maxscore = score;
+    qpos = qs - h->aq; tpos = ts - h->at;
+    for(extend = 1, maxext = 0; (qpos >= 0) && (tpos >= 0); extend++){
+        score += hsp_score(h, qpos, tpos);
+        if(maxscore <= score){ maxscore = score; maxext = extend; }
+        else { if(score < 0) break; if((maxscore - score) >= dropoff) break; }
+        qpos -= h->aq; tpos -= h->at;
+        }
+    qpos = qs + length * h->aq; tpos = ts + length * h->at;            /* HSP_query_end / _target_end before the update */
+    qs -= maxext * h->aq; ts -= maxext * h->at; length += maxext;
+    score = maxscore;
+    /* ... then right */
+    for(extend = 1, maxext = 0; ((qpos + h->aq) <= h->qlen) && ((tpos + h->at) <= h->tlen); extend++){
+        score += hsp_score(h, qpos, tpos);
+        if(maxscore <= score){ maxscore = score; maxext = extend; }
+        else { if(score < 0) break; if((maxscore - score) >= dropoff) break; }
+        qpos += h->aq; tpos += h->at;
+        }
+    length += maxext;
+    o->query_start = qs; o->target_start = ts; o->length = length; o->score = maxscore;
+    /* HSP_find_cobs, hspset.c:426-441 */
+    score = 0;
+    for(i = 0, qpos = qs, tpos = ts; i < length; i++, qpos += h->aq, tpos += h->at){
+        score += hsp_score(h, qpos, tpos);
+        if(score >= (maxscore >> 1)) break;
+        }
+    o->cobs = i;
+    }
+
+void oracle_hsp_extend(const c4gpu_params *params, int match_type, const uint8_t *query, int32_t qlen,
+                       const uint8_t *target, int32_t tlen, int32_t seedlen, int32_t dropoff,
+                       int32_t query_start, int32_t target_start, c4gpu_hsp *out){
+    hsp_ctx h = {params, match_type, query, target, qlen, tlen, 1, match_type == C4GPU_MATCH_PROTEIN2DNA ? 3 : 1};
+    hsp_grow(&h, seedlen, dropoff, query_start, target_start, out);
+    }
+
+int32_t oracle_hsp_set(const c4gpu_params *params, int match_type, const uint8_t *query, int32_t qlen,
+                       const uint8_t *target, int32_t tlen, int32_t seedlen, int32_t dropoff, int32_t threshold,
+                       const int32_t *seed_q, const int32_t *seed_t, int32_t n, c4gpu_hsp *out){
+    hsp_ctx h = {params, match_type, query, target, qlen, tlen, 1, match_type == C4GPU_MATCH_PROTEIN2DNA ? 3 : 1};
+    /* horizon[section_pos][query_frame][target_frame], hspset.c:321-327,936-958 (seed_repeat == 1) */
+    int *horizon = calloc((size_t)qlen * h.aq * h.at + 1, sizeof(int));
+    int k, total = 0;
+    for(k = 0; k < n; k++){
+        const int diag = seed_t[k] * h.aq - seed_q[k] * h.at, qf = seed_q[k] % h.aq, tf = seed_t[k] % h.at;
+        const int section = (diag + qlen) % qlen;
+        int *hz = &horizon[((size_t)section * h.aq + qf) * h.at + tf];
+        c4gpu_hsp o;
+        if(seed_t[k] < *hz) continue;
+        hsp_grow(&h, seedlen, dropoff, seed_q[k], seed_t[k], &o);
+        if(o.score >= threshold) out[total++] = o;                     /* HSP_store, hspset.c:885-888 */
+        *hz = o.target_start + o.length * h.at;                        /* HSP_target_end */
+        }
+    free(horizon);
+    return total;
+    }

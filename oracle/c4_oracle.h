@@ -52,6 +52,17 @@ int  oracle_find_path_region(const c4gpu_model *model, const c4gpu_params *param
                       const c4gpu_region *region, int dpmemory_mb, c4gpu_score threshold,
                       const oracle_subopt *subopt, c4gpu_alignment *out);
 
+/* HSPset_seed_hsp's HSP for one seed with nothing in its way (src/comparison/hspset.c:933-997: HSP_trim_ends :837-870,
+ * HSP_init :722-741, HSP_extend without masking :743-812) and HSP_find_cobs (:426-441) */
+void oracle_hsp_extend(const c4gpu_params *params, int match_type, const uint8_t *query, int32_t qlen,
+                       const uint8_t *target, int32_t tlen, int32_t seedlen, int32_t dropoff,
+                       int32_t query_start, int32_t target_start, c4gpu_hsp *out);
+/* one HSPset fed `n` seeds in order (seed_repeat 1, no filter): horizon test (hspset.c:952-958), threshold
+ * (HSP_store :885-888), cobs at finalise.  Returns the number of HSPs written to out (at most n). */
+int32_t oracle_hsp_set(const c4gpu_params *params, int match_type, const uint8_t *query, int32_t qlen,
+                       const uint8_t *target, int32_t tlen, int32_t seedlen, int32_t dropoff, int32_t threshold,
+                       const int32_t *seed_q, const int32_t *seed_t, int32_t n, c4gpu_hsp *out);
+
 /* one raw Viterbi call in any mode (Viterbi_interpreted, src/c4/viterbi.c:655-837); used by the parity
  * tests of c4gpu_viterbi_batch.  checkpoints (may be NULL) receives
  * [cp][row < max_target_advance][i <= Q][state][cell_size] ints; ops receives the raw transition path. */

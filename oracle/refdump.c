@@ -39,6 +39,7 @@
 #include "heuristic.h"
 #include "sar.h"
 #include "gam.h"
+#include "hspset.h"
 
 static gint state_index(C4_Model *m, C4_State *s){
     register guint i;
@@ -621,6 +622,68 @@ static void run_golden(gchar *model_name, gchar *input_path, gboolean with_splic
     return;
     }
 
+/* ---- HSP seeding (src/comparison/hspset.c:933): per seed the HSP a fresh HSPset grows from it (no horizon in the way),
+ * and the HSP list of ONE HSPset fed all seeds in order (horizon filter, threshold, store order, cobs) -------------- */
+static void run_hsp(gchar *match_name, gchar *input_path){
+    register FILE *fp = fopen(input_path, "r");
+    register Match_Type type = (!strcmp(match_name, "protein2dna")) ? Match_Type_PROTEIN2DNA
+                             : (!strcmp(match_name, "protein2protein")) ? Match_Type_PROTEIN2PROTEIN : Match_Type_DNA2DNA;
+    register Match *match = Match_find(type);
+    register HSP_Param *hsp_param = HSP_Param_create(match, TRUE);
+    gchar *line = g_malloc(1<<22);
+    if(!fp)
+        g_error("cannot open [%s]", input_path);
+    printf("{\"params\":{\"match\":\"%s\",\"seedlen\":%d,\"wordlen\":%d,\"dropoff\":%d,\"threshold\":%d,"
+           "\"query_advance\":%d,\"target_advance\":%d,\"seed_repeat\":%d}}\n", match_name, hsp_param->seedlen,
+           hsp_param->wordlen, hsp_param->dropoff, hsp_param->threshold, match->query->advance, match->target->advance,
+           hsp_param->seed_repeat);
+    while(fgets(line, 1<<22, fp)){
+        gchar **f, **seeds;
+        Sequence *query, *target;
+        register gint k, first = 1;
+        register HSPset *all;
+        g_strchomp(line);
+        if((!line[0]) || (line[0] == '#'))
+            continue;
+        f = g_strsplit(line, "\t", 4);                   /* id, query, target, "q:t,q:t,..." */
+        query = Sequence_create(f[0], NULL, f[1], 0, Sequence_Strand_UNKNOWN, NULL);
+        target = Sequence_create("tg", NULL, f[2], 0, Sequence_Strand_UNKNOWN, NULL);
+        seeds = g_strsplit(f[3], ",", -1);
+        all = HSPset_create(query, target, hsp_param);
+        printf("{\"id\":\"%s\",\"single\":[", f[0]);
+        for(k = 0; seeds[k] && seeds[k][0]; k++){
+            register gint q = atoi(seeds[k]), t = atoi(strchr(seeds[k], ':') + 1);
+            register HSPset *one = HSPset_create(query, target, hsp_param);
+            HSPset_seed_hsp(one, q, t);
+            HSPset_finalise(one);
+            if(one->hsp_list->len){
+                register HSP *h = one->hsp_list->pdata[0];
+                printf("%s[%d,%d,%d,%d,%d]", first?"":",", h->query_start, h->target_start, h->length, h->score, h->cobs);
+            } else {
+                printf("%snull", first?"":",");
+                }
+            first = 0;
+            HSPset_destroy(one);
+            HSPset_seed_hsp(all, q, t);
+            }
+        HSPset_finalise(all);
+        printf("],\"set\":[");
+        for(k = 0; k < (gint)all->hsp_list->len; k++){
+            register HSP *h = all->hsp_list->pdata[k];
+            printf("%s[%d,%d,%d,%d,%d]", k?",":"", h->query_start, h->target_start, h->length, h->score, h->cobs);
+            }
+        printf("]}\n");
+        HSPset_destroy(all);
+        Sequence_destroy(query);
+        Sequence_destroy(target);
+        g_strfreev(f);
+        g_strfreev(seeds);
+        }
+    fclose(fp);
+    g_free(line);
+    return;
+    }
+
 int Argument_main(Argument *arg){
     register ArgumentSet *as = ArgumentSet_create("refdump options");
     gchar *cmd, *model_name, *input_path;
@@ -655,6 +718,7 @@ int Argument_main(Argument *arg){
     Alphabet_ArgumentSet_create(arg);
     Alignment_ArgumentSet_create(arg);
     Splice_ArgumentSet_create(arg);
+    HSPset_ArgumentSet_create(arg);
     Argument_process(arg, "refdump", "reference table/golden dumper", "");
     if(!strcmp(cmd, "tables"))
         dump_tables();
@@ -666,6 +730,8 @@ int Argument_main(Argument *arg){
         gchar **d = g_strsplit(derived, ",", 2);   /* --derived "<match state>,<span state>" */
         run_span(g_strdup(model_name), input_path, atoi(d[0]), atoi(d[1]));
         }
+    else if(!strcmp(cmd, "hsp"))
+        run_hsp(g_strdup(model_name), input_path);
     else if(!strcmp(cmd, "golden"))
         run_golden(g_strdup(model_name), input_path, with_splice, revcomp_target,
                    subopt_max, subopt_threshold, derived);

@@ -63,6 +63,12 @@ def load():
         lib.oracle_find_path_region.argtypes = [C.POINTER(_abi.Model), C.POINTER(_abi.Params), C.c_char_p,
                                                 C.c_int32, C.c_char_p, C.c_int32, C.POINTER(_abi.Region), C.c_int,
                                                 C.c_int32, C.c_void_p, C.POINTER(_abi.Alignment)]
+        lib.oracle_hsp_extend.argtypes = [C.POINTER(_abi.Params), C.c_int, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32,
+                                          C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_abi.Hsp)]
+        lib.oracle_hsp_set.restype = C.c_int32
+        lib.oracle_hsp_set.argtypes = [C.POINTER(_abi.Params), C.c_int, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32,
+                                       C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                       C.c_int32, C.POINTER(_abi.Hsp)]
         lib.oracle_viterbi_subopt.argtypes = [C.POINTER(_abi.Model), C.POINTER(_abi.Params), C.c_int,
                                               C.c_char_p, C.c_int32, C.c_char_p, C.c_int32,
                                               C.POINTER(_abi.Region), C.POINTER(_abi.Continuation), C.c_int,
@@ -174,3 +180,23 @@ def span_pair(src_model, dst_model, params, q, t):
             "query_end": vo.query_end, "target_end": vo.target_end, "ops": [vo.ops[k] for k in range(vo.n_ops)]}
     lib.oracle_viterbi_out_clear(vo)
     return src_score, cells, dst_score, path
+
+
+MATCH_TYPES = {"dna2dna": _abi.MATCH_DNA2DNA, "protein2protein": _abi.MATCH_PROTEIN2PROTEIN, "protein2dna": _abi.MATCH_PROTEIN2DNA}
+
+
+def hsp_extend(params, match, q, t, seedlen, dropoff, qs, ts):
+    """HSPset_seed_hsp's HSP of one seed with nothing in its way: [query_start, target_start, length, score, cobs]."""
+    h = _abi.Hsp()
+    load().oracle_hsp_extend(params, MATCH_TYPES[match], q, len(q), t, len(t), seedlen, dropoff, qs, ts, h)
+    return h.aslist()
+
+
+def hsp_set(params, match, q, t, seedlen, dropoff, threshold, seeds):
+    """One HSPset fed the seeds in order: the list of HSPs it holds after HSPset_finalise."""
+    n = len(seeds)
+    sq = (C.c_int32 * max(1, n))(*[s[0] for s in seeds])
+    st = (C.c_int32 * max(1, n))(*[s[1] for s in seeds])
+    out = (_abi.Hsp * max(1, n))()
+    k = load().oracle_hsp_set(params, MATCH_TYPES[match], q, len(q), t, len(t), seedlen, dropoff, threshold, sq, st, n, out)
+    return [out[i].aslist() for i in range(k)]

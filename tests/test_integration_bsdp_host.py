@@ -63,8 +63,8 @@ def run_pair(tmp_path, model, extra, env_extra, n=6, seed=5):
         with open(path, "w") as f:
             for name, seq in recs:
                 f.write(">%s\n%s\n" % (name, seq))
-    args = ["-m", model, "--gappedextension", "no", "--showalignment", "yes", "--showvulgar", "yes", "-V", "0"] + \
-        list(extra) + [qf, tf]
+    mode = [] if "--gappedextension" in extra else ["--gappedextension", "no"]       # BSDP unless the case says otherwise
+    args = ["-m", model] + mode + ["--showalignment", "yes", "--showvulgar", "yes", "-V", "0"] + list(extra) + [qf, tf]
     ref = subprocess.run([CPU_EXE] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     gpu = subprocess.run([GPU_EXE] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900,
                          env=dict(os.environ, C4GPU_VERBOSE="1", **env_extra))
@@ -115,6 +115,19 @@ def test_several_flushes_keep_the_submission_order(tmp_path):
     assert re.search(r"in (\d+) flush", err) and int(re.search(r"in (\d+) flush", err).group(1)) >= 3
 
 
+@pytest.mark.parametrize("model,extra", [("est2genome", []), ("est2genome", ["--gappedextension", "yes"]), ("affine:local", []),
+                                         ("protein2dna", []), ("protein2genome", ["--hspfilter", "3"]), ("ungapped", []),
+                                         ("est2genome", ["--dnahspthreshold", "40", "--dnahspdropoff", "10"])])
+def test_seeding_seam_is_byte_identical_with_host_extensions(tmp_path, model, extra):
+    """The seeding seam (integration/c4gpu_hsp.c): word hits are written down during the scan, extended in one batch
+    per target scan and replayed through the horizon test and HSPset_add_known_hsp.  C4GPU_HSP_HOST=1: the extensions
+    come from the reference's own HSPset_seed_hsp on scratch sets; the device route is checked in test_integration_gpu.py."""
+    ref, gpu, err = run_pair(tmp_path, model, extra, {"C4GPU_BSDP_HOST": "1", "C4GPU_HSP_HOST": "1"})
+    assert gpu == ref and ref.count(b"vulgar:") >= 3
+    m = re.search(r"c4gpu hsp: (\d+) word hits of (\d+) HSP sets extended in (\d+) device batch", err)
+    assert m and int(m.group(1)) > 100 and int(m.group(3)) <= int(m.group(2)), err[-600:]
+
+
 def test_switching_the_seam_off(tmp_path):
-    ref, gpu, err = run_pair(tmp_path, "est2genome", [], {"C4GPU_BSDP_OFF": "1"})
-    assert gpu == ref and "c4gpu bsdp" not in err
+    ref, gpu, err = run_pair(tmp_path, "est2genome", [], {"C4GPU_BSDP_OFF": "1", "C4GPU_HSP_OFF": "1"})
+    assert gpu == ref and "c4gpu bsdp" not in err and "c4gpu hsp" not in err

@@ -257,6 +257,7 @@ def test_heuristic_bsdp_mode_runs_its_sub_dps_in_device_batches(tmp_path, model,
     assert gpu == ref
     assert ref.count(b"vulgar:") >= 4
     assert "stay on the CPU" not in err and "stay one call at a time" not in err, err[-1500:]
+    assert "c4gpu hsp:" in err and "HSP extensions of this scan on the CPU" not in err, err[-800:]   # the seeding seam too
     s_ok, s_all, p_ok, p_all = hb.served(err)
     assert s_all > 20 and p_all > 10
     if "-S" in extra:                                     # nothing is ever blocked: every call comes from a batch

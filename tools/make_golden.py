@@ -229,6 +229,69 @@ def run_span(cases, match_state, span_state, model="est2genome"):
     return recs
 
 
+def hsp_cases(kind, n, seed):
+    """Pairs with shared words and every shared-word position as a seed, in target-scan order (the order the FSM scan
+    reports them): `kind` dna2dna / protein2protein / protein2dna.  Plus the inputs of src/comparison/hspset.test.c."""
+    rng = random.Random(seed)
+    w = 12 if kind == "dna2dna" else 6
+    cases = []
+    for k in range(n):
+        if kind == "dna2dna":
+            q = rand_dna(rng, rng.choice([60, 150, 400]), "ACGT" if k % 5 else "ACGTN")
+            t = rand_dna(rng, rng.randint(0, 80)) + mutate(rng, q, rng.choice([0.02, 0.06, 0.12]), "ACGT") + rand_dna(rng, rng.randint(0, 80))
+            if k % 4 == 3:
+                t += mutate(rng, q[len(q) // 3:], 0.04, "ACGT")          # a second copy on other diagonals
+            trans = lambda s: s
+            step = 1
+        else:
+            q = rand_dna(rng, rng.choice([30, 80, 200]), AA)
+            m = mutate(rng, q, rng.choice([0.03, 0.1]), AA)
+            if kind == "protein2protein":
+                t = rand_dna(rng, rng.randint(0, 30), AA) + m + rand_dna(rng, rng.randint(0, 30), AA)
+                trans = lambda s: s
+                step = 1
+            else:
+                t = rand_dna(rng, rng.randint(0, 40)) + "".join(rng.choice(CODON[a]) for a in m) + rand_dna(rng, rng.randint(0, 40))
+                rev = {c: a for a, cs in CODON.items() for c in cs}
+                trans = lambda s: "".join(rev.get(s[i:i + 3], "X") for i in range(0, len(s) - 2, 3))
+                step = 3
+        seeds = []
+        words = {}
+        for i in range(len(q) - w + 1):
+            words.setdefault(q[i:i + w], []).append(i)
+        for j in range(0, len(t) - w * step + 1):
+            word = trans(t[j:j + w * step])
+            for i in words.get(word, ()):
+                seeds.append("%d:%d" % (i, j))
+        if seeds:
+            cases.append(("hsp_%s%03d" % (kind[:3], k), q, t, ",".join(seeds)))
+    if kind == "dna2dna":       # hspset.test.c:49-66
+        cases.append(("kat_d2d", "AAAAGTGAGAGAGAGAGAGAGGCGAAAAAAAAAACCCCCCCCCCACCCCGCGA",
+                      "TTTTGTGAGAGTGTGAGAGAGGCGTTTTTTTTTTCCCCCCCCCCTCCCCGCCT", "8:8,36:36"))
+    if kind == "protein2dna":
+        cases.append(("kat_p2d", "PNKDEGSCPIECDFLCRHQYISDP",
+                      "ACGTACGTACGTACGAGTGCGTGCCCCCTTNNNTGTGACTACATCTGCAAAACGTACGTACGT", "8:24"))
+    return cases
+
+
+def run_hsp(kind, cases, extra=()):
+    with tempfile.NamedTemporaryFile("w", suffix=".tsv", delete=False) as f:
+        for cid, q, t, seeds in cases:
+            f.write("%s\t%s\t%s\t%s\n" % (cid, q, t, seeds))
+        path = f.name
+    out = subprocess.run([REFDUMP, "--cmd", "hsp", "--model", kind, "--input", path] + list(extra),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout.decode()
+    os.unlink(path)
+    lines = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+    params, recs = lines[0]["params"], lines[1:]
+    assert len(recs) == len(cases)
+    for r, (cid, q, t, seeds) in zip(recs, cases):
+        assert r["id"] == cid
+        r["query"], r["target"] = q, t
+        r["seeds"] = [[int(x) for x in sd.split(":")] for sd in seeds.split(",")]
+    return [{"params": params}] + recs
+
+
 def main():
     rng = random.Random(20260928)
     sets = []
@@ -336,6 +399,18 @@ def main():
                          tuple(PARAM_VARIANTS[tag])))
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])
+    # HSP seeding (hspset.c:933): per-seed HSPs and whole-set HSP lists, default and lowered thresholds / dropoffs
+    for name, kind, extra in (("hsp_dna2dna", "dna2dna", ()), ("hsp_dna2dna_low", "dna2dna", ("--dnahspthreshold", "20", "--dnahspdropoff", "8")),
+                              ("hsp_protein2protein", "protein2protein", ()),
+                              ("hsp_protein2dna", "protein2dna", ("--proteinhspthreshold", "12")),
+                              ("hsp_protein2dna_drop", "protein2dna", ("--proteinhspdropoff", "5", "--proteinhspthreshold", "5"))):
+        if only and name not in only:
+            continue
+        recs = run_hsp(kind, hsp_cases(kind, 14, 31 + len(name)), extra)
+        with open(os.path.join(OUT, name + ".jsonl"), "w") as f:
+            for r in recs:
+                f.write(json.dumps(r, separators=(",", ":")) + "\n")
+        print(name, len(recs) - 1, "pairs,", sum(len(r["seeds"]) for r in recs[1:]), "seeds,", sum(len(r["set"]) for r in recs[1:]), "HSPs")
     if not only or "scoring_data_alt" in only:
         out = subprocess.run([REFDUMP, "--cmd", "data"] + ALT_FLAGS, stdout=subprocess.PIPE, check=True).stdout.decode()
         dd = json.loads(out)
