@@ -12,6 +12,8 @@
  *   c4gpu_optimal_*_batch    <->  Optimal_find_score / _find_path    src/c4/optimal.c:123,368
  *   c4gpu_splice_predict     <->  SplicePredictor_predict_array_int  src/sequence/splice.c:383
  *   c4gpu_alignment_format   <->  Alignment_print_{sugar,cigar,vulgar}_block  src/c4/alignment.c:1622-1779
+ *   c4gpu_hsp_extend_batch   <->  HSPset_seed_hsp (HSP_trim_ends/_init/_extend) src/comparison/hspset.c:933-997
+ *   c4gpu_batch_run_regions  <->  Optimal_find_path with a region (--refine)   src/hub/gam.c:605-655
  */
 #ifndef INCLUDED_C4GPU_H
 #define INCLUDED_C4GPU_H
