@@ -41,7 +41,9 @@ for extra in (["-S", "no"], [], ["--refine", "region", "-S", "no"], ["--refine",
     ref, t_ref, _ = run(cpu_exe, extra)
     gpu, t_gpu, err = run(gpu_exe, extra)
     off, t_off, _ = run(gpu_exe, extra, {"C4GPU_BSDP_OFF": "1"})
-    assert gpu == ref and off == ref, "outputs differ for %r" % (extra,)
+    hoff, t_hoff, _ = run(gpu_exe, extra, {"C4GPU_HSP_OFF": "1"})
+    assert gpu == ref and off == ref and hoff == ref, "outputs differ for %r" % (extra,)
+    hs = re.search(r"c4gpu hsp: (\d+) word hits of \d+ HSP sets extended in (\d+) device batch", err)
     m = re.search(r"(\d+) of (\d+) score calls and (\d+) of (\d+) path calls served from them; (\d+) of (\d+) refinements", err)
     served = "%d of %d" % (int(m.group(1)) + int(m.group(3)), int(m.group(2)) + int(m.group(4))) if m else "?"
     refined = "%s of %s" % (m.group(5), m.group(6)) if m else "?"
@@ -50,4 +52,7 @@ for extra in (["-S", "no"], [], ["--refine", "region", "-S", "no"], ["--refine",
     print("| `%s` | reference (compiled Viterbi, 1 core) | %.2f | %d | - | - |" % (flags, t_ref, nal))
     print("| `%s` | exonerate-gpu, BSDP + refinement batches | %.2f | %d | %s | %s |" % (flags, t_gpu, nal, served, refined))
     print("| `%s` | exonerate-gpu, seam off (one device call per refinement) | %.2f | %d | - | - |" % (flags, t_off, nal))
+    print("| `%s` | exonerate-gpu, seeding on the host (C4GPU_HSP_OFF=1), rest as row 2 | %.2f | %d | - | - |" % (flags, t_hoff, nal))
+    if hs:
+        print("| `%s` | (row 2: %s word hits extended in %s device launches) | | | | |" % (flags, hs.group(1), hs.group(2)))
 print("\nAll outputs byte-identical to the reference's.")
