@@ -1201,3 +1201,6 @@ int32_t oracle_hsp_set(const c4gpu_params *params, int match_type, const uint8_t
     free(horizon);
     return total;
     }
+
+/* ---- SDP (src/sdp/): restated in its own file, same translation unit ------------------------------------------- */
+#include "c4_oracle_sdp.c"

@@ -63,6 +63,16 @@ int32_t oracle_hsp_set(const c4gpu_params *params, int match_type, const uint8_t
                        const uint8_t *target, int32_t tlen, int32_t seedlen, int32_t dropoff, int32_t threshold,
                        const int32_t *seed_q, const int32_t *seed_t, int32_t n, c4gpu_hsp *out);
 
+/* SDP (src/sdp/sdp.c:743 SDP_Pair_next_path in the loop of GAM_Result_SDP_create, gam.c:852-890) on the HSPs of one pair:
+ * up to max_alignments alignments (out[] must hold that many; clear each with oracle_alignment_clear), the number found
+ * is returned.  query_advance / target_advance: the match advances of the HSPset (1/1, or 1/3 for protein2dna);
+ * dropoff: --extensionthreshold; singlepass: --singlepass.  *use_boundary (may be NULL): SDP.use_boundary (sdp.c:322). */
+int32_t oracle_sdp(const c4gpu_model *model, const c4gpu_params *params,
+                   const uint8_t *query, int32_t qlen, const uint8_t *target, int32_t tlen,
+                   const c4gpu_hsp *hsps, int32_t n_hsps, int32_t query_advance, int32_t target_advance,
+                   int32_t dropoff, int32_t singlepass, c4gpu_score threshold, int32_t max_alignments,
+                   c4gpu_alignment *out, int32_t *use_boundary);
+
 /* one raw Viterbi call in any mode (Viterbi_interpreted, src/c4/viterbi.c:655-837); used by the parity
  * tests of c4gpu_viterbi_batch.  checkpoints (may be NULL) receives
  * [cp][row < max_target_advance][i <= Q][state][cell_size] ints; ops receives the raw transition path. */

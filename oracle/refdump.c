@@ -40,6 +40,8 @@
 #include "sar.h"
 #include "gam.h"
 #include "hspset.h"
+#include "comparison.h"
+#include "sdp.h"
 
 static gint state_index(C4_Model *m, C4_State *s){
     register guint i;
@@ -684,6 +686,121 @@ static void run_hsp(gchar *match_name, gchar *input_path){
     return;
     }
 
+/* ---- SDP (src/sdp/sdp.c:743 SDP_Pair_next_path over src/sdp/scheduler.c:1445 Scheduler_Pair_calculate, interpreted
+ * Scheduler_Cell_process scheduler.c:859): the loop of GAM_Result_SDP_create (gam.c:852-890) on a Comparison whose
+ * HSPset was grown from the given word hits; dumps the HSPs (the oracle's input) and every alignment ------------------ */
+static void run_sdp(gchar *model_name, gchar *input_path, gint subopt_max, gint threshold){
+    register Model_Type type;
+    register FILE *fp = fopen(input_path, "r");
+    register Alphabet *dna = Alphabet_create(Alphabet_Type_DNA, FALSE),
+                      *protein = Alphabet_create(Alphabet_Type_PROTEIN, FALSE);
+    register Alphabet *qa, *ta;
+    register C4_Model *model;
+    register gboolean query_is_protein = FALSE, target_is_protein = FALSE;
+    register Match *match;
+    register HSP_Param *hsp_param;
+    register Comparison_Param *cparam;
+    register SDP *sdp;
+    register SDP_ArgumentSet *sas = SDP_ArgumentSet_create(NULL);
+    gchar *line = g_malloc(1<<24);
+    if(!fp)
+        g_error("cannot open [%s]", input_path);
+    if(strstr(model_name, ":protein")){
+        query_is_protein = target_is_protein = TRUE;
+        model_name[strlen(model_name)-strlen(":protein")] = '\0';
+        }
+    type = Model_Type_from_string(model_name);
+    switch(type){
+        case Model_Type_PROTEIN2DNA: case Model_Type_PROTEIN2DNA_BESTFIT:
+        case Model_Type_PROTEIN2GENOME: case Model_Type_PROTEIN2GENOME_BESTFIT:
+            query_is_protein = TRUE;
+            break;
+        default:
+            break;
+        }
+    qa = query_is_protein?protein:dna;
+    ta = target_is_protein?protein:dna;
+    match = Match_find(query_is_protein ? (target_is_protein ? Match_Type_PROTEIN2PROTEIN : Match_Type_PROTEIN2DNA)
+                                        : Match_Type_DNA2DNA);
+    hsp_param = HSP_Param_create(match, TRUE);
+    cparam = Comparison_Param_create(qa->type, ta->type,
+                 (!query_is_protein) ? hsp_param : NULL,
+                 (query_is_protein && target_is_protein) ? hsp_param : NULL,
+                 (query_is_protein && !target_is_protein) ? hsp_param : NULL);
+    model = Model_Type_get_model(type, qa->type, ta->type);
+    sdp = SDP_create(model);
+    printf("{\"params\":{\"model\":\"%s\",\"use_boundary\":%d,\"dropoff\":%d,\"singlepass\":%d,\"threshold\":%d,"
+           "\"hsp_threshold\":%d,\"n_spans\":%d,\"spans\":[", model->name, sdp->use_boundary, sas->dropoff,
+           sas->single_pass_subopt, threshold, hsp_param->threshold, model->span_list->len);
+    {
+        register guint k;
+        for(k = 0; k < model->span_list->len; k++){
+            register C4_Span *span = model->span_list->pdata[k];
+            printf("%s[%d,%d,%d,%d,%d,%d,%d]", k?",":"", span->span_state->id, span->min_query, span->max_query,
+                   span->min_target, span->max_target, span->query_loop ? span->query_loop->id : -1,
+                   span->target_loop ? span->target_loop->id : -1);
+            }
+    }
+    printf("]}}\n");
+    while(fgets(line, 1<<24, fp)){
+        gchar **f, **seeds;
+        Sequence *query, *target;
+        Comparison *comparison;
+        HSPset *hspset;
+        gpointer user_data;
+        register gint k;
+        g_strchomp(line);
+        if((!line[0]) || (line[0] == '#'))
+            continue;
+        f = g_strsplit(line, "\t", 4);                  /* id, query, target, "q:t,q:t,..." word hits */
+        query = Sequence_create(f[0], NULL, f[1], 0, Sequence_Strand_FORWARD, qa);
+        target = Sequence_create("tg", NULL, f[2], 0, Sequence_Strand_FORWARD, ta);
+        seeds = g_strsplit(f[3], ",", -1);
+        comparison = Comparison_create(cparam, query, target);
+        hspset = comparison->dna_hspset ? comparison->dna_hspset
+               : comparison->protein_hspset ? comparison->protein_hspset : comparison->codon_hspset;
+        for(k = 0; seeds[k] && seeds[k][0]; k++)
+            HSPset_seed_hsp(hspset, atoi(seeds[k]), atoi(strchr(seeds[k], ':') + 1));
+        Comparison_finalise(comparison);
+        printf("{\"id\":\"%s\",\"qlen\":%d,\"tlen\":%d,\"hsps\":[", f[0], query->len, target->len);
+        for(k = 0; k < (gint)hspset->hsp_list->len; k++){
+            register HSP *h = hspset->hsp_list->pdata[k];
+            printf("%s[%d,%d,%d,%d,%d]", k?",":"", h->query_start, h->target_start, h->length, h->score, h->cobs);
+            }
+        printf("],\"alignments\":[");
+        if(Comparison_has_hsps(comparison)){
+            register SubOpt *subopt = SubOpt_create(query->len, target->len);
+            register SDP_Pair *sdp_pair;
+            register Alignment *alignment;
+            user_data = Model_Type_create_data(type, query, target);
+            sdp_pair = SDP_Pair_create(sdp, subopt, comparison, user_data);
+            for(k = 0; k < subopt_max; k++){
+                alignment = SDP_Pair_next_path(sdp_pair, threshold);
+                if(!alignment)
+                    break;
+                printf("%s{", k?",":"");
+                dump_alignment_fields(alignment, query, target);
+                printf("}");
+                SubOpt_add_alignment(subopt, alignment);
+                Alignment_destroy(alignment);
+                }
+            SDP_Pair_destroy(sdp_pair);
+            SubOpt_destroy(subopt);
+            Model_Type_destroy_data(type, user_data);
+            }
+        printf("]}\n");
+        fflush(stdout);
+        Comparison_destroy(comparison);
+        Sequence_destroy(query);
+        Sequence_destroy(target);
+        g_strfreev(f);
+        g_strfreev(seeds);
+        }
+    fclose(fp);
+    g_free(line);
+    return;
+    }
+
 int Argument_main(Argument *arg){
     register ArgumentSet *as = ArgumentSet_create("refdump options");
     gchar *cmd, *model_name, *input_path;
@@ -719,6 +836,7 @@ int Argument_main(Argument *arg){
     Alignment_ArgumentSet_create(arg);
     Splice_ArgumentSet_create(arg);
     HSPset_ArgumentSet_create(arg);
+    SDP_ArgumentSet_create(arg);
     Argument_process(arg, "refdump", "reference table/golden dumper", "");
     if(!strcmp(cmd, "tables"))
         dump_tables();
@@ -732,6 +850,8 @@ int Argument_main(Argument *arg){
         }
     else if(!strcmp(cmd, "hsp"))
         run_hsp(g_strdup(model_name), input_path);
+    else if(!strcmp(cmd, "sdp"))
+        run_sdp(g_strdup(model_name), input_path, subopt_max > 0 ? subopt_max : 1, subopt_threshold);
     else if(!strcmp(cmd, "golden"))
         run_golden(g_strdup(model_name), input_path, with_splice, revcomp_target,
                    subopt_max, subopt_threshold, derived);

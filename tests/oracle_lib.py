@@ -24,8 +24,8 @@ _lib = None
 def load():
     global _lib
     if _lib is None:
-        src = os.path.join(ROOT, "oracle", "c4_oracle.c")
-        if (not os.path.exists(SO)) or os.path.getmtime(SO) < os.path.getmtime(src):
+        srcs = [os.path.join(ROOT, "oracle", f) for f in ("c4_oracle.c", "c4_oracle_sdp.c")]
+        if (not os.path.exists(SO)) or os.path.getmtime(SO) < max(os.path.getmtime(x) for x in srcs):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "port"],
                                   stdout=subprocess.DEVNULL)
         lib = C.CDLL(SO)
@@ -76,6 +76,10 @@ def load():
         lib.oracle_viterbi_span.argtypes = [C.POINTER(_abi.Model), C.POINTER(_abi.Params), C.c_int,
                                             C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(_abi.Region),
                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(ViterbiOut)]
+        lib.oracle_sdp.restype = C.c_int32
+        lib.oracle_sdp.argtypes = [C.POINTER(_abi.Model), C.POINTER(_abi.Params), C.c_char_p, C.c_int32, C.c_char_p,
+                                   C.c_int32, C.POINTER(_abi.Hsp), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_int32, C.c_int32, C.POINTER(_abi.Alignment), C.POINTER(C.c_int32)]
         lib.oracle_cells_visited.restype = C.c_int64
         lib.oracle_cells_visited.argtypes = [C.c_int]
         _lib = lib
@@ -200,3 +204,21 @@ def hsp_set(params, match, q, t, seedlen, dropoff, threshold, seeds):
     out = (_abi.Hsp * max(1, n))()
     k = load().oracle_hsp_set(params, MATCH_TYPES[match], q, len(q), t, len(t), seedlen, dropoff, threshold, sq, st, n, out)
     return [out[i].aslist() for i in range(k)]
+
+
+def sdp(model, params, q, t, hsps, query_advance=1, target_advance=1, dropoff=50, singlepass=True, threshold=100,
+        max_alignments=8, qid="qy"):
+    """The loop of GAM_Result_SDP_create (gam.c:852) on one pair's HSPs ([query_start, target_start, length, score,
+    cobs] each, in HSPset order): (use_boundary, [alignment dicts with score / region / ops / vulgar])."""
+    lib = load()
+    n = len(hsps)
+    hs = (_abi.Hsp * max(1, n))(*[_abi.Hsp(*h) for h in hsps])
+    out = (_abi.Alignment * max_alignments)()
+    ub = C.c_int32(-1)
+    k = lib.oracle_sdp(model, params, q, len(q), t, len(t), hs, n, query_advance, target_advance, dropoff,
+                       1 if singlepass else 0, threshold, max_alignments, out, C.byref(ub))
+    res = []
+    for i in range(k):
+        res.append(alignment_to_dict(model, out[i], lib.oracle_alignment_format, qid, len(q), len(t)))
+        lib.oracle_alignment_clear(out[i])
+    return ub.value, res

@@ -292,6 +292,103 @@ def run_hsp(kind, cases, extra=()):
     return [{"params": params}] + recs
 
 
+def word_hits(q, t, w, kind):
+    """Every shared word of the pair in target-scan order (what the seeder's FSM scan reports)."""
+    if kind == "protein2dna":
+        rev = {c: a for a, cs in CODON.items() for c in cs}
+        trans = lambda x: "".join(rev.get(x[i:i + 3], "X") for i in range(0, len(x) - 2, 3))
+        step = 3
+    else:
+        trans = lambda x: x
+        step = 1
+    words = {}
+    for i in range(len(q) - w + 1):
+        words.setdefault(q[i:i + w], []).append(i)
+    seeds = []
+    for j in range(0, len(t) - w * step + 1):
+        for i in words.get(trans(t[j:j + w * step]), ()):
+            seeds.append("%d:%d" % (i, j))
+    return seeds
+
+
+def indels(rng, s, alphabet, every, unit=1):
+    """Deletions and insertions of 1-4 units roughly every `every` positions."""
+    out, i = [], 0
+    while i < len(s):
+        step = rng.randint(every // 2, every * 3 // 2)
+        out.append(s[i:i + step])
+        i += step
+        if i < len(s):
+            k = rng.randint(1, 4) * unit
+            if rng.random() < 0.5:
+                i += k
+            else:
+                out.append(rand_dna(rng, k, alphabet))
+    return "".join(out)
+
+
+def sdp_cases(model, n, seed):
+    """Pairs for SDP (sdp.c:743): the gapped model families with indels / introns / frameshifts between the HSPs, a second
+    copy of the gene in some targets (later alignments of the pair), every shared word as a word hit."""
+    rng = random.Random(seed)
+    cases = []
+    base = []
+    if model.startswith("affine") and model.endswith(":protein"):
+        kind, w = "protein2protein", 5
+        for k in range(n):
+            q = rand_dna(rng, rng.choice([40, 90, 200, 350]), AA)
+            body = indels(rng, mutate(rng, q, rng.choice([0.05, 0.15]), AA), AA, rng.choice([25, 60]))
+            t = rand_dna(rng, rng.randint(0, 30), AA) + body + rand_dna(rng, rng.randint(0, 30), AA)
+            if k % 4 == 3:
+                t += rand_dna(rng, 10, AA) + mutate(rng, q[len(q) // 3:], 0.1, AA)
+            base.append(("prot%03d" % k, q, t))
+    elif model.startswith("affine"):
+        kind, w = "dna2dna", 10
+        for k in range(n):
+            q = rand_dna(rng, rng.choice([60, 150, 300, 500]), "ACGT" if k % 5 else "ACGTN")
+            body = indels(rng, mutate(rng, q, rng.choice([0.02, 0.06, 0.1]), "ACGT"), "ACGT", rng.choice([30, 70, 150]))
+            t = rand_dna(rng, rng.randint(0, 60)) + body + rand_dna(rng, rng.randint(0, 60))
+            if k % 4 == 3:
+                t += rand_dna(rng, 25) + indels(rng, mutate(rng, q[len(q) // 4:], 0.05, "ACGT"), "ACGT", 80)
+            base.append(("dna%03d" % k, q, t))
+    elif model == "est2genome":
+        kind, w = "dna2dna", 10
+        for cid, q, t in est_pairs(rng, n):
+            if rng.random() < 0.5:
+                t = indels(rng, t, "ACGT", 120)
+            base.append((cid, q, t))
+    elif model == "protein2dna":
+        kind, w = "protein2dna", 4
+        base = p2d_pairs(rng, n)
+    else:
+        kind, w = "protein2dna", 4
+        base = p2g_pairs(rng, n)
+    for k, (cid, q, t) in enumerate(base):
+        if k % 4 == 3 and kind != "protein2protein" and not model.startswith("affine"):
+            t = t + rand_dna(rng, 30) + t[len(t) // 4:]                   # second copy: later alignments of the pair
+        seeds = word_hits(q, t, w, kind)
+        if seeds:
+            cases.append(("sdp_" + cid, q, t, ",".join(seeds)))
+    return cases
+
+
+def run_sdp(model, cases, extra=()):
+    with tempfile.NamedTemporaryFile("w", suffix=".tsv", delete=False) as f:
+        for cid, q, t, seeds in cases:
+            f.write("%s\t%s\t%s\t%s\n" % (cid, q, t, seeds))
+        path = f.name
+    out = subprocess.run([REFDUMP, "--cmd", "sdp", "--model", model, "--input", path] + list(extra),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout.decode()
+    os.unlink(path)
+    lines = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+    params, recs = lines[0]["params"], lines[1:]
+    assert len(recs) == len(cases)
+    for r, (cid, q, t, seeds) in zip(recs, cases):
+        assert r["id"] == cid
+        r["query"], r["target"] = q, t
+    return [{"params": params}] + recs
+
+
 def main():
     rng = random.Random(20260928)
     sets = []
@@ -399,6 +496,26 @@ def main():
                          tuple(PARAM_VARIANTS[tag])))
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])
+    # SDP (sdp.c:743, scheduler.c:859-1065): alignments of GAM_Result_SDP_create's loop from the reference's own HSPs
+    sub = ("--suboptmax", "4", "--suboptthreshold", "40")
+    for name, model, n, extra in (
+            ("sdp_affine_local", "affine:local", 24, ("--dnawordlen", "10") + sub),
+            ("sdp_affine_local_protein", "affine:local:protein", 16, ("--proteinwordlen", "5") + sub),
+            ("sdp_est2genome", "est2genome", 20, ("--dnawordlen", "10") + sub),
+            ("sdp_est2genome_drop", "est2genome", 14, ("--dnawordlen", "10", "--extensionthreshold", "12", "--dnahspthreshold", "30") + sub),
+            ("sdp_est2genome_altparams", "est2genome", 14, tuple(ALT_FLAGS) + ("--dnawordlen", "10", "--singlepass", "no",
+                                                                        "--dnahspthreshold", "8") + sub),
+            ("sdp_protein2dna", "protein2dna", 16, ("--proteinwordlen", "4") + sub),
+            ("sdp_protein2genome", "protein2genome", 20, ("--proteinwordlen", "4") + sub),
+            ("sdp_protein2genome_altparams", "protein2genome", 14, tuple(ALT_FLAGS) + ("--proteinwordlen", "4", "--extensionthreshold", "25") + sub)):
+        if only and name not in only:
+            continue
+        recs = run_sdp(model, sdp_cases(model, n, 77 + len(name)), extra)
+        with open(os.path.join(OUT, name + ".jsonl"), "w") as f:
+            for r in recs:
+                f.write(json.dumps(r, separators=(",", ":")) + "\n")
+        print(name, len(recs) - 1, "pairs,", sum(len(r["hsps"]) for r in recs[1:]), "HSPs,",
+              sum(len(r["alignments"]) for r in recs[1:]), "alignments", recs[0]["params"])
     # HSP seeding (hspset.c:933): per-seed HSPs and whole-set HSP lists, default and lowered thresholds / dropoffs
     for name, kind, extra in (("hsp_dna2dna", "dna2dna", ()), ("hsp_dna2dna_low", "dna2dna", ("--dnahspthreshold", "20", "--dnahspdropoff", "8")),
                               ("hsp_protein2protein", "protein2protein", ()),
