@@ -309,6 +309,32 @@ class Engine:
             raise _err("c4gpu_hsp_extend_batch")
         return [out[i].aslist() for i in range(n)]
 
+    def sdp(self, model, pairs, hsps, query_advance=1, target_advance=1, dropoff=50, threshold=100, max_alignments=4):
+        """The reference's default gapped-extension heuristic (SDP, GAM_Result_SDP_create gam.c:852) for a batch: per pair
+        the list of alignments found from its HSPs ([query_start, target_start, length, score, cobs] each), both
+        Scheduler passes on the device (c4gpu_sdp_batch; affine and protein2dna families)."""
+        arr, keep = _pairs(pairs)
+        flat = [h for hs in hsps for h in hs]
+        first = [0]
+        for hs in hsps:
+            first.append(first[-1] + len(hs))
+        ch = (_abi.Hsp * max(1, len(flat)))(*[_abi.Hsp(*h) for h in flat])
+        cf = (C.c_int32 * len(first))(*first)
+        out = (_abi.Alignment * max(1, len(pairs) * max_alignments))()
+        n_out = (C.c_int32 * max(1, len(pairs)))()
+        if _lib().c4gpu_sdp_batch(self.ctx, model.c, model.params, arr, len(pairs), ch, cf, query_advance, target_advance,
+                                  dropoff, threshold, max_alignments, out, n_out) != 0:
+            raise _err("c4gpu_sdp_batch")
+        res = []
+        for i in range(len(pairs)):
+            mine = []
+            for k in range(n_out[i]):
+                a = out[i * max_alignments + k]
+                mine.append(Alignment(model, a, len(pairs[i][0]), len(pairs[i][1])))
+                _lib().c4gpu_alignment_clear(a)
+            res.append(mine)
+        return res
+
     def splice_predict(self, params, target):
         t = target if isinstance(target, bytes) else target.encode()
         bufs = [(C.c_int32 * max(1, len(t)))() for _ in range(4)]

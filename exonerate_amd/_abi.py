@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libc4gpu.so")
 
-ABI_VERSION = 3            # C4GPU_ABI_VERSION of include/c4gpu.h these structures mirror
+ABI_VERSION = 4            # C4GPU_ABI_VERSION of include/c4gpu.h these structures mirror
 MAX_STATES, MAX_TRANSITIONS, MAX_CALCS, MAX_SHADOWS, NAME_LEN = 16, 48, 16, 4, 48
 SPLICE_MAX_LEN = 32
 CELL_MAX = 1 + MAX_SHADOWS + 3
@@ -179,6 +179,9 @@ PROTOTYPES = [
     ("c4gpu_model_device_family", C.c_int, [C.POINTER(Model)]),
     ("c4gpu_hsp_extend_batch", C.c_int, [C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(Pair), C.c_int32, C.c_int32,
                                          C.c_int32, C.POINTER(HspSeed), C.c_int32, C.POINTER(Hsp)]),
+    ("c4gpu_sdp_batch", C.c_int, [C.c_void_p, C.POINTER(Model), C.POINTER(Params), C.POINTER(Pair), C.c_int32, C.POINTER(Hsp),
+                                  C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                  C.POINTER(Alignment), C.POINTER(C.c_int32)]),
     ("c4gpu_batch_viterbi_model", C.c_int, [C.c_void_p, C.POINTER(Model), C.c_int, C.POINTER(ViterbiJob), C.c_int32,
                                             C.POINTER(ViterbiResult)]),
     ("c4gpu_batch_scores", C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(Region)]),

@@ -16,6 +16,9 @@
 #include <map>
 #include <memory>
 #include <vector>
+#include <thread>
+#include <atomic>
+#include <mutex>
 
 #include "c4gpu.h"
 #include "c4_internal.h"
@@ -474,6 +477,27 @@ struct JobOut {
     std::vector<int> checkpoints; // CKPT + dump_checkpoints
 };
 
+// Host loops over hundreds of thousands of independent small items (the sub-alignments between checkpoints: 778 443 per
+// pass for 4 096 pairs of 1 kb x 1 kb under the reference's -D 32 rule) are split over a few threads; `fn(first, last)`
+// works on its own items only.  C4GPU_HOST_THREADS=1 keeps everything on the calling thread.
+template <typename F> void parallel_for(long long n, long long min_per_thread, F &&fn) {
+    static const int hw = [] {
+        const char *e = getenv("C4GPU_HOST_THREADS");
+        const int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        return std::max(1, std::min(v, 16));
+    }();
+    const int t = (int)std::min<long long>(hw, n / std::max<long long>(1, min_per_thread));
+    if (t <= 1) { if (n > 0) fn(0LL, n); return; }
+    const long long chunk = (n + t - 1) / t;
+    std::vector<std::thread> th;
+    for (int k = 1; k < t; k++) {
+        const long long a = k * chunk, b = std::min(n, a + chunk);
+        if (a < b) th.emplace_back([&fn, a, b] { fn(a, b); });
+    }
+    fn(0LL, std::min(n, chunk));
+    for (auto &x : th) x.join();
+}
+
 // The windowed region pass (c4_viterbi_kernel.h, SEED): what a launch needs to know about the column dumps.
 struct SeedPlan {
     int mode = 0;                  // 1: the score pass writes dumps; 2: the region windows start from them
@@ -510,7 +534,10 @@ struct Engine {
     std::vector<DevJob> h_jobs;
     std::vector<DevResult> h_res;
     std::vector<uint32_t> h_runs;
+    std::vector<DevVsa> h_vsa;
+    std::vector<int> h_dump;
     std::vector<JobSpec> fp_specs;          // ... and of find_path_batch
+    std::vector<JobSpec> fp_sub_specs;      // its sub-alignment launch (every entry rewritten; only resized when the count changes)
     std::vector<JobOut> fp_outs;
     // per-pair SubOpt of the Optimal_find_path in progress (NULL entries / NULL table: nothing blocked)
     const std::vector<const c4gpu_subopt *> *pair_sub = nullptr;
@@ -621,7 +648,10 @@ struct Engine {
                                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
         };
         const int n = (int)specs.size();
-        out.assign(n, JobOut());
+        // every field of entries [0, n) is rewritten after the launch; a vector that is reused for launches of very
+        // different sizes (4 096 checkpoint jobs, then 778 443 sub-alignments, every step) is never shrunk: building
+        // and tearing down its tail was the largest host item of such a step
+        if ((int)out.size() < n) out.resize(n);
         if (!n) return 0;
         const bool use_local = local && local_exact && !cont && (mode == MODE_SCORE || mode == MODE_REGION);
         // packed region-start slot: (query_start << tshift) | target_start must fit 31 bits for every job
@@ -680,10 +710,26 @@ struct Engine {
         long long max_runs = 0, sub_cols = 0, span_total = 0, seed_total = 0;
         if (seed && seed->mode == 1) seed->off.assign(n, -1);
         std::vector<int> sub_t, sub_q;
+        // the fields that do not depend on the jobs before it ...
+        parallel_for(n, 32768, [&](long long first, long long last) {
+            for (long long x = first; x < last; x++) {
+                const JobSpec &s = specs[order[x]];
+                DevJob &j = jobs[x];
+                memset(&j, 0, sizeof j);
+                j.seed_off = -1;
+                if (seed) j.seed_kshift = seed->kshift;
+                j.pair = s.pair; j.q0 = s.region.query_start; j.t0 = s.region.target_start;
+                j.Q = s.region.query_length; j.T = s.region.target_length;
+                j.first_state = s.first_state; j.final_state = s.final_state; j.cp_count = s.cp_count;
+                j.tshift = nbits(j.T);
+                memcpy(j.first_cell, s.first_cell, sizeof j.first_cell);
+                j.ckpt_off = -1;
+            }
+        });
+        // ... and the running offsets into the launch's buffers
         for (int x = 0; x < n; x++) {
             const JobSpec &s = specs[order[x]];
             DevJob &j = jobs[x];
-            memset(&j, 0, sizeof j);
             if (span) {
                 j.span_off = span_total;
                 span_total += (long long)(s.region.query_length + 1) * (s.region.target_length + 1) * span_cs;
@@ -694,9 +740,7 @@ struct Engine {
                 sub_cols += s.region.target_length + 2;
                 for (const auto &p : rp) { sub_t.push_back(p.first); sub_q.push_back(p.second); }
             }
-            j.seed_off = -1;
             if (seed) {
-                j.seed_kshift = seed->kshift;
                 if (seed->mode == 1) {            // dumps d = 1 .. T >> kshift, two columns of Q + 1 rows each
                     j.seed_off = seed_total; j.seed_rows = s.region.query_length + 1;
                     seed->off[order[x]] = seed_total;
@@ -706,16 +750,11 @@ struct Engine {
                     j.seed_off = seed->off[order[x]]; j.seed_rows = seed->rows[order[x]];
                 }
             }
-            j.pair = s.pair; j.q0 = s.region.query_start; j.t0 = s.region.target_start;
-            j.Q = s.region.query_length; j.T = s.region.target_length;
-            j.first_state = s.first_state; j.final_state = s.final_state; j.cp_count = s.cp_count;
-            j.tshift = nbits(j.T);
-            memcpy(j.first_cell, s.first_cell, sizeof j.first_cell);
-            j.ops_off = ops_total; j.ops_cap = 0; j.vsa_off = (int)vsa_total; j.ckpt_off = -1;
-            total_cells += cells(order[x]);
+            j.ops_off = ops_total; j.ops_cap = 0; j.vsa_off = (int)vsa_total;
+            total_cells += (long long)(j.Q + 1) * (j.T + 1);
             max_T = std::max<long long>(max_T, j.T);
-            const long long strips = (j.Q + 1 + 64 * ki->R - 1) / (64 * ki->R);
             if (mode == MODE_PATH) {
+                const long long strips = (j.Q + 1 + 64 * ki->R - 1) / (64 * ki->R);
                 j.ops_cap = 3 * (j.Q + j.T) + 16;
                 max_runs = std::max<long long>(max_runs, j.ops_cap);
                 ops_total += j.ops_cap;
@@ -752,8 +791,10 @@ struct Engine {
         res.resize(n);
         std::vector<uint32_t> &runs = h_runs;
         runs.clear();
-        std::vector<DevVsa> vsa(vsa_total);
-        std::vector<int> dump(dump_total);
+        std::vector<DevVsa> &vsa = h_vsa;         // kept between launches: fresh vectors of this size are zeroed and
+        std::vector<int> &dump = h_dump;          // page-faulted in on every call (50 MB for a C2-shaped batch)
+        vsa.resize(vsa_total);
+        dump.resize(dump_total);
         for (int attempt = 0; attempt < 2; attempt++) {
             int zero = 0;
             unsigned long long zero64 = 0;
@@ -834,21 +875,25 @@ struct Engine {
             break;
         }
         lap("runs downloaded");
-        for (int x = 0; x < n; x++) {
-            JobOut &o = out[order[x]];
-            o.res = res[x];
-            if (res[x].flags & FLAG_OPS_OVERFLOW) { c4h::set_error("traceback path longer than its buffer"); return -1; }
-            if (mode == MODE_PATH) {        // the walk wrote END -> START
-                o.runs.assign_reversed(runs.data() + res[x].ops_off, res[x].n_ops);
-            }
-            if (mode == MODE_CKPT) {
-                o.vsa.assign(vsa.begin() + jobs[x].vsa_off, vsa.begin() + jobs[x].vsa_off + res[x].n_vsa);
-                if (jobs[x].ckpt_off >= 0) {
+        std::atomic<int> overflow{0};
+        parallel_for(n, 32768, [&](long long first, long long last) {
+            for (long long x = first; x < last; x++) {
+                JobOut &o = out[order[x]];
+                o.res = res[x];
+                if (res[x].flags & FLAG_OPS_OVERFLOW) { overflow = 1; continue; }
+                if (mode == MODE_PATH) o.runs.assign_reversed(runs.data() + res[x].ops_off, res[x].n_ops);   // the walk wrote END -> START
+                else o.runs.n = 0;
+                if (mode == MODE_CKPT) o.vsa.assign(vsa.begin() + jobs[x].vsa_off, vsa.begin() + jobs[x].vsa_off + res[x].n_vsa);
+                else o.vsa.clear();
+                if (mode == MODE_CKPT && jobs[x].ckpt_off >= 0) {
                     const long long ck = (long long)jobs[x].cp_count * ki->max_at * (jobs[x].Q + 1) * ki->n_states * ki->cs;
                     o.checkpoints.assign(dump.begin() + jobs[x].ckpt_off, dump.begin() + jobs[x].ckpt_off + ck);
+                } else {
+                    o.checkpoints.clear();
                 }
             }
-        }
+        });
+        if (overflow) { c4h::set_error("traceback path longer than its buffer"); return -1; }
         return 0;
     }
 };
@@ -1231,12 +1276,20 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
         lap("checkpoint jobs listed");
         if (eng.run(seqs, MODE_CKPT, true, specs, outs)) return -1;
         lap("checkpoint pass done");
-        // expand from the back so that segment indices stay valid
-        for (int x = (int)refs.size() - 1; x >= 0; x--) {
+        // expand from the back so that segment indices stay valid; the jobs of one pair are adjacent in the list and
+        // pairs do not touch each other's segments
+        std::vector<int> group;
+        for (size_t x = 0; x < refs.size(); x++)
+            if (!x || refs[x].pair != refs[x - 1].pair) group.push_back((int)x);
+        group.push_back((int)refs.size());
+        parallel_for((long long)group.size() - 1, 256, [&](long long g0, long long g1) {
+          for (long long g = g0; g < g1; g++)
+            for (int x = group[g + 1] - 1; x >= group[g]; x--) {
             std::vector<Segment> &sg = plan[refs[x].pair].segs;
             const int k = refs[x].seg;
             if (first_round) red_score[refs[x].pair] = outs[x].res.score;
             std::vector<Segment> children;
+            children.reserve(outs[x].vsa.size());
             for (int v = (int)outs[x].vsa.size() - 1; v >= 0; v--) {     // path order = reverse of the list
                 const DevVsa &dv = outs[x].vsa[v];
                 Segment c;
@@ -1257,7 +1310,8 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
             }
             sg.erase(sg.begin() + k);
             sg.insert(sg.begin() + k, children.begin(), children.end());
-        }
+            }
+        });
         first_round = false;
     }
     lap("segments expanded");
@@ -1265,24 +1319,27 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
     specs.clear();
     struct Ref2 { int pair, seg; };
     std::vector<Ref2> refs2;
-    {
-        size_t total = 0;
-        for (int i : red) total += plan[i].segs.size();
-        specs.reserve(total); refs2.reserve(total);
-    }
-    for (int i : red) {
-        std::vector<Segment> &sg = plan[i].segs;
-        for (size_t k = 0; k < sg.size(); k++) {
-            JobSpec s; s.pair = i; s.region = sg[k].region;
-            s.first_state = sg[k].first_state;
-            if (k > 0) memcpy(s.first_cell, sg[k - 1].final_cell, sizeof s.first_cell);
-            s.final_state = (k + 1 < sg.size()) ? sg[k + 1].first_state : m->end_state;
-            specs.push_back(s);
-            refs2.push_back(Ref2{i, (int)k});
+    std::vector<size_t> seg_first(red.size() + 1, 0);          // first sub-alignment job of each reduced-space pair
+    for (size_t r = 0; r < red.size(); r++) seg_first[r + 1] = seg_first[r] + plan[red[r]].segs.size();
+    std::vector<JobSpec> &sub_specs = eng.fp_sub_specs;
+    if (sub_specs.size() != seg_first[red.size()]) sub_specs.resize(seg_first[red.size()]);
+    refs2.resize(seg_first[red.size()]);
+    parallel_for((long long)red.size(), 256, [&](long long r0, long long r1) {
+        for (long long r = r0; r < r1; r++) {
+            const int i = red[r];
+            const std::vector<Segment> &sg = plan[i].segs;
+            for (size_t k = 0; k < sg.size(); k++) {
+                JobSpec s; s.pair = i; s.region = sg[k].region;
+                s.first_state = sg[k].first_state;
+                if (k > 0) memcpy(s.first_cell, sg[k - 1].final_cell, sizeof s.first_cell);
+                s.final_state = (k + 1 < sg.size()) ? sg[k + 1].first_state : m->end_state;
+                sub_specs[seg_first[r] + k] = s;
+                refs2[seg_first[r] + k] = Ref2{i, (int)k};
+            }
         }
-    }
+    });
     lap("sub-alignment jobs listed");
-    if (eng.run(seqs, MODE_PATH, true, specs, outs)) return -1;
+    if (eng.run(seqs, MODE_PATH, true, sub_specs, outs)) return -1;
     lap("sub-alignment pass done");
     {
         std::vector<int> cap(n, 0);
@@ -1296,7 +1353,10 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
         struct Repair { int pair, next_seg; int seed[CELL_MAX]; };
         std::vector<Repair> repairs;
         std::vector<int> repairing(n, -1);                 // first sub-alignment to recompute, per pair
-        for (size_t x = 0; x < refs2.size(); x++) {
+        std::mutex repairs_lock;
+        parallel_for((long long)red.size(), 256, [&](long long r0, long long r1) {
+          for (long long r = r0; r < r1; r++)
+            for (size_t x = seg_first[r]; x < seg_first[r + 1]; x++) {
             const int i = refs2[x].pair, k = refs2[x].seg;
             c4gpu_alignment &a = alignments[i];
             std::vector<Segment> &sg = plan[i].segs;
@@ -1314,11 +1374,15 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
                 if (k + 1 < (int)sg.size()) {
                     Repair rp; rp.pair = i; rp.next_seg = k + 1;
                     memcpy(rp.seed, outs[x].res.final_cell, sizeof rp.seed);
+                    std::lock_guard<std::mutex> hold(repairs_lock);
                     repairs.push_back(rp);
                     repairing[i] = k + 1;
                 }
             }
-        }
+            }
+        });
+        // the repair launches below take the pairs in list order
+        std::sort(repairs.begin(), repairs.end(), [](const Repair &x, const Repair &y) { return x.pair < y.pair; });
         // Optimal_compute_subalignments (optimal.c:266-313) for the stale tails, all affected pairs in
         // lock-step: one small launch per remaining sub-alignment, each seeded with the cell its predecessor
         // actually produced.
@@ -1761,3 +1825,6 @@ int c4gpu_batch_kernel_stats(c4gpu_batch *b, int mode, int reset, double *ms, in
 }
 
 }  // extern "C"
+
+// ---- SDP on the device (seeded flavour): its own file, same translation unit ------------------------------------
+#include "c4_sdp.inc"

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define C4GPU_ABI_VERSION 3
+#define C4GPU_ABI_VERSION 4
 
 /* src/c4/c4.h:28-30 */
 typedef int32_t c4gpu_score;
@@ -357,6 +357,19 @@ typedef struct { int32_t query_start, target_start, length, score, cobs; } c4gpu
 int         c4gpu_hsp_extend_batch(c4gpu_ctx *ctx, const c4gpu_params *params, int match_type,
                                    const c4gpu_pair *pairs, int32_t n_pairs, int32_t seedlen, int32_t dropoff,
                                    const c4gpu_hsp_seed *seeds, int32_t n_seeds, c4gpu_hsp *out);
+
+/* SDP, the default gapped-extension heuristic (SDP_Pair_next_path src/sdp/sdp.c:743 in the loop of GAM_Result_SDP_create
+ * src/hub/gam.c:852-890), for every pair of a batch — the flavour without a boundary, which the reference uses for models
+ * without shadows and spans (SDP_create sdp.c:322-341: the affine and protein2dna families; -1 for every other model).
+ * hsps: the HSPs of all pairs, pair i's are [hsp_first[i], hsp_first[i+1]) in the order SDP_Pair_create_seed_list meets
+ * them (sdp.c:447-463); query_advance / target_advance: the match advances of the HSPset (1 / 1, or 1 / 3 for
+ * protein2dna); dropoff: --extensionthreshold.  Both passes of Scheduler_Pair_calculate (scheduler.c:1445) run on the
+ * device for all pairs at once; the --singlepass yes loop over the seeds follows on the host.  out[i * max_alignments + k]
+ * is pair i's k-th alignment (clear each with c4gpu_alignment_clear), n_out[i] their number. */
+int         c4gpu_sdp_batch(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params,
+                            const c4gpu_pair *pairs, int32_t n_pairs, const c4gpu_hsp *hsps, const int32_t *hsp_first,
+                            int32_t query_advance, int32_t target_advance, int32_t dropoff, c4gpu_score threshold,
+                            int32_t max_alignments, c4gpu_alignment *out, int32_t *n_out);
 
 /* Alignment_print_{sugar,cigar,vulgar}_block (alignment.c:1622-1779); coordinates are region
  * coordinates on the given strands ('+', '-', '.'), flipped to the forward strand when
