@@ -14,6 +14,7 @@
  *   c4gpu_alignment_format   <->  Alignment_print_{sugar,cigar,vulgar}_block  src/c4/alignment.c:1622-1779
  *   c4gpu_hsp_extend_batch   <->  HSPset_seed_hsp (HSP_trim_ends/_init/_extend) src/comparison/hspset.c:933-997
  *   c4gpu_batch_run_regions  <->  Optimal_find_path with a region (--refine)   src/hub/gam.c:605-655
+ *   c4gpu_sdp_batch          <->  GAM_Result_SDP_create's loop (SDP_Pair_next_path) src/hub/gam.c:852-890, src/sdp/sdp.c:743
  */
 #ifndef INCLUDED_C4GPU_H
 #define INCLUDED_C4GPU_H

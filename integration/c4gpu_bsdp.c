@@ -844,9 +844,15 @@ GAM_Result *GAM_Result_heuristic_create(GAM *gam, Comparison *comparison){
         && (!Comparison_Param_get_HSPSet_Argument_Set(comparison->param)->geneseed_threshold)
         && (g_getenv("C4GPU_BSDP_HOST") || (shim_get_ctx() != NULL))
         && (!g_getenv("C4GPU_BSDP_OFF"));
+    /* --gappedextension yes: the SDP seam (c4gpu_sdp.c) takes the pairs of the models it covers */
+    if(gam->gas->use_gapped_extension && (bsdp_mode == BSDP_OFF) && (!shim_sdp_replaying())
+    && shim_sdp_collect(gam, comparison))
+        return NULL;
     if(!batchable){
-        if(bsdp_mode == BSDP_OFF)
+        if((bsdp_mode == BSDP_OFF) && (!shim_sdp_replaying())){
             shim_bsdp_flush();                    /* keep the output order */
+            shim_sdp_flush();
+            }
         return GAM_Result_heuristic_create_cpu(gam, comparison);
         }
     if(!Comparison_has_hsps(comparison))          /* gam.c:1122 (a comparison whose word hits grew no HSP: c4gpu_hsp.c) */

@@ -1,0 +1,293 @@
+/* c4gpu_sdp.c — the SDP seam of the exonerate-gpu shim (fourth file).
+ *
+ * The reference's default heuristic (--gappedextension yes) hands every candidate pair to GAM_Result_SDP_create
+ * (src/hub/gam.c:852-890), whose loop asks SDP_Pair_next_path (src/sdp/sdp.c:743) for one alignment after the other;
+ * the first call runs the two Scheduler passes (sdp.c:538-600), one pair at a time, on one core.  For the models the
+ * reference runs WITHOUT a boundary (SDP_create, sdp.c:322-341: no shadows, no spans, one match transition — the affine
+ * and protein2dna families, BASELINE config 1) this file
+ *   1. lets the front of GAM_Result_heuristic_create (c4gpu_bsdp.c) COLLECT (gam, comparison) here instead;
+ *   2. at a flush gives the HSPs of all collected pairs to c4gpu_sdp_batch: both passes of every pair in two launches,
+ *      then the reference's single-pass loop over the seeds (sdp.c:776-795) inside the library;
+ *   3. REPLAYS every pair in submission order through the reference's own GAM_Result_heuristic_create, with the front
+ *      of SDP_Pair_next_path handing out the batch's alignments in order — and NULL as soon as the next one is below the
+ *      threshold of that call (which --bestn / --percent raise between calls: gam.c:870).
+ * Thresholds, --bestn bookkeeping, ryo / vulgar printing stay the reference's.  Not taken (the reference's own function
+ * runs): models that need the boundary flavour, --refine (GAM_Result_add_alignment then blocks the REFINED alignment's
+ * cells, gam.c:663-673), --singlepass no, --geneseed, pairs whose HSP sets differ in their advances, and pairs that
+ * fill all 16 alignment slots of the batch.  C4GPU_SDP_HOST=1 replaces step 2 by the reference's own SDP on the host
+ * (tests of the seam without a device); C4GPU_SDP_OFF=1 switches the seam off.
+ */
+#include <string.h>
+#include <stdlib.h>
+
+#include "gam.h"
+#include "sdp.h"
+#include "comparison.h"
+#include "alignment.h"
+#include "modeltype.h"
+#include "hspset.h"
+
+#include "c4gpu.h"
+#include "c4gpu_shim.h"
+
+extern GAM_Result *GAM_Result_heuristic_create_cpu(GAM *gam, Comparison *comparison);
+extern Alignment *SDP_Pair_next_path_cpu(SDP_Pair *sdp_pair, C4_Score threshold);
+
+#define SHIM_SDP_MAX 16
+
+typedef struct {
+    GAM *gam;
+    Comparison *comparison;
+    gboolean have;                 /* the batch holds this pair's alignments */
+    gint n, served;
+    c4gpu_alignment alns[SHIM_SDP_MAX];
+} ShimSdpPending;
+
+static GPtrArray *sdp_pending = NULL;
+static ShimSdpPending *sdp_cur = NULL;
+static struct { long pairs, served_pairs, alignments, flushes; double device_ms, replay_ms; } sst;
+
+static gboolean sdp_eligible(GAM *gam, Comparison *comparison){
+    if((shim_batch_size() <= 0) || g_getenv("C4GPU_SDP_OFF") || sdp_cur)
+        return FALSE;
+    if((!gam->gas->use_gapped_extension) || (!gam->sdp) || gam->sdp->use_boundary)
+        return FALSE;
+    if(!gam->sdp->sas->single_pass_subopt)
+        return FALSE;
+    if(gam->gas->refinement != GAM_Refinement_NONE)
+        return FALSE;
+    if(Comparison_Param_get_HSPSet_Argument_Set(comparison->param)->geneseed_threshold)
+        return FALSE;
+    if((!g_getenv("C4GPU_SDP_HOST")) && (!shim_get_ctx()))
+        return FALSE;
+    return TRUE;
+    }
+
+/* the HSPs of a comparison in the order SDP_Pair_create_seed_list meets them (sdp.c:447-463); FALSE when its sets do
+ * not share one pair of advances */
+static gboolean sdp_gather_hsps(Comparison *comparison, GArray *hsps, gint *qa, gint *ta){
+    register gint s, k;
+    HSPset *sets[3];
+    sets[0] = comparison->dna_hspset; sets[1] = comparison->protein_hspset; sets[2] = comparison->codon_hspset;
+    *qa = *ta = 0;
+    for(s = 0; s < 3; s++){
+        if((!sets[s]) || (!sets[s]->hsp_list->len))
+            continue;
+        for(k = 0; k < (gint)sets[s]->hsp_list->len; k++){
+            register HSP *h = sets[s]->hsp_list->pdata[k];
+            c4gpu_hsp c;
+            if(!*qa){
+                *qa = HSP_query_advance(h); *ta = HSP_target_advance(h);
+            } else if((*qa != HSP_query_advance(h)) || (*ta != HSP_target_advance(h))){
+                return FALSE;
+                }
+            c.query_start = h->query_start; c.target_start = h->target_start;
+            c.length = h->length; c.score = h->score; c.cobs = h->cobs;
+            g_array_append_val(hsps, c);
+            }
+        }
+    return hsps->len > 0;
+    }
+
+/* C4GPU_SDP_HOST: the alignments the reference's own SDP finds, in a private SubOpt as GAM_Result_add_alignment keeps */
+static void sdp_host_pair(ShimSdpPending *p){
+    register GAM *gam = p->gam;
+    register gpointer ud = Model_Type_create_data(gam->gas->type, p->comparison->query, p->comparison->target);
+    register SubOpt *so = SubOpt_create(p->comparison->query->len, p->comparison->target->len);
+    register SDP_Pair *sdp_pair = SDP_Pair_create(gam->sdp, so, p->comparison, ud);
+    register Alignment *a;
+    register guint k;
+    p->n = 0;
+    while((p->n < SHIM_SDP_MAX) && (a = SDP_Pair_next_path_cpu(sdp_pair, gam->gas->threshold))){
+        register c4gpu_alignment *c = &p->alns[p->n++];
+        memset(c, 0, sizeof(*c));
+        c->score = a->score;
+        c->region.query_start = a->region->query_start;   c->region.target_start = a->region->target_start;
+        c->region.query_length = a->region->query_length; c->region.target_length = a->region->target_length;
+        c->n_ops = a->operation_list->len;
+        c->op_transition = malloc(sizeof(int32_t) * (c->n_ops ? c->n_ops : 1));
+        c->op_length = malloc(sizeof(int32_t) * (c->n_ops ? c->n_ops : 1));
+        for(k = 0; k < a->operation_list->len; k++){
+            register AlignmentOperation *ao = a->operation_list->pdata[k];
+            c->op_transition[k] = ao->transition->id;
+            c->op_length[k] = ao->length;
+            }
+        c->valid = 1;
+        SubOpt_add_alignment(so, a);
+        Alignment_destroy(a);
+        }
+    SDP_Pair_destroy(sdp_pair);
+    SubOpt_destroy(so);
+    Model_Type_destroy_data(gam->gas->type, ud);
+    p->have = (p->n < SHIM_SDP_MAX);
+    return;
+    }
+
+static void sdp_device_batch(GPtrArray *todo){
+    register guint i, n = todo->len;
+    register ShimSdpPending *p = todo->pdata[0];
+    register GAM *gam = p->gam;
+    register GHashTable *flat = g_hash_table_new(g_direct_hash, g_direct_equal);
+    register GPtrArray *strings = g_ptr_array_new();
+    register GArray *hsps = g_array_new(FALSE, FALSE, sizeof(c4gpu_hsp));
+    c4gpu_pair *pair = g_new0(c4gpu_pair, n);
+    int32_t *first = g_new0(int32_t, n + 1), *n_out = g_new0(int32_t, n);
+    c4gpu_alignment *out = g_new0(c4gpu_alignment, (gsize)n * SHIM_SDP_MAX);
+    gboolean *usable = g_new0(gboolean, n);
+    gint qa = 0, ta = 0;
+    gpointer ud;
+    c4gpu_model fm;
+    c4gpu_params params;
+    for(i = 0; i < n; i++){
+        register gchar *qs, *ts;
+        gint pqa, pta;
+        register guint before = hsps->len;
+        p = todo->pdata[i];
+        if(!(qs = g_hash_table_lookup(flat, p->comparison->query))){
+            qs = Sequence_get_str(p->comparison->query);
+            g_hash_table_insert(flat, p->comparison->query, qs);
+            g_ptr_array_add(strings, qs);
+            }
+        if(!(ts = g_hash_table_lookup(flat, p->comparison->target))){
+            ts = Sequence_get_str(p->comparison->target);
+            g_hash_table_insert(flat, p->comparison->target, ts);
+            g_ptr_array_add(strings, ts);
+            }
+        pair[i].query = (const uint8_t*)qs;  pair[i].query_len = p->comparison->query->len;
+        pair[i].target = (const uint8_t*)ts; pair[i].target_len = p->comparison->target->len;
+        first[i] = before;
+        usable[i] = sdp_gather_hsps(p->comparison, hsps, &pqa, &pta);
+        if(usable[i] && qa && ((pqa != qa) || (pta != ta)))
+            usable[i] = FALSE;
+        if(usable[i]){
+            qa = pqa; ta = pta;
+        } else {
+            g_array_set_size(hsps, before);             /* this pair brings no HSPs to the batch: nothing comes back */
+            }
+        }
+    first[n] = hsps->len;
+    p = todo->pdata[0];
+    ud = Model_Type_create_data(gam->gas->type, p->comparison->query, p->comparison->target);
+    if(qa && shim_flatten_any(gam->sdp->model, ud, &fm, FALSE)){
+        shim_params(ud, &params);
+        if(c4gpu_sdp_batch(shim_get_ctx(), &fm, &params, pair, n, (const c4gpu_hsp*)hsps->data, first, qa, ta,
+                           gam->sdp->sas->dropoff, gam->gas->threshold, SHIM_SDP_MAX, out, n_out) == 0){
+            for(i = 0; i < n; i++){
+                register gint k;
+                p = todo->pdata[i];
+                p->n = n_out[i];
+                for(k = 0; k < n_out[i]; k++)
+                    p->alns[k] = out[(gsize)i * SHIM_SDP_MAX + k];
+                p->have = usable[i] && (n_out[i] < SHIM_SDP_MAX);
+                }
+        } else {
+            g_warning("c4gpu: %s -- SDP stays on the CPU for this batch", c4gpu_last_error());
+            }
+        }
+    Model_Type_destroy_data(gam->gas->type, ud);
+    for(i = 0; i < strings->len; i++)
+        g_free(strings->pdata[i]);
+    g_ptr_array_free(strings, TRUE);
+    g_hash_table_destroy(flat);
+    g_array_free(hsps, TRUE);
+    g_free(pair); g_free(first); g_free(n_out); g_free(out); g_free(usable);
+    return;
+    }
+
+void shim_sdp_flush(void){
+    register guint i;
+    register gint k;
+    register GPtrArray *todo = sdp_pending;
+    gint64 t0 = g_get_monotonic_time(), t1;
+    if((!todo) || (!todo->len))
+        return;
+    sdp_pending = NULL;
+    sst.flushes++;
+    if(g_getenv("C4GPU_SDP_HOST")){
+        for(i = 0; i < todo->len; i++)
+            sdp_host_pair(todo->pdata[i]);
+    } else {
+        sdp_device_batch(todo);
+        }
+    t1 = g_get_monotonic_time();
+    for(i = 0; i < todo->len; i++){                       /* replay in submission order */
+        register ShimSdpPending *p = todo->pdata[i];
+        register GAM_Result *gam_result;
+        sdp_cur = p;
+        gam_result = GAM_Result_heuristic_create_cpu(p->gam, p->comparison);
+        sdp_cur = NULL;
+        if(gam_result){
+            GAM_Result_submit(gam_result);
+            GAM_Result_destroy(gam_result);
+            }
+        sst.pairs++;
+        if(p->have){
+            sst.served_pairs++;
+            sst.alignments += p->served;
+            }
+        for(k = 0; k < p->n; k++)
+            c4gpu_alignment_clear(&p->alns[k]);
+        Comparison_destroy(p->comparison);
+        GAM_destroy(p->gam);
+        g_free(p);
+        }
+    g_ptr_array_free(todo, TRUE);
+    sst.device_ms += (t1 - t0) / 1e3;
+    sst.replay_ms += (g_get_monotonic_time() - t1) / 1e3;
+    return;
+    }
+
+/* called by the front of GAM_Result_heuristic_create (c4gpu_bsdp.c): TRUE = the pair was taken, its result is submitted
+ * by the flush */
+gboolean shim_sdp_collect(GAM *gam, Comparison *comparison){
+    register ShimSdpPending *p;
+    if(!sdp_eligible(gam, comparison))
+        return FALSE;
+    if(!Comparison_has_hsps(comparison))                   /* gam.c:1122 */
+        return TRUE;
+    if(sdp_pending && sdp_pending->len && (((ShimSdpPending*)sdp_pending->pdata[0])->gam != gam))
+        shim_sdp_flush();
+    if(!sdp_pending)
+        sdp_pending = g_ptr_array_new();
+    p = g_new0(ShimSdpPending, 1);
+    p->gam = GAM_share(gam);
+    p->comparison = Comparison_share(comparison);
+    g_ptr_array_add(sdp_pending, p);
+    if((gint)sdp_pending->len >= shim_batch_size())
+        shim_sdp_flush();
+    return TRUE;
+    }
+
+gboolean shim_sdp_replaying(void){
+    return sdp_cur != NULL;
+    }
+
+/* sdp.c:743 — in a replay the batch's alignments, in order */
+Alignment *SDP_Pair_next_path(SDP_Pair *sdp_pair, C4_Score threshold){
+    register ShimSdpPending *p = sdp_cur;
+    register c4gpu_alignment *c;
+    register Alignment *alignment;
+    register Region *region;
+    register gint k;
+    if((!p) || (!p->have))
+        return SDP_Pair_next_path_cpu(sdp_pair, threshold);
+    if(p->served >= p->n)
+        return NULL;
+    c = &p->alns[p->served];
+    if(c->score < threshold)                               /* sdp.c:780-781: seeds come in score order */
+        return NULL;
+    p->served++;
+    region = Region_create(c->region.query_start, c->region.target_start, c->region.query_length, c->region.target_length);
+    alignment = Alignment_create(sdp_pair->sdp->model, region, c->score);
+    for(k = 0; k < c->n_ops; k++)
+        Alignment_add(alignment, sdp_pair->sdp->model->transition_list->pdata[c->op_transition[k]], c->op_length[k]);
+    Region_destroy(region);
+    return alignment;
+    }
+
+void shim_sdp_report(void){
+    if(g_getenv("C4GPU_VERBOSE") && sst.pairs)
+        g_message("c4gpu sdp: %ld pairs in %ld flush(es): %ld served from device batches (%ld alignments); batches %.0f ms, "
+                  "replay %.0f ms", sst.pairs, sst.flushes, sst.served_pairs, sst.alignments, sst.device_ms, sst.replay_ms);
+    return;
+    }

@@ -684,7 +684,9 @@ GAM_Result *GAM_Result_exhaustive_create(GAM *gam, Sequence *query, Sequence *ta
 void GAM_report(GAM *gam){        /* analysis.c:1421: after the last pair */
     shim_flush();
     shim_bsdp_flush();
+    shim_sdp_flush();
     shim_bsdp_report();
+    shim_sdp_report();
     shim_hsp_report();
     GAM_report_cpu(gam);
     return;

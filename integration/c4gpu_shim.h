@@ -6,6 +6,8 @@
 #include "c4.h"
 #include "ungapped.h"
 #include "optimal.h"
+#include "gam.h"
+#include "comparison.h"
 #include "c4gpu.h"
 
 c4gpu_ctx *shim_get_ctx(void);
@@ -21,5 +23,10 @@ void shim_hsp_report(void);
 void shim_bsdp_flush(void);
 void shim_bsdp_report(void);
 Alignment *shim_bsdp_find_path(Optimal *optimal, Region *region, SubOpt *subopt);
+/* c4gpu_sdp.c */
+gboolean shim_sdp_collect(GAM *gam, Comparison *comparison);
+gboolean shim_sdp_replaying(void);
+void shim_sdp_flush(void);
+void shim_sdp_report(void);
 
 #endif /* INCLUDED_C4GPU_SHIM_H */

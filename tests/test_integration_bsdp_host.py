@@ -131,3 +131,44 @@ def test_seeding_seam_is_byte_identical_with_host_extensions(tmp_path, model, ex
 def test_switching_the_seam_off(tmp_path):
     ref, gpu, err = run_pair(tmp_path, "est2genome", [], {"C4GPU_BSDP_OFF": "1", "C4GPU_HSP_OFF": "1"})
     assert gpu == ref and "c4gpu bsdp" not in err and "c4gpu hsp" not in err
+
+
+# ---- the SDP seam (integration/c4gpu_sdp.c): --gappedextension yes, the models the reference runs without a boundary ----
+
+def sdp_served(err):
+    m = re.search(r"c4gpu sdp: (\d+) pairs in (\d+) flush\(es\): (\d+) served from device batches \((\d+) alignments\)", err)
+    assert m, err[-1500:]
+    return [int(x) for x in m.groups()]
+
+
+@pytest.mark.parametrize("model,extra", [
+    ("affine:local", []), ("affine:local", ["--bestn", "1"]), ("affine:local", ["--percent", "40", "--extensionthreshold", "20"]),
+    ("protein2dna", []), ("protein2dna", ["-S", "no", "--score", "60"]),
+])
+def test_sdp_seam_is_byte_identical_with_host_alignments(tmp_path, model, extra):
+    """C4GPU_SDP_HOST=1: the collection, the hand-out of a batch's alignments by the front of SDP_Pair_next_path
+    (thresholds that rise between calls under --bestn / --percent included) and the replay order, with the reference's
+    own SDP computing the batch on the host."""
+    ref, gpu, err = run_pair(tmp_path, model, ["--gappedextension", "yes"] + extra,
+                             {"C4GPU_SDP_HOST": "1", "C4GPU_HSP_HOST": "1"}, n=8, seed=21)
+    assert gpu == ref and ref.count(b"vulgar:") >= 6
+    pairs, flushes, served_pairs, alignments = sdp_served(err)
+    assert flushes == 1 and served_pairs == pairs >= 6 and alignments >= 6
+
+
+def test_sdp_seam_leaves_boundary_models_and_refinement_alone(tmp_path):
+    for model, extra in (("est2genome", []), ("affine:local", ["--refine", "region"])):
+        ref, gpu, err = run_pair(tmp_path, model, ["--gappedextension", "yes"] + extra,
+                                 {"C4GPU_SDP_HOST": "1", "C4GPU_HSP_HOST": "1", "C4GPU_DISABLE": "1"}, n=4, seed=22)
+        assert gpu == ref and ref.count(b"vulgar:") >= 3
+        assert "c4gpu sdp:" not in err
+
+
+def test_sdp_seam_in_small_flushes_and_switched_off(tmp_path):
+    ref, gpu, err = run_pair(tmp_path, "affine:local", ["--gappedextension", "yes"],
+                             {"C4GPU_SDP_HOST": "1", "C4GPU_HSP_HOST": "1", "C4GPU_BATCH": "3"}, n=8, seed=23)
+    assert gpu == ref
+    assert sdp_served(err)[1] >= 3
+    ref, gpu, err = run_pair(tmp_path, "affine:local", ["--gappedextension", "yes"],
+                             {"C4GPU_SDP_HOST": "1", "C4GPU_HSP_HOST": "1", "C4GPU_SDP_OFF": "1"}, n=4, seed=23)
+    assert gpu == ref and "c4gpu sdp:" not in err

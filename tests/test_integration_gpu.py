@@ -2,6 +2,7 @@
 (integration/_build/exonerate-gpu; every Optimal Viterbi call of accelerated models goes to libc4gpu.so)
 prints byte-identical output to the unmodified reference with its compiled CPU Viterbi
 (oracle/_ref/exonerate-compiled).  Both binaries are built in the build container and travel with the repo."""
+import re
 import os, subprocess, random
 import pytest
 
@@ -211,11 +212,11 @@ def test_low_complexity_inputs_tie_everywhere(tmp_path, model):
 
 @pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
                     reason="reference binaries are built in the build container (make -C integration)")
-def test_c1_protein_heuristic_run_passes_through_untouched(tmp_path):
-    """BASELINE config 1 (plumbing only): `--model affine:local`, 100 protein queries of ~300 aa against one
-    ~10 kaa target, the DEFAULT heuristic mode.  Nothing on this route is ours (seeding, HSPs, SDP/BSDP stay
-    reference code; the small Optimal calls are below the device cut-off): the drop-in must print what the reference
-    prints and must not have touched the device."""
+def test_c1_protein_heuristic_run_takes_the_sdp_batches(tmp_path):
+    """BASELINE config 1: `--model affine:local`, 100 protein queries of ~300 aa against one ~10 kaa target, the DEFAULT
+    heuristic mode (seeding + SDP).  The word hits are extended on the device (c4gpu_hsp.c) and every candidate pair's
+    SDP comes from one c4gpu_sdp_batch (c4gpu_sdp.c); the drop-in must print what the reference prints.  With the device
+    switched off (--gpu no) the same run passes through untouched."""
     rng = random.Random(20260929)
     aa = "ARNDCQEGHILKMFPSTWYV"
     queries = ["".join(rng.choice(aa) for _ in range(rng.randint(250, 350))) for _ in range(100)]
@@ -235,7 +236,13 @@ def test_c1_protein_heuristic_run_passes_through_untouched(tmp_path):
     gpu_out, gpu_err = _run(GPU_EXE, args, {"C4GPU_VERBOSE": "1"})
     assert gpu_out == ref_out
     assert ref_out.count("vulgar:") >= 20
-    assert "c4gpu:" not in gpu_err, gpu_err[-1500:]
+    m = re.search(r"c4gpu sdp: (\d+) pairs in (\d+) flush\(es\): (\d+) served from device batches \((\d+) alignments\)", gpu_err)
+    assert m, gpu_err[-1500:]
+    pairs, flushes, served_pairs, alignments = [int(x) for x in m.groups()]
+    assert served_pairs == pairs >= 20 and alignments >= 20 and flushes == 1
+    assert "c4gpu hsp:" in gpu_err
+    off_out, off_err = _run(GPU_EXE, ["--gpu", "no"] + args, {"C4GPU_VERBOSE": "1"})
+    assert off_out == ref_out and "c4gpu sdp:" not in off_err
 
 
 @pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
@@ -267,6 +274,26 @@ def test_heuristic_bsdp_mode_runs_its_sub_dps_in_device_batches(tmp_path, model,
     if "--refine" in extra:
         m = re.search(r"(\d+) of (\d+) refinements from refinement batches", err)
         assert m and int(m.group(2)) >= 4 and int(m.group(1)) >= int(m.group(2)) - 3, err[-800:]
+
+
+@pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
+                    reason="reference binaries are built in the build container (make -C integration)")
+@pytest.mark.parametrize("model,extra,batch", [
+    ("affine:local", [], "4096"), ("affine:local", ["--bestn", "1"], "4096"), ("affine:local", ["--percent", "40"], "3"),
+    ("protein2dna", [], "4096"), ("protein2dna", ["-S", "no", "--extensionthreshold", "20"], "4096"),
+])
+def test_heuristic_sdp_mode_takes_its_alignments_from_device_batches(tmp_path, model, extra, batch):
+    """The DEFAULT heuristic mode (--gappedextension yes: SDP) for the models the reference runs without a boundary:
+    both Scheduler passes of every collected pair in two launches per flush (c4gpu_sdp_batch behind
+    integration/c4gpu_sdp.c), the reference's own GAM_Result_SDP_create loop replayed on top.  Byte-identical output."""
+    import test_integration_bsdp_host as hb
+    ref, gpu, err = hb.run_pair(tmp_path, model, ["--gappedextension", "yes"] + extra, {"C4GPU_BATCH": batch}, n=8, seed=21)
+    assert gpu == ref
+    assert ref.count(b"vulgar:") >= 6
+    assert "SDP stays on the CPU" not in err, err[-1500:]
+    pairs, flushes, served_pairs, alignments = hb.sdp_served(err)
+    assert served_pairs == pairs >= 6 and alignments >= 6
+    assert "c4gpu hsp:" in err
 
 
 @pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
