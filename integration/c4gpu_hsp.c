@@ -95,11 +95,15 @@ static void hsp_replay(ShimSeedSet *ss, const c4gpu_hsp *hsp){
         register gint diag_pos = (seed[1] * aq) - (seed[0] * at);
         register gint query_frame = seed[0] % aq, target_frame = seed[1] % at;
         register gint section_pos = (diag_pos + hsp_set->query->len) % hsp_set->query->len;
-        register gint *horizon = &hsp_set->horizon[0][section_pos][query_frame][target_frame];
-        if((gint)seed[1] < *horizon)
+        /* a seed more than a query length above the main diagonal (query_start * target advance > target_start + query
+         * length: protein2dna hits at the very start of a target) has a NEGATIVE section_pos in the reference
+         * (hspset.c:943-944, its g_assert compiled out): an out-of-bounds horizon entry there, none here */
+        register gint *horizon = (section_pos >= 0) ? &hsp_set->horizon[0][section_pos][query_frame][target_frame] : NULL;
+        if(horizon && ((gint)seed[1] < *horizon))
             continue;
         HSPset_add_known_hsp(hsp_set, hsp[k].query_start, hsp[k].target_start, hsp[k].length);
-        *horizon = hsp[k].target_start + hsp[k].length * at;             /* HSP_target_end */
+        if(horizon)
+            *horizon = hsp[k].target_start + hsp[k].length * at;         /* HSP_target_end */
         hst.stored++;
         }
     return;

@@ -1191,12 +1191,16 @@ int32_t oracle_hsp_set(const c4gpu_params *params, int match_type, const uint8_t
     for(k = 0; k < n; k++){
         const int diag = seed_t[k] * h.aq - seed_q[k] * h.at, qf = seed_q[k] % h.aq, tf = seed_t[k] % h.at;
         const int section = (diag + qlen) % qlen;
-        int *hz = &horizon[((size_t)section * h.aq + qf) * h.at + tf];
+        /* diag + qlen < 0 (a seed more than a query length above the main diagonal: query_start * target advance >
+         * target_start + query length, only possible with a target advance of 3) gives the reference a NEGATIVE
+         * section_pos (hspset.c:943-944; its g_assert is compiled out) and an out-of-bounds horizon entry: undefined
+         * there, so no parity target — such a seed neither reads nor writes a horizon here */
+        int *hz = (section >= 0) ? &horizon[((size_t)section * h.aq + qf) * h.at + tf] : NULL;
         c4gpu_hsp o;
-        if(seed_t[k] < *hz) continue;
+        if(hz && (seed_t[k] < *hz)) continue;
         hsp_grow(&h, seedlen, dropoff, seed_q[k], seed_t[k], &o);
         if(o.score >= threshold) out[total++] = o;                     /* HSP_store, hspset.c:885-888 */
-        *hz = o.target_start + o.length * h.at;                        /* HSP_target_end */
+        if(hz) *hz = o.target_start + o.length * h.at;                 /* HSP_target_end */
         }
     free(horizon);
     return total;

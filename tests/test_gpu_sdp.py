@@ -117,7 +117,9 @@ def test_dna_and_protein2dna_pairs_against_oracle(eng):
                 seeds = []
                 for j in range(len(t) - 3 * w + 1):
                     word = "".join(rev.get(t[j + 3 * x:j + 3 * x + 3], "X") for x in range(w))
-                    seeds += [(i, j) for i in words.get(word, ())]
+                    # not the hits more than a query length above the main diagonal: the reference's horizon index is
+                    # out of bounds for them (hspset.c:943), so they have no parity target
+                    seeds += [(i, j) for i in words.get(word, ()) if j - 3 * i + len(q) >= 0]
                 h = oracle_lib.hsp_set(params, match, q.encode(), t.encode(), w, 20, 30, seeds)
             if h:
                 pairs.append((q, t)); hsps.append(h)

@@ -3,7 +3,7 @@ ROOT=$(pwd)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 : > gpurun_out/sdp_repeat2.log
-for i in $(seq 1 25); do
+for i in $(seq 1 20); do
   timeout 300 python -X faulthandler -m pytest tests/test_gpu_sdp.py -m gpu -q -p no:cacheprovider >> gpurun_out/sdp_repeat2.log 2>&1
   echo "run $i rc=$?" >> gpurun_out/sdp_repeat2.log
 done
