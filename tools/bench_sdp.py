@@ -80,6 +80,19 @@ def main():
             dt = time.perf_counter() - t0
             print(f"| reference binary, whole run on the same FASTA files (its own seeding + SDP, 1 core) | {n} queries | - | "
                   f"{r.stdout.decode().count('vulgar:')} | {dt * 1e3:.1f} | - |")
+            gpu = os.path.join(ROOT, "integration", "_build", "exonerate-gpu")
+            if os.path.exists(gpu):
+                args = ["-m", "affine:local", "--showalignment", "no", "--showvulgar", "yes", "-V", "0",
+                        os.path.join(d, "q.fa"), os.path.join(d, "t.fa")]
+                subprocess.run([gpu] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE)           # module load
+                t0 = time.perf_counter()
+                g = subprocess.run([gpu] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, C4GPU_VERBOSE="1"))
+                dt = time.perf_counter() - t0
+                note = [l for l in g.stderr.decode().splitlines() if "c4gpu sdp:" in l or "c4gpu hsp:" in l]
+                print(f"| exonerate-gpu, whole run (seeding and SDP seams; output {'identical' if g.stdout == r.stdout else 'DIFFERENT'}) | "
+                      f"{n} queries | - | {g.stdout.decode().count('vulgar:')} | {dt * 1e3:.1f} | - |")
+                for l in note:
+                    print("|   " + l.split("Message:")[-1].strip().replace("|", "/") + " | | | | | |")
     print(f"\ndevice alignments identical to the oracle's: {'yes' if same else 'NO'}")
     eng.close()
 

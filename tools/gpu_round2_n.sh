@@ -3,10 +3,12 @@ ROOT=$(pwd)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 : > gpurun_out/sdp_repeat2.log
-for i in $(seq 1 20); do
+for i in $(seq 1 15); do
   timeout 300 python -X faulthandler -m pytest tests/test_gpu_sdp.py -m gpu -q -p no:cacheprovider >> gpurun_out/sdp_repeat2.log 2>&1
   echo "run $i rc=$?" >> gpurun_out/sdp_repeat2.log
 done
-grep -c "rc=0" gpurun_out/sdp_repeat2.log; grep -n "rc=[1-9]\|Fatal" gpurun_out/sdp_repeat2.log | head
-timeout 1500 python -m pytest tests/test_integration_gpu.py -m gpu -q -p no:cacheprovider -k "sdp or heuristic or c1 or passthrough" > gpurun_out/pytest_gpu_n_int.log 2>&1
-tail -15 gpurun_out/pytest_gpu_n_int.log
+grep -c "rc=0" gpurun_out/sdp_repeat2.log; grep -n "rc=[1-9]\|Fatal\|failed" gpurun_out/sdp_repeat2.log | head
+timeout 1500 python -m pytest tests/test_integration_gpu.py -m gpu -q -p no:cacheprovider -k "sdp or c1" > gpurun_out/pytest_gpu_n_int.log 2>&1
+tail -5 gpurun_out/pytest_gpu_n_int.log
+(cd /tmp && timeout 600 python $ROOT/tools/bench_sdp.py 100 > $ROOT/gpurun_out/sdp_bench.md 2> $ROOT/gpurun_out/sdp_bench.err)
+cat gpurun_out/sdp_bench.md; tail -3 gpurun_out/sdp_bench.err
