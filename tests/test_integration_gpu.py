@@ -212,6 +212,28 @@ def test_low_complexity_inputs_tie_everywhere(tmp_path, model):
 
 @pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
                     reason="reference binaries are built in the build container (make -C integration)")
+def test_one_pair_outside_the_matrix_alphabet_does_not_cost_the_batch(tmp_path):
+    """A selenocysteine (U) passes the reference's protein alphabet but is outside the 24 letters of its substitution
+    matrix (the reference scores it by indexing past the row: submat.c:27-61), so the library refuses the sequence; the
+    batching seam leaves that pair to the CPU function and keeps the other pairs of the flush on the device."""
+    rng = random.Random(77)
+    aa = lambda n: "".join(rng.choice("ARNDCQEGHILKMFPSTWYV") for _ in range(n))
+    qs = [("qy%d" % k, aa(150 + 10 * k)) for k in range(4)]
+    qs[2] = ("qy2", qs[2][1][:70] + "U" + qs[2][1][71:])
+    ts = [("tg", aa(60) + "".join(q[:100] + aa(5) + q[100:] for _, q in qs) + aa(60))]
+    qf, tf = str(tmp_path / "q.fa"), str(tmp_path / "t.fa")
+    _fasta(qf, qs)
+    _fasta(tf, ts)
+    args = ["-m", "affine:local", "-E", "yes", "-S", "no", "--showalignment", "yes", "--showvulgar", "yes", "-V", "0", qf, tf]
+    ref_out, _ = _run(CPU_EXE, args)
+    gpu_out, gpu_err = _run(GPU_EXE, args, {"C4GPU_VERBOSE": "1"})
+    assert gpu_out == ref_out and ref_out.count("vulgar:") == 4
+    assert "1 of 4 pairs hold residues outside the substitution matrix alphabet" in gpu_err, gpu_err[-1500:]
+    assert "batch of 3 pairs" in gpu_err, gpu_err[-1500:]
+
+
+@pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
+                    reason="reference binaries are built in the build container (make -C integration)")
 def test_c1_protein_heuristic_run_takes_the_sdp_batches(tmp_path):
     """BASELINE config 1: `--model affine:local`, 100 protein queries of ~300 aa against one ~10 kaa target, the DEFAULT
     heuristic mode (seeding + SDP).  The word hits are extended on the device (c4gpu_hsp.c) and every candidate pair's
