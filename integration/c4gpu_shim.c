@@ -537,8 +537,6 @@ static void shim_flush(void){
     c4gpu_model fm;
     c4gpu_params params;
     c4gpu_pair *pair;
-    gint *bi;
-    guint in_batch;
     gchar **str;
     GPtrArray *todo = shim_pending;
     gint64 t_start = g_get_monotonic_time(), t_gpu0 = 0, t_gpu1 = 0;
@@ -552,10 +550,6 @@ static void shim_flush(void){
     threshold = gam->gas->threshold;
     dpmemory = gam->optimal->find_path->vas->traceback_memory_limit;
     pair = g_new0(c4gpu_pair, n);
-    bi = g_new(gint, n);                 /* pair i of the collection is pair bi[i] of the batch (-1: not in it) */
-    for(i = 0; i < n; i++)
-        bi[i] = i;
-    in_batch = n;
     str = g_new0(gchar*, 2*n);
     {   /* one flattened copy per Sequence: pairs that share a Sequence share the buffer, and the library
          * keeps one device copy (and one set of splice arrays) per buffer */
@@ -582,39 +576,6 @@ static void shim_flush(void){
     if(shim_flatten(gam->optimal->find_path->model, ud, &fm)){
         shim_params(ud, &params);
         batch = c4gpu_batch_create(shim_ctx, &fm, &params, pair, n);
-        if(!batch){
-            /* one residue outside the 24-letter matrix alphabet fails the upload of the whole batch (the reference
-             * indexes its matrices out of bounds there, submat.c:27-61): such pairs go to the per-call path (which hands
-             * them to the CPU function), the others keep the batch.  Codon models are left alone: what their targets may
-             * hold is decided by the translation tables on the device. */
-            register gboolean simple = TRUE;
-            register gint c;
-            register guint good = 0;
-            for(c = 0; c < fm.n_calcs; c++)
-                if(fm.calcs[c].kind == C4GPU_CALC_MATCH_P2D)
-                    simple = FALSE;
-            for(i = 0; simple && (i < n); i++){
-                register gint k;
-                register gboolean ok = TRUE;
-                for(k = 0; ok && (k < pair[i].query_len); k++) ok = params.submat_index[pair[i].query[k]] < 24;
-                for(k = 0; ok && (k < pair[i].target_len); k++) ok = params.submat_index[pair[i].target[k]] < 24;
-                if(ok){
-                    bi[i] = good;
-                    pair[good++] = pair[i];
-                } else {
-                    bi[i] = -1;
-                    }
-                }
-            if(simple && good && (good < n)){
-                g_warning("c4gpu: %u of %u pairs hold residues outside the substitution matrix alphabet and stay on the CPU",
-                          n - good, n);
-                batch = c4gpu_batch_create(shim_ctx, &fm, &params, pair, good);
-                in_batch = good;
-                }
-            if(!batch)
-                for(i = 0; i < n; i++)
-                    bi[i] = i;
-            }
         }
     Model_Type_destroy_data(gam->gas->type, ud);
     if(batch && gam->gas->percent_threshold){
@@ -624,13 +585,11 @@ static void shim_flush(void){
         for(i = 0; i < n; i++){
             gpointer v;
             sp = todo->pdata[i];
-            if(bi[i] < 0)
-                continue;
             if(!g_hash_table_lookup_extended(seen, sp->query, NULL, &v)){
                 v = GINT_TO_POINTER(shim_query_threshold(gam, sp->query));
                 g_hash_table_insert(seen, sp->query, v);
                 }
-            per_pair[bi[i]] = GPOINTER_TO_INT(v);
+            per_pair[i] = GPOINTER_TO_INT(v);
             }
         c4gpu_batch_set_thresholds(batch, per_pair);
         g_free(per_pair);
@@ -645,10 +604,10 @@ static void shim_flush(void){
                 break;
             for(i = 0; i < n; i++){
                 sp = todo->pdata[i];
-                if(sp->done || (bi[i] < 0))
-                    continue;                          /* this pair left the loop in an earlier round / is not in the batch */
+                if(sp->done)
+                    continue;                          /* this pair left the loop in an earlier round */
                 sp->round = g_renew(c4gpu_alignment, sp->round, k+1);
-                if(c4gpu_batch_alignment(batch, bi[i], &sp->round[k]) != 0)
+                if(c4gpu_batch_alignment(batch, i, &sp->round[k]) != 0)
                     memset(&sp->round[k], 0, sizeof(c4gpu_alignment));
                 sp->round_total = k+1;
                 sp->done = !sp->round[k].valid;        /* the entry that ends the pair's loop is kept */
@@ -659,7 +618,7 @@ static void shim_flush(void){
                 }
             }
         if(shim_verbose)
-            g_message("c4gpu: batch of %d pairs, %d round(s) on the device", in_batch, k);
+            g_message("c4gpu: batch of %d pairs, %d round(s) on the device", n, k);
     } else {
         g_warning("c4gpu: %s -- batch falls back to per-call", c4gpu_last_error());
         }
@@ -670,7 +629,6 @@ static void shim_flush(void){
         g_free(str[i]);
     g_free(str);
     g_free(pair);
-    g_free(bi);
     /* replay in submission order through the reference's own code */
     for(i = 0; i < n; i++){
         register GAM_Result *gam_result;
