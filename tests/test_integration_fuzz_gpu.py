@@ -114,3 +114,49 @@ def test_random_inputs_and_flags(tmp_path, model, flags, batch, seed):
     # name would be identical by construction
     err = gpu.stderr.decode()
     assert "c4gpu:" in err and "using the CPU Viterbi" not in err and "falls back" not in err, err[-1500:]
+
+
+# ---- the heuristic modes (seeding seam + BSDP or SDP seam), random flags -----------------------------------------------
+HCASES = []
+_hr = random.Random(int(os.environ.get("C4_FUZZ_SEED", "20260929")))
+for _model in ("affine:local", "protein2dna", "est2genome", "protein2genome"):
+    for _rep in range(int(os.environ.get("C4_FUZZ_REPS", "4"))):
+        hflags = ["--gappedextension", _hr.choice(["yes", "no"])]
+        if _hr.random() < 0.4:
+            hflags += ["-S", "no"]
+        if _hr.random() < 0.3:
+            hflags += ["--bestn", str(_hr.randint(1, 2))]
+        if _hr.random() < 0.3:
+            hflags += ["--percent", str(_hr.choice([20, 40]))]
+        if _hr.random() < 0.3:
+            hflags += ["--score", str(_hr.choice([60, 150]))]
+        if _hr.random() < 0.5:
+            hflags += ["--extensionthreshold", str(_hr.choice([12, 25, 80]))]
+        if _hr.random() < 0.5:
+            hflags += ["--gapopen", str(_hr.choice([-7, -12, -20])), "--gapextend", str(_hr.choice([-2, -4, -6]))]
+        if _model.startswith("protein2") and _hr.random() < 0.5:
+            hflags += ["--codongapopen", str(_hr.choice([-11, -18])), "--codongapextend", str(_hr.choice([-3, -8])),
+                       "--frameshift", str(_hr.choice([-13, -28]))]
+        if _hr.random() < 0.3:
+            hflags += ["--dnahspthreshold", "40", "--proteinhspthreshold", "25"]
+        HCASES.append((_model, tuple(hflags), _hr.choice(["4096", "3"]), _hr.randint(0, 10**6)))
+
+
+@pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
+                    reason="reference binaries are built in the build container (make -C integration)")
+@pytest.mark.parametrize("model,flags,batch,seed", HCASES)
+def test_random_heuristic_runs(tmp_path, model, flags, batch, seed):
+    """The default (heuristic) mode with random flags: word hits extended on the device, then BSDP's sub-DPs
+    (--gappedextension no) or, for the models the reference runs without a boundary, the SDP passes
+    (--gappedextension yes) in device batches.  Byte-identical output; the seam that applies must have done the work."""
+    import test_integration_bsdp_host as hb
+    ref, gpu, err = hb.run_pair(tmp_path, model, list(flags), {"C4GPU_BATCH": batch}, n=6, seed=seed)
+    assert gpu == ref, (model, flags, batch)
+    assert "c4gpu hsp:" in err, err[-1500:]
+    if "no" == flags[1]:
+        assert "c4gpu bsdp:" in err and "stay on the CPU" not in err, err[-1500:]
+    elif model in ("affine:local", "protein2dna"):
+        pairs, flushes, served_pairs, alignments = hb.sdp_served(err)
+        assert served_pairs == pairs and "SDP stays on the CPU" not in err, err[-1500:]
+    else:
+        assert "c4gpu sdp:" not in err                        # boundary flavour: the reference's own SDP
