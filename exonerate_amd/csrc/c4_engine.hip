@@ -60,6 +60,27 @@ struct c4gpu_ctx {
 
 namespace {
 
+// Host loops over hundreds of thousands of independent small items (the sub-alignments between checkpoints: 778 443 per
+// pass for 4 096 pairs of 1 kb x 1 kb under the reference's -D 32 rule) are split over a few threads; `fn(first, last)`
+// works on its own items only.  C4GPU_HOST_THREADS=1 keeps everything on the calling thread.
+template <typename F> void parallel_for(long long n, long long min_per_thread, F &&fn) {
+    static const int hw = [] {
+        const char *e = getenv("C4GPU_HOST_THREADS");
+        const int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        return std::max(1, std::min(v, 16));
+    }();
+    const int t = (int)std::min<long long>(hw, n / std::max<long long>(1, min_per_thread));
+    if (t <= 1) { if (n > 0) fn(0LL, n); return; }
+    const long long chunk = (n + t - 1) / t;
+    std::vector<std::thread> th;
+    for (int k = 1; k < t; k++) {
+        const long long a = k * chunk, b = std::min(n, a + chunk);
+        if (a < b) th.emplace_back([&fn, a, b] { fn(a, b); });
+    }
+    fn(0LL, std::min(n, chunk));
+    for (auto &x : th) x.join();
+}
+
 // ---- small RAII device buffer ------------------------------------------------------------------------------
 template <class T>
 struct DevBuf {
@@ -386,9 +407,29 @@ struct ResidentSeqs {
             } else toff[i] = ti->second;
         }
         n_utargets = (int)ut.size();
-        std::vector<uint8_t> hq(total_q + 64, 'A'), ht(total_t + 64, 'A');
-        for (int i : uq) if (qlen[i]) memcpy(&hq[qoff[i]], pairs[i].query, qlen[i]);
-        for (int i : ut) if (tlen[i]) memcpy(&ht[toff[i]], pairs[i].target, tlen[i]);
+        // one host buffer per side, every byte written exactly once (residues, 'A' in the gaps up to the next multiple
+        // of four and in the 64-byte tail the kernels may read into) by several threads: a value-initialised vector of
+        // this size (410 MB of targets for the north-star batch) is page-faulted in and written twice on one core
+        struct HostBuf {
+            std::unique_ptr<uint8_t[]> p; size_t n;
+            explicit HostBuf(size_t n_) : p(new uint8_t[n_]), n(n_) {}
+            uint8_t *data() { return p.get(); }
+            size_t size() const { return n; }
+        } hq((size_t)total_q + 64), ht((size_t)total_t + 64);
+        auto gather = [&](HostBuf &dst, const std::vector<int> &uniq, bool query, long long total) {
+            parallel_for((long long)uniq.size(), 16, [&](long long first, long long last) {
+                for (long long x = first; x < last; x++) {
+                    const int i = uniq[x];
+                    const int len = query ? qlen[i] : tlen[i];
+                    uint8_t *d = dst.data() + (query ? qoff[i] : toff[i]);
+                    if (len) memcpy(d, query ? pairs[i].query : pairs[i].target, len);
+                    for (int k = len; k < ((len + 3) & ~3); k++) d[k] = 'A';
+                }
+            });
+            memset(dst.data() + total, 'A', 64);
+        };
+        gather(hq, uq, true, total_q);
+        gather(ht, ut, false, total_t);
         PrepTables pt;
         memcpy(pt.submat_index, params->submat_index, 256);
         memcpy(pt.nt2d, params->nt2d, 256);
@@ -476,27 +517,6 @@ struct JobOut {
     std::vector<DevVsa> vsa;      // CKPT: sub-alignments, last section first
     std::vector<int> checkpoints; // CKPT + dump_checkpoints
 };
-
-// Host loops over hundreds of thousands of independent small items (the sub-alignments between checkpoints: 778 443 per
-// pass for 4 096 pairs of 1 kb x 1 kb under the reference's -D 32 rule) are split over a few threads; `fn(first, last)`
-// works on its own items only.  C4GPU_HOST_THREADS=1 keeps everything on the calling thread.
-template <typename F> void parallel_for(long long n, long long min_per_thread, F &&fn) {
-    static const int hw = [] {
-        const char *e = getenv("C4GPU_HOST_THREADS");
-        const int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
-        return std::max(1, std::min(v, 16));
-    }();
-    const int t = (int)std::min<long long>(hw, n / std::max<long long>(1, min_per_thread));
-    if (t <= 1) { if (n > 0) fn(0LL, n); return; }
-    const long long chunk = (n + t - 1) / t;
-    std::vector<std::thread> th;
-    for (int k = 1; k < t; k++) {
-        const long long a = k * chunk, b = std::min(n, a + chunk);
-        if (a < b) th.emplace_back([&fn, a, b] { fn(a, b); });
-    }
-    fn(0LL, std::min(n, chunk));
-    for (auto &x : th) x.join();
-}
 
 // The windowed region pass (c4_viterbi_kernel.h, SEED): what a launch needs to know about the column dumps.
 struct SeedPlan {
