@@ -21,7 +21,7 @@ def main():
     for seed in range(first, first + count):
         rng = random.Random(4242 + seed)
         mname, alpha, adv, extra = MODELS[seed % len(MODELS)]
-        variant = rng.choice([None, None, "altparams"])
+        variant = rng.choice([None, "altparams", "posgap", "posgap"])
         drop = rng.choice([50, 50, 12, 25, 100])
         thr = rng.choice([30, 40, 80])
         hspthr = rng.choice([None, "20", "40"])
