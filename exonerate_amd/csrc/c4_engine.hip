@@ -379,6 +379,12 @@ struct ResidentSeqs {
     DevBuf<int> d_utlen;
 
     int build(c4gpu_ctx *ctx, int family, const c4gpu_params *params, const c4gpu_pair *pairs, int n) {
+        static const bool trace = getenv("C4GPU_TRACE") != nullptr;
+        const auto t_begin = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (trace) fprintf(stderr, "c4gpu trace: staging: %-24s at %.3f ms\n", what,
+                               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+        };
         n_pairs = n;
         qoff.resize(n); toff.resize(n); qlen.resize(n); tlen.resize(n);
         total_q = total_t = 0;
@@ -430,6 +436,7 @@ struct ResidentSeqs {
         };
         gather(hq, uq, true, total_q);
         gather(ht, ut, false, total_t);
+        lap("sequences gathered");
         PrepTables pt;
         memcpy(pt.submat_index, params->submat_index, 256);
         memcpy(pt.nt2d, params->nt2d, 256);
@@ -441,6 +448,7 @@ struct ResidentSeqs {
             d_toff.upload(toff.data(), n, s) || d_qlen.upload(qlen.data(), n, s) || d_tlen.upload(tlen.data(), n, s) ||
             d_utoff.upload(utoff.data(), n_utargets, s) || d_utlen.upload(utlen.data(), n_utargets, s))
             return -1;
+        if (trace) { HIP_OK(hipStreamSynchronize(s)); lap("uploaded"); }
         int zero = 0;
         if (bad.upload(&zero, 1, s)) return -1;
         const int blocks = 1024;
@@ -469,9 +477,11 @@ struct ResidentSeqs {
             dev.tn4 = tn4.p;
         }
         HIP_OK(hipGetLastError());
+        lap("kernels queued");
         int hbad = 0;
         if (bad.download(&hbad, 1, s)) return -1;
         HIP_OK(hipStreamSynchronize(s));
+        lap("coded, splice arrays built");
         if (hbad) {
             c4h::set_error(hbad == 2 ? "a target codon translates outside the substitution matrix alphabet (non-IUPAC base?)"
                                      : "a residue is outside the 24-letter substitution matrix alphabet "
