@@ -1858,3 +1858,4 @@ int c4gpu_batch_kernel_stats(c4gpu_batch *b, int mode, int reset, double *ms, in
 
 // ---- SDP on the device (seeded flavour): its own file, same translation unit ------------------------------------
 #include "c4_sdp.inc"
+#include "c4_sdp_bnd.inc"
