@@ -2,9 +2,9 @@
  *
  * The reference's default heuristic (--gappedextension yes) hands every candidate pair to GAM_Result_SDP_create
  * (src/hub/gam.c:852-890), whose loop asks SDP_Pair_next_path (src/sdp/sdp.c:743) for one alignment after the other;
- * the first call runs the two Scheduler passes (sdp.c:538-600), one pair at a time, on one core.  For the models the
- * reference runs WITHOUT a boundary (SDP_create, sdp.c:322-341: no shadows, no spans, one match transition — the affine
- * and protein2dna families, BASELINE config 1) this file
+ * the first call runs the two Scheduler passes (sdp.c:538-600), one pair at a time, on one core.  For both flavours of
+ * SDP_create (sdp.c:322-366: bidirectional from the seeds for affine / protein2dna, BASELINE config 1; boundary + spans
+ * for est2genome / protein2genome) this file
  *   1. lets the front of GAM_Result_heuristic_create (c4gpu_bsdp.c) COLLECT (gam, comparison) here instead;
  *   2. at a flush gives the HSPs of all collected pairs to c4gpu_sdp_batch: both passes of every pair in two launches,
  *      then the reference's single-pass loop over the seeds (sdp.c:776-795) inside the library;
@@ -12,10 +12,11 @@
  *      of SDP_Pair_next_path handing out the batch's alignments in order — and NULL as soon as the next one is below the
  *      threshold of that call (which --bestn / --percent raise between calls: gam.c:870).
  * Thresholds, --bestn bookkeeping, ryo / vulgar printing stay the reference's.  Not taken (the reference's own function
- * runs): models that need the boundary flavour, --refine (GAM_Result_add_alignment then blocks the REFINED alignment's
- * cells, gam.c:663-673), --singlepass no, --geneseed, pairs whose HSP sets differ in their advances, and pairs that
- * fill all 16 alignment slots of the batch.  C4GPU_SDP_HOST=1 replaces step 2 by the reference's own SDP on the host
- * (tests of the seam without a device); C4GPU_SDP_OFF=1 switches the seam off.
+ * runs): --refine (GAM_Result_add_alignment then blocks the REFINED alignment's cells, gam.c:663-673), --singlepass no,
+ * --geneseed, pairs whose HSP sets differ in their advances, pairs that fill all 16 alignment slots of the batch, and
+ * batches whose lattices do not fit the device (the library keeps ~32 bytes per cell: a flush is cut at C4GPU_BATCH_GB).
+ * C4GPU_SDP_HOST=1 replaces step 2 by the reference's own SDP on the host (tests of the seam without a device);
+ * C4GPU_SDP_OFF=1 switches the seam off.
  */
 #include <string.h>
 #include <stdlib.h>
@@ -44,13 +45,14 @@ typedef struct {
 } ShimSdpPending;
 
 static GPtrArray *sdp_pending = NULL;
+static gdouble sdp_pending_bytes = 0.0;
 static ShimSdpPending *sdp_cur = NULL;
 static struct { long pairs, served_pairs, alignments, flushes; double device_ms, replay_ms; } sst;
 
 static gboolean sdp_eligible(GAM *gam, Comparison *comparison){
     if((shim_batch_size() <= 0) || g_getenv("C4GPU_SDP_OFF") || sdp_cur)
         return FALSE;
-    if((!gam->gas->use_gapped_extension) || (!gam->sdp) || gam->sdp->use_boundary)
+    if((!gam->gas->use_gapped_extension) || (!gam->sdp))
         return FALSE;
     if(!gam->sdp->sas->single_pass_subopt)
         return FALSE;
@@ -202,6 +204,7 @@ void shim_sdp_flush(void){
     if((!todo) || (!todo->len))
         return;
     sdp_pending = NULL;
+    sdp_pending_bytes = 0.0;
     sst.flushes++;
     if(g_getenv("C4GPU_SDP_HOST")){
         for(i = 0; i < todo->len; i++)
@@ -253,7 +256,10 @@ gboolean shim_sdp_collect(GAM *gam, Comparison *comparison){
     p->gam = GAM_share(gam);
     p->comparison = Comparison_share(comparison);
     g_ptr_array_add(sdp_pending, p);
-    if((gint)sdp_pending->len >= shim_batch_size())
+    /* the device keeps ~32 bytes per lattice cell of a pair (pointers, sweep record, boundary map, thaw records) */
+    sdp_pending_bytes += 32.0 * ((gdouble)comparison->query->len + 1.0) * ((gdouble)comparison->target->len + 1.0);
+    if(((gint)sdp_pending->len >= shim_batch_size())
+    || (sdp_pending_bytes > (g_getenv("C4GPU_BATCH_GB") ? atof(g_getenv("C4GPU_BATCH_GB")) : 96.0) * 1e9))
         shim_sdp_flush();
     return TRUE;
     }

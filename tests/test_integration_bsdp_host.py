@@ -144,6 +144,7 @@ def sdp_served(err):
 @pytest.mark.parametrize("model,extra", [
     ("affine:local", []), ("affine:local", ["--bestn", "1"]), ("affine:local", ["--percent", "40", "--extensionthreshold", "20"]),
     ("protein2dna", []), ("protein2dna", ["-S", "no", "--score", "60"]),
+    ("est2genome", []), ("est2genome", ["--bestn", "1", "--extensionthreshold", "20"]), ("protein2genome", []),
 ])
 def test_sdp_seam_is_byte_identical_with_host_alignments(tmp_path, model, extra):
     """C4GPU_SDP_HOST=1: the collection, the hand-out of a batch's alignments by the front of SDP_Pair_next_path
@@ -156,8 +157,8 @@ def test_sdp_seam_is_byte_identical_with_host_alignments(tmp_path, model, extra)
     assert flushes == 1 and served_pairs == pairs >= 6 and alignments >= 6
 
 
-def test_sdp_seam_leaves_boundary_models_and_refinement_alone(tmp_path):
-    for model, extra in (("est2genome", []), ("affine:local", ["--refine", "region"])):
+def test_sdp_seam_leaves_refinement_alone(tmp_path):
+    for model, extra in (("est2genome", ["--refine", "region"]), ("affine:local", ["--refine", "region"])):
         ref, gpu, err = run_pair(tmp_path, model, ["--gappedextension", "yes"] + extra,
                                  {"C4GPU_SDP_HOST": "1", "C4GPU_HSP_HOST": "1", "C4GPU_DISABLE": "1"}, n=4, seed=22)
         assert gpu == ref and ref.count(b"vulgar:") >= 3

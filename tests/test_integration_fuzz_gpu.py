@@ -155,8 +155,6 @@ def test_random_heuristic_runs(tmp_path, model, flags, batch, seed):
     assert "c4gpu hsp:" in err, err[-1500:]
     if "no" == flags[1]:
         assert "c4gpu bsdp:" in err and "stay on the CPU" not in err, err[-1500:]
-    elif model in ("affine:local", "protein2dna"):
+    else:
         pairs, flushes, served_pairs, alignments = hb.sdp_served(err)
         assert served_pairs == pairs and "SDP stays on the CPU" not in err, err[-1500:]
-    else:
-        assert "c4gpu sdp:" not in err                        # boundary flavour: the reference's own SDP

@@ -303,10 +303,12 @@ def test_heuristic_bsdp_mode_runs_its_sub_dps_in_device_batches(tmp_path, model,
 @pytest.mark.parametrize("model,extra,batch", [
     ("affine:local", [], "4096"), ("affine:local", ["--bestn", "1"], "4096"), ("affine:local", ["--percent", "40"], "3"),
     ("protein2dna", [], "4096"), ("protein2dna", ["-S", "no", "--extensionthreshold", "20"], "4096"),
+    ("est2genome", [], "4096"), ("est2genome", ["--bestn", "1"], "3"), ("protein2genome", [], "4096"),
+    ("protein2genome", ["--percent", "30", "--extensionthreshold", "25"], "4096"),
 ])
 def test_heuristic_sdp_mode_takes_its_alignments_from_device_batches(tmp_path, model, extra, batch):
-    """The DEFAULT heuristic mode (--gappedextension yes: SDP) for the models the reference runs without a boundary:
-    both Scheduler passes of every collected pair in two launches per flush (c4gpu_sdp_batch behind
+    """The DEFAULT heuristic mode (--gappedextension yes: SDP), both flavours (bidirectional from the seeds: affine,
+    protein2dna; boundary + spans: est2genome, protein2genome): both Scheduler passes of every collected pair in two launches per flush (c4gpu_sdp_batch behind
     integration/c4gpu_sdp.c), the reference's own GAM_Result_SDP_create loop replayed on top.  Byte-identical output."""
     import test_integration_bsdp_host as hb
     ref, gpu, err = hb.run_pair(tmp_path, model, ["--gappedextension", "yes"] + extra, {"C4GPU_BATCH": batch}, n=8, seed=21)
