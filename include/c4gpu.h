@@ -360,8 +360,9 @@ int         c4gpu_hsp_extend_batch(c4gpu_ctx *ctx, const c4gpu_params *params, i
                                    const c4gpu_hsp_seed *seeds, int32_t n_seeds, c4gpu_hsp *out);
 
 /* SDP, the default gapped-extension heuristic (SDP_Pair_next_path src/sdp/sdp.c:743 in the loop of GAM_Result_SDP_create
- * src/hub/gam.c:852-890), for every pair of a batch — the flavour without a boundary, which the reference uses for models
- * without shadows and spans (SDP_create sdp.c:322-341: the affine and protein2dna families; -1 for every other model).
+ * src/hub/gam.c:852-890), for every pair of a batch, in the flavour SDP_create picks for the model (sdp.c:322-366):
+ * bidirectional from the seeds (no shadows, no spans, one match transition: the affine and protein2dna families) or
+ * boundary + span freeze / thaw (est2genome, protein2genome).  -1 for models outside those (spans on the query axis).
  * hsps: the HSPs of all pairs, pair i's are [hsp_first[i], hsp_first[i+1]) in the order SDP_Pair_create_seed_list meets
  * them (sdp.c:447-463); query_advance / target_advance: the match advances of the HSPset (1 / 1, or 1 / 3 for
  * protein2dna); dropoff: --extensionthreshold.  Both passes of Scheduler_Pair_calculate (scheduler.c:1445) run on the

@@ -25,7 +25,8 @@ cpu_exe = ROOT + "/oracle/_ref/exonerate-compiled"
 def run(exe, extra, env=None):
     e = dict(os.environ, C4GPU_VERBOSE="1")
     e.update(env or {})
-    args = ["-m", "est2genome", "--gappedextension", "no", "--showalignment", "no", "--showvulgar", "yes", "-V", "0"] + extra
+    mode = [] if "--gappedextension" in extra else ["--gappedextension", "no"]
+    args = ["-m", "est2genome"] + mode + ["--showalignment", "no", "--showvulgar", "yes", "-V", "0"] + extra
     t0 = time.perf_counter()
     r = subprocess.run([exe] + args + [out + "/q.fa", out + "/t.fa"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
     dt = time.perf_counter() - t0
@@ -55,4 +56,22 @@ for extra in (["-S", "no"], [], ["--refine", "region", "-S", "no"], ["--refine",
     print("| `%s` | exonerate-gpu, seeding on the host (C4GPU_HSP_OFF=1), rest as row 2 | %.2f | %d | - | - |" % (flags, t_hoff, nal))
     if hs:
         print("| `%s` | (row 2: %s word hits extended in %s device launches) | | | | |" % (flags, hs.group(1), hs.group(2)))
+print("\nAll outputs byte-identical to the reference's.")
+
+# the default mode: --gappedextension yes = SDP (boundary flavour for est2genome), integration/c4gpu_sdp.c
+print("\n# Default heuristic mode (--gappedextension yes: seeding + SDP), same input\n")
+print("| flags | binary | wall s | alignments | pairs served from SDP device batches |")
+print("|---|---|---|---|---|")
+for extra in (["--gappedextension", "yes", "-S", "no"], ["--gappedextension", "yes"]):
+    ref, t_ref, _ = run(cpu_exe, extra)
+    gpu, t_gpu, err = run(gpu_exe, extra)
+    off, t_off, _ = run(gpu_exe, extra, {"C4GPU_SDP_OFF": "1"})
+    assert gpu == ref and off == ref, "outputs differ for %r" % (extra,)
+    m = re.search(r"c4gpu sdp: (\d+) pairs in (\d+) flush\(es\): (\d+) served from device batches \((\d+) alignments\); batches (\d+) ms", err)
+    flags = " ".join(extra)
+    nal = ref.count("vulgar:")
+    print("| `%s` | reference (compiled scheduler, 1 core) | %.2f | %d | - |" % (flags, t_ref, nal))
+    print("| `%s` | exonerate-gpu, SDP batches | %.2f | %d | %s |" % (flags, t_gpu, nal,
+          ("%s of %s in %s flushes, %s ms in the batches" % (m.group(3), m.group(1), m.group(2), m.group(5))) if m else "?"))
+    print("| `%s` | exonerate-gpu, SDP seam off (the reference's scheduler on the host) | %.2f | %d | - |" % (flags, t_off, nal))
 print("\nAll outputs byte-identical to the reference's.")
