@@ -13,8 +13,9 @@
  *      threshold of that call (which --bestn / --percent raise between calls: gam.c:870).
  * Thresholds, --bestn bookkeeping, ryo / vulgar printing stay the reference's.  Not taken (the reference's own function
  * runs): --refine (GAM_Result_add_alignment then blocks the REFINED alignment's cells, gam.c:663-673), --singlepass no,
- * --geneseed, pairs whose HSP sets differ in their advances, pairs that fill all 16 alignment slots of the batch, and
- * batches whose lattices do not fit the device (the library keeps ~32 bytes per cell: a flush is cut at C4GPU_BATCH_GB).
+ * --geneseed, pairs whose HSP sets differ in their advances, pairs that fill all 16 alignment slots of the batch,
+ * pairs whose lattice holds more than C4GPU_SDP_MAX_CELLS cells (default 4e6: the device form sweeps the lattice, the
+ * reference only the cells inside the X-drop), and batches whose lattices do not fit the device (the library keeps ~32 bytes per cell: a flush is cut at C4GPU_BATCH_GB).
  * C4GPU_SDP_HOST=1 replaces step 2 by the reference's own SDP on the host (tests of the seam without a device);
  * C4GPU_SDP_OFF=1 switches the seam off.
  */
@@ -137,6 +138,7 @@ static void sdp_device_batch(GPtrArray *todo){
     c4gpu_alignment *out = g_new0(c4gpu_alignment, (gsize)n * SHIM_SDP_MAX);
     gboolean *usable = g_new0(gboolean, n);
     gint qa = 0, ta = 0;
+    gdouble max_cells = g_getenv("C4GPU_SDP_MAX_CELLS") ? atof(g_getenv("C4GPU_SDP_MAX_CELLS")) : 4.0e6;
     gpointer ud;
     c4gpu_model fm;
     c4gpu_params params;
@@ -158,6 +160,15 @@ static void sdp_device_batch(GPtrArray *todo){
         pair[i].query = (const uint8_t*)qs;  pair[i].query_len = p->comparison->query->len;
         pair[i].target = (const uint8_t*)ts; pair[i].target_len = p->comparison->target->len;
         first[i] = before;
+        /* the device sweeps the whole lattice of a pair (dead cells skipped, but one step per anti-diagonal), the
+         * reference's scheduler only the cells inside the X-drop: measured, the batch wins on lattices of config 1's size
+         * (300 x 10 000: 0.3 ms per pair against 0.8 ms) and loses by an order of magnitude at 1 000 x 100 000
+         * (profiles/r02_heuristic.md) — larger lattices stay with the reference's function unless C4GPU_SDP_MAX_CELLS says
+         * otherwise */
+        if(((gdouble)pair[i].query_len + 1.0) * ((gdouble)pair[i].target_len + 1.0) > max_cells){
+            usable[i] = FALSE;
+            continue;
+            }
         usable[i] = sdp_gather_hsps(p->comparison, hsps, &pqa, &pta);
         if(usable[i] && qa && ((pqa != qa) || (pta != ta)))
             usable[i] = FALSE;
@@ -257,7 +268,11 @@ gboolean shim_sdp_collect(GAM *gam, Comparison *comparison){
     p->comparison = Comparison_share(comparison);
     g_ptr_array_add(sdp_pending, p);
     /* the device keeps ~32 bytes per lattice cell of a pair (pointers, sweep record, boundary map, thaw records) */
-    sdp_pending_bytes += 32.0 * ((gdouble)comparison->query->len + 1.0) * ((gdouble)comparison->target->len + 1.0);
+    {
+        register gdouble cells = ((gdouble)comparison->query->len + 1.0) * ((gdouble)comparison->target->len + 1.0);
+        if(cells <= (g_getenv("C4GPU_SDP_MAX_CELLS") ? atof(g_getenv("C4GPU_SDP_MAX_CELLS")) : 4.0e6))
+            sdp_pending_bytes += 32.0 * cells;
+    }
     if(((gint)sdp_pending->len >= shim_batch_size())
     || (sdp_pending_bytes > (g_getenv("C4GPU_BATCH_GB") ? atof(g_getenv("C4GPU_BATCH_GB")) : 96.0) * 1e9))
         shim_sdp_flush();

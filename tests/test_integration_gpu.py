@@ -311,13 +311,18 @@ def test_heuristic_sdp_mode_takes_its_alignments_from_device_batches(tmp_path, m
     protein2dna; boundary + spans: est2genome, protein2genome): both Scheduler passes of every collected pair in two launches per flush (c4gpu_sdp_batch behind
     integration/c4gpu_sdp.c), the reference's own GAM_Result_SDP_create loop replayed on top.  Byte-identical output."""
     import test_integration_bsdp_host as hb
-    ref, gpu, err = hb.run_pair(tmp_path, model, ["--gappedextension", "yes"] + extra, {"C4GPU_BATCH": batch}, n=8, seed=21)
+    # C4GPU_SDP_MAX_CELLS: by default only lattices of config 1's size go to the device (it sweeps the whole lattice)
+    ref, gpu, err = hb.run_pair(tmp_path, model, ["--gappedextension", "yes"] + extra,
+                                {"C4GPU_BATCH": batch, "C4GPU_SDP_MAX_CELLS": "1e9"}, n=8, seed=21)
     assert gpu == ref
     assert ref.count(b"vulgar:") >= 6
     assert "SDP stays on the CPU" not in err, err[-1500:]
     pairs, flushes, served_pairs, alignments = hb.sdp_served(err)
     assert served_pairs == pairs >= 6 and alignments >= 6
     assert "c4gpu hsp:" in err
+    if model == "est2genome" and not extra:              # ... and larger ones stay with the reference's scheduler
+        ref, gpu, err = hb.run_pair(tmp_path, model, ["--gappedextension", "yes"], {"C4GPU_SDP_MAX_CELLS": "1000"}, n=8, seed=21)
+        assert gpu == ref and hb.sdp_served(err)[2] == 0
 
 
 @pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
