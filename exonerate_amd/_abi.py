@@ -179,6 +179,7 @@ PROTOTYPES = [
     ("c4gpu_model_device_family", C.c_int, [C.POINTER(Model)]),
     ("c4gpu_hsp_extend_batch", C.c_int, [C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(Pair), C.c_int32, C.c_int32,
                                          C.c_int32, C.POINTER(HspSeed), C.c_int32, C.POINTER(Hsp)]),
+    ("c4gpu_sdp_lattice_cells", C.c_double, [C.POINTER(Hsp), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     ("c4gpu_sdp_batch", C.c_int, [C.c_void_p, C.POINTER(Model), C.POINTER(Params), C.POINTER(Pair), C.c_int32, C.POINTER(Hsp),
                                   C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.POINTER(Alignment), C.POINTER(C.c_int32)]),

@@ -368,6 +368,11 @@ int         c4gpu_hsp_extend_batch(c4gpu_ctx *ctx, const c4gpu_params *params, i
  * protein2dna); dropoff: --extensionthreshold.  Both passes of Scheduler_Pair_calculate (scheduler.c:1445) run on the
  * device for all pairs at once; the --singlepass yes loop over the seeds follows on the host.  out[i * max_alignments + k]
  * is pair i's k-th alignment (clear each with c4gpu_alignment_clear), n_out[i] their number. */
+/* c4gpu_sdp_batch first sweeps, per pair, the box around its HSPs widened by C4GPU_SDP_MARGIN (default 384) positions;
+ * a pair whose scheduler comes within one advance of an open box edge is run again on its whole lattice (same results
+ * either way).  The cells of that box, for callers that decide by size what to send: */
+double      c4gpu_sdp_lattice_cells(const c4gpu_hsp *hsps, int32_t n_hsps, int32_t query_advance, int32_t target_advance,
+                                    int32_t query_len, int32_t target_len);
 int         c4gpu_sdp_batch(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params,
                             const c4gpu_pair *pairs, int32_t n_pairs, const c4gpu_hsp *hsps, const int32_t *hsp_first,
                             int32_t query_advance, int32_t target_advance, int32_t dropoff, c4gpu_score threshold,

@@ -160,17 +160,14 @@ static void sdp_device_batch(GPtrArray *todo){
         pair[i].query = (const uint8_t*)qs;  pair[i].query_len = p->comparison->query->len;
         pair[i].target = (const uint8_t*)ts; pair[i].target_len = p->comparison->target->len;
         first[i] = before;
-        /* the device sweeps the whole lattice of a pair (dead cells skipped, but one step per anti-diagonal), the
-         * reference's scheduler only the cells inside the X-drop: measured, the batch wins on lattices of config 1's size
-         * (300 x 10 000: 0.3 ms per pair against 0.8 ms) and loses by an order of magnitude at 1 000 x 100 000
-         * (profiles/r02_heuristic.md) — larger lattices stay with the reference's function unless C4GPU_SDP_MAX_CELLS says
-         * otherwise */
-        if(((gdouble)pair[i].query_len + 1.0) * ((gdouble)pair[i].target_len + 1.0) > max_cells){
-            usable[i] = FALSE;
-            continue;
-            }
+        /* the device sweeps the box around a pair's HSPs (dead cells skipped, but one step per anti-diagonal), the
+         * reference's scheduler only the cells inside the X-drop: boxes above C4GPU_SDP_MAX_CELLS cells stay with the
+         * reference's function (profiles/r02_heuristic.md) */
         usable[i] = sdp_gather_hsps(p->comparison, hsps, &pqa, &pta);
         if(usable[i] && qa && ((pqa != qa) || (pta != ta)))
+            usable[i] = FALSE;
+        if(usable[i] && (c4gpu_sdp_lattice_cells(&g_array_index(hsps, c4gpu_hsp, before), hsps->len - before, pqa, pta,
+                                                 pair[i].query_len, pair[i].target_len) > max_cells))
             usable[i] = FALSE;
         if(usable[i]){
             qa = pqa; ta = pta;
@@ -267,11 +264,17 @@ gboolean shim_sdp_collect(GAM *gam, Comparison *comparison){
     p->gam = GAM_share(gam);
     p->comparison = Comparison_share(comparison);
     g_ptr_array_add(sdp_pending, p);
-    /* the device keeps ~32 bytes per lattice cell of a pair (pointers, sweep record, boundary map, thaw records) */
+    /* the device keeps ~32 bytes per cell of the box it sweeps (pointers, sweep record, boundary map, thaw records) */
     {
-        register gdouble cells = ((gdouble)comparison->query->len + 1.0) * ((gdouble)comparison->target->len + 1.0);
-        if(cells <= (g_getenv("C4GPU_SDP_MAX_CELLS") ? atof(g_getenv("C4GPU_SDP_MAX_CELLS")) : 4.0e6))
-            sdp_pending_bytes += 32.0 * cells;
+        register GArray *hsps = g_array_new(FALSE, FALSE, sizeof(c4gpu_hsp));
+        gint qa, ta;
+        if(sdp_gather_hsps(comparison, hsps, &qa, &ta)){
+            register gdouble cells = c4gpu_sdp_lattice_cells((const c4gpu_hsp*)hsps->data, hsps->len, qa, ta,
+                                                             comparison->query->len, comparison->target->len);
+            if(cells <= (g_getenv("C4GPU_SDP_MAX_CELLS") ? atof(g_getenv("C4GPU_SDP_MAX_CELLS")) : 4.0e6))
+                sdp_pending_bytes += 32.0 * cells;
+            }
+        g_array_free(hsps, TRUE);
     }
     if(((gint)sdp_pending->len >= shim_batch_size())
     || (sdp_pending_bytes > (g_getenv("C4GPU_BATCH_GB") ? atof(g_getenv("C4GPU_BATCH_GB")) : 96.0) * 1e9))
