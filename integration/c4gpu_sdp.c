@@ -14,8 +14,9 @@
  * Thresholds, --bestn bookkeeping, ryo / vulgar printing stay the reference's.  Not taken (the reference's own function
  * runs): --refine (GAM_Result_add_alignment then blocks the REFINED alignment's cells, gam.c:663-673), --singlepass no,
  * --geneseed, pairs whose HSP sets differ in their advances, pairs that fill all 16 alignment slots of the batch,
- * pairs whose lattice holds more than C4GPU_SDP_MAX_CELLS cells (default 4e6: the device form sweeps the lattice, the
- * reference only the cells inside the X-drop), and batches whose lattices do not fit the device (the library keeps ~32 bytes per cell: a flush is cut at C4GPU_BATCH_GB).
+ * pairs whose HSP box (c4gpu_sdp_lattice_cells: what the device sweeps) holds more than C4GPU_SDP_MAX_CELLS cells
+ * (default 4e6: the device pays one step per anti-diagonal of the box, the reference only for the cells inside the
+ * X-drop), and flushes that would not fit the device (~32 bytes per box cell: a flush is cut at C4GPU_BATCH_GB).
  * C4GPU_SDP_HOST=1 replaces step 2 by the reference's own SDP on the host (tests of the seam without a device);
  * C4GPU_SDP_OFF=1 switches the seam off.
  */
