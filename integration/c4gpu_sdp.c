@@ -15,8 +15,8 @@
  * runs): --refine (GAM_Result_add_alignment then blocks the REFINED alignment's cells, gam.c:663-673), --singlepass no,
  * --geneseed, pairs whose HSP sets differ in their advances, pairs that fill all 16 alignment slots of the batch,
  * pairs whose HSP box (c4gpu_sdp_lattice_cells: what the device sweeps) holds more than C4GPU_SDP_MAX_CELLS cells
- * (default 4e6: the device pays one step per anti-diagonal of the box, the reference only for the cells inside the
- * X-drop), and flushes that would not fit the device (~32 bytes per box cell: a flush is cut at C4GPU_BATCH_GB).
+ * (default 2e7, from the sweep in profiles/r02_sdp_limit.md: the device pays one step per anti-diagonal of the box, the
+ * reference only for the cells inside the X-drop), and flushes that would not fit the device (~32 bytes per box cell: a flush is cut at C4GPU_BATCH_GB).
  * C4GPU_SDP_HOST=1 replaces step 2 by the reference's own SDP on the host (tests of the seam without a device);
  * C4GPU_SDP_OFF=1 switches the seam off.
  */
@@ -139,7 +139,7 @@ static void sdp_device_batch(GPtrArray *todo){
     c4gpu_alignment *out = g_new0(c4gpu_alignment, (gsize)n * SHIM_SDP_MAX);
     gboolean *usable = g_new0(gboolean, n);
     gint qa = 0, ta = 0;
-    gdouble max_cells = g_getenv("C4GPU_SDP_MAX_CELLS") ? atof(g_getenv("C4GPU_SDP_MAX_CELLS")) : 4.0e6;
+    gdouble max_cells = g_getenv("C4GPU_SDP_MAX_CELLS") ? atof(g_getenv("C4GPU_SDP_MAX_CELLS")) : 2.0e7;
     gpointer ud;
     c4gpu_model fm;
     c4gpu_params params;
@@ -272,7 +272,7 @@ gboolean shim_sdp_collect(GAM *gam, Comparison *comparison){
         if(sdp_gather_hsps(comparison, hsps, &qa, &ta)){
             register gdouble cells = c4gpu_sdp_lattice_cells((const c4gpu_hsp*)hsps->data, hsps->len, qa, ta,
                                                              comparison->query->len, comparison->target->len);
-            if(cells <= (g_getenv("C4GPU_SDP_MAX_CELLS") ? atof(g_getenv("C4GPU_SDP_MAX_CELLS")) : 4.0e6))
+            if(cells <= (g_getenv("C4GPU_SDP_MAX_CELLS") ? atof(g_getenv("C4GPU_SDP_MAX_CELLS")) : 2.0e7))
                 sdp_pending_bytes += 32.0 * cells;
             }
         g_array_free(hsps, TRUE);

@@ -311,7 +311,7 @@ def test_heuristic_sdp_mode_takes_its_alignments_from_device_batches(tmp_path, m
     protein2dna; boundary + spans: est2genome, protein2genome): both Scheduler passes of every collected pair in two launches per flush (c4gpu_sdp_batch behind
     integration/c4gpu_sdp.c), the reference's own GAM_Result_SDP_create loop replayed on top.  Byte-identical output."""
     import test_integration_bsdp_host as hb
-    # C4GPU_SDP_MAX_CELLS: by default only lattices of config 1's size go to the device (it sweeps the whole lattice)
+    # C4GPU_SDP_MAX_CELLS: by default only HSP boxes of up to 2e7 cells go to the device (it sweeps the whole box)
     ref, gpu, err = hb.run_pair(tmp_path, model, ["--gappedextension", "yes"] + extra,
                                 {"C4GPU_BATCH": batch, "C4GPU_SDP_MAX_CELLS": "1e9"}, n=8, seed=21)
     assert gpu == ref

@@ -73,5 +73,5 @@ for extra in (["--gappedextension", "yes", "-S", "no"], ["--gappedextension", "y
     print("| `%s` | reference (compiled scheduler, 1 core) | %.2f | %d | - |" % (flags, t_ref, nal))
     print("| `%s` | exonerate-gpu, SDP batches forced (C4GPU_SDP_MAX_CELLS=1e12: the device sweeps 10^8-cell lattices) | %.2f | %d | %s |" % (flags, t_gpu, nal,
           ("%s of %s in %s flushes, %s ms in the batches" % (m.group(3), m.group(1), m.group(2), m.group(5))) if m else "?"))
-    print("| `%s` | exonerate-gpu, default (lattices above 4e6 cells keep the reference's scheduler) | %.2f | %d | - |" % (flags, t_off, nal))
+    print("| `%s` | exonerate-gpu, default (HSP boxes above 2e7 cells keep the reference's scheduler) | %.2f | %d | - |" % (flags, t_off, nal))
 print("\nAll outputs byte-identical to the reference's.")
