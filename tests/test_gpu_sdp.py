@@ -136,125 +136,27 @@ def test_dna_and_protein2dna_pairs_against_oracle(eng):
 
 @pytest.mark.parametrize("seed", range(6))
 def test_device_sdp_fuzz_against_oracle(eng, seed):
-    """Seeded random batches of the three boundary-free families with non-default penalties, matrices, --extensionthreshold
-    and thresholds, HSPs grown from every shared word (lowered HSP thresholds: many weak seeds), against the oracle."""
-    from golden_util import PARAM_VARIANTS, apply_flags
-    from test_library_fuzz_gpu import CODON
-    rng = random.Random(500 + seed)
-    rev = {c: a for a, cs in CODON.items() for c in cs}
-    for _ in range(2):
-        variant = rng.choice([None, "altparams", "posgap"])
-        params = ex.default_params() if variant is None else apply_flags(ex.default_params(), PARAM_VARIANTS[variant])
-        kind = rng.choice(["dna", "protein", "p2d"])
-        dropoff, threshold = rng.choice([12, 50, 120]), rng.choice([30, 80])
-        if kind == "dna":
-            model, match, adv, w, alpha = ex.Model("affine:local", params=params), "dna2dna", (1, 1), 10, "ACGT"
-        elif kind == "protein":
-            model = ex.Model("affine:local", query_alphabet=ex.ALPHABET_PROTEIN, target_alphabet=ex.ALPHABET_PROTEIN, params=params)
-            match, adv, w, alpha = "protein2protein", (1, 1), 4, AA
-        else:
-            model, match, adv, w, alpha = ex.Model("protein2dna", params=params), "protein2dna", (1, 3), 4, AA
-        pairs, hsps = [], []
-        for k in range(10):
-            q = "".join(rng.choice(alpha) for _ in range(rng.randint(60, 500)))
-            body = _mut(rng, q, rng.choice([0.03, 0.1, 0.2]), alpha)
-            if kind == "p2d":
-                body = "".join(rng.choice(CODON[a]) for a in body)
-                if rng.random() < 0.5:
-                    p = rng.randint(5, len(body) - 5)
-                    body = body[:p] + rng.choice("ACGT") + body[p:]
-            flank = "ACGT" if kind != "protein" else AA
-            t = "".join(rng.choice(flank) for _ in range(rng.randint(300, 900))) + body + \
-                "".join(rng.choice(flank) for _ in range(rng.randint(0, 900)))
-            if rng.random() < 0.3:
-                t += body[len(body) // 3:]
-            words = {}
-            for i in range(len(q) - w + 1):
-                words.setdefault(q[i:i + w], []).append(i)
-            if kind == "p2d":
-                seeds = []
-                for j in range(len(t) - 3 * w + 1):
-                    word = "".join(rev.get(t[j + 3 * x:j + 3 * x + 3], "X") for x in range(w))
-                    seeds += [(i, j) for i in words.get(word, ()) if j - 3 * i + len(q) >= 0]
-            else:
-                seeds = [(i, j) for j in range(len(t) - w + 1) for i in words.get(t[j:j + w], ())]
-            h = oracle_lib.hsp_set(params, match, q.encode(), t.encode(), w, rng.choice([10, 30]), rng.choice([15, 30]), seeds)
-            if h:
-                pairs.append((q, t)); hsps.append(h)
-        if not pairs:
-            continue
-        got = eng.sdp(model, pairs, hsps, adv[0], adv[1], dropoff, threshold, 4)
-        for (q, t), h, alns in zip(pairs, hsps, got):
-            ub, exp = oracle_lib.sdp(model.c, model.params, q.encode(), t.encode(), h, adv[0], adv[1], dropoff, True, threshold, 4)
-            assert [a.as_dict() for a in alns] == exp, (seed, kind, variant, dropoff, threshold, len(q), len(t), len(h))
+    """Seeded random batches of the three boundary-free families (tests/sdp_cases.py) against the oracle."""
+    from sdp_cases import seeded_fuzz_cases
+    for cs in seeded_fuzz_cases(seed):
+        model, adv = cs["model"], cs["adv"]
+        got = eng.sdp(model, cs["pairs"], cs["hsps"], adv[0], adv[1], cs["dropoff"], cs["threshold"], 4)
+        for (q, t), h, alns in zip(cs["pairs"], cs["hsps"], got):
+            ub, exp = oracle_lib.sdp(model.c, model.params, q.encode(), t.encode(), h, adv[0], adv[1], cs["dropoff"], True, cs["threshold"], 4)
+            assert [a.as_dict() for a in alns] == exp, (seed, cs["kind"], cs["variant"], cs["dropoff"], cs["threshold"], len(q), len(t), len(h))
 
 
 @pytest.mark.parametrize("seed", range(6))
 def test_device_sdp_boundary_fuzz_against_oracle(eng, seed):
-    """The boundary flavour (est2genome, protein2genome): genes with several introns on either strand sense, a second copy
-    of the gene, indels and frameshifts, non-default penalties and intron windows (so that stored span seeds expire),
-    lowered --extensionthreshold; every shared word a word hit.  Against the oracle (pinned on the reference's SDP)."""
-    from golden_util import PARAM_VARIANTS, apply_flags
-    from test_library_fuzz_gpu import CODON
-    rng = random.Random(900 + seed)
-    rev = {c: a for a, cs in CODON.items() for c in cs}
-    dna = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
-    for _ in range(2):
-        variant = rng.choice([None, "altparams", "tightintron"])
-        params = ex.default_params() if variant is None else apply_flags(ex.default_params(), PARAM_VARIANTS[variant])
-        kind = rng.choice(["e2g", "p2g"])
-        dropoff, threshold = rng.choice([15, 50, 90]), rng.choice([40, 100])
-        model = ex.Model("est2genome" if kind == "e2g" else "protein2genome", params=params)
-        adv, w = ((1, 1), 10) if kind == "e2g" else ((1, 3), 4)
-        pairs, hsps = [], []
-        for k in range(8):
-            if kind == "e2g":
-                q = dna(rng.randint(150, 700))
-                cuts = sorted(rng.sample(range(30, len(q) - 30), rng.randint(1, 3)))
-                revs = rng.random() < 0.3
-                gene, last = "", 0
-                for c in cuts + [len(q)]:
-                    gene += _mut(rng, q[last:c], 0.03, "ACGT")
-                    if c < len(q):
-                        gene += ("CT" if revs else "GT") + dna(rng.choice([30, 60, 150, 400])) + ("AC" if revs else "AG")
-                    last = c
-            else:
-                q = "".join(rng.choice(AA) for _ in range(rng.randint(60, 220)))
-                coding = "".join(rng.choice(CODON[a]) for a in _mut(rng, q, 0.04, AA))
-                cuts = sorted(rng.sample(range(20, len(coding) - 20), rng.randint(1, 3)))
-                gene, last = "", 0
-                for c in cuts + [len(coding)]:
-                    gene += coding[last:c]
-                    if c < len(coding):
-                        gene += "GT" + dna(rng.choice([30, 60, 150, 400])) + "AG"
-                    last = c
-                if rng.random() < 0.3:
-                    p = rng.randint(10, len(gene) - 10)
-                    gene = gene[:p] + rng.choice("ACGT") + gene[p:]
-            t = dna(rng.randint(300, 900)) + gene + dna(rng.randint(50, 600))
-            if rng.random() < 0.3:
-                t += gene[len(gene) // 3:] + dna(40)
-            words = {}
-            for i in range(len(q) - w + 1):
-                words.setdefault(q[i:i + w], []).append(i)
-            if kind == "p2g":
-                seeds = []
-                for j in range(len(t) - 3 * w + 1):
-                    word = "".join(rev.get(t[j + 3 * x:j + 3 * x + 3], "X") for x in range(w))
-                    seeds += [(i, j) for i in words.get(word, ()) if j - 3 * i + len(q) >= 0]
-                h = oracle_lib.hsp_set(params, "protein2dna", q.encode(), t.encode(), w, 20, rng.choice([15, 30]), seeds)
-            else:
-                seeds = [(i, j) for j in range(len(t) - w + 1) for i in words.get(t[j:j + w], ())]
-                h = oracle_lib.hsp_set(params, "dna2dna", q.encode(), t.encode(), w, 30, rng.choice([20, 40]), seeds)
-            if h:
-                pairs.append((q, t)); hsps.append(h)
-        if not pairs:
-            continue
-        got = eng.sdp(model, pairs, hsps, adv[0], adv[1], dropoff, threshold, 4)
+    """The boundary flavour (est2genome, protein2genome; tests/sdp_cases.py) against the oracle (pinned on the reference's SDP)."""
+    from sdp_cases import boundary_fuzz_cases
+    for cs in boundary_fuzz_cases(seed):
+        model, adv = cs["model"], cs["adv"]
+        got = eng.sdp(model, cs["pairs"], cs["hsps"], adv[0], adv[1], cs["dropoff"], cs["threshold"], 4)
         n = 0
-        for (q, t), h, alns in zip(pairs, hsps, got):
-            ub, exp = oracle_lib.sdp(model.c, model.params, q.encode(), t.encode(), h, adv[0], adv[1], dropoff, True, threshold, 4)
+        for (q, t), h, alns in zip(cs["pairs"], cs["hsps"], got):
+            ub, exp = oracle_lib.sdp(model.c, model.params, q.encode(), t.encode(), h, adv[0], adv[1], cs["dropoff"], True, cs["threshold"], 4)
             assert ub == 1
-            assert [a.as_dict() for a in alns] == exp, (seed, kind, variant, dropoff, threshold, len(q), len(t), len(h))
+            assert [a.as_dict() for a in alns] == exp, (seed, cs["kind"], cs["variant"], cs["dropoff"], cs["threshold"], len(q), len(t), len(h))
             n += len(exp)
         assert n >= 3
