@@ -312,7 +312,8 @@ class Engine:
     def sdp(self, model, pairs, hsps, query_advance=1, target_advance=1, dropoff=50, threshold=100, max_alignments=4):
         """The reference's default gapped-extension heuristic (SDP, GAM_Result_SDP_create gam.c:852) for a batch: per pair
         the list of alignments found from its HSPs ([query_start, target_start, length, score, cobs] each), both
-        Scheduler passes on the device (c4gpu_sdp_batch; affine and protein2dna families)."""
+        Scheduler passes on the device (c4gpu_sdp_batch: one sparse wavefront per pair, both SDP flavours).  A pair the
+        device could not serve (its traceback did not fit the device's memory) yields None."""
         arr, keep = _pairs(pairs)
         flat = [h for hs in hsps for h in hs]
         first = [0]
@@ -327,6 +328,9 @@ class Engine:
             raise _err("c4gpu_sdp_batch")
         res = []
         for i in range(len(pairs)):
+            if n_out[i] < 0:
+                res.append(None)
+                continue
             mine = []
             for k in range(n_out[i]):
                 a = out[i * max_alignments + k]
@@ -334,6 +338,15 @@ class Engine:
                 _lib().c4gpu_alignment_clear(a)
             res.append(mine)
         return res
+
+    @staticmethod
+    def sdp_stats(reset=False):
+        """Counters of this thread's sdp() calls: kernel ms of the passes / walks, staging / host ms, jobs, reruns, unserved."""
+        d = [C.c_double() for _ in range(4)]
+        n = [C.c_int64() for _ in range(3)]
+        _lib().c4gpu_sdp_stats(1 if reset else 0, *[C.byref(x) for x in d + n])
+        return dict(pass_ms=d[0].value, walk_ms=d[1].value, stage_ms=d[2].value, host_ms=d[3].value, jobs=n[0].value,
+                    reruns=n[1].value, unserved=n[2].value)
 
     def splice_predict(self, params, target):
         t = target if isinstance(target, bytes) else target.encode()

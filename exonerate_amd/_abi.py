@@ -183,6 +183,8 @@ PROTOTYPES = [
     ("c4gpu_sdp_batch", C.c_int, [C.c_void_p, C.POINTER(Model), C.POINTER(Params), C.POINTER(Pair), C.c_int32, C.POINTER(Hsp),
                                   C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.POINTER(Alignment), C.POINTER(C.c_int32)]),
+    ("c4gpu_sdp_stats", None, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                               C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("c4gpu_batch_viterbi_model", C.c_int, [C.c_void_p, C.POINTER(Model), C.c_int, C.POINTER(ViterbiJob), C.c_int32,
                                             C.POINTER(ViterbiResult)]),
     ("c4gpu_batch_scores", C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(Region)]),

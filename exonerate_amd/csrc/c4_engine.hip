@@ -23,6 +23,8 @@
 #include "c4gpu.h"
 #include "c4_internal.h"
 #include "c4_launch.h"
+#include "c4_sdp_launch.h"
+#include "c4_sdp_host.h"
 
 using namespace c4k;
 
@@ -56,6 +58,9 @@ struct c4gpu_ctx {
     // share of pairs whose region start the windowed region pass found within its hop budget in recent batches
     // (-1: not known yet): alignments that span most of their target make the two-pass form the dearer one
     double window_rate = -1.0;
+    // SDP (c4_sdp_dev.inc): the arena the passes' step records grow in, kept between calls
+    void *sdp_arena = nullptr;
+    size_t sdp_arena_bytes = 0;
 };
 
 namespace {
@@ -1510,6 +1515,7 @@ void c4gpu_ctx_destroy(c4gpu_ctx *ctx) {
     if (!ctx) return;
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->sdp_arena) (void)hipFree(ctx->sdp_arena);
     delete ctx;
 }
 
@@ -1857,5 +1863,4 @@ int c4gpu_batch_kernel_stats(c4gpu_batch *b, int mode, int reset, double *ms, in
 }  // extern "C"
 
 // ---- SDP on the device (seeded flavour): its own file, same translation unit ------------------------------------
-#include "c4_sdp.inc"
-#include "c4_sdp_bnd.inc"
+#include "c4_sdp_dev.inc"

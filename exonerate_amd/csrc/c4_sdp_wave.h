@@ -467,7 +467,7 @@ SDP_HD int walk_path(const SdpWalkTab &W, const SdpJob &job, const uint8_t *aren
 // ---- the device driver ------------------------------------------------------------------------------------------
 // One wave per pair (block = 64 threads, blockIdx.x = job).  Strips in ascending order; inside a strip the event-driven
 // step loop described at the top of this file.
-constexpr int SDP_BEST_LDS = 768;                      // seeds of a pair whose best start / end lives in LDS (the rest: global)
+constexpr int SDP_BEST_LDS = 256;                      // seeds of a pair whose best start / end lives in LDS (the rest: global)
 
 template <class M, bool FWD, bool BND>
 struct WaveSweep {
@@ -564,6 +564,7 @@ struct WaveSweep {
             SdpDSeed nseed = SdpDSeed{-1, SDP_NO_EVENT, 0, 0, 0};
             auto load_seed = [&]() {
                 nseed = SdpDSeed{-1, SDP_NO_EVENT, 0, 0, 0};
+                if constexpr (FWD && BND) return;              // the forward boundary pass starts from the boundary cells only
                 if (sp < job.n_seeds) {
                     const SdpDSeed s = seeds[sp];
                     if (s.strip == strip) {
@@ -748,7 +749,7 @@ struct SdpWalkLaunch {
     unsigned long long *runs_used, runs_cap;
     SdpWalkOut *out;
 };
-__global__ void sdp_walk_kernel2(const SdpWalkLaunch A) {
+static __global__ void sdp_walk_kernel2(const SdpWalkLaunch A) {
     const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (s >= A.n_seeds) return;
     SdpWalkOut w = {LOW, 0, 0, 0, SDP_OK, 0, 0};

@@ -366,13 +366,19 @@ int         c4gpu_hsp_extend_batch(c4gpu_ctx *ctx, const c4gpu_params *params, i
  * hsps: the HSPs of all pairs, pair i's are [hsp_first[i], hsp_first[i+1]) in the order SDP_Pair_create_seed_list meets
  * them (sdp.c:447-463); query_advance / target_advance: the match advances of the HSPset (1 / 1, or 1 / 3 for
  * protein2dna); dropoff: --extensionthreshold.  Both passes of Scheduler_Pair_calculate (scheduler.c:1445) run on the
- * device for all pairs at once; the --singlepass yes loop over the seeds follows on the host.  out[i * max_alignments + k]
- * is pair i's k-th alignment (clear each with c4gpu_alignment_clear), n_out[i] their number. */
-/* c4gpu_sdp_batch first sweeps, per pair, the box around its HSPs widened by C4GPU_SDP_MARGIN (default 384) positions;
- * a pair whose scheduler comes within one advance of an open box edge is run again on its whole lattice (same results
- * either way).  The cells of that box, for callers that decide by size what to send: */
+ * device for all pairs at once — one wavefront per pair that visits, like the reference's scheduler, only the cells
+ * inside the X-drop (memory and time follow the visited cells, not the lattice sizes) — and the --singlepass yes loop
+ * over the seeds follows on the host.  out[i * max_alignments + k] is pair i's k-th alignment (clear each with
+ * c4gpu_alignment_clear), n_out[i] their number, or -1 for a pair the device could not serve (its traceback did not fit
+ * the memory left on the device): the caller runs the reference's SDP for that pair; the others are unaffected. */
+/* The cells of the box around a pair's HSPs widened by 384 positions: an upper bound of what the passes visit when no
+ * extension runs past that margin (for callers that plan by size; c4gpu_sdp_batch itself has no size limit): */
 double      c4gpu_sdp_lattice_cells(const c4gpu_hsp *hsps, int32_t n_hsps, int32_t query_advance, int32_t target_advance,
                                     int32_t query_len, int32_t target_len);
+/* Counters of the calling thread's c4gpu_sdp_batch calls (kernel ms of the passes and of the walks by HIP events,
+ * staging and host ms, jobs launched, pairs run again with a larger arena, pairs not served); reset != 0 clears them. */
+void        c4gpu_sdp_stats(int reset, double *pass_ms, double *walk_ms, double *stage_ms, double *host_ms, int64_t *jobs,
+                            int64_t *reruns, int64_t *unserved);
 int         c4gpu_sdp_batch(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params,
                             const c4gpu_pair *pairs, int32_t n_pairs, const c4gpu_hsp *hsps, const int32_t *hsp_first,
                             int32_t query_advance, int32_t target_advance, int32_t dropoff, c4gpu_score threshold,

@@ -13,10 +13,9 @@
  *      threshold of that call (which --bestn / --percent raise between calls: gam.c:870).
  * Thresholds, --bestn bookkeeping, ryo / vulgar printing stay the reference's.  Not taken (the reference's own function
  * runs): --refine (GAM_Result_add_alignment then blocks the REFINED alignment's cells, gam.c:663-673), --singlepass no,
- * --geneseed, pairs whose HSP sets differ in their advances, pairs that fill all 16 alignment slots of the batch,
- * pairs whose HSP box (c4gpu_sdp_lattice_cells: what the device sweeps) holds more than C4GPU_SDP_MAX_CELLS cells
- * (default 2e7, from the sweep in profiles/r02_sdp_limit.md: the device pays one step per anti-diagonal of the box, the
- * reference only for the cells inside the X-drop), and flushes that would not fit the device (~32 bytes per box cell: a flush is cut at C4GPU_BATCH_GB).
+ * --geneseed, pairs whose HSP sets differ in their advances, pairs that fill all 16 alignment slots of the batch and
+ * pairs the library reports as not served (n_out = -1: their traceback did not fit the device).  There is no size limit:
+ * the device passes are sparse wavefronts that visit what the reference's scheduler visits (c4_sdp_wave.h).
  * C4GPU_SDP_HOST=1 replaces step 2 by the reference's own SDP on the host (tests of the seam without a device);
  * C4GPU_SDP_OFF=1 switches the seam off.
  */
@@ -139,7 +138,6 @@ static void sdp_device_batch(GPtrArray *todo){
     c4gpu_alignment *out = g_new0(c4gpu_alignment, (gsize)n * SHIM_SDP_MAX);
     gboolean *usable = g_new0(gboolean, n);
     gint qa = 0, ta = 0;
-    gdouble max_cells = g_getenv("C4GPU_SDP_MAX_CELLS") ? atof(g_getenv("C4GPU_SDP_MAX_CELLS")) : 2.0e7;
     gpointer ud;
     c4gpu_model fm;
     c4gpu_params params;
@@ -161,14 +159,8 @@ static void sdp_device_batch(GPtrArray *todo){
         pair[i].query = (const uint8_t*)qs;  pair[i].query_len = p->comparison->query->len;
         pair[i].target = (const uint8_t*)ts; pair[i].target_len = p->comparison->target->len;
         first[i] = before;
-        /* the device sweeps the box around a pair's HSPs (dead cells skipped, but one step per anti-diagonal), the
-         * reference's scheduler only the cells inside the X-drop: boxes above C4GPU_SDP_MAX_CELLS cells stay with the
-         * reference's function (profiles/r02_heuristic.md) */
         usable[i] = sdp_gather_hsps(p->comparison, hsps, &pqa, &pta);
         if(usable[i] && qa && ((pqa != qa) || (pta != ta)))
-            usable[i] = FALSE;
-        if(usable[i] && (c4gpu_sdp_lattice_cells(&g_array_index(hsps, c4gpu_hsp, before), hsps->len - before, pqa, pta,
-                                                 pair[i].query_len, pair[i].target_len) > max_cells))
             usable[i] = FALSE;
         if(usable[i]){
             qa = pqa; ta = pta;
@@ -186,10 +178,10 @@ static void sdp_device_batch(GPtrArray *todo){
             for(i = 0; i < n; i++){
                 register gint k;
                 p = todo->pdata[i];
-                p->n = n_out[i];
-                for(k = 0; k < n_out[i]; k++)
+                p->n = (n_out[i] < 0) ? 0 : n_out[i];     /* -1: the device could not serve this pair (memory): CPU */
+                for(k = 0; k < p->n; k++)
                     p->alns[k] = out[(gsize)i * SHIM_SDP_MAX + k];
-                p->have = usable[i] && (n_out[i] < SHIM_SDP_MAX);
+                p->have = usable[i] && (n_out[i] >= 0) && (n_out[i] < SHIM_SDP_MAX);
                 }
         } else {
             g_warning("c4gpu: %s -- SDP stays on the CPU for this batch", c4gpu_last_error());
@@ -265,18 +257,11 @@ gboolean shim_sdp_collect(GAM *gam, Comparison *comparison){
     p->gam = GAM_share(gam);
     p->comparison = Comparison_share(comparison);
     g_ptr_array_add(sdp_pending, p);
-    /* the device keeps ~32 bytes per cell of the box it sweeps (pointers, sweep record, boundary map, thaw records) */
-    {
-        register GArray *hsps = g_array_new(FALSE, FALSE, sizeof(c4gpu_hsp));
-        gint qa, ta;
-        if(sdp_gather_hsps(comparison, hsps, &qa, &ta)){
-            register gdouble cells = c4gpu_sdp_lattice_cells((const c4gpu_hsp*)hsps->data, hsps->len, qa, ta,
-                                                             comparison->query->len, comparison->target->len);
-            if(cells <= (g_getenv("C4GPU_SDP_MAX_CELLS") ? atof(g_getenv("C4GPU_SDP_MAX_CELLS")) : 2.0e7))
-                sdp_pending_bytes += 32.0 * cells;
-            }
-        g_array_free(hsps, TRUE);
-    }
+    /* the device passes visit, like the reference's scheduler, only the cells inside the X-drop and keep ~25 bytes of
+     * traceback per visited cell in an arena that c4gpu_sdp_batch sizes itself; what a flush stages per pair are the
+     * sequences (shared ones once): a flush is cut when the distinct residues pass C4GPU_BATCH_GB / 20 (splice arrays and
+     * codes are ~20 bytes per target residue) */
+    sdp_pending_bytes += 20.0 * (comparison->query->len + comparison->target->len);
     if(((gint)sdp_pending->len >= shim_batch_size())
     || (sdp_pending_bytes > (g_getenv("C4GPU_BATCH_GB") ? atof(g_getenv("C4GPU_BATCH_GB")) : 96.0) * 1e9))
         shim_sdp_flush();

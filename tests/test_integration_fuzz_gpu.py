@@ -150,7 +150,7 @@ def test_random_heuristic_runs(tmp_path, model, flags, batch, seed):
     (--gappedextension no) or, for the models the reference runs without a boundary, the SDP passes
     (--gappedextension yes) in device batches.  Byte-identical output; the seam that applies must have done the work."""
     import test_integration_bsdp_host as hb
-    ref, gpu, err = hb.run_pair(tmp_path, model, list(flags), {"C4GPU_BATCH": batch, "C4GPU_SDP_MAX_CELLS": "1e9"}, n=6, seed=seed)
+    ref, gpu, err = hb.run_pair(tmp_path, model, list(flags), {"C4GPU_BATCH": batch}, n=6, seed=seed)
     assert gpu == ref, (model, flags, batch)
     assert "c4gpu hsp:" in err, err[-1500:]
     if "no" == flags[1]:
