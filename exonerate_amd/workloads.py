@@ -85,14 +85,17 @@ def _encode_protein(rng, prot):
     return b"".join(cod[chr(a)][int(rng.integers(0, len(cod[chr(a)])))] for a in prot)
 
 
-def protein_vs_contig(n_proteins, plen=500, contig_len=1000000, seed=20260931, introns=False, mutation=0.05):
+def protein_vs_contig(n_proteins, plen=500, contig_len=1000000, seed=20260931, introns=False, mutation=0.05, plant_every=1):
     """C3 (protein2dna) / C5 (protein2genome, introns=True): `n_proteins` proteins against ONE contig that
     holds a codon-encoded, `mutation`-mutated copy of each at a known place.  Returns (proteins, contig,
-    [(start, end) of each planted gene])."""
+    [(start, end) of each planted gene]).  plant_every = k: only proteins 0, k, 2k, .. have a gene in the contig (BASELINE
+    config 3 names 1 024 proteins of ~500 aa against ONE 1 Mb contig, which 1 024 genes of 1.5 kb do not fit into); the
+    places of the others are None."""
     rng = np.random.default_rng([seed, 0])
     proteins = [_rand(rng, plen, AA) for _ in range(n_proteins)]
+    planted = [i for i in range(n_proteins) if i % plant_every == 0]
     genes = []
-    for p in proteins:
+    for p in (proteins[i] for i in planted):
         m = _mutate(rng, p, mutation, AA)
         coding = _encode_protein(rng, m)
         if introns:
@@ -109,7 +112,7 @@ def protein_vs_contig(n_proteins, plen=500, contig_len=1000000, seed=20260931, i
     total = sum(len(g) for g in genes)
     gaps = contig_len - total
     assert gaps > 0, "contig too short for the planted genes"
-    cutp = np.sort(rng.integers(0, gaps + 1, size=n_proteins))
+    cutp = np.sort(rng.integers(0, gaps + 1, size=len(genes)))
     out, places, last, pos = [], [], 0, 0
     for g, c in zip(genes, cutp):
         flank = _rand(rng, int(c - last)).tobytes()
@@ -122,4 +125,9 @@ def protein_vs_contig(n_proteins, plen=500, contig_len=1000000, seed=20260931, i
     out.append(_rand(rng, contig_len - pos).tobytes())
     contig = b"".join(out)
     assert len(contig) == contig_len
+    if plant_every != 1:
+        full = [None] * n_proteins
+        for i, pl in zip(planted, places):
+            full[i] = pl
+        places = full
     return [p.tobytes() for p in proteins], contig, places

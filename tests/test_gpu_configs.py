@@ -20,20 +20,25 @@ def eng():
 
 
 def test_c2_affine_local_1kb_batch(eng):
-    """C2: 1 024 pairs in one batch; every 64th checked against the oracle (reduced space at -D 32)."""
+    """C2 at BASELINE's size: 4 096 pairs of 1 kb x 1 kb in one batch; every 64th checked against the oracle (reduced
+    space at -D 32: ~190 sub-alignments per pair)."""
     model = ex.Model("affine:local")
-    pairs = workloads.affine_dna_pairs(1024, 1000)
+    pairs = workloads.affine_dna_pairs(4096, 1000)
     alns = eng.find_path(model, pairs, dpmemory=32)
     assert all(a is not None for a in alns)
-    for i in range(0, 1024, 64):
+    for i in range(0, 4096, 64):
         q, t = pairs[i]
         assert alns[i].as_dict() == oracle_lib.find_path(model.c, model.params, q, t, dpmemory=32), i
 
 
-def _check_against_windows(eng, model, proteins, contig, places, margin):
+def _check_against_windows(eng, model, proteins, contig, places, margin, check_every=1):
     pairs = [(p, contig) for p in proteins]                  # one shared buffer: uploaded once
     alns = eng.find_path(model, pairs, dpmemory=32)
-    for p, (g0, g1), a in zip(proteins, places, alns):
+    assert all(a is not None for a in alns)
+    for k, (p, place, a) in enumerate(zip(proteins, places, alns)):
+        if k % check_every or place is None:
+            continue
+        g0, g1 = place
         w0, w1 = max(0, g0 - margin), min(len(contig), g1 + margin)
         exp = oracle_lib.find_path(model.c, model.params, p, contig[w0:w1], dpmemory=32)
         assert a is not None and exp is not None
@@ -45,10 +50,10 @@ def _check_against_windows(eng, model, proteins, contig, places, margin):
 
 
 def test_c3_protein2dna_shared_megabase_contig(eng):
-    """C3 shape: 500 aa proteins against ONE 1 Mb contig (T = 10^6 columns per job, unpacked region slots
-    not needed: 9 + 20 bits)."""
-    proteins, contig, places = workloads.protein_vs_contig(16, 500, 1000000)
-    _check_against_windows(eng, ex.Model("protein2dna"), proteins, contig, places, 1500)
+    """C3 at BASELINE's size: 1 024 proteins of 500 aa against ONE 1 Mb contig (T = 10^6 columns per job; 5 x 10^11 cells
+    per pass); every fourth protein has its gene in the contig, every 64th is checked against the oracle on a window."""
+    proteins, contig, places = workloads.protein_vs_contig(1024, 500, 1000000, plant_every=4)
+    _check_against_windows(eng, ex.Model("protein2dna"), proteins, contig, places, 1500, check_every=64)
 
 
 def test_c5_shape_protein2genome_shared_contig(eng):
@@ -66,3 +71,36 @@ def test_shared_buffers_give_the_same_results_as_private_copies(eng):
     b = eng.find_path(model, private)
     assert [x.as_dict() if x else None for x in a] == [x.as_dict() if x else None for x in b]
     assert a[0] is not None
+
+
+def test_c4_north_star_batch_against_the_reference_binary(eng):
+    """C4 at BASELINE's size (the configuration bench.py times): 4 096 cDNAs of 1 kb against their 100 kb windows in one
+    batch, est2genome, -D 32.  Every pair must align; the vulgar lines of a sample — one pair per host core, up to 64,
+    spread over the batch — are compared with the reference's own compiled exonerate run here (oracle/_ref, travels as a
+    binary)."""
+    import os, subprocess, tempfile
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "exonerate-compiled")
+    if not os.path.exists(exe):
+        pytest.skip("the reference binary is built in the build container")
+    model = ex.Model("est2genome")
+    pairs = workloads.est2genome_pairs(4096, 1000, 100000)
+    alns = eng.find_path(model, pairs, dpmemory=32)
+    assert all(a is not None for a in alns)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    n = max(4, min(cores, 64))
+    sample = [(k * 4096) // n for k in range(n)]
+    with tempfile.TemporaryDirectory() as d:
+        procs = []
+        for k in sample:
+            open(os.path.join(d, "q%d.fa" % k), "w").write(">qy\n%s\n" % pairs[k][0].decode())
+            open(os.path.join(d, "t%d.fa" % k), "w").write(">tg\n%s\n" % pairs[k][1].decode())
+            procs.append(subprocess.Popen([exe, "-m", "est2genome", "-E", "yes", "-S", "no", "--revcomp", "no", "--showalignment", "no",
+                                           "--showvulgar", "yes", "-V", "0", os.path.join(d, "q%d.fa" % k), os.path.join(d, "t%d.fa" % k)],
+                                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL))
+        outs = [p.communicate(timeout=1500)[0].decode() for p in procs]
+    for k, o in zip(sample, outs):
+        ref = [l.strip() for l in o.splitlines() if l.startswith("vulgar:")]
+        assert ref and alns[k].vulgar("qy", "tg") == ref[0], k

@@ -348,3 +348,38 @@ def test_heuristic_bsdp_on_north_star_shaped_input(tmp_path):
     assert s_ok + p_ok >= 0.95 * (s_all + p_all), gpu_err[-800:]
     m = re.search(r"(\d+) of (\d+) refinements from refinement batches", gpu_err)
     assert m and int(m.group(1)) == int(m.group(2)) >= 6, gpu_err[-800:]
+
+
+@pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
+                    reason="reference binaries are built in the build container (make -C integration)")
+def test_c5_heuristic_protein2genome_against_a_10mb_chromosome(tmp_path):
+    """BASELINE config 5's HEURISTIC leg near its size: 32 proteins of 300 aa against ONE 10 Mb chromosome holding their
+    intron-split genes, -m protein2genome in the reference's default mode (seeding -> HSPs -> SDP with spans,
+    GAM_Result_SDP_create gam.c:852) and with --gappedextension no (BSDP).  The drop-in must print what the reference
+    prints, byte for byte, with the word hits extended on the device and — default settings, no size limit — EVERY
+    candidate pair's SDP served from the device batches."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from exonerate_amd import workloads
+    import test_integration_bsdp_host as hb
+    proteins, contig, places = workloads.protein_vs_contig(32, 300, 10000000, seed=20260935, introns=True)
+    qf, tf = str(tmp_path / "q.fa"), str(tmp_path / "t.fa")
+    _fasta(qf, [("p%d" % i, p.decode()) for i, p in enumerate(proteins)])
+    _fasta(tf, [("chr", contig.decode())])
+    base = ["-m", "protein2genome", "--showalignment", "no", "--showvulgar", "yes", "-V", "0"]
+    modes = {"sdp": [], "bsdp": ["--gappedextension", "no"]}
+    refs = {k: subprocess.Popen([CPU_EXE] + base + m + [qf, tf], stdout=subprocess.PIPE, stderr=subprocess.PIPE) for k, m in modes.items()}
+    got = {}
+    for k, m in modes.items():
+        got[k] = _run(GPU_EXE, base + m + [qf, tf], {"C4GPU_VERBOSE": "1"})
+    for k in modes:
+        out, err = refs[k].communicate(timeout=1500)
+        assert refs[k].returncode == 0, err.decode()[-800:]
+        assert got[k][0] == out.decode(), k
+        assert out.count(b"vulgar:") >= 32
+        assert "c4gpu hsp:" in got[k][1], got[k][1][-1500:]
+    err = got["sdp"][1]
+    assert "SDP stays on the CPU" not in err, err[-1500:]
+    pairs, flushes, served_pairs, alignments = hb.sdp_served(err)
+    assert served_pairs == pairs >= 32 and alignments >= 32
+    assert "c4gpu bsdp:" in got["bsdp"][1] and "stay on the CPU" not in got["bsdp"][1], got["bsdp"][1][-1500:]
