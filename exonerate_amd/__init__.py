@@ -88,6 +88,15 @@ class Alignment:
         self.ops = [(c_alignment.op_transition[i], c_alignment.op_length[i]) for i in range(c_alignment.n_ops)]
         self.qlen, self.tlen = qlen, tlen
 
+    @classmethod
+    def from_parts(cls, model, score, region, ops, qlen, tlen):
+        """An alignment from its numbers (what exonerate_amd.parallel gathers from the other ranks)."""
+        self = cls.__new__(cls)
+        self.model, self.score, self.region = model, score, tuple(region)
+        self.ops = [(int(t), int(l)) for t, l in ops]
+        self.qlen, self.tlen = qlen, tlen
+        return self
+
     def _c(self):
         a = _abi.Alignment()
         a.score = self.score

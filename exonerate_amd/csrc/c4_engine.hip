@@ -539,6 +539,11 @@ struct SeedPlan {
     int kshift = 11;               // a dump every 1 << kshift columns
     std::vector<long long> off;    // per spec: mode 1 (out) start of the job's dumps; mode 2 (in) the dump to start from, -1 = none
     std::vector<int> rows;         // per spec, mode 2: rows of a dumped column (Q + 1 of the score pass)
+    // mode 2, windows chained on the device (DevJob::seed_base ..): per spec the pair's first dump, the dump the first
+    // window starts from, its lattice column, the target_start of the score pass's rectangle; hops: windows per job
+    std::vector<long long> base;
+    std::vector<int> d, t0w, t0_base;
+    int hops = 0;
 };
 
 struct Engine {
@@ -783,6 +788,10 @@ struct Engine {
                                   ki->seedw;
                 } else {
                     j.seed_off = seed->off[order[x]]; j.seed_rows = seed->rows[order[x]];
+                    if (seed->hops) {
+                        j.seed_base = seed->base[order[x]]; j.win_d = seed->d[order[x]]; j.win_t0w = seed->t0w[order[x]];
+                        j.win_t0_base = seed->t0_base[order[x]]; j.win_hops = seed->hops;
+                    }
                 }
             }
             j.ops_off = ops_total; j.ops_cap = 0; j.vsa_off = (int)vsa_total;
@@ -1036,79 +1045,77 @@ int windowed_region_pass(Engine &eng, const ResidentSeqs &seqs, const std::vecto
     sp1.mode = 1; sp1.kshift = kshift;
     if (eng.run(seqs, MODE_SCORE, false, specs, outs, &sp1)) return -1;
     out.assign(n, DevResult());
-    struct Hop { int x, rows, endcol, fstate, d; };
-    std::vector<Hop> hops;
+    // the windows of a pair follow each other inside one workgroup (viterbi_kernel_mw, SEED 2): ONE launch over the first
+    // windows of all wanted pairs; a job walks left from the end cell, one dump interval per window, until its payload is a
+    // real start or its hop budget is spent
+    std::vector<int> want;
     for (int x = 0; x < n; x++) {
         out[x] = outs[x].res;
         out[x].qs = out[x].ts = 0;
         if (!outs[x].res.end_set || outs[x].res.score < thr(pairs[x])) continue;
-        hops.push_back(Hop{x, outs[x].res.qe, outs[x].res.te, eng.model->end_state, (outs[x].res.te - 1) >> kshift});
+        want.push_back(x);
     }
-    int round = 0;
-    const size_t wanted = hops.size();
+    const size_t wanted = want.size();
     const int max_hops = getenv("C4GPU_WINDOW_HOPS") ? atoi(getenv("C4GPU_WINDOW_HOPS")) : 12;
-    while (!hops.empty()) {
-        if (round >= max_hops) {
-            // the paths still open run back further than the hop budget: the one-pass kernel over their whole
-            // rectangles finishes them (same result: it is what the windows reproduce piece by piece)
-            std::vector<JobSpec> fs(hops.size());
-            for (size_t h = 0; h < hops.size(); h++) { fs[h].pair = pairs[hops[h].x]; fs[h].region = plan[pairs[hops[h].x]].ar; }
-            if (eng.run(seqs, MODE_REGION, false, fs, outs)) return -1;
-            for (size_t h = 0; h < hops.size(); h++) {
-                const DevResult &r = outs[h].res;
-                DevResult &o = out[hops[h].x];
-                if (r.score != o.score || r.qe != o.qe || r.te != o.te) {
-                    c4h::set_error("windowed region pass: the one-pass kernel disagrees with the score pass");
-                    return -1;
-                }
-                o.qs = r.qs; o.ts = r.ts;
-            }
-            break;
-        }
-        std::vector<JobSpec> hs(hops.size());
+    std::vector<int> open;                                       // pairs whose path runs back further than the hop budget
+    long long windows = 0;
+    if (!want.empty()) {
+        std::vector<JobSpec> hs(want.size());
         SeedPlan sp2;
-        sp2.mode = 2; sp2.kshift = kshift;
-        sp2.off.resize(hops.size()); sp2.rows.resize(hops.size());
-        std::vector<int> t0w(hops.size());
-        for (size_t h = 0; h < hops.size(); h++) {
-            const Hop &hp = hops[h];
-            const c4gpu_region &ar = plan[pairs[hp.x]].ar;
-            t0w[h] = hp.d >= 1 ? (hp.d << kshift) - (dc - 1) : 0;       // window column 0 = lattice column t0w
-            hs[h].pair = pairs[hp.x];
-            hs[h].region = c4gpu_region{ar.query_start, ar.target_start + t0w[h], hp.rows, hp.endcol - t0w[h]};
-            hs[h].final_state = hp.fstate;
+        sp2.mode = 2; sp2.kshift = kshift; sp2.hops = std::max(1, max_hops);
+        sp2.off.resize(want.size()); sp2.rows.resize(want.size()); sp2.base.resize(want.size());
+        sp2.d.resize(want.size()); sp2.t0w.resize(want.size()); sp2.t0_base.resize(want.size());
+        for (size_t h = 0; h < want.size(); h++) {
+            const int x = want[h];
+            const c4gpu_region &ar = plan[pairs[x]].ar;
+            const int d = (outs[x].res.te - 1) >> kshift;
+            const int t0w = d >= 1 ? (d << kshift) - (dc - 1) : 0;      // window column 0 = lattice column t0w
+            hs[h].pair = pairs[x];
+            hs[h].region = c4gpu_region{ar.query_start, ar.target_start + t0w, outs[x].res.qe, outs[x].res.te - t0w};
+            hs[h].final_state = eng.model->end_state;
             sp2.rows[h] = ar.query_length + 1;
-            sp2.off[h] = hp.d >= 1 ? sp1.off[hp.x] + (long long)(hp.d - 1) * dc * (ar.query_length + 1) * seedw : -1;
+            sp2.base[h] = sp1.off[x];
+            sp2.off[h] = d >= 1 ? sp1.off[x] + (long long)(d - 1) * dc * (ar.query_length + 1) * seedw : -1;
+            sp2.d[h] = d; sp2.t0w[h] = t0w; sp2.t0_base[h] = ar.target_start;
         }
-        if (eng.run(seqs, MODE_REGION, false, hs, outs, &sp2)) return -1;
-        std::vector<Hop> next;
-        for (size_t h = 0; h < hops.size(); h++) {
-            const Hop &hp = hops[h];
-            const DevResult &r = outs[h].res;
-            if (!r.end_set || (round == 0 && r.score != out[hp.x].score)) {
+        std::vector<JobOut> wouts;
+        if (eng.run(seqs, MODE_REGION, false, hs, wouts, &sp2)) return -1;
+        for (size_t h = 0; h < want.size(); h++) {
+            const DevResult &r = wouts[h].res;
+            DevResult &o = out[want[h]];
+            if (!r.end_set || r.score != o.score) {
                 c4h::set_error("windowed region pass: a window's corner cell differs from the score pass");
                 return -1;
             }
-            const int payload = r.pad;
-            if (payload >= 0) {
-                const int tshift = nbits(hs[h].region.target_length);
-                out[hp.x].qs = payload >> tshift;
-                out[hp.x].ts = (payload & ((1 << tshift) - 1)) + t0w[h];
-            } else {                                                    // entered through the dump: identity of the cell
-                if (hp.d < 1) { c4h::set_error("windowed region pass: dump identity without a dump"); return -1; }
-                const int v = -payload - 1, jc = v % dc, rest = v / dc;
-                next.push_back(Hop{hp.x, rest / kw->n_states, t0w[h] + jc, rest % kw->n_states, hp.d - 1});
-            }
+            windows += r.n_vsa;
+            if (r.pad >= 0) { o.qs = r.qs; o.ts = r.ts; }
+            else open.push_back(want[h]);
         }
-        hops.swap(next);
-        round++;
     }
+    if (!open.empty()) {
+        // the one-pass kernel over their whole rectangles finishes them (same result: it is what the windows reproduce
+        // piece by piece)
+        std::vector<JobSpec> fs(open.size());
+        for (size_t h = 0; h < open.size(); h++) { fs[h].pair = pairs[open[h]]; fs[h].region = plan[pairs[open[h]]].ar; }
+        if (eng.run(seqs, MODE_REGION, false, fs, outs)) return -1;
+        for (size_t h = 0; h < open.size(); h++) {
+            const DevResult &r = outs[h].res;
+            DevResult &o = out[open[h]];
+            if (r.score != o.score || r.qe != o.qe || r.te != o.te) {
+                c4h::set_error("windowed region pass: the one-pass kernel disagrees with the score pass");
+                return -1;
+            }
+            o.qs = r.qs; o.ts = r.ts;
+        }
+    }
+    const std::vector<int> &hops = open;
+    const long long round = windows;
     if (wanted >= 64) {
         const double rate = 1.0 - (double)hops.size() / (double)wanted;
         eng.ctx->window_rate = eng.ctx->window_rate < 0 ? rate : 0.5 * eng.ctx->window_rate + 0.5 * rate;
     }
     if (getenv("C4GPU_TRACE"))
-        fprintf(stderr, "c4gpu trace: windowed region pass: %d pairs, dumps every %d columns, %d window launches, %zu of %zu "
+        fprintf(stderr, "c4gpu trace: windowed region pass: %d pairs, dumps every %d columns, %lld windows in one launch, %zu of %zu "
                 "paths left to the one-pass kernel\n", n, 1 << kshift, round, hops.size(), wanted);
     return 0;
 }

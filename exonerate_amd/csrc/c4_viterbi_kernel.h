@@ -81,6 +81,11 @@ struct DevJob {
     long long span_off;                  // SPAN kernels: this job's matrix starts at span_in/span_out + span_off
     long long seed_off;                  // SEED 1: this job's dumps start at seed + seed_off; SEED 2: the dump to start from (-1: none)
     int seed_kshift, seed_rows;          // dump spacing = 1 << seed_kshift columns; rows per dumped column (Q + 1 of the score pass)
+    // SEED 2, windows chained on the device: a window whose corner payload is the identity of a dumped cell goes on, in the
+    // same workgroup, with the window one dump interval further left (what the host did between launches in round 2)
+    long long seed_base;                 // the pair's first dump (seed_off of dump d = seed_base + (d - 1) * DC * seed_rows * SEEDW)
+    int win_d, win_t0w;                  // the dump this window starts from (0: column 0, no dump); lattice column of window column 0
+    int win_t0_base, win_hops;           // target_start of the whole-rectangle pass; windows one job may run (0: no chaining)
 };
 struct DevResult {
     int score, qs, ts, qe, te, end_set, last_srp, n_ops, flags, n_vsa, cell_size, pad;
@@ -1278,6 +1283,8 @@ void viterbi_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *jobs,
                        DevScratch scratch, int *queue) {
     using DP = WaveDP<M, R, MODE, false, LOCAL, PACK, SUB, 0, SEED>;
     __shared__ int corner_lds[3];
+    __shared__ DevJob job_lds;           // SEED 2: the window being run (rewritten between the hops of one job)
+    __shared__ int hop_more;
     __shared__ KParams kp_lds;
     __shared__ int next_job;
     __shared__ int rings[(NW > 1 ? NW - 1 : 1) * DP::RING * DP::BND];
@@ -1299,13 +1306,19 @@ void viterbi_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *jobs,
         const int jid = next_job;
         __syncthreads();
         if (jid >= n_jobs) break;
-        const DevJob &job = jobs[jid];
+        if constexpr (SEED == 2) {
+            if (threadIdx.x == 0) job_lds = jobs[jid];
+            __syncthreads();
+        }
+        const DevJob &job = (SEED == 2) ? job_lds : jobs[jid];
+        int hop = 0, first_score = 0;
+      next_hop:
         DP dp;
         dp.kp = &kp_lds;
         dp.lane = threadIdx.x & 63;
         dp.carry_ok = scratch.carry != 0;
         if constexpr (SEED == 2) {
-            if (threadIdx.x == 0) corner_lds[2] = 0;
+            if (threadIdx.x == 0) { corner_lds[2] = 0; hop_more = 0; }
             __syncthreads();
         }
         dp.template run_mw<NW>(job, seqs, bnd, (typename DP::lds_int *)rings, wid);
@@ -1337,13 +1350,36 @@ void viterbi_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *jobs,
                 else { res.qs = bqs; res.ts = bts; }
             }
             if constexpr (SEED == 2) {          // the window's corner cell: score, raw payload (start or entry-cell identity)
-                res.end_set = corner_lds[2]; res.score = corner_lds[0]; res.pad = corner_lds[1];
+                const int payload = corner_lds[1];
+                if (hop == 0) first_score = corner_lds[0];
+                res.end_set = corner_lds[2]; res.score = first_score; res.pad = payload;
                 res.qe = job.Q; res.te = job.T;
                 res.flags = corner_lds[2] ? 0 : FLAG_NO_END;
+                res.n_vsa = hop + 1;                                       // windows this job ran
+                if (corner_lds[2] && payload >= 0) {                       // a real region start (window coordinates)
+                    res.qs = payload >> job.tshift;
+                    res.ts = (payload & ((1 << job.tshift) - 1)) + job.win_t0w;
+                } else if (corner_lds[2] && job.win_d >= 1 && hop + 1 < job.win_hops) {
+                    // entered through the dump: the identity of the cell; the next window ends in that cell and state
+                    constexpr int DC = DP::DC;
+                    const int v = -payload - 1, jc = v % DC, rest = v / DC;
+                    const int d2 = job.win_d - 1, t0w2 = d2 >= 1 ? (d2 << job.seed_kshift) - (DC - 1) : 0;
+                    const int endcol = job.win_t0w + jc;
+                    job_lds.Q = rest / M::NS; job_lds.final_state = rest % M::NS;
+                    job_lds.T = endcol - t0w2; job_lds.t0 = job.win_t0_base + t0w2;
+                    job_lds.seed_off = d2 >= 1 ? job.seed_base + (long long)(d2 - 1) * DC * job.seed_rows * DP::SEEDW : -1;
+                    int tb = 0;
+                    while ((1LL << tb) <= job_lds.T) tb++;
+                    job_lds.tshift = tb; job_lds.win_d = d2; job_lds.win_t0w = t0w2;
+                    hop_more = 1;
+                }
             }
-            results[jid] = res;
+            if (!(SEED == 2 && hop_more)) results[jid] = res;
         }
         __syncthreads();
+        if constexpr (SEED == 2) {
+            if (hop_more) { hop++; goto next_hop; }
+        }
     }
 }
 

@@ -22,13 +22,17 @@ def _worker(rank, world, port, q):
     def align(model_type, pairs):
         m = _abi.Model()
         assert lib.c4gpu_model_get(model_type.encode(), 0, 0, params, m) == 0
-        return [oracle_lib.find_path(m, params, a.encode(), b.encode()) for a, b in pairs]
+        return [oracle_lib.find_path(m, params, a, b) for a, b in pairs]
 
     recs = load_set("est2genome")[:12]
     pairs = [(r["query"], r["target"]) for r in recs] if rank == 0 else []
     out = parallel.distributed_find_path(align, "est2genome", pairs)
-    if rank == 1:      # every rank gets the full list, in submission order
-        q.put([o["vulgar"].split(" ", 2)[2] for o in out])
+    if rank == 1:      # every rank gets the full list (score, region, operations as tensors), in submission order
+        import exonerate_amd as ex
+        model = ex.Model("est2genome")
+        lines = [ex.Alignment.from_parts(model, o["score"], o["region"], o["ops"], len(r["query"]), len(r["target"])).vulgar()
+                 for o, r in zip(out, recs)]
+        q.put([l.split(" ", 2)[2] for l in lines])
     dist.barrier()
     dist.destroy_process_group()
 
