@@ -74,6 +74,36 @@ def cpu_baseline(args, rank, model, pairs, batch, eng):
             "checked_bit_exact_vs_gpu": True}
 
 
+def reference_one_core(pair):
+    """The reference's own compiled exonerate on one pair, one core: (cells/s record, its vulgar line), or None when the
+    binary did not travel."""
+    import subprocess, tempfile
+    q, t = pair
+    exe = os.path.join(ROOT, "oracle", "_ref", "exonerate-compiled")
+    cells = (len(q) + 1) * (len(t) + 1)
+    if not os.path.exists(exe) or cells > 3e8:
+        return None
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            open(os.path.join(d, "q.fa"), "w").write(">qy\n%s\n" % q.decode())
+            open(os.path.join(d, "t.fa"), "w").write(">tg\n%s\n" % t.decode())
+            c0 = time.perf_counter()
+            r = subprocess.run([exe, "-m", "est2genome", "-E", "yes", "-S", "no", "--revcomp", "no",
+                                "--showalignment", "no", "--showvulgar", "yes", "-V", "0",
+                                os.path.join(d, "q.fa"), os.path.join(d, "t.fa")],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            cpu_s = time.perf_counter() - c0
+    except (OSError, subprocess.SubprocessError):
+        return None
+    lines = [l.strip() for l in r.stdout.decode().splitlines() if l.startswith("vulgar:")]
+    if r.returncode != 0 or not lines:
+        return None
+    return ({"value": cells / cpu_s, "unit": "cells/s", "cores": 1, "kind": "reference",
+             "sample": "pair 0 of the batch (%d x %d) through the reference's own exonerate (compiled Viterbi, -m est2genome "
+                       "-E yes -S no --revcomp no), %.1f s wall incl. all passes, before the process group was formed"
+                       % (len(q), len(t), cpu_s)}, lines[0])
+
+
 def cpu_baseline_all_cores(pairs, batch):
     """the reference's only multi-core story is N independent processes
     (--querychunkid/--querychunktotal, exonerate.c:64-75): one reference process per host core, each on its own
@@ -125,6 +155,12 @@ class _StubBatch:
 
     def alignment(self, i):
         return None
+
+    def export(self):
+        import numpy as np
+        head = np.zeros((self.n, 7), dtype=np.int32)
+        head[:, 0] = 1; head[:, 1] = 100; head[:, 6] = 2
+        return np.concatenate([head.ravel(), np.tile(np.array([11, 5, 23, 1], dtype=np.int32), self.n)])
 
     def close(self):
         pass
@@ -180,6 +216,12 @@ def main():
 
     import torch
     use_dist = world > 1 or os.environ.get("C4_BENCH_FORCE_DIST") == "1"     # the latter: exercise RCCL on 1 GPU
+    # At N > 1 the reference's CPU leg (rank 0, one core, pair 0 of the batch) runs BEFORE the process group exists: the
+    # other ranks wait in the rendezvous instead of in a collective; its vulgar line is compared with the GPU's later.
+    early_cpu = None
+    if use_dist and rank == 0 and not stub and not args.no_cpu_baseline:
+        from exonerate_amd import workloads as _w
+        early_cpu = reference_one_core(_w.est2genome_pairs(1, args.qlen, args.tlen, first=0)[0])
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -239,17 +281,55 @@ def main():
             dist.barrier()
         sync()
 
-    def timed(b, steps, warmup):
+    cdev = None
+    if use_dist:
+        from exonerate_amd import parallel
+        cdev = parallel.collective_device()
+    work = {"delivered": 0, "gathered_ints": 0}
+
+    def one_step(b, n_local):
+        """One pass of the hot path over this rank's batch, as a work-queue step: rank 0 broadcasts the job
+        header and scatters the work items (global pair ids; the residues are resident), every rank aligns its shard,
+        the results (score, region, operations of every pair: c4gpu_batch_export) are gathered — tensors over RCCL/xGMI."""
+        if use_dist:
+            head = torch.tensor([n_local, world, 2, 32] if rank == 0 else [0, 0, 0, 0], dtype=torch.int64, device=cdev)
+            dist.broadcast(head, src=0)                                   # job header: items per rank, ranks, mode, -D
+            mine = torch.empty(n_local, dtype=torch.int64, device=cdev)
+            if rank == 0:
+                ids = torch.arange(world * n_local, dtype=torch.int64, device=cdev)
+                dist.scatter(mine, [ids[r * n_local:(r + 1) * n_local].contiguous() for r in range(world)], src=0)
+            else:
+                dist.scatter(mine, None, src=0)
+            assert int(head[0].item()) == n_local and int(mine[0].item()) == rank * n_local, "work items do not match the resident shard"
+        b.run(2)
+        flat = b.export()                                                 # host copy of this rank's results, one stream
+        if use_dist:
+            got = parallel.all_gather_ragged(torch.from_numpy(flat).to(cdev), cdev)
+            if rank == 0:
+                total = 0
+                for g in got:
+                    hd = g[:7 * n_local].view(n_local, 7)
+                    assert int(g.numel()) == 7 * n_local + 2 * int(hd[:, 6].sum().item()), "truncated result stream"
+                    total += int(hd[:, 0].sum().item())
+                work["delivered"] += total
+                work["gathered_ints"] += sum(int(g.numel()) for g in got)
+        else:
+            work["delivered"] += int(flat[:7 * n_local].reshape(n_local, 7)[:, 0].sum())
+            work["gathered_ints"] += int(flat.size)
+
+    def timed(b, steps, warmup, n_local=None):
         """W untimed + exactly K timed steps between barriers; max over ranks."""
+        n_local = len(pairs) if n_local is None else n_local
         barrier()
         for _ in range(warmup):
-            b.run(2)
+            one_step(b, n_local)
         for m in range(4):
             b.kernel_stats(m, reset=True)
+        work["delivered"] = work["gathered_ints"] = 0
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            b.run(2)
+            one_step(b, n_local)
         barrier()
         el = time.perf_counter() - t0
         if use_dist:
@@ -273,12 +353,26 @@ def main():
             both.append((q, t))
             both.append((revcomp(q), t))
         rcb = ex.ResidentBatch(eng, model, both)
-        rc_el = timed(rcb, 1, 1)
+        delivered_fwd = dict(work)
+        rc_el = timed(rcb, 1, 1, len(both))
+        work.update(delivered_fwd)
         rc = {"value": 2 * first_pass_cells * world / rc_el, "unit": "cells/s", "ms_per_step": rc_el * 1e3,
               "rectangles_per_gpu": len(both),
               "aligned_in_sample": sum(1 for i in range(min(len(both), 64)) if rcb.alignment(i) is not None),
               "note": "--revcomp yes: every cDNA on both strands (2 x the first-pass cells), one timed step"}
         rcb.close()
+
+    # results compared across ranks: every rank aligns the same probe pair (pair 0 of rank 0's shard) on its own device;
+    # the streams must be identical
+    probe_same = None
+    if use_dist and not stub:
+        probe = workloads.est2genome_pairs(1, args.qlen, args.tlen, first=0)
+        pb = ex.ResidentBatch(eng, model, probe)
+        pb.run(2)
+        streams = parallel.all_gather_ragged(torch.from_numpy(pb.export()).to(cdev), cdev)
+        pb.close()
+        probe_same = all(torch.equal(streams[0], x) for x in streams[1:]) and int(streams[0][0].item()) == 1
+        assert probe_same, "ranks disagree on the probe pair"
 
     out = None
     if rank == 0:
@@ -346,12 +440,25 @@ def main():
                                  "binding roof: measured issue rate of the kernel's instruction mix x 1024 SIMDs "
                                  "(DESIGN.md section 5)"},
             "kernel_ms": {"score": stats[0]["ms"], "region": stats[2]["ms"], "checkpoint": stats[3]["ms"], "path": stats[1]["ms"]},
+            # the step as a work-queue step: job header broadcast + work-item scatter + result gather (tensors over RCCL
+            # when there is a process group), all inside the timed region
+            "work_queue": {"collectives": "broadcast + scatter + all_gather (torch.distributed, backend %s)"
+                                          % (("gloo" if stub else "nccl = RCCL") if use_dist else "none: one process"),
+                           "alignments_delivered_per_step": work["delivered"] / max(1, args.steps),
+                           "result_ints_per_step": work["gathered_ints"] / max(1, args.steps),
+                           "probe_pair_identical_on_all_ranks": probe_same},
         }
         if rc:
             out["revcomp"] = rc
-        # the CPU legs run at N=1 only (the contract: rank 0 at N=1): at N>1 the other ranks would sit in the
-        # process-group teardown while rank 0 times a host program
-        if not args.no_cpu_baseline and world == 1 and not stub:
+        # the all-cores leg runs at N=1 only; at N>1 the one-core leg ran before the process group was formed (early_cpu)
+        if early_cpu is not None:
+            rec, ref_line = early_cpu
+            got = batch.alignment(0)
+            assert got is not None and got.vulgar("qy", "tg") == ref_line, "GPU vulgar differs from the reference: %r vs %r" % (got and got.vulgar(), ref_line)
+            rec["vulgar_identical_to_gpu"] = True
+            out["cpu_baseline"] = rec
+            out["speedup_vs_cpu_1core"] = value / rec["value"] / world
+        if not args.no_cpu_baseline and not use_dist and not stub:
             out["cpu_baseline"] = cpu_baseline(args, rank, model, pairs, batch, eng)
             out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["value"] / world
             if out["cpu_baseline"]["kind"] == "reference":

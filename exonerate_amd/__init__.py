@@ -407,6 +407,16 @@ class ResidentBatch:
         _lib().c4gpu_batch_scores(self.h, s, r)
         return list(s)[:self.n], [x.astuple() for x in r][:self.n]
 
+    def export(self):
+        """All alignments as one int32 numpy array (c4gpu_batch_export): a row of 7 ints per pair (valid, score, region (4),
+        n_ops), then the (transition, length) pairs of all valid alignments in pair order."""
+        import numpy as np
+        need = _lib().c4gpu_batch_export(self.h, None, 0)
+        buf = np.empty(max(1, need), dtype=np.int32)
+        got = _lib().c4gpu_batch_export(self.h, buf.ctypes.data_as(C.POINTER(C.c_int32)), need)
+        assert got == need
+        return buf[:need]
+
     def alignment(self, i):
         a = _abi.Alignment()
         if _lib().c4gpu_batch_alignment(self.h, i, a) != 0:

@@ -189,6 +189,7 @@ PROTOTYPES = [
                                             C.POINTER(ViterbiResult)]),
     ("c4gpu_batch_scores", C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(Region)]),
     ("c4gpu_batch_alignment", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Alignment)]),
+    ("c4gpu_batch_export", C.c_int64, [C.c_void_p, C.POINTER(C.c_int32), C.c_int64]),
     ("c4gpu_batch_kernel_stats", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double),
                                            C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("c4gpu_alignment_format", C.c_int, [C.POINTER(Model), C.POINTER(Alignment), C.c_int,

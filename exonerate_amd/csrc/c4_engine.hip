@@ -1856,6 +1856,24 @@ int c4gpu_batch_alignment(c4gpu_batch *b, int32_t i, c4gpu_alignment *out) {
     return 0;
 }
 
+// every alignment of the batch in one int32 stream: first a row of 7 ints per pair (valid, score, region (4), n_ops), then
+// the (transition, length) pairs of all valid alignments in pair order; returns the ints needed (written only when they
+// fit `cap`): what a rank ships to the rank that prints
+int64_t c4gpu_batch_export(c4gpu_batch *b, int32_t *out, int64_t cap) {
+    int64_t need = 7 * (int64_t)b->alignments.size();
+    for (const c4gpu_alignment &a : b->alignments) need += a.valid ? 2 * (int64_t)a.n_ops : 0;
+    if (!out || need > cap) return need;
+    int64_t pos = 0, ops = 7 * (int64_t)b->alignments.size();
+    for (const c4gpu_alignment &a : b->alignments) {
+        out[pos++] = a.valid; out[pos++] = a.valid ? a.score : 0;
+        out[pos++] = a.region.query_start; out[pos++] = a.region.target_start;
+        out[pos++] = a.region.query_length; out[pos++] = a.region.target_length;
+        out[pos++] = a.valid ? a.n_ops : 0;
+        if (a.valid) for (int k = 0; k < a.n_ops; k++) { out[ops++] = a.op_transition[k]; out[ops++] = a.op_length[k]; }
+    }
+    return need;
+}
+
 int c4gpu_batch_kernel_stats(c4gpu_batch *b, int mode, int reset, double *ms, int64_t *launches, int64_t *cells) {
     c4gpu_ctx *ctx = b->ctx;
     if (mode < 0 || mode > 3) return -1;

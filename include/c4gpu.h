@@ -334,6 +334,11 @@ int          c4gpu_batch_viterbi_model(c4gpu_batch *b, const c4gpu_model *model,
 int          c4gpu_batch_next_paths(c4gpu_batch *b, int dpmemory_mb, c4gpu_score threshold);
 int          c4gpu_batch_scores(c4gpu_batch *b, c4gpu_score *scores, c4gpu_region *regions);
 int          c4gpu_batch_alignment(c4gpu_batch *b, int32_t i, c4gpu_alignment *out);
+/* Every alignment the batch holds after c4gpu_batch_run, as one int32 stream: first one row of 7 ints per pair (valid,
+ * score, query_start, target_start, query_length, target_length, n_ops), then the (transition, length) pairs of all valid
+ * alignments in pair order.  Returns the number of ints the stream takes; it is written only when that fits `cap`
+ * (out = NULL sizes the buffer).  What a rank of a sharded run hands to the result gather (bench.py --gpus N). */
+int64_t      c4gpu_batch_export(c4gpu_batch *b, int32_t *out, int64_t cap);
 /* Accumulated device time (ms), launches and lattice cells of the Viterbi kernel of one mode
  * (C4GPU_MODE_*) since the last reset, measured with HIP events on the launch stream.  The first call
  * switches the measurement on. */

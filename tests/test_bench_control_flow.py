@@ -28,6 +28,10 @@ def test_gpus_flag_starts_one_rank_per_gpu_and_prints_one_line():
     assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 2 * 2 * 1001 * 100001) < 1e-3 * 2 * 2 * 1001 * 100001
     assert out["data"].startswith("stub") and "cpu_baseline" not in out
     assert out["value_incl_staging"] < out["value"] and out["staging_ms"] > 0
+    # the timed step is a work-queue step: header broadcast, work-item scatter, result gather of every rank's stream
+    wq = out["work_queue"]
+    assert "gloo" in wq["collectives"] and wq["alignments_delivered_per_step"] == 2 * 2
+    assert wq["result_ints_per_step"] == 2 * (2 * 7 + 2 * 4)
 
 
 def test_single_rank_and_launcher_environment():
