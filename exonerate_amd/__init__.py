@@ -348,6 +348,35 @@ class Engine:
             res.append(mine)
         return res
 
+    def seed_scan(self, width, wordlen, words, symbols):
+        """The seeder's word scan on the device (c4gpu_seed_scan).  words: {code: number of emissions} in emission-list
+        order (the k-th word's emissions follow those of the words before it); symbols: bytes of automaton columns
+        (0 = outside the alphabet).  Returns ([(position of the word's last symbol, emission index)], device ms)."""
+        import numpy as np
+        codes = (C.c_uint64 * max(1, len(words)))(*[c for c, _ in words])
+        first = [0]
+        for _, n in words:
+            first.append(first[-1] + n)
+        cf = (C.c_int32 * len(first))(*first)
+        tab = _lib().c4gpu_wordtab_create(self.ctx, width, wordlen, codes, cf, len(words))
+        if not tab:
+            raise _err("c4gpu_wordtab_create")
+        try:
+            n_hits = C.c_int64(0)
+            cap = 1 << 16
+            while True:
+                buf = np.empty((max(1, cap), 2), dtype=np.int32)
+                if _lib().c4gpu_seed_scan(self.ctx, tab, symbols, len(symbols), buf.ctypes.data, cap, C.byref(n_hits)) != 0:
+                    raise _err("c4gpu_seed_scan")
+                if n_hits.value <= cap:
+                    break
+                cap = n_hits.value
+            ms = C.c_double(0)
+            _lib().c4gpu_wordtab_stats(tab, C.byref(ms), None, None, None)
+            return [tuple(int(x) for x in r) for r in buf[:n_hits.value]], ms.value
+        finally:
+            _lib().c4gpu_wordtab_destroy(tab)
+
     @staticmethod
     def sdp_stats(reset=False):
         """Counters of this thread's sdp() calls: kernel ms of the passes / walks, staging / host ms, jobs, reruns, unserved."""

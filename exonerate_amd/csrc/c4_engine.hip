@@ -1889,3 +1889,4 @@ int c4gpu_batch_kernel_stats(c4gpu_batch *b, int mode, int reset, double *ms, in
 
 // ---- SDP on the device (seeded flavour): its own file, same translation unit ------------------------------------
 #include "c4_sdp_dev.inc"
+#include "c4_seed_dev.inc"

@@ -14,6 +14,7 @@
  *   c4gpu_alignment_format   <->  Alignment_print_{sugar,cigar,vulgar}_block  src/c4/alignment.c:1622-1779
  *   c4gpu_hsp_extend_batch   <->  HSPset_seed_hsp (HSP_trim_ends/_init/_extend) src/comparison/hspset.c:933-997
  *   c4gpu_batch_run_regions  <->  Optimal_find_path with a region (--refine)   src/hub/gam.c:605-655
+ *   c4gpu_seed_scan          <->  Seeder_add_target's automaton walk src/comparison/seeder.c:649-720,852-915
  *   c4gpu_sdp_batch          <->  GAM_Result_SDP_create's loop (SDP_Pair_next_path) src/hub/gam.c:852-890, src/sdp/sdp.c:743
  */
 #ifndef INCLUDED_C4GPU_H
@@ -363,6 +364,25 @@ typedef struct { int32_t query_start, target_start, length, score, cobs; } c4gpu
 int         c4gpu_hsp_extend_batch(c4gpu_ctx *ctx, const c4gpu_params *params, int match_type,
                                    const c4gpu_pair *pairs, int32_t n_pairs, int32_t seedlen, int32_t dropoff,
                                    const c4gpu_hsp_seed *seeds, int32_t n_seeds, c4gpu_hsp *out);
+
+/* The seeder's word scan (Seeder_add_target -> FSM_traverse / Seeder_VFSM_traverse_single -> Seeder_FSM_traverse_func,
+ * src/comparison/seeder.c:649-720,852-915; src/struct/fsm.c:186-198).  A word table holds the words the queries put into
+ * the seeder's automaton — all of one length `wordlen` — as codes over the automaton's columns: code = sum of
+ * column[i] * width^(wordlen - 1 - i), columns 1 .. width - 1 (column 0: a symbol outside the alphabet, which resets the
+ * automaton).  Word k reports emissions emit_first[k] .. emit_first[k + 1] - 1 (the caller's list: the word's own seeds,
+ * then its neighbours' seeds, seeder.c:676-692).  c4gpu_seed_scan walks one symbol string (a target, or one translated
+ * frame of it, mapped through the automaton's traversal filter) and returns every word hit in the reference's order:
+ * position of the word's LAST symbol ascending, then emission order.  hits: room for `cap` hits; *n_hits: how many there
+ * are (when that exceeds cap nothing is written: call again with room for all of them). */
+typedef struct c4gpu_wordtab c4gpu_wordtab;
+typedef struct { int32_t pos, emit; } c4gpu_word_hit;
+c4gpu_wordtab *c4gpu_wordtab_create(c4gpu_ctx *ctx, int32_t width, int32_t wordlen, const uint64_t *codes,
+                                    const int32_t *emit_first, int32_t n_words);
+void        c4gpu_wordtab_destroy(c4gpu_wordtab *t);
+int         c4gpu_seed_scan(c4gpu_ctx *ctx, c4gpu_wordtab *t, const uint8_t *symbols, int32_t n, c4gpu_word_hit *hits,
+                            int64_t cap, int64_t *n_hits);
+/* device time of the scans of a table (HIP events), their number, symbols scanned, hits found */
+void        c4gpu_wordtab_stats(const c4gpu_wordtab *t, double *scan_ms, int64_t *scans, int64_t *symbols, int64_t *hits);
 
 /* SDP, the default gapped-extension heuristic (SDP_Pair_next_path src/sdp/sdp.c:743 in the loop of GAM_Result_SDP_create
  * src/hub/gam.c:852-890), for every pair of a batch, in the flavour SDP_create picks for the model (sdp.c:322-366):

@@ -58,8 +58,11 @@ static gboolean hsp_eligible(HSPset *hsp_set){
     }
 
 void HSPset_seed_hsp(HSPset *hsp_set, guint query_start, guint target_start){
-    register ShimSeedSet *ss = hsp_pending ? g_hash_table_lookup(hsp_pending, hsp_set) : NULL;
+    register ShimSeedSet *ss;
     guint seed[2];
+    if(shim_seed_recording(hsp_set, query_start, target_start))        /* C4GPU_SEED_CHECK: the reference's own walk, written down */
+        return;
+    ss = hsp_pending ? g_hash_table_lookup(hsp_pending, hsp_set) : NULL;
     if(!ss){
         if(!hsp_eligible(hsp_set)){
             HSPset_seed_hsp_cpu(hsp_set, query_start, target_start);

@@ -687,6 +687,7 @@ void GAM_report(GAM *gam){        /* analysis.c:1421: after the last pair */
     shim_sdp_flush();
     shim_bsdp_report();
     shim_sdp_report();
+    shim_seed_report();
     shim_hsp_report();
     GAM_report_cpu(gam);
     return;

@@ -8,6 +8,7 @@
 #include "optimal.h"
 #include "gam.h"
 #include "comparison.h"
+#include "hspset.h"
 #include "c4gpu.h"
 
 c4gpu_ctx *shim_get_ctx(void);
@@ -23,6 +24,9 @@ void shim_hsp_report(void);
 void shim_bsdp_flush(void);
 void shim_bsdp_report(void);
 Alignment *shim_bsdp_find_path(Optimal *optimal, Region *region, SubOpt *subopt);
+/* c4gpu_seed.c */
+gboolean shim_seed_recording(HSPset *hsp_set, guint query_start, guint target_start);
+void shim_seed_report(void);
 /* c4gpu_sdp.c */
 gboolean shim_sdp_collect(GAM *gam, Comparison *comparison);
 gboolean shim_sdp_replaying(void);

@@ -173,3 +173,34 @@ def test_sdp_seam_in_small_flushes_and_switched_off(tmp_path):
     ref, gpu, err = run_pair(tmp_path, "affine:local", ["--gappedextension", "yes"],
                              {"C4GPU_SDP_HOST": "1", "C4GPU_HSP_HOST": "1", "C4GPU_SDP_OFF": "1"}, n=4, seed=23)
     assert gpu == ref and "c4gpu sdp:" not in err
+
+
+# ---- the word-scan seam (integration/c4gpu_seed.c): the automaton walk of Seeder_add_target ----
+
+@pytest.mark.parametrize("model,extra", [
+    ("est2genome", []), ("affine:local", ["--gappedextension", "yes"]), ("protein2dna", []), ("protein2genome", ["--gappedextension", "yes"]),
+    ("ungapped", []), ("est2genome", ["--fsmmemory", "1"]), ("affine:local", ["--forcefsm", "compact", "--gappedextension", "yes"]),
+    ("est2genome", ["--dnawordlen", "9"]), ("protein2dna", ["--proteinwordlen", "4", "--proteinwordlimit", "3"]),
+])
+def test_word_scan_seam_equals_the_reference_walk(tmp_path, model, extra):
+    """C4GPU_SEED_HOST=1: the words and emission lists read off the reference's automaton (trie before compilation, or the
+    VFSM leaf table with --forcefsm compact), a dictionary scan in place of the device scan, the hits delivered like
+    Seeder_WordInfo_seed; C4GPU_SEED_CHECK=1: the reference's own walk runs first and every seed must be the same, in the
+    same order (the drop-in aborts otherwise).  Byte-identical output on top."""
+    env = {"C4GPU_SEED_HOST": "1", "C4GPU_SEED_CHECK": "1", "C4GPU_HSP_HOST": "1", "C4GPU_SDP_HOST": "1", "C4GPU_BSDP_HOST": "1"}
+    ref, gpu, err = run_pair(tmp_path, model, extra, env, n=6, seed=31)
+    assert gpu == ref and ref.count(b"vulgar:") >= 3
+    m = re.search(r"c4gpu seed: (\d+) targets walked in (\d+) device scans \((\d+) symbols\): (\d+) word hits", err)
+    assert m and int(m.group(4)) > 100, err[-800:]
+    assert "every seed equal to the reference's own walk" in err
+    if model.startswith("protein2"):
+        assert int(m.group(2)) == 3 * int(m.group(1))                  # three translated frames per target
+
+
+def test_word_scan_seam_switched_off_and_with_a_saturation_threshold(tmp_path):
+    env = {"C4GPU_SEED_HOST": "1", "C4GPU_HSP_HOST": "1", "C4GPU_BSDP_HOST": "1"}
+    ref, gpu, err = run_pair(tmp_path, "est2genome", [], dict(env, C4GPU_SEED_OFF="1"))
+    assert gpu == ref and "c4gpu seed:" not in err
+    # --saturatethreshold: a running count per word in walk order, the reference's own walk keeps it
+    ref, gpu, err = run_pair(tmp_path, "est2genome", ["--saturatethreshold", "5"], env)
+    assert gpu == ref and "c4gpu seed:" not in err

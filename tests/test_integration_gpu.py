@@ -383,3 +383,24 @@ def test_c5_heuristic_protein2genome_against_a_10mb_chromosome(tmp_path):
     pairs, flushes, served_pairs, alignments = hb.sdp_served(err)
     assert served_pairs == pairs >= 32 and alignments >= 32
     assert "c4gpu bsdp:" in got["bsdp"][1] and "stay on the CPU" not in got["bsdp"][1], got["bsdp"][1][-1500:]
+
+
+@pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
+                    reason="reference binaries are built in the build container (make -C integration)")
+@pytest.mark.parametrize("model,extra", [
+    ("est2genome", ["--gappedextension", "yes"]), ("affine:local", ["--gappedextension", "yes"]), ("protein2dna", ["--gappedextension", "yes"]),
+    ("protein2genome", ["--gappedextension", "yes"]), ("affine:local", ["--forcefsm", "compact", "--gappedextension", "yes"]),
+    ("est2genome", ["--gappedextension", "no"]),
+])
+def test_word_scan_on_the_device_equals_the_reference_walk(tmp_path, model, extra):
+    """The automaton walk of Seeder_add_target on the device (integration/c4gpu_seed.c -> c4gpu_seed_scan), with
+    C4GPU_SEED_CHECK=1: the reference's own FSM / VFSM traversal runs first and every word hit of the device scan must be
+    the same seed in the same place of the list (the drop-in aborts otherwise); the rest of the heuristic pipeline (HSP
+    extension, SDP or BSDP) runs on the device as usual and the output must be the reference's, byte for byte."""
+    import test_integration_bsdp_host as hb
+    ref, gpu, err = hb.run_pair(tmp_path, model, extra, {"C4GPU_SEED_CHECK": "1"}, n=8, seed=41)
+    assert gpu == ref and ref.count(b"vulgar:") >= 4
+    m = re.search(r"c4gpu seed: (\d+) targets walked in (\d+) device scans \((\d+) symbols\): (\d+) word hits", err)
+    assert m and int(m.group(4)) > 100, err[-800:]
+    assert "every seed equal to the reference's own walk" in err and "scanned on the CPU" not in err
+    assert "c4gpu hsp:" in err
