@@ -1518,6 +1518,19 @@ c4gpu_ctx *c4gpu_ctx_create(int device_ordinal) {
 
 int c4gpu_model_device_family(const c4gpu_model *model) { return model_family(*model); }
 
+// Load the code objects a heuristic run touches first (sequence preparation, HSP extension, word scan; the SDP passes of
+// every family) without launching anything: hipFuncGetAttributes resolves a kernel, which loads its translation unit's
+// code object.  Meant for a background thread while the host still reads sequences (the drop-in: c4gpu_shim.c).
+void c4gpu_ctx_warm(c4gpu_ctx *ctx) {
+    if (!ctx || hipSetDevice(ctx->device) != hipSuccess) return;
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, (const void *)encode_kernel);
+    const c4sdp::SdpKernels *ks[4] = {c4sdp::sdp_kernels_affine(), c4sdp::sdp_kernels_protein2dna(), c4sdp::sdp_kernels_est2genome(),
+                                      c4sdp::sdp_kernels_protein2genome()};
+    for (const c4sdp::SdpKernels *k : ks) { (void)hipFuncGetAttributes(&a, k->rev_func); (void)hipFuncGetAttributes(&a, k->fwd_func); }
+    (void)hipGetLastError();
+}
+
 void c4gpu_ctx_destroy(c4gpu_ctx *ctx) {
     if (!ctx) return;
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

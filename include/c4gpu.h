@@ -209,6 +209,10 @@ const char *c4gpu_last_error(void);
  * HIP runtime is unavailable: there is NO CPU fallback in this library. */
 c4gpu_ctx  *c4gpu_ctx_create(int device_ordinal);
 void        c4gpu_ctx_destroy(c4gpu_ctx *ctx);
+/* Loads the code objects a heuristic run touches first (sequence preparation, HSP extension, word scan, SDP passes) without
+ * launching anything; thread-safe beside other calls on the context: meant for a background thread of a caller that still
+ * has host work to do before its first batch (integration/c4gpu_shim.c starts the context that way). */
+void        c4gpu_ctx_warm(c4gpu_ctx *ctx);
 /* Use an externally owned HIP stream (e.g. torch's current stream) for all launches; NULL = default. */
 void        c4gpu_ctx_set_stream(c4gpu_ctx *ctx, void *hip_stream);
 int         c4gpu_ctx_device_info(c4gpu_ctx *ctx, char *name, size_t name_len, int *n_cu, int64_t *mem_bytes);

@@ -207,6 +207,7 @@ void shim_sdp_flush(void){
     sdp_pending = NULL;
     sdp_pending_bytes = 0.0;
     sst.flushes++;
+    shim_mark("sdp flush: batch");
     if(g_getenv("C4GPU_SDP_HOST")){
         for(i = 0; i < todo->len; i++)
             sdp_host_pair(todo->pdata[i]);
@@ -214,6 +215,7 @@ void shim_sdp_flush(void){
         sdp_device_batch(todo);
         }
     t1 = g_get_monotonic_time();
+    shim_mark("sdp flush: replay");
     for(i = 0; i < todo->len; i++){                       /* replay in submission order */
         register ShimSdpPending *p = todo->pdata[i];
         register GAM_Result *gam_result;

@@ -43,7 +43,8 @@ typedef struct { Sequence *query; HSP_Param *param; guint query_pos, target_pos;
 
 typedef struct {
     Seeder *seeder;
-    gboolean usable;
+    gboolean usable, hopeless;           /* table built / this seeder keeps the reference's walk */
+    gint64 walked;                        /* symbols the reference's walk has seen while the table was not worth building */
     gint width, wordlen;
     guchar column[ALPHABETSIZE];          /* residue -> automaton column (0: outside the alphabet) */
     gboolean upper;                       /* the VFSM walk upper-cases (seeder.c:704) */
@@ -54,7 +55,7 @@ typedef struct {
 
 static GHashTable *seed_tabs = NULL;      /* Seeder* -> ShimSeedTab* */
 static GArray *seed_record = NULL;        /* C4GPU_SEED_CHECK: what the reference's own walk hands to HSPset_seed_hsp */
-static struct { long targets, scans, symbols, hits, checked; double scan_ms, host_ms; } sdst;
+static struct { long targets, cpu_targets, scans, symbols, hits, checked, words, emits; double scan_ms, host_ms, table_ms; } sdst;
 
 gboolean shim_seed_recording(HSPset *hsp_set, guint query_start, guint target_start){
     ShimSeedRec r;
@@ -90,35 +91,80 @@ static void seed_add_word(ShimSeedTab *st, guint64 code, Seeder_WordInfo *word_i
     return;
     }
 
-/* the pre-compile trie (fsm.c:112-135): column c of a node leads to the child array, the last level holds the data */
-static void seed_walk_trie(ShimSeedTab *st, FSM *f, FSM_Node *n, gint depth, guint64 code){
-    register gint c;
-    for(c = 1; c < f->width; c++){
-        register guint64 next = code * f->width + c;
-        if(depth + 1 == st->wordlen){
-            if(n[c].data)
-                seed_add_word(st, next, n[c].data);
-        } else if(n[c].next){
-            seed_walk_trie(st, f, n[c].next, depth + 1, next);
+/* The words of the automaton, level by level.  Before FSM_compile (fsm.c:136-184) `next` is NULL where the trie has no
+ * child; after it every `next` is set, but a failure link leads to a node no deeper than its origin, so in a level-order
+ * walk the edges into nodes not seen before are exactly the trie's own: the walk reads both forms.  Column c of a node at
+ * the last level holds the word's data. */
+typedef struct { FSM_Node *node; guint64 code; } ShimTrieItem;
+static void seed_walk_trie(ShimSeedTab *st, FSM *f){
+    register GArray *level = g_array_new(FALSE, FALSE, sizeof(ShimTrieItem)), *next_level, *words;
+    register GHashTable *seen = g_hash_table_new(g_direct_hash, g_direct_equal);
+    register gint depth, c;
+    register guint k;
+    ShimTrieItem it;
+    it.node = f->root; it.code = 0;
+    g_array_append_val(level, it);
+    g_hash_table_insert(seen, f->root, f->root);
+    for(depth = 0; depth + 1 < st->wordlen; depth++){
+        next_level = g_array_new(FALSE, FALSE, sizeof(ShimTrieItem));
+        for(k = 0; k < level->len; k++){
+            register ShimTrieItem *p = &g_array_index(level, ShimTrieItem, k);
+            for(c = 1; c < f->width; c++){
+                register FSM_Node *child = p->node[c].next;
+                if(child && !g_hash_table_lookup(seen, child)){
+                    g_hash_table_insert(seen, child, child);
+                    it.node = child; it.code = p->code * f->width + c;
+                    g_array_append_val(next_level, it);
+                    }
+                }
             }
+        g_array_free(level, TRUE);
+        level = next_level;
         }
+    g_hash_table_destroy(seen);
+    /* the reference's traversal meets the words in no particular order; ours does not depend on it either (hash table) */
+    words = level;
+    for(k = 0; k < words->len; k++){
+        register ShimTrieItem *p = &g_array_index(words, ShimTrieItem, k);
+        for(c = 1; c < f->width; c++)
+            if(p->node[c].data)
+                seed_add_word(st, p->code * f->width + c, p->node[c].data);
+        }
+    g_array_free(words, TRUE);
     return;
     }
 
-static ShimSeedTab *seed_table(Seeder *seeder){
+/* Is the table worth building yet?  Reading the words off the automaton costs about as much as the reference's walk over
+ * 16 symbols per trie node (measured: 0.5 us per node against 20-50 ns per walked symbol); until the targets of this seeder
+ * add up to that, the reference's own walk serves them (a 100-protein seeder with word neighbourhoods against one 10 kaa
+ * target is walked in a millisecond and its 660 000 words would take 270 ms to read). */
+static gboolean seed_worth_it(ShimSeedTab *st, Sequence *target){
+    register Seeder *seeder = st->seeder;
+    register gdouble nodes = seeder->seeder_fsm ? (gdouble)seeder->seeder_fsm->fsm->chunk_count
+                                                : (gdouble)seeder->seeder_vfsm->vfsm->lrw / 64.0;
+    register gdouble factor = g_getenv("C4GPU_SEED_FACTOR") ? atof(g_getenv("C4GPU_SEED_FACTOR")) : 16.0;
+    return (gdouble)(st->walked + target->len) >= factor * nodes;
+    }
+
+static ShimSeedTab *seed_state(Seeder *seeder){
     register ShimSeedTab *st;
-    register gint i;
-    gint32 zero = 0;
     if(!seed_tabs)
         seed_tabs = g_hash_table_new(g_direct_hash, g_direct_equal);
     if((st = g_hash_table_lookup(seed_tabs, seeder)))
-        return st->usable ? st : NULL;
+        return st;
     st = g_new0(ShimSeedTab, 1);
     st->seeder = seeder;
     g_hash_table_insert(seed_tabs, seeder, st);
-    if(seeder->is_prepared || seeder->saturate_threshold || (seeder->sas->word_ambiguity > 1)
-    || (seeder->dna_loader && seeder->codon_loader))
-        return NULL;
+    if(seeder->saturate_threshold || (seeder->sas->word_ambiguity > 1) || (seeder->dna_loader && seeder->codon_loader))
+        st->hopeless = TRUE;
+    return st;
+    }
+
+static gboolean seed_build(ShimSeedTab *st){
+    register Seeder *seeder = st->seeder;
+    register gint i;
+    gint32 zero = 0;
+    gint64 t_begin = g_get_monotonic_time();
     st->wordlen = seeder->any_hsp_param->wordlen;
     st->codes = g_array_new(FALSE, FALSE, sizeof(guint64));
     st->first = g_array_new(FALSE, FALSE, sizeof(gint32));
@@ -126,14 +172,14 @@ static ShimSeedTab *seed_table(Seeder *seeder){
     g_array_append_val(st->first, zero);
     if(seeder->seeder_fsm){
         register FSM *f = seeder->seeder_fsm->fsm;
-        if(f->is_compiled)
-            return NULL;
         st->width = f->width;
         for(i = 0; i < ALPHABETSIZE; i++)
             st->column[i] = f->traversal_filter[i];
         st->column[0] = 0;
-        seed_walk_trie(st, f, f->root, 0, 0);
-        FSM_compile(f);                                        /* Seeder_prepare, seeder.c:779-784 */
+        seed_walk_trie(st, f);
+        shim_mark("  trie read");
+        if(!f->is_compiled)
+            FSM_compile(f);                                    /* Seeder_prepare, seeder.c:779-784 */
     } else {
         register VFSM *vfsm = seeder->seeder_vfsm->vfsm;
         register VFSM_Int leaf;
@@ -145,7 +191,7 @@ static ShimSeedTab *seed_table(Seeder *seeder){
         st->column[0] = 0;
         if((gint)vfsm->depth != st->wordlen){
             g_free(word);
-            return NULL;
+            return FALSE;
             }
         for(leaf = 0; leaf < vfsm->lrw; leaf++){
             register Seeder_WordInfo *word_info = seeder->seeder_vfsm->leaf[leaf];
@@ -167,13 +213,16 @@ static ShimSeedTab *seed_table(Seeder *seeder){
     } else {
         st->tab = c4gpu_wordtab_create(shim_get_ctx(), st->width, st->wordlen, (const uint64_t*)st->codes->data,
                                        (const int32_t*)st->first->data, st->codes->len);
+        shim_mark("  word table on the device");
         if(!st->tab){
             g_warning("c4gpu: %s -- the word scan stays on the CPU", c4gpu_last_error());
-            return NULL;
+            return FALSE;
             }
         }
     st->usable = TRUE;
-    return st;
+    sdst.words += st->codes->len; sdst.emits += st->emits->len;
+    sdst.table_ms += (g_get_monotonic_time() - t_begin) / 1e3;
+    return TRUE;
     }
 
 /* Seeder_WordInfo_seed, seeder.c:624-647 (no saturation threshold here) */
@@ -270,8 +319,23 @@ void Seeder_add_target(Seeder *seeder, Sequence *target){
     static gint off = -1;
     if(off < 0)
         off = (g_getenv("C4GPU_SEED_OFF") || (shim_batch_size() <= 0)) ? 1 : 0;
-    if((!off) && (g_getenv("C4GPU_SEED_HOST") || shim_get_ctx()))
-        st = seed_table(seeder);
+    shim_mark("Seeder_add_target");
+    if((!off) && (g_getenv("C4GPU_SEED_HOST") || shim_get_ctx())){
+        st = seed_state(seeder);
+        if(st->hopeless)
+            st = NULL;
+        else if(!st->usable){
+            if(!seed_worth_it(st, target)){
+                st->walked += target->len;
+                sdst.cpu_targets++;
+                st = NULL;
+            } else if(!seed_build(st)){
+                st->hopeless = TRUE;
+                st = NULL;
+                }
+            }
+        }
+    shim_mark("word table ready");
     if(!st){
         Seeder_add_target_cpu(seeder, target);
         return;
@@ -319,6 +383,7 @@ void Seeder_add_target(Seeder *seeder, Sequence *target){
         g_array_free(theirs, TRUE);
         g_array_free(mine, TRUE);
         }
+    shim_mark("target scanned, seeds delivered");
     /* Report matches, seeder.c:899-913 */
     for(i = 0; i < (gint)seeder->active_queryinfo_list->len; i++){
         query_info = seeder->active_queryinfo_list->pdata[i];
@@ -330,6 +395,7 @@ void Seeder_add_target(Seeder *seeder, Sequence *target){
         query_info->curr_comparison = NULL;
         }
     g_ptr_array_set_size(seeder->active_queryinfo_list, 0);
+    shim_mark("comparisons reported");
     return;
     }
 
@@ -352,9 +418,13 @@ void Seeder_destroy(Seeder *seeder){
     }
 
 void shim_seed_report(void){
+    if(g_getenv("C4GPU_VERBOSE") && sdst.cpu_targets)
+        g_message("c4gpu seed: %ld targets left to the reference's walk (their seeder's word table was not worth reading yet)",
+                  sdst.cpu_targets);
     if(g_getenv("C4GPU_VERBOSE") && sdst.targets)
         g_message("c4gpu seed: %ld targets walked in %ld device scans (%ld symbols): %ld word hits; scans %.0f ms, "
-                  "delivery %.0f ms%s", sdst.targets, sdst.scans, sdst.symbols, sdst.hits, sdst.scan_ms, sdst.host_ms,
+                  "delivery %.0f ms, word tables (%ld words, %ld emissions) %.0f ms%s", sdst.targets, sdst.scans, sdst.symbols,
+                  sdst.hits, sdst.scan_ms, sdst.host_ms, sdst.words, sdst.emits, sdst.table_ms,
                   sdst.checked ? "; every seed equal to the reference's own walk" : "");
     return;
     }

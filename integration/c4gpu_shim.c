@@ -29,7 +29,7 @@
 
 extern gpointer Bootstrapper_lookup_cpu(gchar *name);
 
-static c4gpu_ctx *shim_ctx = NULL;
+static c4gpu_ctx * volatile shim_ctx = NULL;
 static gboolean shim_tried = FALSE, shim_verbose = FALSE;
 
 /* ---- command line: --gpu / --gpudevice / --gpubatch beside -C/--compiled (codegen.c:25-37) ---------------- */
@@ -37,6 +37,8 @@ static gboolean shim_tried = FALSE, shim_verbose = FALSE;
  * definition is renamed Codegen_ArgumentSet_create_cpu by the Makefile and this one adds ours after it. */
 extern Codegen_ArgumentSet *Codegen_ArgumentSet_create_cpu(Argument *arg);
 static struct { gboolean use_gpu; gint device; gint batch; } shim_args = {TRUE, 0, 4096};
+
+static void shim_start_ctx(void);
 
 Codegen_ArgumentSet *Codegen_ArgumentSet_create(Argument *arg){
     register Codegen_ArgumentSet *cas = Codegen_ArgumentSet_create_cpu(arg);
@@ -52,22 +54,80 @@ Codegen_ArgumentSet *Codegen_ArgumentSet_create(Argument *arg){
                 "Pairs of an exhaustive run collected per GPU batch (0 = one Viterbi call at a time)", "4096",
                 Argument_parse_int, &shim_args.batch);
         Argument_absorb_ArgumentSet(arg, as);
+    } else {
+        shim_start_ctx();                 /* options parsed: open the device beside the rest of the start-up */
         }
     return cas;
     }
 
+/* The context is opened on a thread of its own as soon as the options are known (the first Codegen_ArgumentSet_create(NULL)
+ * of Viterbi_create, while Analysis_create still builds its models): HIP start-up (~120 ms) and the first code-object loads
+ * then run beside the host's own start-up work (reading the queries, building the word automaton) instead of in front of
+ * the first batch.  shim_get_ctx waits for the context only; the code-object loads go on in the background. */
+static gint64 shim_t0 = 0, shim_t_open = 0, shim_t_ready = 0, shim_t_warm = 0, shim_waited = 0;
+static void __attribute__((constructor)) shim_clock_start(void){ shim_t0 = g_get_monotonic_time(); }
+void shim_mark(const gchar *what){          /* C4GPU_TRACE: where the wall time of a run goes */
+    static gint on = -1;
+    if(on < 0)
+        on = g_getenv("C4GPU_TRACE") ? 1 : 0;
+    if(on)
+        g_printerr("c4gpu mark: %8.1f ms  %s\n", (g_get_monotonic_time() - shim_t0) / 1e3, what);
+    return;
+    }
+static GThread *shim_ctx_thread = NULL;
+static GMutex shim_ctx_lock;
+static GCond shim_ctx_cond;
+static gboolean shim_ctx_ready = FALSE;
+static gchar *shim_ctx_error = NULL;
+
+static gpointer shim_ctx_open(gpointer data){
+    register c4gpu_ctx *ctx;
+    shim_t_open = g_get_monotonic_time();
+    ctx = c4gpu_ctx_create(g_getenv("C4GPU_DEVICE") ? atoi(g_getenv("C4GPU_DEVICE")) : shim_args.device);
+    shim_t_ready = g_get_monotonic_time();
+    g_mutex_lock(&shim_ctx_lock);
+    shim_ctx = ctx;
+    if(!ctx)
+        shim_ctx_error = g_strdup(c4gpu_last_error());
+    shim_ctx_ready = TRUE;
+    g_cond_broadcast(&shim_ctx_cond);
+    g_mutex_unlock(&shim_ctx_lock);
+    if(ctx && !g_getenv("C4GPU_NO_WARM"))
+        c4gpu_ctx_warm(ctx);
+    shim_t_warm = g_get_monotonic_time();
+    return NULL;
+    }
+
+static void shim_start_ctx(void){
+    if(shim_tried)
+        return;
+    shim_tried = TRUE;
+    shim_verbose = (g_getenv("C4GPU_VERBOSE") != NULL);
+    if((!shim_args.use_gpu) || g_getenv("C4GPU_DISABLE"))
+        return;
+    if(c4gpu_abi_version() != C4GPU_ABI_VERSION){
+        g_warning("c4gpu: libc4gpu.so has ABI version %d, this binary was built for %d -- using the CPU Viterbi",
+                  c4gpu_abi_version(), C4GPU_ABI_VERSION);
+        return;
+        }
+    shim_ctx_thread = g_thread_new("c4gpu-ctx", shim_ctx_open, NULL);
+    return;
+    }
+
 c4gpu_ctx *shim_get_ctx(void){
-    if(!shim_tried){
-        shim_tried = TRUE;
-        shim_verbose = (g_getenv("C4GPU_VERBOSE") != NULL);
-        if(shim_args.use_gpu && (!g_getenv("C4GPU_DISABLE")) && (c4gpu_abi_version() != C4GPU_ABI_VERSION)){
-            g_warning("c4gpu: libc4gpu.so has ABI version %d, this binary was built for %d -- using the CPU Viterbi",
-                      c4gpu_abi_version(), C4GPU_ABI_VERSION);
-        } else if(shim_args.use_gpu && (!g_getenv("C4GPU_DISABLE"))){
-            shim_ctx = c4gpu_ctx_create(g_getenv("C4GPU_DEVICE") ? atoi(g_getenv("C4GPU_DEVICE")) : shim_args.device);
-            if(!shim_ctx)
-                g_warning("c4gpu: %s -- using the CPU Viterbi", c4gpu_last_error());
-            }
+    shim_start_ctx();
+    if(shim_ctx_thread && !shim_ctx_ready){
+        gint64 w0 = g_get_monotonic_time();
+        g_mutex_lock(&shim_ctx_lock);
+        while(!shim_ctx_ready)
+            g_cond_wait(&shim_ctx_cond, &shim_ctx_lock);
+        g_mutex_unlock(&shim_ctx_lock);
+        shim_waited += g_get_monotonic_time() - w0;
+        }
+    if(shim_ctx_error){
+        g_warning("c4gpu: %s -- using the CPU Viterbi", shim_ctx_error);
+        g_free(shim_ctx_error);
+        shim_ctx_error = NULL;
         }
     return shim_ctx;
     }
@@ -682,6 +742,7 @@ GAM_Result *GAM_Result_exhaustive_create(GAM *gam, Sequence *query, Sequence *ta
     }
 
 void GAM_report(GAM *gam){        /* analysis.c:1421: after the last pair */
+    shim_mark("GAM_report: last flushes");
     shim_flush();
     shim_bsdp_flush();
     shim_sdp_flush();
@@ -689,6 +750,15 @@ void GAM_report(GAM *gam){        /* analysis.c:1421: after the last pair */
     shim_sdp_report();
     shim_seed_report();
     shim_hsp_report();
+    if(shim_ctx_thread){                  /* the background code-object loads are over before the process winds down */
+        g_thread_join(shim_ctx_thread);
+        shim_ctx_thread = NULL;
+        if(shim_verbose)
+            g_message("c4gpu start-up: device opened on its own thread from %.0f to %.0f ms after process start, code objects loaded "
+                      "by %.0f ms; the main thread waited %.0f ms for it; end of the run at %.0f ms", (shim_t_open - shim_t0) / 1e3,
+                      (shim_t_ready - shim_t0) / 1e3, (shim_t_warm - shim_t0) / 1e3, shim_waited / 1e3,
+                      (g_get_monotonic_time() - shim_t0) / 1e3);
+        }
     GAM_report_cpu(gam);
     return;
     }

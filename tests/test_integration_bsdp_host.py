@@ -187,7 +187,10 @@ def test_word_scan_seam_equals_the_reference_walk(tmp_path, model, extra):
     VFSM leaf table with --forcefsm compact), a dictionary scan in place of the device scan, the hits delivered like
     Seeder_WordInfo_seed; C4GPU_SEED_CHECK=1: the reference's own walk runs first and every seed must be the same, in the
     same order (the drop-in aborts otherwise).  Byte-identical output on top."""
-    env = {"C4GPU_SEED_HOST": "1", "C4GPU_SEED_CHECK": "1", "C4GPU_HSP_HOST": "1", "C4GPU_SDP_HOST": "1", "C4GPU_BSDP_HOST": "1"}
+    # C4GPU_SEED_FACTOR=0: the word table is read at the first target (by default only once a seeder's targets add up to 16
+    # symbols per trie node: small runs keep the reference's walk)
+    env = {"C4GPU_SEED_HOST": "1", "C4GPU_SEED_CHECK": "1", "C4GPU_HSP_HOST": "1", "C4GPU_SDP_HOST": "1", "C4GPU_BSDP_HOST": "1",
+           "C4GPU_SEED_FACTOR": "0"}
     ref, gpu, err = run_pair(tmp_path, model, extra, env, n=6, seed=31)
     assert gpu == ref and ref.count(b"vulgar:") >= 3
     m = re.search(r"c4gpu seed: (\d+) targets walked in (\d+) device scans \((\d+) symbols\): (\d+) word hits", err)
@@ -197,8 +200,23 @@ def test_word_scan_seam_equals_the_reference_walk(tmp_path, model, extra):
         assert int(m.group(2)) == 3 * int(m.group(1))                  # three translated frames per target
 
 
+@pytest.mark.parametrize("model,extra", [("est2genome", []), ("protein2dna", []), ("affine:local", ["--gappedextension", "yes"])])
+def test_word_table_read_after_the_automaton_was_compiled(tmp_path, model, extra):
+    """The first targets of a seeder go through the reference's own walk (which compiles the automaton: failure links
+    everywhere); once the targets add up, the words are read off the COMPILED automaton level by level and the later
+    targets are scanned from the table — seed for seed what the reference's walk finds (C4GPU_SEED_CHECK)."""
+    env = {"C4GPU_SEED_HOST": "1", "C4GPU_SEED_CHECK": "1", "C4GPU_HSP_HOST": "1", "C4GPU_SDP_HOST": "1", "C4GPU_BSDP_HOST": "1"}
+    for factor in ("0.05", "0.2", "0.5", "1", "2"):
+        ref, gpu, err = run_pair(tmp_path, model, extra, dict(env, C4GPU_SEED_FACTOR=factor), n=8, seed=33)
+        assert gpu == ref
+        if "left to the reference's walk" in err and "device scans" in err:
+            assert "every seed equal to the reference's own walk" in err
+            return
+    assert False, "no factor made the seeder switch in the middle of its targets: " + err[-600:]
+
+
 def test_word_scan_seam_switched_off_and_with_a_saturation_threshold(tmp_path):
-    env = {"C4GPU_SEED_HOST": "1", "C4GPU_HSP_HOST": "1", "C4GPU_BSDP_HOST": "1"}
+    env = {"C4GPU_SEED_HOST": "1", "C4GPU_HSP_HOST": "1", "C4GPU_BSDP_HOST": "1", "C4GPU_SEED_FACTOR": "0"}
     ref, gpu, err = run_pair(tmp_path, "est2genome", [], dict(env, C4GPU_SEED_OFF="1"))
     assert gpu == ref and "c4gpu seed:" not in err
     # --saturatethreshold: a running count per word in walk order, the reference's own walk keeps it
