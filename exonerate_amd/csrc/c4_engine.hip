@@ -556,6 +556,8 @@ struct Engine {
     // candidate the reference has.  True while the calc magnitudes are small against 987654321; checked
     // here, and parameters outside that range get the general kernels (all masks kept) instead.
     bool local_exact = true;
+    bool pk16_params_ok = false;         // see init: the parameters allow the packed 16-bit score pass
+    int pk16_match_max = 1, pk16_max_intron = 0;
     DevBuf<KParams> kparams;
     // reusable device buffers
     DevBuf<DevJob> d_jobs;
@@ -624,6 +626,13 @@ struct Engine {
                 }
             // a real candidate is at least -(states x largest calc); a phantom one at most LOW + 3 calcs
             local_exact = (pmax + smax) * (m->n_states + 4) < 4.0e8;
+            // the packed 16-bit score pass (c4_viterbi16_kernel.h): every constant far inside 16 bits, a usual intron window
+            double mmax = 0;
+            for (int i = 0; i < 24 * 24; i++) mmax = std::max(mmax, (double)kp.submat[i]);
+            pk16_match_max = (int)std::max(1.0, mmax);
+            pk16_params_ok = pmax <= 16000.0 && smax <= 16000.0 && params->min_intron >= 0 && params->min_intron <= 30000 &&
+                             params->max_intron >= params->min_intron;
+            pk16_max_intron = params->max_intron;
             if (getenv("C4GPU_LOCAL_EXACT") && atoi(getenv("C4GPU_LOCAL_EXACT")) == 0) local_exact = false;   // test hook
         }
         for (int c = 0; c < 4096; c++) {
@@ -717,6 +726,16 @@ struct Engine {
         if (seed) {
             ki = get_kernel_mw(family, mode, true, mode == MODE_REGION, 4, false, seed->mode);
             if (!ki || !use_local || (mode == MODE_REGION && !pack)) { c4h::set_error("no seeded kernel for this launch"); return -1; }
+            // the score pass with dumps: two jobs per lane in packed 16-bit halves where every score fits (C4GPU_PK16=0: never)
+            const int pk_env = getenv("C4GPU_PK16") ? atoi(getenv("C4GPU_PK16")) : 1;      // read on every call: a test switches it
+            const KernelInfo *kpk = (seed->mode == 1 && pk_env && pk16_params_ok && n >= 2) ? get_kernel_pk16(family) : nullptr;
+            if (kpk) {
+                bool fits = true;
+                for (int i = 0; i < n && fits; i++)
+                    fits = (double)(specs[i].region.query_length + 1) * pk16_match_max <= 16000.0 &&
+                           (long long)specs[i].region.target_length + 4 <= (long long)pk16_max_intron;
+                if (fits) ki = kpk;
+            }
         } else if (mw_env && !cont && (mode == MODE_SCORE || mode == MODE_REGION)) {
             const KernelInfo *kmw = get_kernel_mw(family, mode, use_local, pack, 4, pts != nullptr);
             if (kmw) {

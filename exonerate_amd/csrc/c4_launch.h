@@ -58,6 +58,10 @@ const KernelInfo *get_kernel(int family, int mode, bool cont, bool local, bool p
 // starts from a dump and reports its corner cell); local, 4 waves only
 const KernelInfo *get_kernel_mw(int family, int mode, bool local, bool pack, int waves = 4, bool sub = false, int seed = 0);
 
+// the packed 16-bit score pass with column dumps (c4_viterbi16_kernel.h): two jobs per lane; NULL = not compiled for the family.
+// Launched over the same job / result arrays as the 32-bit kernel (workgroup p runs jobs 2p and 2p + 1).
+const KernelInfo *get_kernel_pk16(int family);
+
 #define C4K_DEFINE_KERNEL_SPAN(SYMBOL, M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV, SPANV)                                          \
     static hipError_t SYMBOL##_launch(const LaunchArgs &a) {                                               \
         hipLaunchKernelGGL((viterbi_kernel<M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV, SPANV>), dim3(a.grid), dim3(64), 0,        \

@@ -1,0 +1,437 @@
+// c4_viterbi16_kernel.h — the whole-rectangle FIND_SCORE pass of the windowed region scheme (c4_viterbi_kernel.h, SEED = 1)
+// with TWO jobs per lane in packed 16-bit halves.
+//
+// The score pass is pure max-plus when nothing but the score is carried (first valid transition assigns, later ones
+// replace on strict <, viterbi.c:766-775 = a maximum), and the local-scope shortcuts of the 32-bit kernel already make the
+// validity of every transition a compile-time fact.  So a register can hold the same cell of two independent jobs —
+// job A in the low half, job B in the high half — and v_pk_add_i16 (saturating) / v_pk_max_i16 evaluate both at once:
+// the DPP row exchange, the LDS rings between the cooperating waves and every add / max serve two rectangles.  What does
+// not pack — the substitution-score reads (two LDS reads and a v_perm per row), the per-column splice scores (clamp
+// and v_perm per array), the end-cell bookkeeping (behind the same rare wave-uniform branch) — is per column or rare.
+//
+// Exactness (the host only picks this kernel when all of it holds, Engine::pk16_ok):
+//   * every score a result can depend on fits 16 bits: (Q + 1) x the largest substitution score <= 16 000, calc constants
+//     below 16 000 in magnitude;
+//   * "unset" is -32 768 and adds saturate: a value that is unset or saturated in the reference's sense (-987 654 321 + x)
+//     would need +32 768 to reach the 0 every match state has from START in the same cell — more than a whole query can
+//     contribute — so it never wins a maximum that a result reads, exactly as the 32-bit kernel's phantom candidates
+//     (c4_viterbi_kernel.h, eval_cell: the row-0 note);
+//   * the intron-start shadow (a target position: 17+ bits) becomes the intron's length so far, a saturating 15-bit
+//     counter: the post-splice calc only asks whether the length lies in [min, max] (intron.c:150-160); lengths beyond
+//     32 767 saturate, which is still "long enough", and the upper limit cannot fail when T + 4 <= max_intron (checked);
+//   * the column dumps the region windows start from are written in the 32-bit kernel's own format (scores sign-extended,
+//     shadow = column - length - 2): a window computes from them what it computes from the 32-bit pass's dumps wherever a
+//     result can see it, and the host checks every window's corner score against this pass's score as before.
+// The two jobs of a lane need not have the same size: cells outside a job's own rectangle hold garbage that only flows
+// away from the rectangle (every transition advances), its loads are clamped, its end cells are ignored.
+#pragma once
+#include "c4_viterbi_kernel.h"
+
+namespace c4k {
+
+// inline asm keeps each of these ONE instruction: the builtin forms (__builtin_elementwise_add_sat on short2 ...) are folded
+// into per-half compares and selects around the mask logic and cost 8 % of the pass; operands in VGPRs: with the launch
+// constants as scalar operands the kernel spills 62 SGPRs and is 2 % slower (measured, profiles/r03_pk16.md)
+__device__ __forceinline__ int pk_add(int a, int b) { int r; asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ int pk_sub(int a, int b) { int r; asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ int pk_max(int a, int b) { int r; asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// per half: 0xffff where the half is negative, else 0
+__device__ __forceinline__ int pk_neg_mask(int d, int fifteen) { int r; asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(r) : "v"(fifteen), "v"(d)); return r; }
+__device__ __forceinline__ int pk_pack(int lo, int hi) { return (int)__builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
+__device__ __forceinline__ int pk_half(int x, int h) { return h ? (x >> 16) : ((x << 16) >> 16); }
+__device__ __forceinline__ int clamp16(int x) { return x < -32768 ? -32768 : (x > 32767 ? 32767 : x); }
+
+constexpr int NEG16 = (int)0x80008000u;          // -32 768 in both halves
+
+template <class M, int R>
+struct WaveDP16 {
+    using F = Facts<M>;
+    using W32 = WaveDP<M, R, MODE_SCORE, false, true, false, false, 0, 1>;     // the 32-bit score pass: dump layout
+    static constexpr int NS = M::NS, NCOL = M::MAXAT + 1, W = 64 * R, DC = M::MAXAT, SEEDW = W32::SEEDW;
+    static constexpr bool live(int s) { return M::NDES > 0 && W32::slot_live(s, 0); }
+    static constexpr int NEXP = F::n_exported();
+    static constexpr int BND = NEXP * 2;                 // ints per column between strips: score pair + length pair per exported state
+    static constexpr int RING = 256;
+    static constexpr int CH = (64 + NCOL - 1) / NCOL * NCOL;
+    static_assert(!F::has_phase(), "split-codon calcs are not packed");
+    static_assert(M::NDES <= 1, "one shadow designation");
+    typedef __attribute__((address_space(3))) int lds_int;
+    struct C16 { int sc[NS]; int il[NS]; };
+
+    const KParams *kp;
+    int lane;
+    // per job (0 = low half, 1 = high half)
+    const uint8_t *qc[2], *tc[2];
+    const int *ss[2];
+    long long ss_stride;
+    int Q[2], T[2], q0[2], t0[2], tlast[2], seed_rows[2], seed_kshift;
+    int *seed_wr[2];
+    int Qm, Tm;                                         // the larger of the two
+    int min_len_pk, at_pk[4], cv_pk[16], fifteen;
+    C16 col[NCOL][R], nbr[NCOL], expo, nx_carry;
+    int qrow[2][R];
+    int nx_tcode[2], nx_sp[2][4];
+    lds_int *ring_in, *ring_out;
+    bool use_ring_in, use_ring_out, carry_ok, carry_cols;
+    int best[2], best_i[2], best_j[2], best_pk;
+    bool best_set[2];
+    int sbest[2], sbest_i[2], sbest_j[2];
+    bool sbest_set[2];
+
+    template <class Fn>
+    __device__ __forceinline__ static void for_exported(Fn &&fn) {
+        int slot = 0;
+        static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+            if constexpr (F::exported(S)) { fn(S_, slot); slot += 2; }
+        });
+    }
+    __device__ __forceinline__ static void write_empty_column(int *colp) {
+        for_exported([&](auto S_, int slot) __attribute__((always_inline)) { colp[slot] = NEG16; colp[slot + 1] = 0; });
+    }
+    __device__ __forceinline__ void prefetch_carry(int s_next, const int *bnd_in) {
+        const int jx = s_next < 0 ? 0 : (s_next > Tm ? Tm : s_next);
+        const int jc = (carry_cols | use_ring_in) ? jx : 0;
+        if (use_ring_in) {
+            for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
+                const lds_int *p = ring_in + (jc & (RING - 1)) * BND + slot;
+                nx_carry.sc[S] = p[0];
+                if constexpr (live(S)) nx_carry.il[S] = p[1];
+            });
+        } else {
+            for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
+                const int *p = bnd_in + (long long)jc * BND + slot;
+                nx_carry.sc[S] = p[0];
+                if constexpr (live(S)) nx_carry.il[S] = p[1];
+            });
+        }
+    }
+    __device__ __forceinline__ void prefetch_column(int j) {
+        constexpr int mat = F::match_at();
+        static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
+            int ti = t0[H] + j - mat;
+            ti = ti < 0 ? 0 : (ti > tlast[H] ? tlast[H] : ti);
+            nx_tcode[H] = tc[H][(unsigned)ti];
+            if constexpr (F::has_splice()) {
+                int tp = t0[H] + j - 2;
+                tp = tp < 0 ? 0 : (tp > tlast[H] ? tlast[H] : tp);
+                static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
+                    nx_sp[H][K] = ss[H][(long long)K * ss_stride + tp];
+                });
+            }
+        });
+    }
+
+    template <int RR, int PH, bool JINT>
+    __device__ __forceinline__ void eval_cell(int j, int ms, const int (&sp)[4]) {
+        C16 &c = col[PH][RR];
+        static_for<M::NT>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
+            constexpr TrDesc t = M::tr[K];
+            constexpr int PD = (PH - t.at + NCOL) % NCOL;
+            const C16 &src = (t.aq == 0) ? col[PD][RR] : (RR > 0 ? col[PD][RR > 0 ? RR - 1 : 0] : nbr[PD]);
+            int cand;
+            if constexpr (t.in == M::START) cand = 0;
+            else cand = src.sc[t.in];
+            if constexpr (t.calc >= 0) {
+                constexpr CalcDesc cd = M::calc[t.calc];
+                if constexpr (cd.kind == CALC_CONST) cand = pk_add(cand, cv_pk[t.calc]);
+                else if constexpr (cd.kind >= CALC_MATCH_DNA && cd.kind <= CALC_MATCH_P2D) cand = pk_add(cand, ms);
+                else if constexpr (cd.kind == CALC_SPLICE_PRE) cand = pk_add(cand, sp[cd.param]);
+                else if constexpr (cd.kind == CALC_SPLICE_POST) {
+                    // intron length = length so far + this advance + 2 (c4_viterbi_kernel.h: (t0 + j - at) - shadow + 2); too
+                    // short: the transition scores -987654321 (intron.c:150-160); too long cannot happen (T + 4 <= max_intron)
+                    static_assert(live(t.in), "post-splice calc without a length");
+                    const int bad = pk_neg_mask(pk_sub(src.il[t.in], min_len_pk), fifteen);      // length so far < min - at - 2
+                    const int sv = (bad & NEG16) | (~bad & sp[cd.param]);
+                    cand = pk_add(cand, sv);
+                }
+            }
+            if constexpr (!JINT && t.at > 0) cand = (j >= t.at) ? cand : NEG16;
+            int ilc = 0;
+            if constexpr (live(t.out)) {
+                if constexpr (F::owns_shadow(t.in, 0)) ilc = 0;
+                else if constexpr (live(t.in)) ilc = pk_add(src.il[t.in], at_pk[t.at]);
+            }
+            if constexpr (F::code(K) == 1) {                     // the first transition into this state
+                c.sc[t.out] = cand;
+                if constexpr (live(t.out)) c.il[t.out] = ilc;
+            } else {
+                if constexpr (live(t.out)) {
+                    const int win = pk_neg_mask(pk_sub(c.sc[t.out], cand), fifteen);          // strict <: the newcomer wins
+                    c.il[t.out] = (win & ilc) | (~win & c.il[t.out]);
+                }
+                c.sc[t.out] = pk_max(c.sc[t.out], cand);
+            }
+        });
+    }
+
+    template <bool JINT, int PH>
+    __device__ __forceinline__ void step(int s, int i0, bool last_strip, const int *bnd_in, int *bnd_out) {
+        const int j = s - lane;
+        int ms[R];
+        static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+            ms[RR] = pk_pack(kp->submat[qrow[0][RR] + nx_tcode[0]], kp->submat[qrow[1][RR] + nx_tcode[1]]);
+        });
+        int sp[4] = {0, 0, 0, 0};
+        if constexpr (F::has_splice()) {
+            static_for<M::NC>([&](auto CI_) __attribute__((always_inline)) { constexpr int CI = CI_;
+                constexpr CalcDesc cd = M::calc[CI];
+                if constexpr (cd.kind == CALC_SPLICE_PRE)
+                    sp[cd.param] = pk_pack(clamp16(kp->calc_value[CI] + nx_sp[0][cd.param]), clamp16(kp->calc_value[CI] + nx_sp[1][cd.param]));
+                if constexpr (cd.kind == CALC_SPLICE_POST)
+                    sp[cd.param] = pk_pack(clamp16(nx_sp[0][cd.param]), clamp16(nx_sp[1][cd.param]));
+            });
+        }
+        for_exported([&](auto S_, int) __attribute__((always_inline)) { constexpr int S = S_;
+            nbr[PH].sc[S] = dpp_shr1(nx_carry.sc[S], expo.sc[S]);
+            if constexpr (live(S)) nbr[PH].il[S] = dpp_shr1(nx_carry.il[S], expo.il[S]);
+        });
+        prefetch_carry(s + 1, bnd_in);
+        prefetch_column(j + 1);
+        static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+            eval_cell<RR, PH, JINT>(j, ms[RR], sp);
+        });
+        // end cell (viterbi.c:778-791): a new maximum is rare; one packed maximum over the lane's cells decides
+        {
+            int m = col[PH][0].sc[M::END];
+            static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_; if constexpr (RR > 0) m = pk_max(m, col[PH][RR].sc[M::END]); });
+            const bool cand = (pk_sub(best_pk, m) & NEG16) != 0;
+            if (__builtin_amdgcn_ballot_w64(cand)) {
+                static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
+                    const bool jact = (j >= 0) & (j <= T[H]);
+                    static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                        const int tsc = pk_half(col[PH][RR].sc[M::END], H);
+                        const bool upd = jact & (i0 + RR <= Q[H]) & (!best_set[H] | (best[H] < tsc));
+                        best[H] = upd ? tsc : best[H];
+                        best_i[H] = upd ? i0 + RR : best_i[H];
+                        best_j[H] = upd ? j : best_j[H];
+                        best_set[H] = best_set[H] | upd;
+                    });
+                });
+                best_pk = pk_pack(best_set[0] ? best[0] : -32768, best_set[1] ? best[1] : -32768);
+            }
+        }
+        for_exported([&](auto S_, int) __attribute__((always_inline)) { constexpr int S = S_;
+            expo.sc[S] = col[PH][R - 1].sc[S];
+            if constexpr (live(S)) expo.il[S] = col[PH][R - 1].il[S];
+        });
+        if (!last_strip && lane == 63 && j >= 0 && j <= Tm) {
+            if (use_ring_out) {
+                for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
+                    lds_int *p = ring_out + (j & (RING - 1)) * BND + slot;
+                    p[0] = expo.sc[S];
+                    if constexpr (live(S)) p[1] = expo.il[S];
+                });
+            } else {
+                for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
+                    int *p = bnd_out + (long long)j * BND + slot;
+                    p[0] = expo.sc[S];
+                    if constexpr (live(S)) p[1] = expo.il[S];
+                });
+            }
+        }
+        // the DC columns that end in d*K go to each job's dumps, in the 32-bit pass's format
+        if (((unsigned)(s + DC - 1) & (unsigned)((1 << seed_kshift) - 1)) <= (unsigned)(DC + 62)) {
+            const int d = (j + DC - 1) >> seed_kshift;
+            const unsigned which = (unsigned)(j - ((d << seed_kshift) - (DC - 1)));
+            static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
+                if ((j >= 0) & (j <= T[H]) & (d >= 1) & (which < (unsigned)DC) & ((d << seed_kshift) <= T[H])) {
+                    static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                        const int i = i0 + RR;
+                        if (i <= Q[H]) {
+                            int *p = seed_wr[H] + (((long long)(d - 1) * DC + which) * seed_rows[H] + i) * SEEDW;
+                            static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                                store_dword<S * 4>(p, pk_half(col[PH][RR].sc[S], H));
+                                if constexpr (live(S))
+                                    store_dword<W32::dump_pos(S, 0) * 4>(p, t0[H] + j - pk_half(col[PH][RR].il[S], H) - 2);
+                            });
+                        }
+                    });
+                }
+            });
+        }
+    }
+
+    __device__ __forceinline__ void strip_begin() {
+        static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
+            sbest[H] = best[H]; sbest_i[H] = best_i[H]; sbest_j[H] = best_j[H]; sbest_set[H] = best_set[H];
+            best_set[H] = false; best[H] = LOW;
+        });
+        best_pk = NEG16;
+    }
+    __device__ __forceinline__ void strip_end() {
+        static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
+            const bool keep_old = sbest_set[H] & (!best_set[H] | (sbest[H] > best[H]) |
+                                                  ((sbest[H] == best[H]) & ((sbest_j[H] < best_j[H]) | ((sbest_j[H] == best_j[H]) & (sbest_i[H] < best_i[H])))));
+            best[H] = keep_old ? sbest[H] : best[H]; best_i[H] = keep_old ? sbest_i[H] : best_i[H]; best_j[H] = keep_old ? sbest_j[H] : best_j[H];
+            best_set[H] = best_set[H] | sbest_set[H];
+        });
+    }
+    __device__ __forceinline__ void reduce_best() {
+        static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
+            for (int off = 32; off > 0; off >>= 1) {
+                const int o_best = __shfl_xor(best[H], off), o_i = __shfl_xor(best_i[H], off), o_j = __shfl_xor(best_j[H], off);
+                const bool o_set = __shfl_xor((int)best_set[H], off) != 0;
+                const bool take = o_set & (!best_set[H] | (o_best > best[H]) |
+                                           ((o_best == best[H]) & ((o_j < best_j[H]) | ((o_j == best_j[H]) & (o_i < best_i[H])))));
+                best[H] = take ? o_best : best[H]; best_i[H] = take ? o_i : best_i[H]; best_j[H] = take ? o_j : best_j[H];
+                best_set[H] = best_set[H] | o_set;
+            }
+        });
+    }
+
+    template <int NW>
+    __device__ __forceinline__ void run_mw(const DevJob &ja, const DevJob &jb, const DevSeqs &seqs, int *bnd, lds_int *rings, int wid) {
+        const DevJob *jp[2] = {&ja, &jb};
+        static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
+            const DevJob &jx = *jp[H];
+            Q[H] = jx.Q; T[H] = jx.T; q0[H] = jx.q0; t0[H] = jx.t0;
+            tlast[H] = seqs.tlen[jx.pair] > 0 ? seqs.tlen[jx.pair] - 1 : 0;
+            qc[H] = seqs.qcode + seqs.qoff[jx.pair];
+            tc[H] = seqs.tcode + seqs.toff[jx.pair];
+            ss[H] = F::has_splice() ? seqs.ss + seqs.toff[jx.pair] : nullptr;
+            seed_wr[H] = seqs.seed + jx.seed_off; seed_rows[H] = jx.seed_rows;
+            best[H] = LOW; best_i[H] = best_j[H] = 0; best_set[H] = false;
+        });
+        ss_stride = seqs.ss_stride;
+        seed_kshift = ja.seed_kshift;
+        Qm = Q[0] > Q[1] ? Q[0] : Q[1]; Tm = T[0] > T[1] ? T[0] : T[1];
+        best_pk = NEG16;
+        fifteen = 0x000f000f;
+        static_for<M::NC>([&](auto CI_) __attribute__((always_inline)) { constexpr int CI = CI_;
+            const int v = clamp16(kp->calc_value[CI]);
+            cv_pk[CI] = pk_pack(v, v);
+        });
+        static_for<4>([&](auto A_) __attribute__((always_inline)) { constexpr int A = A_; at_pk[A] = pk_pack(A, A); });
+        {
+            // "length so far < min_intron - at - 2" for the post-splice transitions (all advance the target by 2)
+            const int lim = clamp16(kp->min_intron - 4);
+            min_len_pk = pk_pack(lim, lim);
+        }
+        const int nstrips = (Qm + 1 + W - 1) / W;
+        const int nsuper = (nstrips + NW - 1) / NW;
+        const int nsteps = Tm + 64;
+        const int nchunks = (nsteps + CH - 1) / CH;
+        const int main_lo = 63 + M::MAXAT, main_hi = Tm;
+        for (int sb = 0; sb < nsuper; sb++) {
+            const int b = sb * NW + wid;
+            const int i0 = b * W + lane * R;
+            static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
+                static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                    const int i = i0 + RR;
+                    qrow[H][RR] = 24 * ((i >= 1 && i <= Q[H]) ? (int)qc[H][q0[H] + i - 1] : 0);
+                });
+            });
+            static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                expo.sc[S] = NEG16; expo.il[S] = 0;
+                static_for<NCOL>([&](auto D_) __attribute__((always_inline)) { constexpr int D = D_;
+                    nbr[D].sc[S] = NEG16; nbr[D].il[S] = 0;
+                    static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_; col[D][RR].sc[S] = NEG16; col[D][RR].il[S] = 0; });
+                });
+            });
+            strip_begin();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            carry_cols = carry_ok & (sb > 0);
+            const int *bnd_in = (sb == 0) ? bnd : bnd + BND + (carry_ok ? (long long)((sb + 1) & 1) * (Tm + 1) * BND : 0);
+            int *bnd_out = bnd + BND + (carry_ok ? (long long)(sb & 1) * (Tm + 1) * BND : 0);
+            use_ring_in = wid > 0; use_ring_out = wid < NW - 1;
+            ring_in = rings + (wid > 0 ? wid - 1 : 0) * RING * BND;
+            ring_out = rings + (wid < NW - 1 ? wid : 0) * RING * BND;
+            const bool last = (b >= nstrips - 1), idle = (b >= nstrips);
+            auto group = [&](auto JI_, int s0) __attribute__((always_inline)) {
+                constexpr bool JI = decltype(JI_)::value != 0;
+                static_for<NCOL>([&](auto P_) __attribute__((always_inline)) { constexpr int P = P_;
+                    step<JI, P>(s0 + P, i0, last, bnd_in, bnd_out);
+                });
+            };
+            for (int t = 0; t < 2 * wid; t++) __syncthreads();
+            if (idle) {
+                for (int k = 0; k < nchunks; k++) __syncthreads();
+            } else {
+                prefetch_column(0 - lane);
+                prefetch_carry(0, bnd_in);
+                int k = 0;
+                for (; k < nchunks && k * CH < main_lo; k++) {
+                    for (int s = k * CH; s < k * CH + CH; s += NCOL) group(IC<0>{}, s);
+                    __syncthreads();
+                }
+                for (; k < nchunks && k * CH + CH - 1 <= main_hi; k++) {
+                    for (int s = k * CH; s < k * CH + CH; s += NCOL) group(IC<1>{}, s);
+                    __syncthreads();
+                }
+                for (; k < nchunks; k++) {
+                    for (int s = k * CH; s < k * CH + CH; s += NCOL) group(IC<0>{}, s);
+                    __syncthreads();
+                }
+            }
+            for (int t = 0; t < 2 * (NW - 1 - wid); t++) __syncthreads();
+            strip_end();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+        }
+    }
+};
+
+// NW cooperating waves per PAIR of jobs: workgroup p of the queue runs jobs 2p and 2p + 1 (the last one alone when the
+// launch holds an odd number: its high half repeats it)
+template <class M, int R, int NW, int WPE>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
+void viterbi16_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, int n_jobs, DevResult *results,
+                         DevScratch scratch, int *queue) {
+    using DP = WaveDP16<M, R>;
+    __shared__ KParams kp_lds;
+    __shared__ int next_job;
+    __shared__ int rings[(NW > 1 ? NW - 1 : 1) * DP::RING * DP::BND];
+    __shared__ int wave_best[NW][2][4];
+    {
+        const int *src = reinterpret_cast<const int *>(kparams);
+        int *dst = reinterpret_cast<int *>(&kp_lds);
+        for (int x = threadIdx.x; x < (int)(sizeof(KParams) / sizeof(int)); x += 64 * NW) dst[x] = src[x];
+    }
+    __syncthreads();
+    const int wid = threadIdx.x >> 6;
+    int *bnd = scratch.bnd + (long long)blockIdx.x * scratch.bnd_stride;
+    if (threadIdx.x == 0) DP::write_empty_column(bnd);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    const int n_pairs = (n_jobs + 1) / 2;
+    for (;;) {
+        if (threadIdx.x == 0) next_job = atomicAdd(queue, 1);
+        __syncthreads();
+        const int pid = next_job;
+        __syncthreads();
+        if (pid >= n_pairs) break;
+        const int ia = 2 * pid, ib = (2 * pid + 1 < n_jobs) ? 2 * pid + 1 : 2 * pid;
+        DP dp;
+        dp.kp = &kp_lds;
+        dp.lane = threadIdx.x & 63;
+        dp.carry_ok = scratch.carry != 0;
+        dp.template run_mw<NW>(jobs[ia], jobs[ib], seqs, bnd, (typename DP::lds_int *)rings, wid);
+        dp.reduce_best();
+        if (dp.lane == 0)
+            for (int h = 0; h < 2; h++) {
+                wave_best[wid][h][0] = dp.best[h]; wave_best[wid][h][1] = dp.best_i[h]; wave_best[wid][h][2] = dp.best_j[h];
+                wave_best[wid][h][3] = dp.best_set[h];
+            }
+        __syncthreads();
+        if (threadIdx.x < 2 && (threadIdx.x == 0 || ib != ia)) {
+            const int h = threadIdx.x;
+            int b = LOW, bi = 0, bj = 0; bool bs = false;
+            for (int w = 0; w < NW; w++) {               // row-major-first merge (viterbi.c:778-791)
+                const int ob = wave_best[w][h][0], oi = wave_best[w][h][1], oj = wave_best[w][h][2];
+                const bool os = wave_best[w][h][3] != 0;
+                const bool take = os && (!bs || ob > b || (ob == b && (oj < bj || (oj == bj && oi < bi))));
+                if (take) { b = ob; bi = oi; bj = oj; }
+                bs = bs || os;
+            }
+            DevResult res;
+            res.flags = bs ? 0 : FLAG_NO_END; res.n_ops = 0; res.n_vsa = 0; res.last_srp = 0; res.pad = 0;
+            res.cell_size = 1 + M::NDES; res.ops_off = 0;
+            for (int l = 0; l < CELL_MAX; l++) res.final_cell[l] = 0;
+            res.score = b; res.end_set = bs; res.qe = bi; res.te = bj; res.qs = 0; res.ts = 0;
+            results[h ? ib : ia] = res;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace c4k

@@ -285,3 +285,37 @@ def test_windowed_and_one_pass_region_agree_at_full_size(eng, monkeypatch):
     assert [a.as_dict() for a in two] == [a.as_dict() for a in one]
     q, t = pairs[0]
     assert two[0].as_dict() == oracle_lib.find_path(model.c, model.params, q, t, dpmemory=32)
+
+
+def test_packed_16_bit_score_pass_agrees_with_the_32_bit_pass(eng, monkeypatch, capfd):
+    """The score pass with column dumps runs two jobs per lane in packed 16-bit halves (c4_viterbi16_kernel.h) where every
+    score fits; C4GPU_PK16=0 keeps the 32-bit kernel.  Same alignments either way on a ragged batch with an odd number of
+    jobs (two jobs of a lane of different sizes), tiny dump intervals, and an intron longer than the 15-bit length counter
+    (45 000 columns: the counter saturates, the intron stays valid); one pair also against the oracle."""
+    rng = random.Random(77)
+    model = ex.Model("est2genome")
+    pairs = []
+    for k, (ql, tl) in enumerate([(900, 30000), (400, 52000), (1000, 9000), (640, 30000), (1000, 100000), (130, 20000), (777, 41000)]):
+        q, t = _seeded_pairs(rng, "est2genome", ql, tl, 1)[0]
+        pairs.append((q, t))
+    q = _rand(rng, 800)
+    pairs.append((q, _rand(rng, 3000) + _mutate(rng, q[:400], 0.03) + "GT" + _rand(rng, 45000) + "AG" + _mutate(rng, q[400:], 0.03) + _rand(rng, 2000)))
+    pairs.append((_rand(rng, 500), _rand(rng, 25000)))                         # unrelated; nine jobs: the last lane pair is half empty
+    monkeypatch.setenv("C4GPU_TRACE", "1")
+    res = {}
+    for pk in ("1", "0"):
+        monkeypatch.setenv("C4GPU_PK16", pk)
+        res[pk] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=32, threshold=20)]
+        assert "windowed region pass" in capfd.readouterr().err
+    assert res["1"] == res["0"]
+    ops = [model.c.transitions[t].label for t, n in res["1"][7]["ops"] if n >= 45000]
+    assert ops == [6], "the long intron is not in the alignment"              # C4_Label_INTRON
+    q, t = pairs[2]
+    assert res["1"][2] == oracle_lib.find_path(model.c, model.params, q.encode(), t.encode(), dpmemory=32, threshold=20)
+    monkeypatch.setenv("C4GPU_SEED_KSHIFT", "6")
+    monkeypatch.setenv("C4GPU_PK16", "1")
+    small = pairs[:4] + pairs[5:6]
+    a = [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=20)]
+    monkeypatch.setenv("C4GPU_PK16", "0")
+    b = [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=20)]
+    assert a == b
