@@ -390,7 +390,9 @@ def main():
         # HBM bytes per launch of the same kernel from the PMC passes committed under profiles/ (bench.py
         # itself cannot read PMCs); only quoted when the run has the configuration that was profiled
         traffic, valu_pmc = None, None
-        kname = "viterbi_kernel_mw<Est2GenomeDesc, %s>" % ("MODE_SCORE + column dumps" if dom_mode == 0 else "MODE_REGION")
+        kname = ("viterbi16_kernel_mw<Est2GenomeDesc> (FIND_SCORE + column dumps, two jobs per lane in packed 16-bit halves)"
+                 if dom_mode == 0 and os.environ.get("C4GPU_PK16", "1") != "0" else
+                 "viterbi_kernel_mw<Est2GenomeDesc, %s>" % ("MODE_SCORE + column dumps" if dom_mode == 0 else "MODE_REGION"))
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
             if tj["config"] == {"pairs_per_gpu": args.pairs, "query_len": args.qlen, "target_len": args.tlen} \
@@ -420,7 +422,10 @@ def main():
                       "bit-exact vulgar vs reference",
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int32", "data": "synthetic" if not stub else "stub (control-flow test, no device)",
+            "vs_baseline": None, "dtype": "int32",
+            "dtype_note": "int32 as the reference (typedef gint C4_Score); the whole-rectangle score pass runs two jobs per lane in "
+                          "saturating packed int16 halves where every score provably fits (bit-identical results; C4GPU_PK16=0 "
+                          "keeps it in int32)", "data": "synthetic" if not stub else "stub (control-flow test, no device)",
             "alignments_per_s": args.pairs * world * args.steps / elapsed,
             # per-batch staging (upload + residue coding + splice arrays) is outside `value`; with it, once per step:
             "staging_ms": staging_s * 1e3,

@@ -39,14 +39,14 @@ bench = json.loads(open(src + "/bench.json").read().strip().splitlines()[-1])
 cfg = bench["config"]
 stats = {r["Name"]: r for r in csv.DictReader(open(f"{dst}/{tag}_kernel_stats.csv"))}
 # the dominant kernel of the step: largest total time among the Viterbi kernels
-dom = max((r for name, r in stats.items() if "viterbi_kernel" in name), key=lambda r: float(r["TotalDurationNs"]))
+dom = max((r for name, r in stats.items() if "viterbi_kernel" in name or "viterbi16_kernel" in name), key=lambda r: float(r["TotalDurationNs"]))
 reg = short(dom["Name"])
 v = agg[reg]
 n = int(v.get("dispatches:SQ_WAVES", v.get("dispatches:FETCH_SIZE", LAUNCHES_IN_PMC_RUN)))
 avg_ns = float(dom["AverageNs"])
 waves = v["SQ_WAVES"] / n
 # template arguments: viterbi_kernel_mw<Model, R, MODE, ...>
-mode = int(reg.split("<")[1].split(",")[2])
+mode = 0 if "viterbi16" in reg else int(reg.split("<")[1].split(",")[2])      # the packed 16-bit kernel is a FIND_SCORE pass
 vj = json.load(open(f"{dst}/valu_issue_latest.json"))
 wave_cycles = 4.0 * v["SQ_WAVE_CYCLES"] / max(v["SQ_WAVES"], 1)          # shader cycles one wave lives (quad-cycle counter)
 waves_per_simd = waves / vj["simds"]
