@@ -733,7 +733,7 @@ struct Engine {
                 bool fits = true;
                 for (int i = 0; i < n && fits; i++)
                     fits = (double)(specs[i].region.query_length + 1) * pk16_match_max <= 16000.0 &&
-                           (long long)specs[i].region.target_length + 4 <= (long long)pk16_max_intron;
+                           (!family_has_splice(family) || (long long)specs[i].region.target_length + 4 <= (long long)pk16_max_intron);
                 if (fits) ki = kpk;
             }
         } else if (mw_env && !cont && (mode == MODE_SCORE || mode == MODE_REGION)) {
@@ -748,6 +748,7 @@ struct Engine {
             const KernelInfo *kmw8 = (ki == kmw && mw_env != 4 && !pts) ? get_kernel_mw(family, mode, use_local, pack, 8) : nullptr;
             if (kmw8 && (long long)n * 8 <= 2LL * 4 * ctx->prop.multiProcessorCount) ki = kmw8;
         }
+        if (seed && getenv("C4GPU_TRACE")) fprintf(stderr, "c4gpu trace:   seeded pass %d with kernel %s\n", seed->mode, ki->name);
         // longest first (persistent waves pull from the queue head)
         std::vector<int> &order = h_order;
         order.resize(n);

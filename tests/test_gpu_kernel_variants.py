@@ -269,6 +269,8 @@ def test_windowed_region_pass_matches_oracle(eng, monkeypatch, capfd, model_type
     alns = eng.find_path(model, pairs, dpmemory=dpm, threshold=20)
     err = capfd.readouterr().err
     assert "windowed region pass" in err, "these inputs no longer take the two-pass route:\n" + err[-800:]
+    # the score pass of the scheme is the packed 16-bit kernel (two jobs per lane) for the family that has one
+    assert ("kernel kpk16_" in err) == (model_type == "est2genome"), err[-800:]
     for (q, t), a in zip(pairs, alns):
         exp = oracle_lib.find_path(model.c, model.params, q.encode(), t.encode(), dpmemory=dpm, threshold=20)
         assert (a.as_dict() if a else None) == exp
