@@ -259,13 +259,25 @@ gboolean shim_sdp_collect(GAM *gam, Comparison *comparison){
     p->gam = GAM_share(gam);
     p->comparison = Comparison_share(comparison);
     g_ptr_array_add(sdp_pending, p);
-    /* the device passes visit, like the reference's scheduler, only the cells inside the X-drop and keep ~25 bytes of
-     * traceback per visited cell in an arena that c4gpu_sdp_batch sizes itself; what a flush stages per pair are the
-     * sequences (shared ones once): a flush is cut when the distinct residues pass C4GPU_BATCH_GB / 20 (splice arrays and
-     * codes are ~20 bytes per target residue) */
+    /* the device passes visit, like the reference's scheduler, only the cells inside the X-drop and keep their traceback
+     * in an arena of 64 KB chunks: measured 7 chunks per seed + 0.25 per HSP position (both flavours, c4_sdp_dev.inc); a
+     * flush is cut when that estimate (x 1.3) or the staged residues (~20 bytes per residue with codes and splice arrays)
+     * pass C4GPU_BATCH_GB, so that one flush's arena stays an allocation of tens of GB */
+    {
+        register GArray *hsps = g_array_new(FALSE, FALSE, sizeof(c4gpu_hsp));
+        gint qa, ta;
+        register guint k;
+        register gdouble positions = 0.0;
+        if(sdp_gather_hsps(comparison, hsps, &qa, &ta)){
+            for(k = 0; k < hsps->len; k++)
+                positions += g_array_index(hsps, c4gpu_hsp, k).length;
+            sdp_pending_bytes += 1.3 * 65536.0 * (7.0 * hsps->len + 0.25 * positions);
+            }
+        g_array_free(hsps, TRUE);
+    }
     sdp_pending_bytes += 20.0 * (comparison->query->len + comparison->target->len);
     if(((gint)sdp_pending->len >= shim_batch_size())
-    || (sdp_pending_bytes > (g_getenv("C4GPU_BATCH_GB") ? atof(g_getenv("C4GPU_BATCH_GB")) : 96.0) * 1e9))
+    || (sdp_pending_bytes > (g_getenv("C4GPU_BATCH_GB") ? atof(g_getenv("C4GPU_BATCH_GB")) : 64.0) * 1e9))
         shim_sdp_flush();
     return TRUE;
     }
