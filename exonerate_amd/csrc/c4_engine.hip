@@ -22,6 +22,7 @@
 
 #include "c4gpu.h"
 #include "c4_internal.h"
+#include "c4_memrule.h"
 #include "c4_launch.h"
 #include "c4_sdp_launch.h"
 #include "c4_sdp_host.h"
@@ -363,6 +364,120 @@ __global__ void subopt_colptr_kernel(const DevJob *jobs, int n_jobs, const int *
     }
 }
 
+// ---- sub-alignments of a checkpoint pass, listed and stitched on the device -------------------------------------
+// Optimal_find_path_reduced_space (optimal.c:160-230) turns the checkpoint traceback of a region into a list of
+// Viterbi_SubAlignments and Optimal_compute_subalignments (optimal.c:266-313) runs one FIND_PATH continuation per entry,
+// each seeded with the final cell of the one before it.  A batch of 4 096 pairs of 1 kb x 1 kb under -D 32 has 778 443 of
+// them: describing them on the host, uploading the descriptions and unpacking as many results was two thirds of a pass.
+// The three kernels below keep that list on the device: the checkpoint kernel's DevVsa records become DevJobs
+// (expand), the path kernel runs them, and one thread per pair checks every predicted final cell against the computed
+// one and concatenates the runs in path order with Alignment_add's merge rule (stitch).  Pairs the fast route cannot
+// finish (a section that itself needs checkpoints, a final cell that differs from its prediction, no END) are flagged
+// and take the host route of find_path_batch.
+enum { FUSE_MAX_OPS_CAP = 0, FUSE_MAX_TB, FUSE_MAX_T, FUSE_MAX_STRIPS, FUSE_OPS_TOTAL, FUSE_STATS };
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(v, off); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// one workgroup (one wave) per checkpoint job x; its children are out[first[x]] .. out[first[x + 1] - 1] in path order
+__global__ __launch_bounds__(64) void fuse_expand_kernel(const DevJob *parents, const DevVsa *vsa, const int *first, int n_parents,
+                                                         DevJob *out, c4h::MemRule rule, int dpmemory_mb, int path_R,
+                                                         int *flags, unsigned long long *stats) {
+    const int x = blockIdx.x;
+    if (x >= n_parents) return;
+    const DevJob &pj = parents[x];
+    const int base = first[x], cnt = first[x + 1] - base;
+    unsigned long long m_cap = 0, m_tb = 0, m_T = 0, m_strips = 0, ops = 0;
+    bool nested = false;
+    for (int k = threadIdx.x; k < cnt; k += 64) {
+        const DevVsa &dv = vsa[pj.vsa_off + (cnt - 1 - k)];              // the list is last section first
+        DevJob j;
+        memset(&j, 0, sizeof j);
+        j.pair = pj.pair; j.q0 = dv.qs; j.t0 = dv.ts; j.Q = dv.ql; j.T = dv.tl;
+        j.first_state = dv.first_state;
+        // optimal.c:204-213,283-301: first cell = final cell of the sub-alignment before it (the parent's first cell for
+        // the first one), final state = first state of the next one (the parent's final state for the last one)
+        j.final_state = (k + 1 < cnt) ? vsa[pj.vsa_off + (cnt - 2 - k)].first_state : pj.final_state;
+        const int *fc = k > 0 ? vsa[pj.vsa_off + (cnt - k)].final_cell : pj.first_cell;
+        for (int l = 0; l < CELL_MAX; l++) j.first_cell[l] = fc[l];
+        int tb = 0;
+        while ((1LL << tb) <= j.T) tb++;
+        j.tshift = tb;
+        j.ckpt_off = -1; j.seed_off = -1;
+        j.ops_cap = 3 * (j.Q + j.T) + 16;
+        out[base + k] = j;
+        nested |= c4h::use_reduced_space(rule, dv.ql, dv.tl, dpmemory_mb);
+        const unsigned long long strips = (unsigned long long)(j.Q + 1 + 64 * path_R - 1) / (unsigned long long)(64 * path_R);
+        const unsigned long long tbw = strips * (unsigned long long)(j.T + 64) * 64ull * (unsigned long long)path_R;
+        m_cap = m_cap > (unsigned long long)j.ops_cap ? m_cap : (unsigned long long)j.ops_cap;
+        m_tb = m_tb > tbw ? m_tb : tbw;
+        m_T = m_T > (unsigned long long)j.T ? m_T : (unsigned long long)j.T;
+        m_strips = m_strips > strips ? m_strips : strips;
+        ops += (unsigned long long)j.ops_cap;
+    }
+    m_cap = wave_max_u64(m_cap); m_tb = wave_max_u64(m_tb); m_T = wave_max_u64(m_T); m_strips = wave_max_u64(m_strips);
+    ops = wave_sum_u64(ops);
+    const bool any_nested = __builtin_amdgcn_ballot_w64(nested) != 0;
+    if (threadIdx.x == 0) {
+        if (any_nested) flags[x] = 1;
+        atomicMax(&stats[FUSE_MAX_OPS_CAP], m_cap); atomicMax(&stats[FUSE_MAX_TB], m_tb); atomicMax(&stats[FUSE_MAX_T], m_T);
+        atomicMax(&stats[FUSE_MAX_STRIPS], m_strips); atomicAdd(&stats[FUSE_OPS_TOTAL], ops);
+    }
+}
+
+struct FusePair { long long off; int count, status; };      // merged (transition, length) pairs at out[2 * off ..]; status 0 = done
+
+// one thread per checkpoint job: verify the chain of final cells, then Alignment_add (alignment.c:75-102) over the runs
+// of its sub-alignments in path order (each job's walk wrote its runs END -> START)
+__global__ void fuse_stitch_kernel(const DevJob *parents, const DevVsa *vsa, const int *first, int n_parents,
+                                   const DevResult *sub, const uint32_t *runs, int path_cs, const int *flags,
+                                   unsigned long long *out_used, int *out, FusePair *pairs) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n_parents) return;
+    FusePair fp; fp.off = 0; fp.count = 0; fp.status = 1;
+    const int base = first[x], cnt = first[x + 1] - base;
+    if (flags[x] || cnt == 0) { pairs[x] = fp; return; }
+    const DevJob &pj = parents[x];
+    long long total = 0;
+    bool bad = false;
+    for (int k = 0; k < cnt; k++) {
+        const DevResult &r = sub[base + k];
+        if (r.flags & (FLAG_OPS_OVERFLOW | FLAG_NO_END)) { bad = true; break; }
+        total += r.n_ops;
+        // the next sub-alignment was seeded with the predicted cell: it must be the one this one produced
+        if (k + 1 < cnt) {
+            const int *pred = vsa[pj.vsa_off + (cnt - 1 - k)].final_cell;
+            for (int l = 0; l < path_cs; l++) bad |= (r.final_cell[l] != pred[l]);
+            if (bad) break;
+        }
+    }
+    if (bad) { pairs[x] = fp; return; }
+    const long long off = (long long)atomicAdd(out_used, (unsigned long long)total);
+    int *o = out + 2 * off;
+    int n = 0;
+    for (int k = 0; k < cnt; k++) {
+        const DevResult &r = sub[base + k];
+        const uint32_t *w = runs + r.ops_off;
+        for (int q = r.n_ops - 1; q >= 0; q--) {
+            const int tr = (int)(w[q] >> 24), len = (int)(w[q] & 0xffffff);
+            if (n && o[2 * (n - 1)] == tr) {
+                o[2 * (n - 1) + 1] += len;
+                if (o[2 * (n - 1) + 1] == 0) n--;
+            } else {
+                o[2 * n] = tr; o[2 * n + 1] = len; n++;
+            }
+        }
+    }
+    fp.off = off; fp.count = n; fp.status = 0;
+    pairs[x] = fp;
+}
+
 struct ResidentSeqs {
     int n_pairs = 0;
     std::vector<long long> qoff, toff;
@@ -372,6 +487,9 @@ struct ResidentSeqs {
     DevBuf<long long> d_qoff, d_toff;
     DevBuf<int> d_qlen, d_tlen, ss;
     DevBuf<uint16_t> tn4;
+    mutable DevBuf<uint2> ss16;            // the packed score pass's splice values (built on its first launch over this batch)
+    mutable bool ss16_built = false;
+    long long ss_len = 0;                 // positions per splice array
     DevBuf<PrepTables> tables;
     DevBuf<c4gpu_splice_model> splice_models;
     DevBuf<int> bad;
@@ -467,13 +585,16 @@ struct ResidentSeqs {
             hipLaunchKernelGGL(encode_kernel, dim3(blocks), dim3(256), 0, s, traw.p, tcode.p, (long long)ht.size(), tables.p, bad.p);
         }
         dev.ss = nullptr;
+        dev.ss16 = nullptr;
         dev.ss_stride = 0;
+        ss16_built = false;
         if (family_has_splice(family)) {
             if (splice_models.upload(params->splice, 4, s) || ss.alloc((size_t)4 * ht.size())) return -1;
             hipLaunchKernelGGL(splice_kernel, dim3(xb, yb, 4), dim3(256), 0, s, traw.p, d_utoff.p, d_utlen.p, n_utargets,
                                splice_models.p, ss.p, (long long)ht.size());
             dev.ss = ss.p;
             dev.ss_stride = (long long)ht.size();
+            ss_len = (long long)ht.size();
         }
         dev.tn4 = nullptr;
         if (family_has_phase(family)) {
@@ -569,6 +690,17 @@ struct Engine {
     DevBuf<int> d_bnd, d_ckpt, d_ckpt_dump, d_queue;
     DevBuf<uint32_t> d_tb;
     DevBuf<int> d_sub_t, d_sub_q, d_sub_colptr, d_span, d_seed;
+    // fused_reduced_paths: checkpoint jobs, their results and sub-alignment lists, the sub-alignment jobs built from them
+    DevBuf<DevJob> d_fjobs, d_fsub_jobs;
+    DevBuf<DevResult> d_fres, d_fsub_res;
+    DevBuf<DevVsa> d_fvsa;
+    DevBuf<int> d_ffirst, d_fflags, d_fout;
+    DevBuf<unsigned long long> d_fstats;
+    DevBuf<FusePair> d_fpairs;
+    std::vector<DevJob> hf_jobs;
+    std::vector<DevResult> hf_res;
+    std::vector<int> hf_first, hf_flags, hf_out;
+    std::vector<FusePair> hf_pairs;
     // reusable host staging of run_impl (a sub-alignment launch lists ~10^5 jobs: fresh vectors of that size
     // are page-faulted in on every call)
     std::vector<int> h_order;
@@ -728,12 +860,18 @@ struct Engine {
             if (!ki || !use_local || (mode == MODE_REGION && !pack)) { c4h::set_error("no seeded kernel for this launch"); return -1; }
             // the score pass with dumps: two jobs per lane in packed 16-bit halves where every score fits (C4GPU_PK16=0: never)
             const int pk_env = getenv("C4GPU_PK16") ? atoi(getenv("C4GPU_PK16")) : 1;      // read on every call: a test switches it
-            const KernelInfo *kpk = (seed->mode == 1 && pk_env && pk16_params_ok && n >= 2) ? get_kernel_pk16(family) : nullptr;
+            const KernelInfo *kpk = (seed->mode == 1 && pk_env && pk16_params_ok && n >= 2) ? get_kernel_pk16(family, pk_env == 2 ? 1 : 0) : nullptr;
             if (kpk) {
                 bool fits = true;
                 for (int i = 0; i < n && fits; i++)
                     fits = (double)(specs[i].region.query_length + 1) * pk16_match_max <= 16000.0 &&
                            (!family_has_splice(family) || (long long)specs[i].region.target_length + 4 <= (long long)pk16_max_intron);
+                if (fits && pk_env == 2 && !seqs.ss16_built) {
+                    // variant 1 reads the four splice values of a column as one packed 8-byte entry: built once per batch
+                    if (seqs.ss16.alloc((size_t)seqs.ss_len)) return -1;
+                    HIP_OK(pk16_build_splice(family, kparams.p, seqs.dev.ss, seqs.dev.ss_stride, seqs.ss_len, seqs.ss16.p, ctx->stream));
+                    seqs.ss16_built = true;
+                }
                 if (fits) ki = kpk;
             }
         } else if (mw_env && !cont && (mode == MODE_SCORE || mode == MODE_REGION)) {
@@ -891,6 +1029,7 @@ struct Engine {
                 HIP_OK(hipGetLastError());
                 a.seqs.sub_colptr = d_sub_colptr.p; a.seqs.sub_rows = d_sub_q.p;
             }
+            a.seqs.ss16 = seqs.ss16_built ? seqs.ss16.p : nullptr;
             a.seqs.seed = nullptr;
             if (seed) {
                 if (seed->mode == 1 && d_seed.alloc((size_t)std::max<long long>(seed_total, 1))) return -1;
@@ -1042,6 +1181,196 @@ int sequential_reduced_path(Engine &eng, const ResidentSeqs &seqs, int pair, int
         memcpy(leaves[k].final_cell, outs[0].res.final_cell, sizeof(int) * CELL_MAX);   // optimal.c:243,301
         for (uint32_t r : outs[0].runs) c4h::alignment_add(a, &cap, (int)(r >> 24), (int)(r & 0xffffff));
     }
+    return 0;
+}
+
+// Steps 3 and 4 of find_path_batch for the pairs in `red` without the host in between (see fuse_expand_kernel): one
+// checkpoint launch, one sub-alignment launch, one stitch; done[i] = 1 for every pair whose alignment was completed
+// here.  The others (and every pair when the route does not apply) are left untouched for the host route.
+int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector<int> &red, const std::vector<PairPlan> &plan,
+                        int dpmemory_mb, c4gpu_alignment *alignments, std::vector<char> &done) {
+    static const bool trace = getenv("C4GPU_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (trace) fprintf(stderr, "c4gpu trace:   fused: %-22s at %.3f ms\n", what,
+                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    };
+    const c4gpu_model *m = eng.model;
+    c4gpu_ctx *ctx = eng.ctx;
+    const int n = (int)red.size();
+    if (!n || eng.pair_sub) return 0;
+    if (getenv("C4GPU_FUSED") && atoi(getenv("C4GPU_FUSED")) == 0) return 0;         // read on every call: a test switches it
+    static const int wpe_env = getenv("C4GPU_WPE") ? atoi(getenv("C4GPU_WPE")) : 0;
+    const KernelInfo *kc = get_kernel(eng.family, MODE_CKPT, true, false, false, wpe_env, false, 0);
+    const KernelInfo *kp = get_kernel(eng.family, MODE_PATH, true, false, false, wpe_env, false, 0);
+    if (!kc || !kp) return 0;
+    hipStream_t s = ctx->stream;
+    const c4h::MemRule rule{m->max_query_advance, m->max_target_advance, m->n_states, m->total_shadow_designations};
+    // -- the checkpoint jobs, longest first (persistent waves pull from the queue head)
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    auto cells = [&](int x) { const c4gpu_region &r = plan[red[x]].ar; return (long long)(r.query_length + 1) * (r.target_length + 1); };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cells(a) > cells(b); });
+    std::vector<DevJob> &jobs = eng.hf_jobs;
+    jobs.resize(n);
+    long long vsa_total = 0, max_ckpt = 0, max_T = 0, ckpt_cells = 0;
+    bool carry = false;
+    for (int x = 0; x < n; x++) {
+        const c4gpu_region &r = plan[red[order[x]]].ar;
+        DevJob &j = jobs[x];
+        memset(&j, 0, sizeof j);
+        j.pair = red[order[x]]; j.q0 = r.query_start; j.t0 = r.target_start; j.Q = r.query_length; j.T = r.target_length;
+        j.first_state = m->start_state; j.final_state = m->end_state;
+        j.cp_count = c4h::checkpoint_rows(m, &r, dpmemory_mb);
+        int tb = 0;
+        while ((1LL << tb) <= j.T) tb++;
+        j.tshift = tb;
+        j.ckpt_off = -1; j.seed_off = -1;
+        j.vsa_off = (int)vsa_total;
+        vsa_total += j.cp_count + 1;
+        max_ckpt = std::max(max_ckpt, (long long)j.cp_count * kc->max_at * (j.Q + 1) * kc->n_states * kc->cs);
+        max_T = std::max<long long>(max_T, j.T);
+        ckpt_cells += (long long)(j.Q + 1) * (j.T + 1);
+        if ((j.Q + 1 + 64 * kc->R - 1) / (64 * kc->R) > kc->waves) carry = true;
+    }
+    if (vsa_total > 0x7fffffffLL) return 0;
+    auto grid_for = [&](const KernelInfo *ki, long long jobs_n, long long bytes_per_wave) -> long long {
+        int blocks_per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, ki->func, 64 * ki->waves, 0) != hipSuccess || blocks_per_cu < 1)
+            blocks_per_cu = 1;
+        long long grid = std::min<long long>(jobs_n, (long long)blocks_per_cu * ctx->prop.multiProcessorCount);
+        const long long budget = (long long)(ctx->prop.totalGlobalMem / 4);
+        if (bytes_per_wave * grid > budget) grid = std::max<long long>(1, budget / std::max<long long>(1, bytes_per_wave));
+        return grid;
+    };
+    int zero = 0;
+    unsigned long long zero64 = 0;
+    {
+        const long long bnd_per_wave = (2 * ((carry ? max_T : 0) + 1) + 1) * (long long)std::max(kc->bnd, 1);
+        const long long grid = grid_for(kc, n, bnd_per_wave * 4 + max_ckpt * 4);
+        if (eng.d_fjobs.upload(jobs.data(), n, s) || eng.d_fres.alloc(n) || eng.d_queue.upload(&zero, 1, s) ||
+            eng.d_bnd.alloc(bnd_per_wave * grid) || eng.d_fvsa.alloc(vsa_total) || eng.d_ckpt.alloc(max_ckpt * grid) ||
+            eng.d_ckpt_dump.alloc(1))
+            return -1;
+        LaunchArgs a;
+        memset(&a.scratch, 0, sizeof a.scratch);
+        a.kp = eng.kparams.p; a.seqs = seqs.dev; a.jobs = eng.d_fjobs.p; a.n_jobs = n; a.results = eng.d_fres.p;
+        a.seqs.sub_colptr = nullptr; a.seqs.sub_rows = nullptr; a.seqs.span_in = nullptr; a.seqs.span_out = nullptr;
+        a.seqs.seed = nullptr;
+        a.vsas = eng.d_fvsa.p; a.ops = nullptr; a.queue = eng.d_queue.p; a.grid = (int)grid; a.stream = s;
+        a.scratch.bnd = eng.d_bnd.p; a.scratch.bnd_stride = bnd_per_wave; a.scratch.carry = carry ? 1 : 0;
+        a.scratch.ckpt = max_ckpt ? eng.d_ckpt.p : nullptr; a.scratch.ckpt_stride = max_ckpt;
+        a.scratch.ckpt_dump = eng.d_ckpt_dump.p;
+        if (ctx->timing) HIP_OK(hipEventRecord(ctx->ev0, s));
+        HIP_OK(kc->launch(a));
+        if (ctx->timing) HIP_OK(hipEventRecord(ctx->ev1, s));
+    }
+    std::vector<DevResult> &res = eng.hf_res;
+    res.resize(n);
+    if (eng.d_fres.download(res.data(), n, s)) return -1;
+    HIP_OK(hipStreamSynchronize(s));
+    if (ctx->timing) {
+        float ms = 0;
+        HIP_OK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        ctx->kernel_ms[MODE_CKPT] += ms; ctx->kernel_launches[MODE_CKPT]++; ctx->kernel_cells[MODE_CKPT] += ckpt_cells;
+    }
+    lap("checkpoint pass");
+    // -- the sub-alignment jobs, on the device
+    std::vector<int> &first = eng.hf_first;
+    first.assign(n + 1, 0);
+    for (int x = 0; x < n; x++) first[x + 1] = first[x] + ((res[x].flags & FLAG_NO_END) ? 0 : res[x].n_vsa);
+    const long long n_sub = first[n];
+    if (!n_sub) return 0;
+    std::vector<unsigned long long> stats(FUSE_STATS, 0);
+    if (eng.d_ffirst.upload(first.data(), n + 1, s) || eng.d_fsub_jobs.alloc(n_sub) || eng.d_fflags.alloc(n) ||
+        eng.d_fstats.upload(stats.data(), FUSE_STATS, s))
+        return -1;
+    HIP_OK(hipMemsetAsync(eng.d_fflags.p, 0, sizeof(int) * n, s));
+    hipLaunchKernelGGL(fuse_expand_kernel, dim3(n), dim3(64), 0, s, eng.d_fjobs.p, eng.d_fvsa.p, eng.d_ffirst.p, n,
+                       eng.d_fsub_jobs.p, rule, dpmemory_mb, kp->R, eng.d_fflags.p, eng.d_fstats.p);
+    HIP_OK(hipGetLastError());
+    if (eng.d_fstats.download(stats.data(), FUSE_STATS, s)) return -1;
+    HIP_OK(hipStreamSynchronize(s));
+    lap("jobs listed");
+    const long long max_runs = (long long)stats[FUSE_MAX_OPS_CAP], max_tb = (long long)stats[FUSE_MAX_TB];
+    const long long sub_T = (long long)stats[FUSE_MAX_T], ops_total = (long long)stats[FUSE_OPS_TOTAL];
+    const bool sub_carry = (long long)stats[FUSE_MAX_STRIPS] > kp->waves;
+    const long long bnd_per_wave = (2 * ((sub_carry ? sub_T : 0) + 1) + 1) * (long long)std::max(kp->bnd, 1);
+    const long long grid = grid_for(kp, n_sub, bnd_per_wave * 4 + max_tb * 4 + max_runs * 4);
+    long long runs_capacity = std::min<long long>(ops_total, std::max<long long>(1 << 20, n_sub * 256));
+    unsigned long long used = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (eng.d_fsub_res.alloc(n_sub) || eng.d_queue.upload(&zero, 1, s) || eng.d_runs_used.upload(&zero64, 1, s) ||
+            eng.d_bnd.alloc(bnd_per_wave * grid) || eng.d_runs.alloc(max_runs * grid) || eng.d_runs_out.alloc(runs_capacity) ||
+            eng.d_tb.alloc(max_tb * grid))
+            return -1;
+        LaunchArgs a;
+        memset(&a.scratch, 0, sizeof a.scratch);
+        a.kp = eng.kparams.p; a.seqs = seqs.dev; a.jobs = eng.d_fsub_jobs.p; a.n_jobs = (int)n_sub; a.results = eng.d_fsub_res.p;
+        a.seqs.sub_colptr = nullptr; a.seqs.sub_rows = nullptr; a.seqs.span_in = nullptr; a.seqs.span_out = nullptr;
+        a.seqs.seed = nullptr;
+        a.vsas = nullptr; a.ops = nullptr; a.queue = eng.d_queue.p; a.grid = (int)grid; a.stream = s;
+        a.scratch.bnd = eng.d_bnd.p; a.scratch.bnd_stride = bnd_per_wave; a.scratch.carry = sub_carry ? 1 : 0;
+        a.scratch.tb = max_tb ? eng.d_tb.p : nullptr; a.scratch.tb_stride = max_tb;
+        a.scratch.runs = eng.d_runs.p; a.scratch.runs_stride = max_runs;
+        a.scratch.runs_out = eng.d_runs_out.p; a.scratch.runs_capacity = runs_capacity;
+        a.scratch.runs_used = eng.d_runs_used.p;
+        if (ctx->timing) HIP_OK(hipEventRecord(ctx->ev0, s));
+        HIP_OK(kp->launch(a));
+        if (ctx->timing) HIP_OK(hipEventRecord(ctx->ev1, s));
+        if (eng.d_runs_used.download(&used, 1, s)) return -1;
+        HIP_OK(hipStreamSynchronize(s));
+        if (ctx->timing) {
+            float ms = 0;
+            HIP_OK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            ctx->kernel_ms[MODE_PATH] += ms; ctx->kernel_launches[MODE_PATH]++;
+        }
+        if ((long long)used <= runs_capacity) break;
+        if (attempt == 1) { c4h::set_error("traceback runs exceed their worst-case buffer"); return -1; }
+        runs_capacity = ops_total;                           // rare: paths with very short runs
+    }
+    lap("sub-alignment pass");
+    // -- verify + concatenate per pair
+    if (eng.d_fout.alloc(2 * (size_t)std::max<unsigned long long>(used, 1)) || eng.d_fpairs.alloc(n) ||
+        eng.d_runs_used.upload(&zero64, 1, s))
+        return -1;
+    hipLaunchKernelGGL(fuse_stitch_kernel, dim3((n + 63) / 64), dim3(64), 0, s, eng.d_fjobs.p, eng.d_fvsa.p, eng.d_ffirst.p, n,
+                       eng.d_fsub_res.p, eng.d_runs_out.p, 1 + m->total_shadow_designations, eng.d_fflags.p, eng.d_runs_used.p,
+                       eng.d_fout.p, eng.d_fpairs.p);
+    HIP_OK(hipGetLastError());
+    std::vector<FusePair> &fps = eng.hf_pairs;
+    fps.resize(n);
+    unsigned long long out_used = 0;
+    if (eng.d_fpairs.download(fps.data(), n, s) || eng.d_runs_used.download(&out_used, 1, s)) return -1;
+    HIP_OK(hipStreamSynchronize(s));
+    std::vector<int> &out = eng.hf_out;
+    out.resize(2 * (size_t)out_used);
+    if (out_used) {
+        if (eng.d_fout.download(out.data(), 2 * (size_t)out_used, s)) return -1;
+        HIP_OK(hipStreamSynchronize(s));
+    }
+    lap("stitched + downloaded");
+    int n_done = 0;
+    for (int x = 0; x < n; x++) {
+        if (fps[x].status != 0) continue;
+        const int i = red[order[x]];
+        c4gpu_alignment &a = alignments[i];
+        a.score = res[x].score;
+        a.region = plan[i].ar;
+        a.valid = 1;
+        a.n_ops = fps[x].count;
+        if (a.n_ops) {
+            a.op_transition = (int32_t *)malloc(sizeof(int32_t) * a.n_ops);
+            a.op_length = (int32_t *)malloc(sizeof(int32_t) * a.n_ops);
+            const int *src = out.data() + 2 * fps[x].off;
+            for (int k = 0; k < a.n_ops; k++) { a.op_transition[k] = src[2 * k]; a.op_length[k] = src[2 * k + 1]; }
+        }
+        done[i] = 1;
+        n_done++;
+    }
+    if (getenv("C4GPU_TRACE"))               // read on every call: a test switches it on
+        fprintf(stderr, "c4gpu trace:   fused: %d of %d pairs finished on the device route, %lld sub-alignments\n", n_done, n, n_sub);
+    lap("alignments built");
     return 0;
 }
 
@@ -1312,6 +1641,15 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
             plan[i].segs.assign(1, s);
             red.push_back(i);
         }
+    if (!red.empty() && !subs) {
+        // the device route first: whatever it finishes leaves the list
+        std::vector<char> done(n, 0);
+        if (fused_reduced_paths(eng, seqs, red, plan, dpmemory_mb, alignments, done)) return -1;
+        std::vector<int> rest;
+        for (int i : red) if (!done[i]) rest.push_back(i);
+        red.swap(rest);
+        lap("device route done");
+    }
     std::vector<c4gpu_score> red_score(n, 0);
     std::vector<char> redo(n, 0);
     bool first_round = true;

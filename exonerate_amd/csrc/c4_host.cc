@@ -10,61 +10,22 @@
 
 #include "c4gpu.h"
 #include "c4_internal.h"
+#include "c4_memrule.h"
 
 namespace c4h {
 
-// Matrix3d_size / Matrix4d_size (exonerate src/struct/matrix.c:74-100,137-171): index blocks + data with
-// the "+= size % sizeof(pointer)" padding rule and the floating-point overflow probe.
-static size_t matrix3d_bytes(int a, int b, int c, size_t cell) {
-    const size_t P = sizeof(void *);
-    unsigned long block = b * P + (unsigned long)b * (c * cell);
-    double dblock = (double)(b * P) + (double)b * (double)(c * cell);
-    block += block % P;
-    dblock += (double)(block % P);
-    unsigned long total = a * P + (unsigned long)a * block;
-    double dtotal = (double)(a * P) + (double)a * dblock;
-    return (dtotal - (double)total) > 1 ? 0 : total;
-}
-
-static size_t matrix4d_bytes(int a, int b, int c, int d, size_t cell) {
-    const size_t P = sizeof(void *);
-    unsigned long block = c * P + (unsigned long)c * (d * cell);
-    double dblock = (double)(c * P) + (double)c * (double)(d * cell);
-    block += block % P;
-    dblock += (double)(block % P);
-    unsigned long sheet = b * P + (unsigned long)b * block;
-    double dsheet = (double)(b * P) + (double)b * dblock;
-    sheet += sheet % P;
-    dsheet += (double)(sheet % P);
-    unsigned long total = a * P + (unsigned long)a * sheet;
-    double dtotal = (double)(a * P) + (double)a * dsheet;
-    return (dtotal - (double)total) > 1 ? 0 : total;
-}
-
-// Viterbi_get_row_size (viterbi.c:108-118): the matrix size passes through a gint
-static size_t viterbi_row_bytes(const c4gpu_model *m, const c4gpu_region *r, int cell_size) {
-    const int mat = (int)matrix4d_bytes(m->max_target_advance + 1, r->query_length + 1, m->n_states, cell_size,
-                                        sizeof(c4gpu_score));
-    if (!mat) return 0;
-    return (size_t)24 /* sizeof(Viterbi_Row) */ + (size_t)mat;
+// the reference's memory rule itself is in c4_memrule.h (shared with the device code, which lists the sub-alignment
+// jobs of a checkpoint pass without the host)
+static MemRule rule_of(const c4gpu_model *m) {
+    return MemRule{m->max_query_advance, m->max_target_advance, m->n_states, m->total_shadow_designations};
 }
 
 bool use_reduced_space(const c4gpu_model *m, const c4gpu_region *r, int dpmemory_mb) {
-    if (r->query_length <= m->max_query_advance * 6) return false;
-    if (r->target_length <= m->max_target_advance * 6) return false;
-    const size_t rows = viterbi_row_bytes(m, r, 1 + m->total_shadow_designations);
-    const size_t traceback = matrix3d_bytes(r->query_length + 1, r->target_length + 1, m->n_states, sizeof(void *));
-    const size_t limit = (size_t)(dpmemory_mb << 20);
-    if (!rows || !traceback) return true;
-    return rows + traceback > limit;
+    return use_reduced_space(rule_of(m), r->query_length, r->target_length, dpmemory_mb);
 }
 
 int checkpoint_rows(const c4gpu_model *m, const c4gpu_region *r, int dpmemory_mb) {
-    const size_t rows = viterbi_row_bytes(m, r, 1 + m->total_shadow_designations + 1);
-    const int avail = (int)(((size_t)(dpmemory_mb << 20)) / rows - 1);
-    const int max_rows = r->target_length / (m->max_target_advance << 1) - 2;
-    if (avail < 1) return 1;
-    return avail < max_rows ? avail : max_rows;
+    return checkpoint_rows(rule_of(m), r->query_length, r->target_length, dpmemory_mb);
 }
 
 // Alignment_add (alignment.c:75-102): run-length merge of equal consecutive transitions

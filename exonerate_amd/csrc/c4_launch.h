@@ -60,7 +60,8 @@ const KernelInfo *get_kernel_mw(int family, int mode, bool local, bool pack, int
 
 // the packed 16-bit score pass with column dumps (c4_viterbi16_kernel.h): two jobs per lane; NULL = not compiled for the family.
 // Launched over the same job / result arrays as the 32-bit kernel (workgroup p runs jobs 2p and 2p + 1).
-const KernelInfo *get_kernel_pk16(int family);
+const KernelInfo *get_kernel_pk16(int family, int variant = 0);
+hipError_t pk16_build_splice(int family, const KParams *kp, const int *ss, long long ss_stride, long long n, void *out, hipStream_t s);
 
 #define C4K_DEFINE_KERNEL_SPAN(SYMBOL, M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV, SPANV)                                          \
     static hipError_t SYMBOL##_launch(const LaunchArgs &a) {                                               \

@@ -32,18 +32,38 @@ namespace c4k {
 // inline asm keeps each of these ONE instruction: the builtin forms (__builtin_elementwise_add_sat on short2 ...) are folded
 // into per-half compares and selects around the mask logic and cost 8 % of the pass; operands in VGPRs: with the launch
 // constants as scalar operands the kernel spills 62 SGPRs and is 2 % slower (measured, profiles/r03_pk16.md)
-__device__ __forceinline__ int pk_add(int a, int b) { int r; asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
+typedef short pk_s2 __attribute__((ext_vector_type(2)));
+// VAR 0: every packed instruction is its own asm statement.  VAR 1: add / max through clang's vector builtins and the
+// "a < b per half" mask as ONE asm statement: the compiler's hazard pass puts a wait state (s_nop) between two dependent asm
+// statements that follow each other (it cannot see that they write whole registers), 58 of them per step in the VAR 0 form
+template <int VAR> __device__ __forceinline__ int pk_add(int a, int b) {
+    if constexpr (VAR == 1) return __builtin_bit_cast(int, __builtin_elementwise_add_sat(__builtin_bit_cast(pk_s2, a), __builtin_bit_cast(pk_s2, b)));
+    else { int r; asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
+}
+template <int VAR> __device__ __forceinline__ int pk_max(int a, int b) {
+    if constexpr (VAR == 1) return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(pk_s2, a), __builtin_bit_cast(pk_s2, b)));
+    else { int r; asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+}
 __device__ __forceinline__ int pk_sub(int a, int b) { int r; asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ int pk_max(int a, int b) { int r; asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // per half: 0xffff where the half is negative, else 0
 __device__ __forceinline__ int pk_neg_mask(int d, int fifteen) { int r; asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(r) : "v"(fifteen), "v"(d)); return r; }
+// per half: 0xffff where a < b (the saturating difference is negative), else 0
+template <int VAR> __device__ __forceinline__ int pk_lt_mask(int a, int b, int fifteen) {
+    if constexpr (VAR == 1) {
+        int r;
+        asm("v_pk_sub_i16 %0, %1, %2 clamp\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=&v"(r) : "v"(a), "v"(b));
+        return r;
+    } else {
+        return pk_neg_mask(pk_sub(a, b), fifteen);
+    }
+}
 __device__ __forceinline__ int pk_pack(int lo, int hi) { return (int)__builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
 __device__ __forceinline__ int pk_half(int x, int h) { return h ? (x >> 16) : ((x << 16) >> 16); }
 __device__ __forceinline__ int clamp16(int x) { return x < -32768 ? -32768 : (x > 32767 ? 32767 : x); }
 
 constexpr int NEG16 = (int)0x80008000u;          // -32 768 in both halves
 
-template <class M, int R>
+template <class M, int R, int VAR = 0>
 struct WaveDP16 {
     using F = Facts<M>;
     using W32 = WaveDP<M, R, MODE_SCORE, false, true, false, false, 0, 1>;     // the 32-bit score pass: dump layout
@@ -63,6 +83,7 @@ struct WaveDP16 {
     // per job (0 = low half, 1 = high half)
     const uint8_t *qc[2], *tc[2];
     const int *ss[2];
+    const uint2 *ss16[2];             // VAR 1: the four splice values of a column in one 8-byte load (ss16_kernel)
     long long ss_stride;
     int Q[2], T[2], q0[2], t0[2], tlast[2], seed_rows[2], seed_kshift;
     int *seed_wr[2];
@@ -71,6 +92,7 @@ struct WaveDP16 {
     C16 col[NCOL][R], nbr[NCOL], expo, nx_carry;
     int qrow[2][R];
     int nx_tcode[2], nx_sp[2][4];
+    uint2 nx_sp16[2];
     lds_int *ring_in, *ring_out;
     bool use_ring_in, use_ring_out, carry_ok, carry_cols;
     int best[2], best_i[2], best_j[2], best_pk;
@@ -114,9 +136,13 @@ struct WaveDP16 {
             if constexpr (F::has_splice()) {
                 int tp = t0[H] + j - 2;
                 tp = tp < 0 ? 0 : (tp > tlast[H] ? tlast[H] : tp);
-                static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
-                    nx_sp[H][K] = ss[H][(long long)K * ss_stride + tp];
-                });
+                if constexpr (VAR == 1) {
+                    nx_sp16[H] = ss16[H][(unsigned)tp];
+                } else {
+                    static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
+                        nx_sp[H][K] = ss[H][(long long)K * ss_stride + tp];
+                    });
+                }
             }
         });
     }
@@ -133,33 +159,33 @@ struct WaveDP16 {
             else cand = src.sc[t.in];
             if constexpr (t.calc >= 0) {
                 constexpr CalcDesc cd = M::calc[t.calc];
-                if constexpr (cd.kind == CALC_CONST) cand = pk_add(cand, cv_pk[t.calc]);
-                else if constexpr (cd.kind >= CALC_MATCH_DNA && cd.kind <= CALC_MATCH_P2D) cand = pk_add(cand, ms);
-                else if constexpr (cd.kind == CALC_SPLICE_PRE) cand = pk_add(cand, sp[cd.param]);
+                if constexpr (cd.kind == CALC_CONST) cand = pk_add<VAR>(cand, cv_pk[t.calc]);
+                else if constexpr (cd.kind >= CALC_MATCH_DNA && cd.kind <= CALC_MATCH_P2D) cand = pk_add<VAR>(cand, ms);
+                else if constexpr (cd.kind == CALC_SPLICE_PRE) cand = pk_add<VAR>(cand, sp[cd.param]);
                 else if constexpr (cd.kind == CALC_SPLICE_POST) {
                     // intron length = length so far + this advance + 2 (c4_viterbi_kernel.h: (t0 + j - at) - shadow + 2); too
                     // short: the transition scores -987654321 (intron.c:150-160); too long cannot happen (T + 4 <= max_intron)
                     static_assert(live(t.in), "post-splice calc without a length");
-                    const int bad = pk_neg_mask(pk_sub(src.il[t.in], min_len_pk), fifteen);      // length so far < min - at - 2
+                    const int bad = pk_lt_mask<VAR>(src.il[t.in], min_len_pk, fifteen);      // length so far < min - at - 2
                     const int sv = (bad & NEG16) | (~bad & sp[cd.param]);
-                    cand = pk_add(cand, sv);
+                    cand = pk_add<VAR>(cand, sv);
                 }
             }
             if constexpr (!JINT && t.at > 0) cand = (j >= t.at) ? cand : NEG16;
             int ilc = 0;
             if constexpr (live(t.out)) {
                 if constexpr (F::owns_shadow(t.in, 0)) ilc = 0;
-                else if constexpr (live(t.in)) ilc = pk_add(src.il[t.in], at_pk[t.at]);
+                else if constexpr (live(t.in)) ilc = pk_add<VAR>(src.il[t.in], at_pk[t.at]);
             }
             if constexpr (F::code(K) == 1) {                     // the first transition into this state
                 c.sc[t.out] = cand;
                 if constexpr (live(t.out)) c.il[t.out] = ilc;
             } else {
                 if constexpr (live(t.out)) {
-                    const int win = pk_neg_mask(pk_sub(c.sc[t.out], cand), fifteen);          // strict <: the newcomer wins
+                    const int win = pk_lt_mask<VAR>(c.sc[t.out], cand, fifteen);          // strict <: the newcomer wins
                     c.il[t.out] = (win & ilc) | (~win & c.il[t.out]);
                 }
-                c.sc[t.out] = pk_max(c.sc[t.out], cand);
+                c.sc[t.out] = pk_max<VAR>(c.sc[t.out], cand);
             }
         });
     }
@@ -172,7 +198,14 @@ struct WaveDP16 {
             ms[RR] = pk_pack(kp->submat[qrow[0][RR] + nx_tcode[0]], kp->submat[qrow[1][RR] + nx_tcode[1]]);
         });
         int sp[4] = {0, 0, 0, 0};
-        if constexpr (F::has_splice()) {
+        if constexpr (F::has_splice() && VAR == 1) {
+            // the values arrive clamped, with the calc constant of a pre-splice transition folded in (ss16_kernel): job A's
+            // four in the halves of nx_sp16[0], job B's in nx_sp16[1]; one v_perm each puts a value of both into one register
+            sp[0] = (int)__builtin_amdgcn_perm(nx_sp16[1].x, nx_sp16[0].x, 0x05040100u);
+            sp[1] = (int)__builtin_amdgcn_perm(nx_sp16[1].x, nx_sp16[0].x, 0x07060302u);
+            sp[2] = (int)__builtin_amdgcn_perm(nx_sp16[1].y, nx_sp16[0].y, 0x05040100u);
+            sp[3] = (int)__builtin_amdgcn_perm(nx_sp16[1].y, nx_sp16[0].y, 0x07060302u);
+        } else if constexpr (F::has_splice()) {
             static_for<M::NC>([&](auto CI_) __attribute__((always_inline)) { constexpr int CI = CI_;
                 constexpr CalcDesc cd = M::calc[CI];
                 if constexpr (cd.kind == CALC_SPLICE_PRE)
@@ -193,7 +226,7 @@ struct WaveDP16 {
         // end cell (viterbi.c:778-791): a new maximum is rare; one packed maximum over the lane's cells decides
         {
             int m = col[PH][0].sc[M::END];
-            static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_; if constexpr (RR > 0) m = pk_max(m, col[PH][RR].sc[M::END]); });
+            static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_; if constexpr (RR > 0) m = pk_max<VAR>(m, col[PH][RR].sc[M::END]); });
             const bool cand = (pk_sub(best_pk, m) & NEG16) != 0;
             if (__builtin_amdgcn_ballot_w64(cand)) {
                 static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
@@ -289,6 +322,7 @@ struct WaveDP16 {
             qc[H] = seqs.qcode + seqs.qoff[jx.pair];
             tc[H] = seqs.tcode + seqs.toff[jx.pair];
             ss[H] = F::has_splice() ? seqs.ss + seqs.toff[jx.pair] : nullptr;
+            ss16[H] = (F::has_splice() && VAR == 1) ? seqs.ss16 + seqs.toff[jx.pair] : nullptr;
             seed_wr[H] = seqs.seed + jx.seed_off; seed_rows[H] = jx.seed_rows;
             best[H] = LOW; best_i[H] = best_j[H] = 0; best_set[H] = false;
         });
@@ -371,13 +405,32 @@ struct WaveDP16 {
     }
 };
 
+// The four splice-site values of every target position as the packed pass adds them: clamped to 16 bits, the calc constant
+// of a pre-splice transition folded in (exactly the value step() builds per column in the VAR 0 form: the same loop over the
+// calcs, the same clamp), interleaved so that a column is one 8-byte load: x = value 0 | value 1 << 16, y = value 2 | value 3 << 16.
+template <class M>
+__global__ void ss16_kernel(const KParams *kp, const int *ss, long long ss_stride, long long n, uint2 *out) {
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        int v[4] = {0, 0, 0, 0};
+        static_for<M::NC>([&](auto CI_) __attribute__((always_inline)) { constexpr int CI = CI_;
+            constexpr CalcDesc cd = M::calc[CI];
+            if constexpr (cd.kind == CALC_SPLICE_PRE) v[cd.param] = clamp16(kp->calc_value[CI] + ss[cd.param * ss_stride + p]);
+            if constexpr (cd.kind == CALC_SPLICE_POST) v[cd.param] = clamp16(ss[cd.param * ss_stride + p]);
+        });
+        uint2 o;
+        o.x = ((unsigned)v[0] & 0xffffu) | ((unsigned)v[1] << 16);
+        o.y = ((unsigned)v[2] & 0xffffu) | ((unsigned)v[3] << 16);
+        out[p] = o;
+    }
+}
+
 // NW cooperating waves per PAIR of jobs: workgroup p of the queue runs jobs 2p and 2p + 1 (the last one alone when the
 // launch holds an odd number: its high half repeats it)
-template <class M, int R, int NW, int WPE>
+template <class M, int R, int NW, int WPE, int VAR = 0>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
 void viterbi16_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, int n_jobs, DevResult *results,
                          DevScratch scratch, int *queue) {
-    using DP = WaveDP16<M, R>;
+    using DP = WaveDP16<M, R, VAR>;
     __shared__ KParams kp_lds;
     __shared__ int next_job;
     __shared__ int rings[(NW > 1 ? NW - 1 : 1) * DP::RING * DP::BND];

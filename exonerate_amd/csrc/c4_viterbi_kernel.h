@@ -56,6 +56,8 @@ struct DevSeqs {
     const long long *qoff, *toff;        // per pair offsets into the concatenated arrays
     const int *tlen;                     // per pair target length (prefetch clamps)
     const int *ss;                       // [4][ss_stride] splice-site scores, same offsets as tcode
+    const uint2 *ss16;                   // the packed score pass: per target position the four splice values as clamped 16-bit halves
+                                         // with their calc constants folded in (c4_viterbi16_kernel.h, ss16_kernel); NULL: not built
     const uint16_t *tn4;                 // per target position: 4-bit base masks of positions p, p-1, p-2, p-3
     long long ss_stride;
     // sub-optimal blocking (SUB kernels): per job T+2 column entries {first blocked row, 2 * index into sub_rows +

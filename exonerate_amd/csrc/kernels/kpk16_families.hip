@@ -5,14 +5,24 @@
 #include "../c4_launch.h"
 #include "../c4_viterbi16_kernel.h"
 namespace c4k {
-#define PK16_KERNEL(NAME, M, RV, NWV, WPEV)                                                                            \
+#define PK16_KERNEL(NAME, M, RV, NWV, WPEV, VARV)                                                                      \
     static hipError_t NAME##_launch(const LaunchArgs &a) {                                                            \
-        hipLaunchKernelGGL((viterbi16_kernel_mw<M, RV, NWV, WPEV>), dim3(a.grid), dim3(64 * NWV), 0, a.stream, a.kp,   \
-                           a.seqs, a.jobs, a.n_jobs, a.results, a.scratch, a.queue);                                   \
+        hipLaunchKernelGGL((viterbi16_kernel_mw<M, RV, NWV, WPEV, VARV>), dim3(a.grid), dim3(64 * NWV), 0, a.stream,   \
+                           a.kp, a.seqs, a.jobs, a.n_jobs, a.results, a.scratch, a.queue);                             \
         return hipGetLastError();                                                                                      \
     }                                                                                                                  \
-    static const KernelInfo NAME = {NAME##_launch, (const void *)viterbi16_kernel_mw<M, RV, NWV, WPEV>, #NAME, RV, 2,  \
+    static const KernelInfo NAME = {NAME##_launch, (const void *)viterbi16_kernel_mw<M, RV, NWV, WPEV, VARV>, #NAME, RV, 2,  \
                                     WaveDP16<M, RV>::BND, M::NS, M::MAXAT, NWV, WaveDP16<M, RV>::SEEDW};
-PK16_KERNEL(kpk16_est2genome, Est2GenomeDesc, 4, 4, 3)
-const KernelInfo *get_kernel_pk16(int family) { return family == FAM_EST2GENOME ? &kpk16_est2genome : nullptr; }
+PK16_KERNEL(kpk16_est2genome, Est2GenomeDesc, 4, 4, 3, 0)
+PK16_KERNEL(kpk16b_est2genome, Est2GenomeDesc, 4, 4, 3, 1)
+// the packed splice array of variant 1 (ss16_kernel): n positions of the batch's concatenated targets
+hipError_t pk16_build_splice(int family, const KParams *kp, const int *ss, long long ss_stride, long long n, void *out, hipStream_t s) {
+    if (family != FAM_EST2GENOME) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((ss16_kernel<Est2GenomeDesc>), dim3(4096), dim3(256), 0, s, kp, ss, ss_stride, n, (uint2 *)out);
+    return hipGetLastError();
+}
+const KernelInfo *get_kernel_pk16(int family, int variant) {
+    if (family != FAM_EST2GENOME) return nullptr;
+    return variant == 1 ? &kpk16b_est2genome : &kpk16_est2genome;
+}
 }

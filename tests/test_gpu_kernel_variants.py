@@ -305,11 +305,13 @@ def test_packed_16_bit_score_pass_agrees_with_the_32_bit_pass(eng, monkeypatch, 
     pairs.append((_rand(rng, 500), _rand(rng, 25000)))                         # unrelated; nine jobs: the last lane pair is half empty
     monkeypatch.setenv("C4GPU_TRACE", "1")
     res = {}
-    for pk in ("1", "0"):
+    for pk in ("1", "2", "0"):                   # 1 and 2: the two forms of the packed pass (c4_viterbi16_kernel.h, VAR)
         monkeypatch.setenv("C4GPU_PK16", pk)
         res[pk] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=32, threshold=20)]
-        assert "windowed region pass" in capfd.readouterr().err
-    assert res["1"] == res["0"]
+        err = capfd.readouterr().err
+        assert "windowed region pass" in err
+        assert ("kpk16b_est2genome" in err) == (pk == "2") and ("kpk16_est2genome" in err) == (pk == "1"), err[-1500:]
+    assert res["1"] == res["0"] and res["2"] == res["0"]
     ops = [model.c.transitions[t].label for t, n in res["1"][7]["ops"] if n >= 45000]
     assert ops == [6], "the long intron is not in the alignment"              # C4_Label_INTRON
     q, t = pairs[2]
@@ -318,6 +320,50 @@ def test_packed_16_bit_score_pass_agrees_with_the_32_bit_pass(eng, monkeypatch, 
     monkeypatch.setenv("C4GPU_PK16", "1")
     small = pairs[:4] + pairs[5:6]
     a = [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=20)]
+    monkeypatch.setenv("C4GPU_PK16", "2")
+    a2 = [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=20)]
     monkeypatch.setenv("C4GPU_PK16", "0")
     b = [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=20)]
-    assert a == b
+    assert a == b and a2 == b
+
+
+@pytest.mark.parametrize("model_type,dpm", [("affine:local", 32), ("affine:local", 1), ("affine:local", 0),
+                                            ("est2genome", 32), ("est2genome", 1), ("est2genome", 0),
+                                            ("protein2dna", 1), ("protein2genome", 1)])
+def test_device_route_of_the_sub_alignments_gives_the_host_route_results(eng, monkeypatch, capfd, model_type, dpm):
+    """Optimal_find_path_reduced_space (optimal.c:160-345): the sub-alignment jobs of a checkpoint pass are listed, run,
+    verified and stitched on the device (fused_reduced_paths); C4GPU_FUSED=0 keeps the host route.  Same alignments either
+    way on ragged batches, one pair also against the oracle; at -D 32 every pair finishes on the device route (at -D 0 a
+    section can itself need checkpoints: those pairs are flagged and take the host route, recursion included)."""
+    rng = random.Random(20260929 + dpm)
+    model = ex.Model(model_type)
+    if model_type.startswith("protein"):
+        proteins, contig, _ = workloads.protein_vs_contig(6, 120, 60000 if model_type == "protein2genome" else 9000, seed=511 + dpm,
+                                                          introns=model_type == "protein2genome")
+        pairs = [(p, contig) for p in proteins]
+        enc = lambda s: s
+    else:
+        pairs = []
+        for ql, tl in [(1000, 1100), (300, 5000), (77, 900), (640, 2000), (1200, 1300), (1000, 12000), (150, 150)]:
+            pairs += _seeded_pairs(rng, model_type, ql, tl, 1)
+        pairs.append((_rand(rng, 400), _rand(rng, 700)))                      # unrelated: below the threshold
+        enc = lambda s: s.encode()
+    monkeypatch.setenv("C4GPU_TRACE", "1")
+    res = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("C4GPU_FUSED", sw)
+        res[sw] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=dpm, threshold=30)]
+        err = capfd.readouterr().err
+        finished = [ln for ln in err.splitlines() if "pairs finished on the device route" in ln]
+        if sw == "0":
+            assert not finished
+        else:
+            assert finished, err[-2000:]
+            if dpm == 32:
+                words = finished[0].split("fused:")[1].split()
+                assert words[0] == words[2], finished[0]                      # "N of N pairs finished ..."
+    assert res["1"] == res["0"]
+    assert any(r is not None for r in res["1"])
+    k = next(i for i, r in enumerate(res["1"]) if r is not None)
+    q, t = pairs[k]
+    assert res["1"][k] == oracle_lib.find_path(model.c, model.params, enc(q), enc(t), dpmemory=dpm, threshold=30)
