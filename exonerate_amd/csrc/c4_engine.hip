@@ -489,6 +489,7 @@ struct ResidentSeqs {
     DevBuf<uint16_t> tn4;
     mutable DevBuf<uint2> ss16;            // the packed score pass's splice values (built on its first launch over this batch)
     mutable bool ss16_built = false;
+    mutable std::mutex ss16_lock;          // two lanes may reach the first packed launch together
     long long ss_len = 0;                 // positions per splice array
     DevBuf<PrepTables> tables;
     DevBuf<c4gpu_splice_model> splice_models;
@@ -678,6 +679,9 @@ struct Engine {
     // here, and parameters outside that range get the general kernels (all masks kept) instead.
     bool local_exact = true;
     bool pk16_params_ok = false;         // see init: the parameters allow the packed 16-bit score pass
+    // largest magnitude one transition can add (calc constants, substitution scores, a splice model's best column sum):
+    // what the continuation kernels without the row-0 mask need to stay exact (cont_free_ok)
+    double calc_bound = 0;
     int pk16_match_max = 1, pk16_max_intron = 0;
     DevBuf<KParams> kparams;
     // reusable device buffers
@@ -758,6 +762,7 @@ struct Engine {
                 }
             // a real candidate is at least -(states x largest calc); a phantom one at most LOW + 3 calcs
             local_exact = (pmax + smax) * (m->n_states + 4) < 4.0e8;
+            calc_bound = pmax + smax;
             // the packed 16-bit score pass (c4_viterbi16_kernel.h): every constant far inside 16 bits, a usual intron window
             double mmax = 0;
             for (int i = 0; i < 24 * 24; i++) mmax = std::max(mmax, (double)kp.submat[i]);
@@ -772,6 +777,15 @@ struct Engine {
             kp.codon_row[c] = row < 24 ? row : 0;        // '-' (empty mask) never scores: such columns are rejected at upload
         }
         return kparams.upload(&kp, 1, ctx->stream);
+    }
+
+    // The continuation kernels compiled without the row-0 validity mask (c4_viterbi_kernel.h, eval_cell: CONT && LOCAL)
+    // hold, in states the reference leaves unset, -987654321 plus at most one calc per cell of a path: exact while
+    // that stays far below every real score of the job, i.e. (Q + T + 2) x the largest calc well under 987654321 / 2.
+    // C4GPU_CONT_FREE=0 keeps the kernels with every mask (read on every call: a test switches it).
+    bool cont_free_ok(long long q_plus_t) const {
+        if (getenv("C4GPU_CONT_FREE") && atoi(getenv("C4GPU_CONT_FREE")) == 0) return false;
+        return (double)(q_plus_t + 2) * std::max(calc_bound, 1.0) < 4.0e8;
     }
 
     // Runs `specs` in `mode`; out[i] corresponds to specs[i].  Calls whose region holds blocked cells
@@ -849,7 +863,18 @@ struct Engine {
             if (i && sp != span) { c4h::set_error("jobs with and without span matrices in one call"); return -1; }
             span = sp;
         }
-        const KernelInfo *ki = get_kernel(family, mode, cont, use_local, pack, pts ? 0 : wpe_env, pts != nullptr, span);
+        bool cont_free = false;
+        if (cont && (mode == MODE_PATH || mode == MODE_CKPT) && !pts && !span) {
+            long long worst = 0;
+            bool cells_leave = false;             // checkpoint cells handed to the caller must be the reference's in every state
+            for (int i = 0; i < n; i++) {
+                worst = std::max(worst, (long long)specs[i].region.query_length + specs[i].region.target_length);
+                cells_leave |= specs[i].dump_checkpoints;
+            }
+            cont_free = !cells_leave && cont_free_ok(worst);
+        }
+        const KernelInfo *ki = get_kernel(family, mode, cont, cont ? cont_free : use_local, pack, pts ? 0 : wpe_env, pts != nullptr, span);
+        if (!ki && cont_free) ki = get_kernel(family, mode, cont, false, pack, pts ? 0 : wpe_env, pts != nullptr, span);
         if (!ki) { c4h::set_error("no compiled kernel for this model/mode"); return -1; }
         const int span_cs = 1 + model->total_shadow_designations;
         // whole-rectangle passes whose query spans several 64*R-row strips run on 4 cooperating waves per
@@ -860,17 +885,22 @@ struct Engine {
             if (!ki || !use_local || (mode == MODE_REGION && !pack)) { c4h::set_error("no seeded kernel for this launch"); return -1; }
             // the score pass with dumps: two jobs per lane in packed 16-bit halves where every score fits (C4GPU_PK16=0: never)
             const int pk_env = getenv("C4GPU_PK16") ? atoi(getenv("C4GPU_PK16")) : 1;      // read on every call: a test switches it
-            const KernelInfo *kpk = (seed->mode == 1 && pk_env && pk16_params_ok && n >= 2) ? get_kernel_pk16(family, pk_env == 2 ? 1 : 0) : nullptr;
+            const KernelInfo *kpk = (seed->mode == 1 && pk_env && pk16_params_ok && n >= 2) ? get_kernel_pk16(family, pk_env == 3 ? 0 : 1) : nullptr;      // 3: the all-asm form (c4_viterbi16_kernel.h, VAR 0)
             if (kpk) {
                 bool fits = true;
                 for (int i = 0; i < n && fits; i++)
                     fits = (double)(specs[i].region.query_length + 1) * pk16_match_max <= 16000.0 &&
                            (!family_has_splice(family) || (long long)specs[i].region.target_length + 4 <= (long long)pk16_max_intron);
-                if (fits && pk_env == 2 && !seqs.ss16_built) {
+                if (fits && pk_env != 3) {
                     // variant 1 reads the four splice values of a column as one packed 8-byte entry: built once per batch
-                    if (seqs.ss16.alloc((size_t)seqs.ss_len)) return -1;
-                    HIP_OK(pk16_build_splice(family, kparams.p, seqs.dev.ss, seqs.dev.ss_stride, seqs.ss_len, seqs.ss16.p, ctx->stream));
-                    seqs.ss16_built = true;
+                    // (finished before the lock is released: the other lane launches on another stream)
+                    std::lock_guard<std::mutex> hold(seqs.ss16_lock);
+                    if (!seqs.ss16_built) {
+                        if (seqs.ss16.alloc((size_t)seqs.ss_len)) return -1;
+                        HIP_OK(pk16_build_splice(family, kparams.p, seqs.dev.ss, seqs.dev.ss_stride, seqs.ss_len, seqs.ss16.p, ctx->stream));
+                        HIP_OK(hipStreamSynchronize(ctx->stream));
+                        seqs.ss16_built = true;
+                    }
                 }
                 if (fits) ki = kpk;
             }
@@ -1201,9 +1231,15 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
     if (!n || eng.pair_sub) return 0;
     if (getenv("C4GPU_FUSED") && atoi(getenv("C4GPU_FUSED")) == 0) return 0;         // read on every call: a test switches it
     static const int wpe_env = getenv("C4GPU_WPE") ? atoi(getenv("C4GPU_WPE")) : 0;
-    const KernelInfo *kc = get_kernel(eng.family, MODE_CKPT, true, false, false, wpe_env, false, 0);
-    const KernelInfo *kp = get_kernel(eng.family, MODE_PATH, true, false, false, wpe_env, false, 0);
+    long long worst = 0;
+    for (int i : red) worst = std::max(worst, (long long)plan[i].ar.query_length + plan[i].ar.target_length);
+    const bool cont_free = eng.cont_free_ok(worst);              // the sub-alignments lie inside their pair's region
+    const KernelInfo *kc = get_kernel(eng.family, MODE_CKPT, true, cont_free, false, wpe_env, false, 0);
+    const KernelInfo *kp = get_kernel(eng.family, MODE_PATH, true, cont_free, false, wpe_env, false, 0);
+    if (!kc) kc = get_kernel(eng.family, MODE_CKPT, true, false, false, wpe_env, false, 0);
+    if (!kp) kp = get_kernel(eng.family, MODE_PATH, true, false, false, wpe_env, false, 0);
     if (!kc || !kp) return 0;
+    if (getenv("C4GPU_TRACE")) fprintf(stderr, "c4gpu trace:   fused: kernels %s, %s\n", kc->name, kp->name);
     hipStream_t s = ctx->stream;
     const c4h::MemRule rule{m->max_query_advance, m->max_target_advance, m->n_states, m->total_shadow_designations};
     // -- the checkpoint jobs, longest first (persistent waves pull from the queue head)
@@ -1476,7 +1512,9 @@ int windowed_region_pass(Engine &eng, const ResidentSeqs &seqs, const std::vecto
 int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gpu_score threshold,
                     c4gpu_alignment *alignments, const std::vector<const c4gpu_subopt *> *subs = nullptr,
                     const uint8_t *active = nullptr, const std::vector<c4gpu_score> *pair_thresholds = nullptr,
-                    const c4gpu_region *initial = nullptr) {
+                    const c4gpu_region *initial = nullptr, bool own_all = true) {
+    // own_all = false: one of two lanes working on the same arrays (find_path_lanes): only the entries of `active` are this
+    // call's to touch, and the caller has cleared them
     const c4gpu_model *m = eng.model;
     const int n = seqs.n_pairs;
     // per-pair thresholds (GAM_get_query_threshold with --percent, gam.c:677-705): never below `threshold`
@@ -1500,7 +1538,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
     std::vector<JobOut> &outs = eng.fp_outs;
     specs.clear();
     std::vector<int> owner;
-    for (int i = 0; i < n; i++) memset(&alignments[i], 0, sizeof(c4gpu_alignment));
+    if (own_all) for (int i = 0; i < n; i++) memset(&alignments[i], 0, sizeof(c4gpu_alignment));
     // -- step 1: where the whole rectangle is too large for a traceback, find the region first
     std::vector<int> region_pairs;
     for (int i = 0; i < n; i++) {
@@ -1517,7 +1555,12 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
     // long targets under a local model, nothing blocked: the two-pass (windowed) form of the region pass
     std::vector<std::pair<int, DevResult>> region_done;
     {
-        const int kshift_env = getenv("C4GPU_SEED_KSHIFT") ? atoi(getenv("C4GPU_SEED_KSHIFT")) : 12;
+        // a dump every 8 192 columns (measured on the north-star batch: score pass 410 ms against 462 ms at 4 096, windows 204
+        // against 181 ms; 16 384: 408 and 272 ms), every 4 096 while some target of the call is too short for that
+        int kshift_env = 13;
+        for (int i : region_pairs)
+            if (plan[i].ar.target_length < (4 << 13) && plan[i].ar.target_length >= (4 << 12)) kshift_env = 12;
+        if (getenv("C4GPU_SEED_KSHIFT")) kshift_env = atoi(getenv("C4GPU_SEED_KSHIFT"));
         const int kshift = std::max(2, std::min(kshift_env, 20));
         const bool off = getenv("C4GPU_WINDOWED") && atoi(getenv("C4GPU_WINDOWED")) == 0;
         const KernelInfo *k1 = get_kernel_mw(eng.family, MODE_SCORE, true, false, 4, false, 1);
@@ -1812,9 +1855,85 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
     for (int i : red)
         if (redo[i] && sequential_reduced_path(eng, seqs, i, dpmemory_mb, plan[i].ar, &alignments[i])) return -1;
     for (int i = 0; i < n; i++) {
+        if (active && !active[i]) continue;
         c4gpu_alignment &a = alignments[i];
         if (a.valid && a.score < thr(i)) c4gpu_alignment_clear(&a);     // optimal.c:408-411
     }
+    return 0;
+}
+
+// ---- two launch lanes ---------------------------------------------------------------------------------------------
+// The passes of Optimal_find_path are persistent kernels that end in a tail: the last round of jobs leaves part of the
+// device idle (the packed score pass of the north-star batch runs 2 048 lane pairs on 768 resident workgroups: 2.67
+// rounds), the windows and the checkpoint pass likewise.  A large batch is therefore cut into two halves of equal work
+// that walk through the passes on two streams from two host threads: the workgroups of one half's next pass start as the
+// other half's tail drains (measured on the north-star batch: 928 -> 839 ms per step; four lanes: 1 036 ms).  Both lanes
+// read the same resident sequences; each has its own stream, events, statistics and launch buffers.  C4GPU_LANES=1
+// keeps one lane, =2 forces two.
+struct SideLane {
+    c4gpu_ctx ctx;
+    Engine eng;
+    ~SideLane() {
+        if (ctx.stream) (void)hipStreamDestroy(ctx.stream);
+        if (ctx.ev0) (void)hipEventDestroy(ctx.ev0);
+        if (ctx.ev1) (void)hipEventDestroy(ctx.ev1);
+    }
+    int init(const c4gpu_ctx *main, const c4gpu_model *m, const c4gpu_params *p) {
+        ctx.device = main->device; ctx.prop = main->prop; ctx.timing = main->timing;
+        HIP_OK(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
+        HIP_OK(hipEventCreate(&ctx.ev0));
+        HIP_OK(hipEventCreate(&ctx.ev1));
+        if (eng.init(&ctx, m, p)) return -1;
+        HIP_OK(hipStreamSynchronize(ctx.stream));
+        return 0;
+    }
+};
+
+// would this call be cut in two?  (callers create the side lane only then)
+bool lanes_wanted(const ResidentSeqs &seqs, const uint8_t *active, bool blocking) {
+    const int env = getenv("C4GPU_LANES") ? atoi(getenv("C4GPU_LANES")) : 0;       // read on every call: a test switches it
+    if (blocking || env == 1) return false;
+    long long n_act = 0;
+    double cells = 0;
+    for (int i = 0; i < seqs.n_pairs; i++) {
+        if (active && !active[i]) continue;
+        n_act++;
+        cells += (double)(seqs.qlen[i] + 1) * (double)(seqs.tlen[i] + 1);
+    }
+    if (env == 2) return n_act >= 2;
+    // each half must still fill the device more than once with whole-rectangle jobs that take long enough to have a tail
+    return n_act >= 2048 && cells / (double)n_act >= 2.0e6;
+}
+
+int find_path_lanes(Engine &eng, SideLane *side, const ResidentSeqs &seqs, int dpmemory_mb, c4gpu_score threshold,
+                    c4gpu_alignment *alignments, const uint8_t *active = nullptr,
+                    const std::vector<c4gpu_score> *pair_thresholds = nullptr, const c4gpu_region *initial = nullptr) {
+    const int n = seqs.n_pairs;
+    if (!side || !lanes_wanted(seqs, active, false))
+        return find_path_batch(eng, seqs, dpmemory_mb, threshold, alignments, nullptr, active, pair_thresholds, initial);
+    // equal work per lane: every pair goes to the lane with fewer first-pass cells so far
+    std::vector<uint8_t> mask[2] = {std::vector<uint8_t>(n, 0), std::vector<uint8_t>(n, 0)};
+    double load[2] = {0, 0};
+    for (int i = 0; i < n; i++) {
+        if (active && !active[i]) continue;
+        const int l = load[1] < load[0] ? 1 : 0;
+        mask[l][i] = 1;
+        load[l] += (double)((initial ? initial[i].query_length : seqs.qlen[i]) + 1) * (double)((initial ? initial[i].target_length : seqs.tlen[i]) + 1);
+    }
+    for (int i = 0; i < n; i++) memset(&alignments[i], 0, sizeof(c4gpu_alignment));
+    side->ctx.timing = eng.ctx->timing;
+    int r1 = 0;
+    std::string err1;
+    const int device = eng.ctx->device;
+    std::thread second([&] {
+        if (hipSetDevice(device) != hipSuccess) { r1 = -1; err1 = "hipSetDevice on the second lane"; return; }
+        r1 = find_path_batch(side->eng, seqs, dpmemory_mb, threshold, alignments, nullptr, mask[1].data(), pair_thresholds, initial, false);
+        if (r1) err1 = c4h::g_error;
+    });
+    const int r0 = find_path_batch(eng, seqs, dpmemory_mb, threshold, alignments, nullptr, mask[0].data(), pair_thresholds, initial, false);
+    second.join();
+    if (r0) return r0;
+    if (r1) { c4h::set_error(err1); return r1; }
     return 0;
 }
 
@@ -1838,6 +1957,7 @@ struct c4gpu_batch {
     // terminal / join / span models of the batch's model, keyed by the flattened model's bytes
     struct ExtraEngine { c4gpu_model model; Engine eng; };
     std::map<std::string, std::unique_ptr<ExtraEngine>> extra;
+    std::unique_ptr<SideLane> side;                  // the second launch lane of large batches (find_path_lanes), made on first use
     void clear_loop() {
         for (c4gpu_subopt *so : subopts) c4gpu_subopt_destroy(so);
         subopts.clear(); in_loop.clear();
@@ -2083,7 +2203,10 @@ int c4gpu_optimal_find_path_batch(c4gpu_ctx *ctx, const c4gpu_model *model, cons
     Engine eng;
     ResidentSeqs seqs;
     if (eng.init(ctx, model, params) || seqs.build(ctx, eng.family, params, pairs, n_pairs)) return -1;
-    return find_path_batch(eng, seqs, dpmemory_mb, threshold, alignments);
+    SideLane side;
+    const bool two = lanes_wanted(seqs, nullptr, false);
+    if (two && side.init(ctx, model, params)) return -1;
+    return find_path_lanes(eng, two ? &side : nullptr, seqs, dpmemory_mb, threshold, alignments);
 }
 
 int c4gpu_optimal_find_path_batch_subopt(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params,
@@ -2135,7 +2258,11 @@ int c4gpu_batch_run(c4gpu_batch *b, int what, int dpmemory_mb, c4gpu_score thres
     for (auto &a : b->alignments) c4gpu_alignment_clear(&a);
     b->alignments.assign(n, c4gpu_alignment{});
     b->clear_loop();
-    if (find_path_batch(b->eng, b->seqs, dpmemory_mb, threshold, b->alignments.data(), nullptr, nullptr,
+    if (!b->side && lanes_wanted(b->seqs, nullptr, false)) {
+        b->side.reset(new SideLane);
+        if (b->side->init(b->ctx, &b->model, &b->params)) { b->side.reset(); return -1; }
+    }
+    if (find_path_lanes(b->eng, b->side.get(), b->seqs, dpmemory_mb, threshold, b->alignments.data(), nullptr,
                         b->pair_thresholds.empty() ? nullptr : &b->pair_thresholds)) return -1;
     b->scores.resize(n); b->regions.resize(n);
     for (int i = 0; i < n; i++) { b->scores[i] = b->alignments[i].score; b->regions[i] = b->alignments[i].region; }
@@ -2158,7 +2285,11 @@ int c4gpu_batch_run_regions(c4gpu_batch *b, const c4gpu_region *regions, const u
     for (auto &a : b->alignments) c4gpu_alignment_clear(&a);
     b->alignments.assign(n, c4gpu_alignment{});
     b->clear_loop();
-    if (find_path_batch(b->eng, b->seqs, dpmemory_mb, threshold, b->alignments.data(), nullptr, active, nullptr, regions))
+    if (!b->side && lanes_wanted(b->seqs, active, false)) {
+        b->side.reset(new SideLane);
+        if (b->side->init(b->ctx, &b->model, &b->params)) { b->side.reset(); return -1; }
+    }
+    if (find_path_lanes(b->eng, b->side.get(), b->seqs, dpmemory_mb, threshold, b->alignments.data(), active, nullptr, regions))
         return -1;
     b->scores.resize(n); b->regions.resize(n);
     for (int i = 0; i < n; i++) { b->scores[i] = b->alignments[i].score; b->regions[i] = b->alignments[i].region; }
@@ -2248,11 +2379,18 @@ int64_t c4gpu_batch_export(c4gpu_batch *b, int32_t *out, int64_t cap) {
 int c4gpu_batch_kernel_stats(c4gpu_batch *b, int mode, int reset, double *ms, int64_t *launches, int64_t *cells) {
     c4gpu_ctx *ctx = b->ctx;
     if (mode < 0 || mode > 3) return -1;
-    if (ms) *ms = ctx->kernel_ms[mode];
-    if (launches) *launches = ctx->kernel_launches[mode];
-    if (cells) *cells = ctx->kernel_cells[mode];
-    if (reset) { ctx->kernel_ms[mode] = 0; ctx->kernel_launches[mode] = 0; ctx->kernel_cells[mode] = 0; }
-    ctx->timing = true;
+    c4gpu_ctx *lanes[2] = {ctx, b->side ? &b->side->ctx : nullptr};        // a large batch runs on two lanes (find_path_lanes)
+    if (ms) *ms = 0;
+    if (launches) *launches = 0;
+    if (cells) *cells = 0;
+    for (c4gpu_ctx *c : lanes) {
+        if (!c) continue;
+        if (ms) *ms += c->kernel_ms[mode];
+        if (launches) *launches += c->kernel_launches[mode];
+        if (cells) *cells += c->kernel_cells[mode];
+        if (reset) { c->kernel_ms[mode] = 0; c->kernel_launches[mode] = 0; c->kernel_cells[mode] = 0; }
+        c->timing = true;
+    }
     return 0;
 }
 

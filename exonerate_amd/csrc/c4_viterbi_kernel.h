@@ -334,7 +334,15 @@ struct WaveDP {
         // that is hundreds of millions higher in the same cell — the same reason the reference's own "unset
         // states still propagate" never shows in a result.  States that are unset in row 0 hold a different
         // near-minimum number; nothing reads them on the way to a reported score, end cell or region start.
-        const bool i_ok = (RR > 0) | (i > 0) | (LOCAL && (MODE == MODE_SCORE || MODE == MODE_REGION));
+        // CONT && LOCAL (continuations: FIND_PATH between checkpoints, FIND_CHECKPOINTS) is the same shortcut for the one
+        // row that has no row above: a continuation's scopes stay CORNER (START only in the origin cell, END only in the far
+        // corner, below), but the transitions that advance the query are evaluated in row 0 as everywhere else.  What they
+        // read there is the empty column (-987654321, slots 0), so a state the reference leaves unset in row 0 holds a
+        // number within the launch's (Q + T) x largest calc of that value instead; every cell a path from the seeded origin
+        // to the corner can visit has a candidate of real magnitude and takes it (first valid transition assigns, later
+        // ones replace on strict <: both forms pick the same transition among the real candidates, in the same order).
+        // The host only picks these kernels while that bound keeps the two ranges apart (Engine::cont_free_ok).
+        const bool i_ok = (RR > 0) | (i > 0) | (LOCAL && (CONT || MODE == MODE_SCORE || MODE == MODE_REGION));
         uint32_t tbw = 0;
         static_for<M::NT>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
             constexpr int k = K;
@@ -343,10 +351,10 @@ struct WaveDP {
             bool valid = true;
             if constexpr (t.aq > 0) valid = valid & i_ok;
             if constexpr (t.at > 0 && !JINT) valid = valid & (j >= t.at);
-            if constexpr (t.in == M::START && !LOCAL)
+            if constexpr (t.in == M::START && (!LOCAL || CONT))
                 valid = valid & (CONT ? ((i - t.aq == 0) & (j - t.at == 0))
                                       : scope_ok(start_scope, i - t.aq == 0, j - t.at == 0));
-            if constexpr (t.out == M::END && !LOCAL)
+            if constexpr (t.out == M::END && (!LOCAL || CONT))
                 valid = valid & (CONT ? ((i == Q) & (j == T)) : scope_ok(end_scope, i == Q, j == T));
             // sub-optimal blocking: MATCH transitions do not enter a blocked cell (viterbi.c:701-704)
             // In the local score / region passes the match state always has START's candidate (score 0) in the

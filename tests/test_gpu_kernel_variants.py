@@ -270,7 +270,7 @@ def test_windowed_region_pass_matches_oracle(eng, monkeypatch, capfd, model_type
     err = capfd.readouterr().err
     assert "windowed region pass" in err, "these inputs no longer take the two-pass route:\n" + err[-800:]
     # the score pass of the scheme is the packed 16-bit kernel (two jobs per lane) for the family that has one
-    assert ("kernel kpk16_" in err) == (model_type == "est2genome"), err[-800:]
+    assert ("kernel kpk16" in err) == (model_type == "est2genome"), err[-800:]
     for (q, t), a in zip(pairs, alns):
         exp = oracle_lib.find_path(model.c, model.params, q.encode(), t.encode(), dpmemory=dpm, threshold=20)
         assert (a.as_dict() if a else None) == exp
@@ -305,13 +305,13 @@ def test_packed_16_bit_score_pass_agrees_with_the_32_bit_pass(eng, monkeypatch, 
     pairs.append((_rand(rng, 500), _rand(rng, 25000)))                         # unrelated; nine jobs: the last lane pair is half empty
     monkeypatch.setenv("C4GPU_TRACE", "1")
     res = {}
-    for pk in ("1", "2", "0"):                   # 1 and 2: the two forms of the packed pass (c4_viterbi16_kernel.h, VAR)
+    for pk in ("1", "3", "0"):                   # 1 and 3: the two forms of the packed pass (c4_viterbi16_kernel.h, VAR 1 and 0)
         monkeypatch.setenv("C4GPU_PK16", pk)
         res[pk] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=32, threshold=20)]
         err = capfd.readouterr().err
         assert "windowed region pass" in err
-        assert ("kpk16b_est2genome" in err) == (pk == "2") and ("kpk16_est2genome" in err) == (pk == "1"), err[-1500:]
-    assert res["1"] == res["0"] and res["2"] == res["0"]
+        assert ("kpk16b_est2genome" in err) == (pk == "1") and ("kpk16_est2genome" in err) == (pk == "3"), err[-1500:]
+    assert res["1"] == res["0"] and res["3"] == res["0"]
     ops = [model.c.transitions[t].label for t, n in res["1"][7]["ops"] if n >= 45000]
     assert ops == [6], "the long intron is not in the alignment"              # C4_Label_INTRON
     q, t = pairs[2]
@@ -320,7 +320,7 @@ def test_packed_16_bit_score_pass_agrees_with_the_32_bit_pass(eng, monkeypatch, 
     monkeypatch.setenv("C4GPU_PK16", "1")
     small = pairs[:4] + pairs[5:6]
     a = [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=20)]
-    monkeypatch.setenv("C4GPU_PK16", "2")
+    monkeypatch.setenv("C4GPU_PK16", "3")
     a2 = [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=20)]
     monkeypatch.setenv("C4GPU_PK16", "0")
     b = [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=20)]
@@ -350,20 +350,57 @@ def test_device_route_of_the_sub_alignments_gives_the_host_route_results(eng, mo
         enc = lambda s: s.encode()
     monkeypatch.setenv("C4GPU_TRACE", "1")
     res = {}
-    for sw in ("1", "0"):
+    # C4GPU_CONT_FREE=0: the continuation kernels that keep the row-0 validity mask (c4_viterbi_kernel.h, CONT && LOCAL)
+    for sw, free in (("1", "1"), ("1", "0"), ("0", "1"), ("0", "0")):
         monkeypatch.setenv("C4GPU_FUSED", sw)
-        res[sw] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=dpm, threshold=30)]
+        monkeypatch.setenv("C4GPU_CONT_FREE", free)
+        res[sw + free] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=dpm, threshold=30)]
         err = capfd.readouterr().err
         finished = [ln for ln in err.splitlines() if "pairs finished on the device route" in ln]
         if sw == "0":
             assert not finished
         else:
             assert finished, err[-2000:]
+            assert ("_ckpt_cont_local," in err) == (free == "1") and ("_path_cont_local" in err) == (free == "1"), err[-2000:]
             if dpm == 32:
                 words = finished[0].split("fused:")[1].split()
                 assert words[0] == words[2], finished[0]                      # "N of N pairs finished ..."
-    assert res["1"] == res["0"]
+    assert res["11"] == res["00"] and res["10"] == res["00"] and res["01"] == res["00"]
+    res["1"] = res["11"]
     assert any(r is not None for r in res["1"])
     k = next(i for i, r in enumerate(res["1"]) if r is not None)
     q, t = pairs[k]
     assert res["1"][k] == oracle_lib.find_path(model.c, model.params, enc(q), enc(t), dpmemory=dpm, threshold=30)
+
+
+@pytest.mark.parametrize("model_type", ["est2genome", "affine:local", "protein2genome"])
+def test_two_launch_lanes_give_the_one_lane_results(eng, monkeypatch, model_type):
+    """A large batch is cut into two halves of equal work that walk through the passes of Optimal_find_path on two streams
+    from two host threads over the same resident sequences (c4_engine.hip, find_path_lanes; default for 2 048 pairs and
+    more).  C4GPU_LANES=2 forces the cut on a small ragged batch: same alignments as one lane, through the one-shot entry
+    point and through a resident batch (whose kernel statistics then count the launches of both lanes)."""
+    rng = random.Random(991)
+    model = ex.Model(model_type)
+    if model_type == "protein2genome":
+        proteins, contig, _ = workloads.protein_vs_contig(7, 150, 80000, seed=77, introns=True)
+        pairs = [(p, contig) for p in proteins]
+    else:
+        pairs = []
+        for ql, tl in [(900, 30000), (400, 52000), (1000, 9000), (640, 30000), (130, 20000), (777, 41000), (1000, 1200)]:
+            pairs += _seeded_pairs(rng, model_type, ql, tl, 1)
+        pairs.append((_rand(rng, 500), _rand(rng, 25000)))
+    res = {}
+    for lanes in ("1", "2"):
+        monkeypatch.setenv("C4GPU_LANES", lanes)
+        res[lanes] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=32, threshold=30)]
+        batch = ex.ResidentBatch(eng, model, pairs)
+        batch.kernel_stats(0, reset=True)
+        batch.kernel_stats(2, reset=True)
+        batch.run(2, 32, 30)
+        batch.run(2, 32, 30)
+        res["b" + lanes] = [(lambda a: a.as_dict() if a else None)(batch.alignment(i)) for i in range(len(pairs))]
+        res["n" + lanes] = batch.kernel_stats(0)["launches"] + batch.kernel_stats(2)["launches"]
+        batch.close()
+    assert res["1"] == res["2"] and res["b1"] == res["1"] and res["b2"] == res["1"]
+    assert any(r is not None for r in res["1"])
+    assert res["n2"] > res["n1"] > 0                  # each lane launches its own passes

@@ -7,7 +7,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01_c"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
-LAUNCHES_IN_PMC_RUN = 2          # bench.py --steps 1 --warmup 1 (fallback when the dispatch count is not in the CSV)
+LAUNCHES_IN_PMC_RUN = 2          # STEPS of the PMC run: bench.py --steps 1 --warmup 1 (also the fallback dispatch count)
 
 shutil.copy(glob.glob(src + "/trace/*/*_kernel_stats.csv")[0], f"{dst}/{tag}_kernel_stats.csv")
 shutil.copy(src + "/bench.json", f"{dst}/{tag}_bench.json")
@@ -61,7 +61,10 @@ out = {
     "rocprof_avg_launch_ms": avg_ns / 1e6,
     "valu": {
         "insts_per_launch": v["SQ_INSTS_VALU"] / n,
-        "lane_ops_per_cell": v["SQ_INSTS_VALU"] / n * 64 / (cfg["pairs_per_gpu"] * (cfg["query_len"] + 1) * (cfg["target_len"] + 1)),
+        # cells per launch: the PMC run makes LAUNCHES_IN_PMC_RUN steps (warm-up + one); a large batch runs as two halves on
+        # two launch lanes, i.e. two dispatches per step of half the pairs each
+        "lane_ops_per_cell": v["SQ_INSTS_VALU"] / n * 64 / (cfg["pairs_per_gpu"] * (cfg["query_len"] + 1) * (cfg["target_len"] + 1)
+                                                            * LAUNCHES_IN_PMC_RUN / n),
         "active_frac_of_wave_cycles": v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"],
         "wait_frac_of_wave_cycles": v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"],
         "waves_per_launch": waves,
