@@ -885,7 +885,7 @@ struct Engine {
             if (!ki || !use_local || (mode == MODE_REGION && !pack)) { c4h::set_error("no seeded kernel for this launch"); return -1; }
             // the score pass with dumps: two jobs per lane in packed 16-bit halves where every score fits (C4GPU_PK16=0: never)
             const int pk_env = getenv("C4GPU_PK16") ? atoi(getenv("C4GPU_PK16")) : 1;      // read on every call: a test switches it
-            const KernelInfo *kpk = (seed->mode == 1 && pk_env && pk16_params_ok && n >= 2) ? get_kernel_pk16(family, pk_env == 3 ? 0 : 1) : nullptr;      // 3: the all-asm form (c4_viterbi16_kernel.h, VAR 0)
+            const KernelInfo *kpk = (seed->mode == 1 && pk_env && pk16_params_ok && n >= 2) ? get_kernel_pk16(family, pk_env == 3 ? 0 : pk_env == 4 ? 2 : 1) : nullptr;      // 3: the all-asm form (c4_viterbi16_kernel.h, VAR 0)
             if (kpk) {
                 bool fits = true;
                 for (int i = 0; i < n && fits; i++)

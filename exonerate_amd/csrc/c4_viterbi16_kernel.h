@@ -37,11 +37,11 @@ typedef short pk_s2 __attribute__((ext_vector_type(2)));
 // "a < b per half" mask as ONE asm statement: the compiler's hazard pass puts a wait state (s_nop) between two dependent asm
 // statements that follow each other (it cannot see that they write whole registers), 58 of them per step in the VAR 0 form
 template <int VAR> __device__ __forceinline__ int pk_add(int a, int b) {
-    if constexpr (VAR == 1) return __builtin_bit_cast(int, __builtin_elementwise_add_sat(__builtin_bit_cast(pk_s2, a), __builtin_bit_cast(pk_s2, b)));
+    if constexpr (VAR >= 1) return __builtin_bit_cast(int, __builtin_elementwise_add_sat(__builtin_bit_cast(pk_s2, a), __builtin_bit_cast(pk_s2, b)));
     else { int r; asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
 }
 template <int VAR> __device__ __forceinline__ int pk_max(int a, int b) {
-    if constexpr (VAR == 1) return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(pk_s2, a), __builtin_bit_cast(pk_s2, b)));
+    if constexpr (VAR >= 1) return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(pk_s2, a), __builtin_bit_cast(pk_s2, b)));
     else { int r; asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 }
 __device__ __forceinline__ int pk_sub(int a, int b) { int r; asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -49,7 +49,7 @@ __device__ __forceinline__ int pk_sub(int a, int b) { int r; asm("v_pk_sub_i16 %
 __device__ __forceinline__ int pk_neg_mask(int d, int fifteen) { int r; asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(r) : "v"(fifteen), "v"(d)); return r; }
 // per half: 0xffff where a < b (the saturating difference is negative), else 0
 template <int VAR> __device__ __forceinline__ int pk_lt_mask(int a, int b, int fifteen) {
-    if constexpr (VAR == 1) {
+    if constexpr (VAR >= 1) {
         int r;
         asm("v_pk_sub_i16 %0, %1, %2 clamp\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=&v"(r) : "v"(a), "v"(b));
         return r;
@@ -136,7 +136,7 @@ struct WaveDP16 {
             if constexpr (F::has_splice()) {
                 int tp = t0[H] + j - 2;
                 tp = tp < 0 ? 0 : (tp > tlast[H] ? tlast[H] : tp);
-                if constexpr (VAR == 1) {
+                if constexpr (VAR >= 1) {
                     nx_sp16[H] = ss16[H][(unsigned)tp];
                 } else {
                     static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
@@ -198,7 +198,7 @@ struct WaveDP16 {
             ms[RR] = pk_pack(kp->submat[qrow[0][RR] + nx_tcode[0]], kp->submat[qrow[1][RR] + nx_tcode[1]]);
         });
         int sp[4] = {0, 0, 0, 0};
-        if constexpr (F::has_splice() && VAR == 1) {
+        if constexpr (F::has_splice() && VAR >= 1) {
             // the values arrive clamped, with the calc constant of a pre-splice transition folded in (ss16_kernel): job A's
             // four in the halves of nx_sp16[0], job B's in nx_sp16[1]; one v_perm each puts a value of both into one register
             sp[0] = (int)__builtin_amdgcn_perm(nx_sp16[1].x, nx_sp16[0].x, 0x05040100u);
@@ -312,8 +312,14 @@ struct WaveDP16 {
         });
     }
 
+    // VAR 2: the cooperating waves keep their distance through progress counters in LDS instead of meeting at a barrier
+    // after every chunk: wave w starts chunk k once wave w-1 has finished chunk k+1 (the row above is there, as with the
+    // barriers) and wave w+1 has finished chunk k-4 (the ring slots it is about to overwrite have been read: a ring holds
+    // 256 columns, a chunk 66, lane 63 writes 63 columns behind the step) -- up to two chunks of slack per neighbour
+    // instead of lock-step.
     template <int NW>
-    __device__ __forceinline__ void run_mw(const DevJob &ja, const DevJob &jb, const DevSeqs &seqs, int *bnd, lds_int *rings, int wid) {
+    __device__ __forceinline__ void run_mw(const DevJob &ja, const DevJob &jb, const DevSeqs &seqs, int *bnd, lds_int *rings, int wid,
+                                           lds_int *prog = nullptr) {
         const DevJob *jp[2] = {&ja, &jb};
         static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
             const DevJob &jx = *jp[H];
@@ -322,7 +328,7 @@ struct WaveDP16 {
             qc[H] = seqs.qcode + seqs.qoff[jx.pair];
             tc[H] = seqs.tcode + seqs.toff[jx.pair];
             ss[H] = F::has_splice() ? seqs.ss + seqs.toff[jx.pair] : nullptr;
-            ss16[H] = (F::has_splice() && VAR == 1) ? seqs.ss16 + seqs.toff[jx.pair] : nullptr;
+            ss16[H] = (F::has_splice() && VAR >= 1) ? seqs.ss16 + seqs.toff[jx.pair] : nullptr;
             seed_wr[H] = seqs.seed + jx.seed_off; seed_rows[H] = jx.seed_rows;
             best[H] = LOW; best_i[H] = best_j[H] = 0; best_set[H] = false;
         });
@@ -377,27 +383,55 @@ struct WaveDP16 {
                     step<JI, P>(s0 + P, i0, last, bnd_in, bnd_out);
                 });
             };
-            for (int t = 0; t < 2 * wid; t++) __syncthreads();
-            if (idle) {
-                for (int k = 0; k < nchunks; k++) __syncthreads();
+            constexpr bool FLAGS = (VAR == 2);
+            auto publish = [&](int done) __attribute__((always_inline)) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(prog + wid, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            };
+            auto wait_for = [&](int w, int done) __attribute__((always_inline)) {
+                while (__hip_atomic_load(prog + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < done) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            };
+            auto before = [&](int k) __attribute__((always_inline)) {
+                if constexpr (FLAGS) {
+                    if (wid > 0) wait_for(wid - 1, k + 2 < nchunks ? k + 2 : nchunks);
+                    if (wid < NW - 1 && k >= 4) wait_for(wid + 1, k - 3);
+                }
+            };
+            auto after = [&](int k) __attribute__((always_inline)) {
+                if constexpr (FLAGS) publish(k + 1);
+                else __syncthreads();
+            };
+            if constexpr (FLAGS) {
+                if (lane == 0) __hip_atomic_store(prog + wid, idle ? 0x40000000 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __syncthreads();
             } else {
+                for (int t = 0; t < 2 * wid; t++) __syncthreads();
+            }
+            if (idle) {
+                if constexpr (!FLAGS) for (int k = 0; k < nchunks; k++) __syncthreads();
+            } else {
+                before(0);                           // the first carry column is read ahead of the first step
                 prefetch_column(0 - lane);
                 prefetch_carry(0, bnd_in);
                 int k = 0;
                 for (; k < nchunks && k * CH < main_lo; k++) {
+                    before(k);
                     for (int s = k * CH; s < k * CH + CH; s += NCOL) group(IC<0>{}, s);
-                    __syncthreads();
+                    after(k);
                 }
                 for (; k < nchunks && k * CH + CH - 1 <= main_hi; k++) {
+                    before(k);
                     for (int s = k * CH; s < k * CH + CH; s += NCOL) group(IC<1>{}, s);
-                    __syncthreads();
+                    after(k);
                 }
                 for (; k < nchunks; k++) {
+                    before(k);
                     for (int s = k * CH; s < k * CH + CH; s += NCOL) group(IC<0>{}, s);
-                    __syncthreads();
+                    after(k);
                 }
             }
-            for (int t = 0; t < 2 * (NW - 1 - wid); t++) __syncthreads();
+            if constexpr (!FLAGS) for (int t = 0; t < 2 * (NW - 1 - wid); t++) __syncthreads();
             strip_end();
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
@@ -435,6 +469,7 @@ void viterbi16_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *job
     __shared__ int next_job;
     __shared__ int rings[(NW > 1 ? NW - 1 : 1) * DP::RING * DP::BND];
     __shared__ int wave_best[NW][2][4];
+    __shared__ int progress[NW];
     {
         const int *src = reinterpret_cast<const int *>(kparams);
         int *dst = reinterpret_cast<int *>(&kp_lds);
@@ -458,7 +493,7 @@ void viterbi16_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *job
         dp.kp = &kp_lds;
         dp.lane = threadIdx.x & 63;
         dp.carry_ok = scratch.carry != 0;
-        dp.template run_mw<NW>(jobs[ia], jobs[ib], seqs, bnd, (typename DP::lds_int *)rings, wid);
+        dp.template run_mw<NW>(jobs[ia], jobs[ib], seqs, bnd, (typename DP::lds_int *)rings, wid, (typename DP::lds_int *)progress);
         dp.reduce_best();
         if (dp.lane == 0)
             for (int h = 0; h < 2; h++) {

@@ -15,6 +15,7 @@ namespace c4k {
                                     WaveDP16<M, RV>::BND, M::NS, M::MAXAT, NWV, WaveDP16<M, RV>::SEEDW};
 PK16_KERNEL(kpk16_est2genome, Est2GenomeDesc, 4, 4, 3, 0)
 PK16_KERNEL(kpk16b_est2genome, Est2GenomeDesc, 4, 4, 3, 1)
+PK16_KERNEL(kpk16c_est2genome, Est2GenomeDesc, 4, 4, 3, 2)
 // the packed splice array of variant 1 (ss16_kernel): n positions of the batch's concatenated targets
 hipError_t pk16_build_splice(int family, const KParams *kp, const int *ss, long long ss_stride, long long n, void *out, hipStream_t s) {
     if (family != FAM_EST2GENOME) return hipErrorInvalidValue;
@@ -23,6 +24,6 @@ hipError_t pk16_build_splice(int family, const KParams *kp, const int *ss, long 
 }
 const KernelInfo *get_kernel_pk16(int family, int variant) {
     if (family != FAM_EST2GENOME) return nullptr;
-    return variant == 1 ? &kpk16b_est2genome : &kpk16_est2genome;
+    return variant == 2 ? &kpk16c_est2genome : variant == 1 ? &kpk16b_est2genome : &kpk16_est2genome;
 }
 }

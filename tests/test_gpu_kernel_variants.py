@@ -305,13 +305,16 @@ def test_packed_16_bit_score_pass_agrees_with_the_32_bit_pass(eng, monkeypatch, 
     pairs.append((_rand(rng, 500), _rand(rng, 25000)))                         # unrelated; nine jobs: the last lane pair is half empty
     monkeypatch.setenv("C4GPU_TRACE", "1")
     res = {}
-    for pk in ("1", "3", "0"):                   # 1 and 3: the two forms of the packed pass (c4_viterbi16_kernel.h, VAR 1 and 0)
+    # 1, 3, 4: the forms of the packed pass (c4_viterbi16_kernel.h: VAR 1 = default, VAR 0 = every instruction its own asm
+    # statement, VAR 2 = progress counters between the cooperating waves instead of a barrier per chunk)
+    for pk in ("1", "3", "4", "0"):
         monkeypatch.setenv("C4GPU_PK16", pk)
         res[pk] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=32, threshold=20)]
         err = capfd.readouterr().err
         assert "windowed region pass" in err
         assert ("kpk16b_est2genome" in err) == (pk == "1") and ("kpk16_est2genome" in err) == (pk == "3"), err[-1500:]
-    assert res["1"] == res["0"] and res["3"] == res["0"]
+        assert ("kpk16c_est2genome" in err) == (pk == "4"), err[-1500:]
+    assert res["1"] == res["0"] and res["3"] == res["0"] and res["4"] == res["0"]
     ops = [model.c.transitions[t].label for t, n in res["1"][7]["ops"] if n >= 45000]
     assert ops == [6], "the long intron is not in the alignment"              # C4_Label_INTRON
     q, t = pairs[2]
@@ -322,9 +325,11 @@ def test_packed_16_bit_score_pass_agrees_with_the_32_bit_pass(eng, monkeypatch, 
     a = [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=20)]
     monkeypatch.setenv("C4GPU_PK16", "3")
     a2 = [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=20)]
+    monkeypatch.setenv("C4GPU_PK16", "4")
+    a4 = [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=20)]
     monkeypatch.setenv("C4GPU_PK16", "0")
     b = [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=20)]
-    assert a == b and a2 == b
+    assert a == b and a2 == b and a4 == b
 
 
 @pytest.mark.parametrize("model_type,dpm", [("affine:local", 32), ("affine:local", 1), ("affine:local", 0),
