@@ -147,6 +147,8 @@ PROTOTYPES = [
     ("c4gpu_model_is_accelerated", C.c_int, [C.POINTER(Model)]),
     ("c4gpu_use_reduced_space", C.c_int, [C.POINTER(Model), C.POINTER(Region), C.c_int]),
     ("c4gpu_checkpoint_rows", C.c_int, [C.POINTER(Model), C.POINTER(Region), C.c_int]),
+    ("c4gpu_memrule_device", C.c_int, [C.c_void_p, C.POINTER(Model), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32,
+                              C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("c4gpu_splice_predict", C.c_int, [C.c_void_p, C.POINTER(Params), C.c_char_p, C.c_int32,
                                        C.POINTER(C.POINTER(C.c_int32))]),
     ("c4gpu_viterbi_batch", C.c_int, [C.c_void_p, C.POINTER(Model), C.POINTER(Params), C.c_int,

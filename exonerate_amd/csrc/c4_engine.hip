@@ -431,6 +431,15 @@ __global__ __launch_bounds__(64) void fuse_expand_kernel(const DevJob *parents, 
     }
 }
 
+// c4gpu_memrule_device: the rule on the device, one size per thread
+__global__ void memrule_probe_kernel(c4h::MemRule rule, int dpmemory_mb, const int *ql, const int *tl, int n, int *reduced, int *rows) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n) return;
+    reduced[x] = c4h::use_reduced_space(rule, ql[x], tl[x], dpmemory_mb) ? 1 : 0;
+    // the reference divides by the row size (viterbi.c:209): only defined where that size did not overflow
+    rows[x] = c4h::viterbi_row_bytes(rule, ql[x], 1 + rule.total_shadow_designations + 1) ? c4h::checkpoint_rows(rule, ql[x], tl[x], dpmemory_mb) : -1;
+}
+
 struct FusePair { long long off; int count, status; };      // merged (transition, length) pairs at out[2 * off ..]; status 0 = done
 
 // one thread per checkpoint job: verify the chain of final cells, then Alignment_add (alignment.c:75-102) over the runs
@@ -1995,6 +2004,20 @@ c4gpu_ctx *c4gpu_ctx_create(int device_ordinal) {
 }
 
 int c4gpu_model_device_family(const c4gpu_model *model) { return model_family(*model); }
+
+int c4gpu_memrule_device(c4gpu_ctx *ctx, const c4gpu_model *model, int dpmemory_mb, const int32_t *query_length,
+                         const int32_t *target_length, int32_t n, int32_t *reduced, int32_t *rows) {
+    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+    DevBuf<int> dq, dt, dr, dw;
+    hipStream_t s = ctx->stream;
+    const c4h::MemRule rule{model->max_query_advance, model->max_target_advance, model->n_states, model->total_shadow_designations};
+    if (dq.upload(query_length, n, s) || dt.upload(target_length, n, s) || dr.alloc(n) || dw.alloc(n)) return -1;
+    hipLaunchKernelGGL(memrule_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rule, dpmemory_mb, dq.p, dt.p, n, dr.p, dw.p);
+    HIP_OK(hipGetLastError());
+    if (dr.download(reduced, n, s) || dw.download(rows, n, s)) return -1;
+    HIP_OK(hipStreamSynchronize(s));
+    return 0;
+}
 
 // Load the code objects a heuristic run touches first (sequence preparation, HSP extension, word scan; the SDP passes of
 // every family) without launching anything: hipFuncGetAttributes resolves a kernel, which loads its translation unit's

@@ -254,6 +254,12 @@ int         c4gpu_model_device_family(const c4gpu_model *model);
  * identical decisions to the reference for a given --dpmemory (Mb). */
 int         c4gpu_use_reduced_space(const c4gpu_model *model, const c4gpu_region *region, int dpmemory_mb);
 int         c4gpu_checkpoint_rows(const c4gpu_model *model, const c4gpu_region *region, int dpmemory_mb);
+/* The same two decisions evaluated ON THE DEVICE for n region sizes (the sub-alignment jobs of a checkpoint pass are
+ * listed there, c4_engine.hip fuse_expand_kernel: the rule's arithmetic is compiled for host and device from one source,
+ * csrc/c4_memrule.h): reduced[k] = Viterbi_use_reduced_space, rows[k] = Viterbi_checkpoint_rows of a region of
+ * query_length[k] x target_length[k].  Test hook: must equal the host functions above for every size. */
+int         c4gpu_memrule_device(c4gpu_ctx *ctx, const c4gpu_model *model, int dpmemory_mb, const int32_t *query_length,
+                                 const int32_t *target_length, int32_t n, int32_t *reduced, int32_t *rows);
 
 /* SplicePredictor_predict_array_int (splice.c:383-397) for the 4 splice types over whole targets, on
  * the device.  out[k] (k = C4GPU_SS*) receives target_len int32 each. */

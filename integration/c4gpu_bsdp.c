@@ -842,7 +842,7 @@ GAM_Result *GAM_Result_heuristic_create(GAM *gam, Comparison *comparison){
     register gboolean batchable = (shim_batch_size() > 0) && (!gam->gas->use_gapped_extension) && gam->heuristic
         && (bsdp_mode == BSDP_OFF)
         && (!Comparison_Param_get_HSPSet_Argument_Set(comparison->param)->geneseed_threshold)
-        && (g_getenv("C4GPU_BSDP_HOST") || (shim_get_ctx() != NULL))
+        && (g_getenv("C4GPU_BSDP_HOST") || (shim_ctx_nowait() != NULL))
         && (!g_getenv("C4GPU_BSDP_OFF"));
     /* --gappedextension yes: the SDP seam (c4gpu_sdp.c) takes the pairs of the models it covers */
     if(gam->gas->use_gapped_extension && (bsdp_mode == BSDP_OFF) && (!shim_sdp_replaying())

@@ -54,7 +54,11 @@ static gboolean hsp_eligible(HSPset *hsp_set){
         return FALSE;
     if(shim_batch_size() <= 0)
         return FALSE;
-    return g_getenv("C4GPU_HSP_HOST") || (shim_get_ctx() != NULL);
+    /* a set the reference's own function has already stored an HSP in (its first word hits came while the device was still
+     * being opened, shim_ctx_nowait) stays with that function: the replay starts from an empty set */
+    if(!hsp_set->is_empty)
+        return FALSE;
+    return g_getenv("C4GPU_HSP_HOST") || (shim_ctx_nowait() != NULL);
     }
 
 void HSPset_seed_hsp(HSPset *hsp_set, guint query_start, guint target_start){

@@ -61,7 +61,7 @@ static gboolean sdp_eligible(GAM *gam, Comparison *comparison){
         return FALSE;
     if(Comparison_Param_get_HSPSet_Argument_Set(comparison->param)->geneseed_threshold)
         return FALSE;
-    if((!g_getenv("C4GPU_SDP_HOST")) && (!shim_get_ctx()))
+    if((!g_getenv("C4GPU_SDP_HOST")) && (!shim_ctx_nowait()))
         return FALSE;
     return TRUE;
     }

@@ -320,7 +320,7 @@ void Seeder_add_target(Seeder *seeder, Sequence *target){
     if(off < 0)
         off = (g_getenv("C4GPU_SEED_OFF") || (shim_batch_size() <= 0)) ? 1 : 0;
     shim_mark("Seeder_add_target");
-    if((!off) && (g_getenv("C4GPU_SEED_HOST") || shim_get_ctx())){
+    if((!off) && (g_getenv("C4GPU_SEED_HOST") || shim_ctx_nowait())){
         st = seed_state(seeder);
         if(st->hopeless)
             st = NULL;

@@ -12,6 +12,8 @@
 #include <string.h>
 #include <stdlib.h>
 #include <stdio.h>
+#include <unistd.h>
+extern int on_exit(void (*function)(int, void *), void *arg);      /* glibc; hidden by _XOPEN_SOURCE */
 
 #include "viterbi.h"
 #include "ungapped.h"
@@ -80,14 +82,30 @@ static GCond shim_ctx_cond;
 static gboolean shim_ctx_ready = FALSE;
 static gchar *shim_ctx_error = NULL;
 
+/* Process exit with the device open: the HIP runtime's own teardown (static destructors of the libraries the lazy front
+ * loaded) costs tens of milliseconds and has nothing left to do for a process that is about to end.  Registered when the
+ * device thread starts, i.e. after everything the program registered itself, so it runs first: flush, then leave.
+ * C4GPU_SLOW_EXIT keeps the ordinary exit. */
+static void shim_fast_exit(int status, void *arg){
+    fflush(NULL);
+    _exit(status);
+    }
+
 static gpointer shim_ctx_open(gpointer data){
-    register c4gpu_ctx *ctx;
+    register c4gpu_ctx *ctx = NULL;
+    register gchar *why = NULL;
     shim_t_open = g_get_monotonic_time();
-    ctx = c4gpu_ctx_create(g_getenv("C4GPU_DEVICE") ? atoi(g_getenv("C4GPU_DEVICE")) : shim_args.device);
+    /* the first call into libc4gpu.so: the lazy front (integration/Makefile) loads it here, on this thread */
+    if(c4gpu_abi_version() != C4GPU_ABI_VERSION)
+        why = g_strdup_printf("libc4gpu.so has ABI version %d, this binary was built for %d", c4gpu_abi_version(), C4GPU_ABI_VERSION);
+    else
+        ctx = c4gpu_ctx_create(g_getenv("C4GPU_DEVICE") ? atoi(g_getenv("C4GPU_DEVICE")) : shim_args.device);
     shim_t_ready = g_get_monotonic_time();
     g_mutex_lock(&shim_ctx_lock);
     shim_ctx = ctx;
-    if(!ctx)
+    if(why)
+        shim_ctx_error = why;
+    else if(!ctx)
         shim_ctx_error = g_strdup(c4gpu_last_error());
     shim_ctx_ready = TRUE;
     g_cond_broadcast(&shim_ctx_cond);
@@ -105,11 +123,8 @@ static void shim_start_ctx(void){
     shim_verbose = (g_getenv("C4GPU_VERBOSE") != NULL);
     if((!shim_args.use_gpu) || g_getenv("C4GPU_DISABLE"))
         return;
-    if(c4gpu_abi_version() != C4GPU_ABI_VERSION){
-        g_warning("c4gpu: libc4gpu.so has ABI version %d, this binary was built for %d -- using the CPU Viterbi",
-                  c4gpu_abi_version(), C4GPU_ABI_VERSION);
-        return;
-        }
+    if(!g_getenv("C4GPU_SLOW_EXIT"))
+        on_exit(shim_fast_exit, NULL);
     shim_ctx_thread = g_thread_new("c4gpu-ctx", shim_ctx_open, NULL);
     return;
     }
@@ -130,6 +145,23 @@ c4gpu_ctx *shim_get_ctx(void){
         shim_ctx_error = NULL;
         }
     return shim_ctx;
+    }
+
+/* The seams in front of SMALL pieces of work (word scan, HSP extension, BSDP's sub-DPs, SDP) ask this way: the context if
+ * the device is open, NULL while it is still being opened -- such a piece then keeps the reference's own function (the
+ * results are the same either way), and a run that is over before the device is ready never waits for it: the whole
+ * est2genome BSDP run of 32 x 32 takes the reference 0.23 s, the device needs 0.15-0.2 s to open.  The seams in front of
+ * large dynamic programmes (the exhaustive batching seam, Viterbi calls of C4GPU_MIN_CELLS and more) do wait
+ * (shim_get_ctx).  C4GPU_WAIT=1: every seam waits (the tests: they count what the device served). */
+c4gpu_ctx *shim_ctx_nowait(void){
+    register gboolean ready;
+    shim_start_ctx();
+    if((!shim_ctx_thread) || g_getenv("C4GPU_WAIT"))
+        return shim_get_ctx();
+    g_mutex_lock(&shim_ctx_lock);
+    ready = shim_ctx_ready;
+    g_mutex_unlock(&shim_ctx_lock);
+    return ready ? shim_get_ctx() : NULL;
     }
 
 /* ---- C4_Model (closed) -> c4gpu_model ------------------------------------------------------------- */
@@ -750,7 +782,9 @@ void GAM_report(GAM *gam){        /* analysis.c:1421: after the last pair */
     shim_sdp_report();
     shim_seed_report();
     shim_hsp_report();
-    if(shim_ctx_thread){                  /* the background code-object loads are over before the process winds down */
+    /* with the ordinary exit the background code-object loads must be over before the process winds down; the fast exit
+     * (shim_fast_exit) needs nobody to wait */
+    if(shim_ctx_thread && (shim_verbose || g_getenv("C4GPU_SLOW_EXIT"))){
         g_thread_join(shim_ctx_thread);
         shim_ctx_thread = NULL;
         if(shim_verbose)

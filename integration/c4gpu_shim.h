@@ -12,6 +12,7 @@
 #include "c4gpu.h"
 
 c4gpu_ctx *shim_get_ctx(void);
+c4gpu_ctx *shim_ctx_nowait(void);       /* NULL while the device is still being opened (small work does not wait) */
 void shim_mark(const gchar *what);
 gint shim_batch_size(void);
 /* closed C4_Model -> c4gpu_model; allow_span: BSDP's span models (cell_start_func / cell_end_func become matrices) */

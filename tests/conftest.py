@@ -6,6 +6,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# the drop-in's seams in front of small pieces of work do not wait for a device that is still being opened
+# (integration/c4gpu_shim.c, shim_ctx_nowait); the tests count what the device served, so here every seam waits
+os.environ.setdefault("C4GPU_WAIT", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

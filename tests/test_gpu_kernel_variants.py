@@ -409,3 +409,30 @@ def test_two_launch_lanes_give_the_one_lane_results(eng, monkeypatch, model_type
     assert res["1"] == res["2"] and res["b1"] == res["1"] and res["b2"] == res["1"]
     assert any(r is not None for r in res["1"])
     assert res["n2"] > res["n1"] > 0                  # each lane launches its own passes
+
+
+def test_memory_rule_on_the_device_is_the_host_rule(eng):
+    """Viterbi_use_reduced_space / Viterbi_checkpoint_rows (viterbi.c:128-150,207-218) decide which passes a region gets;
+    the device lists the sub-alignments of a checkpoint pass and evaluates the rule itself (csrc/c4_memrule.h compiled for
+    host and device).  Same decisions as the host functions (which test_abi.py pins on the oracle) for region sizes from
+    the smallest to the largest a sequence can have, at every --dpmemory the tests use."""
+    import ctypes as C
+    lib = _abi.load()
+    rng = random.Random(4242)
+    sizes = [(q, t) for q in (0, 1, 5, 6, 7, 12, 13, 100, 1000, 1001, 65535, 1 << 20, (1 << 30) - 1)
+             for t in (0, 1, 6, 7, 12, 13, 14, 250, 1000, 4096, 100000, 10 ** 7, (1 << 30) - 1)]
+    sizes += [(rng.randint(0, 5000), rng.randint(0, 200000)) for _ in range(3000)]
+    sizes += [(rng.randint(0, 1 << 30), rng.randint(0, 1 << 30)) for _ in range(500)]
+    n = len(sizes)
+    ql = (C.c_int32 * n)(*[s[0] for s in sizes])
+    tl = (C.c_int32 * n)(*[s[1] for s in sizes])
+    for mt in ("affine:local", "est2genome", "protein2genome"):
+        model = ex.Model(mt)
+        for dpm in (0, 1, 32, 512, 2047):
+            red, rows = (C.c_int32 * n)(), (C.c_int32 * n)()
+            assert lib.c4gpu_memrule_device(eng.ctx, model.c, dpm, ql, tl, n, red, rows) == 0
+            for k, (q, t) in enumerate(sizes):
+                r = _abi.Region(0, 0, q, t)
+                assert red[k] == lib.c4gpu_use_reduced_space(model.c, r, dpm), (mt, dpm, q, t)
+                if red[k] and rows[k] >= 0 and dpm > 0:
+                    assert rows[k] == lib.c4gpu_checkpoint_rows(model.c, r, dpm), (mt, dpm, q, t)

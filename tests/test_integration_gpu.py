@@ -404,3 +404,37 @@ def test_word_scan_on_the_device_equals_the_reference_walk(tmp_path, model, extr
     assert m and int(m.group(4)) > 100, err[-800:]
     assert "every seed equal to the reference's own walk" in err and "scanned on the CPU" not in err
     assert "c4gpu hsp:" in err
+
+
+@pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
+                    reason="reference binaries are built in the build container (make -C integration)")
+@pytest.mark.parametrize("extra", [["--gappedextension", "no", "-S", "no"], ["--gappedextension", "no"], [],
+                                   ["-m", "protein2genome"]])
+def test_small_work_does_not_wait_for_the_device(tmp_path, extra):
+    """Without C4GPU_WAIT the seams in front of small work (word scan, HSP extension, BSDP sub-DPs, SDP) take the device only
+    once it is open (shim_ctx_nowait): whatever comes earlier keeps the reference's own function, mid-run switches
+    included (an HSP set that already holds an HSP stays with the reference's function).  The output is the reference's
+    byte for byte whichever way each piece went; libc4gpu.so itself is bound lazily (no load before main)."""
+    from exonerate_amd import workloads
+    if "protein2genome" in extra:
+        proteins, contig, _ = workloads.protein_vs_contig(12, 200, 400000, seed=5, introns=True)
+        qrecs = [("p%d" % k, p.decode()) for k, p in enumerate(proteins)]
+        trecs = [("chr", contig.decode())]
+        args = list(extra)
+    else:
+        pairs = workloads.est2genome_pairs(8, 1000, 100000, seed=77)
+        qrecs = [("q%d" % k, q.decode()) for k, (q, t) in enumerate(pairs)]
+        trecs = [("t%d" % k, t.decode()) for k, (q, t) in enumerate(pairs)]
+        args = ["-m", "est2genome"] + extra
+    qf, tf = str(tmp_path / "q.fa"), str(tmp_path / "t.fa")
+    _fasta(qf, qrecs)
+    _fasta(tf, trecs)
+    args += ["--showalignment", "yes", "--showvulgar", "yes", "-V", "0", qf, tf]
+    ref_out, _ = _run(CPU_EXE, args)
+    env = {k: v for k, v in os.environ.items() if k != "C4GPU_WAIT"}
+    for rep in range(3):                                   # the switch-over point moves from run to run
+        r = subprocess.run([GPU_EXE] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert r.stdout.decode() == ref_out and ref_out.count("vulgar:") >= 4
+    ldd = subprocess.run(["ldd", GPU_EXE], stdout=subprocess.PIPE).stdout.decode()
+    assert "libc4gpu" not in ldd and "amdhip" not in ldd
