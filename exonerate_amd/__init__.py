@@ -127,6 +127,68 @@ class Alignment:
     def vulgar(self, qid="qy", tid="tg", qstrand="+", tstrand="+", forward_coords=True):
         return self._format(2, qid, tid, qstrand, tstrand, forward_coords)
 
+    def gff(self, query, target, qid="qy", tid="tg", qstrand="+", tstrand="+", on_query=False, genomic=None, result_id=1,
+            date=None, version=None):
+        """Alignment_display_gff (--showtargetgff / --showquerygff with on_query) as the reference prints it
+        (c4gpu_alignment_format_gff).  genomic: gene features before the similarity line; default: a target report of a
+        model with introns (Model_Type_has_genomic_target, gam.c:1229)."""
+        if genomic is None:
+            labels = {self.model.c.transitions[k].label for k in range(self.model.c.n_transitions)}
+            genomic = (not on_query) and (_abi.LABEL_INTRON in labels)
+        q = query if isinstance(query, bytes) else query.encode()
+        t = target if isinstance(target, bytes) else target.encode()
+        req = _abi.GffRequest(qid.encode(), tid.encode(), q, t, len(q), len(t), qstrand.encode(), tstrand.encode(), int(on_query),
+                              int(genomic), result_id, date.encode() if date else None, version.encode() if version else None)
+        cap = 4096 + 64 * (len(self.ops) + 8)
+        for _ in range(2):
+            buf = C.create_string_buffer(cap)
+            n = _lib().c4gpu_alignment_format_gff(self.model.c, self.model.params, self._c(), req, buf, cap)
+            if n >= 0:
+                return buf.value.decode()
+            if n == -(2 ** 31):
+                raise C4GpuError("no GFF dump for this model")
+            cap = -n
+        raise C4GpuError("GFF dump does not fit its buffer")
+
+    def display(self, query, target, qid="qy", tid="tg", qstrand="+", tstrand="+", qdef=None, tdef=None, width=80,
+                forward_coords=True, use_aa_tla=True):
+        """Alignment_display: the human-readable block of --showalignment yes as the reference prints it
+        (c4gpu_alignment_display)."""
+        q = query if isinstance(query, bytes) else query.encode()
+        t = target if isinstance(target, bytes) else target.encode()
+        req = _abi.DisplayRequest(qid.encode(), qdef.encode() if qdef else None, tid.encode(), tdef.encode() if tdef else None,
+                                  q, t, len(q), len(t), qstrand.encode(), tstrand.encode(), width, int(forward_coords),
+                                  int(use_aa_tla))
+        cap = 8192 + 8 * (self.region[2] + self.region[3]) + 256 * len(self.ops)
+        for _ in range(2):
+            buf = C.create_string_buffer(cap)
+            n = _lib().c4gpu_alignment_display(self.model.c, self.model.params, self._c(), req, buf, cap)
+            if n >= 0:
+                return buf.value.decode()
+            if n == -(2 ** 31):
+                raise C4GpuError("no alignment display for this model / alignment")
+            cap = -n
+        raise C4GpuError("alignment display does not fit its buffer")
+
+    def ryo(self, fmt, query, target, qid="qy", tid="tg", qstrand="+", tstrand="+", qdef=None, tdef=None, rank=0,
+            forward_coords=True):
+        """Alignment_display_ryo: a --ryo format string printed for this alignment as the reference prints it
+        (c4gpu_alignment_format_ryo)."""
+        q = query if isinstance(query, bytes) else query.encode()
+        t = target if isinstance(target, bytes) else target.encode()
+        req = _abi.RyoRequest(qid.encode(), qdef.encode() if qdef else None, tid.encode(), tdef.encode() if tdef else None, q, t,
+                              len(q), len(t), qstrand.encode(), tstrand.encode(), int(forward_coords), rank, fmt.encode())
+        cap = 1 << 16
+        for _ in range(2):
+            buf = C.create_string_buffer(cap)
+            n = _lib().c4gpu_alignment_format_ryo(self.model.c, self.model.params, self._c(), req, buf, cap)
+            if n >= 0:
+                return buf.raw[:n].decode()
+            if n == -(2 ** 31):
+                raise C4GpuError("this --ryo string cannot be printed for this model (unknown token, unbalanced braces, %pS on a codon match)")
+            cap = -n
+        raise C4GpuError("ryo output does not fit its buffer")
+
     def as_dict(self, qid="qy"):
         return {"score": self.score, "region": list(self.region), "ops": [list(o) for o in self.ops],
                 "sugar": self.sugar(qid), "cigar": self.cigar(qid), "vulgar": self.vulgar(qid)}

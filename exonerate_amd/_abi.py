@@ -92,6 +92,27 @@ class Alignment(C.Structure):
                 ("valid", C.c_int32)]
 
 
+class GffRequest(C.Structure):
+    _fields_ = [("query_id", C.c_char_p), ("target_id", C.c_char_p), ("query", C.c_char_p), ("target", C.c_char_p),
+                ("query_len", C.c_int32), ("target_len", C.c_int32), ("query_strand", C.c_char), ("target_strand", C.c_char),
+                ("report_on_query", C.c_int32), ("report_on_genomic", C.c_int32), ("result_id", C.c_int32),
+                ("date", C.c_char_p), ("version", C.c_char_p)]
+
+
+class DisplayRequest(C.Structure):
+    _fields_ = [("query_id", C.c_char_p), ("query_def", C.c_char_p), ("target_id", C.c_char_p), ("target_def", C.c_char_p),
+                ("query", C.c_char_p), ("target", C.c_char_p), ("query_len", C.c_int32), ("target_len", C.c_int32),
+                ("query_strand", C.c_char), ("target_strand", C.c_char), ("width", C.c_int32), ("forward_coords", C.c_int32),
+                ("use_aa_tla", C.c_int32)]
+
+
+class RyoRequest(C.Structure):
+    _fields_ = [("query_id", C.c_char_p), ("query_def", C.c_char_p), ("target_id", C.c_char_p), ("target_def", C.c_char_p),
+                ("query", C.c_char_p), ("target", C.c_char_p), ("query_len", C.c_int32), ("target_len", C.c_int32),
+                ("query_strand", C.c_char), ("target_strand", C.c_char), ("forward_coords", C.c_int32), ("rank", C.c_int32),
+                ("format", C.c_char_p)]
+
+
 class HspSeed(C.Structure):
     _fields_ = [("pair", C.c_int32), ("query_start", C.c_int32), ("target_start", C.c_int32)]
 
@@ -202,6 +223,12 @@ PROTOTYPES = [
     ("c4gpu_alignment_format", C.c_int, [C.POINTER(Model), C.POINTER(Alignment), C.c_int,
                                          C.c_char_p, C.c_int32, C.c_char, C.c_char_p, C.c_int32, C.c_char,
                                          C.c_int, C.c_char_p, C.c_size_t]),
+    ("c4gpu_alignment_format_gff", C.c_int, [C.POINTER(Model), C.POINTER(Params), C.POINTER(Alignment), C.POINTER(GffRequest),
+                                    C.c_char_p, C.c_size_t]),
+    ("c4gpu_alignment_display", C.c_int, [C.POINTER(Model), C.POINTER(Params), C.POINTER(Alignment), C.POINTER(DisplayRequest),
+                                 C.c_char_p, C.c_size_t]),
+    ("c4gpu_alignment_format_ryo", C.c_int, [C.POINTER(Model), C.POINTER(Params), C.POINTER(Alignment), C.POINTER(RyoRequest),
+                                    C.c_char_p, C.c_size_t]),
     ("c4gpu_splice_max_score", C.c_float, [C.POINTER(SpliceModel)]),
     # c4m.h
     ("c4m_model_create", C.c_void_p, [C.c_char_p]),

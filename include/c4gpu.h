@@ -428,6 +428,68 @@ int         c4gpu_alignment_format(const c4gpu_model *model, const c4gpu_alignme
                                    const char *target_id, int32_t target_len, char target_strand,
                                    int forward_coords, char *buf, size_t buf_len);
 
+/* Alignment_display_gff (alignment.c:2710-3236): the GFF2 dump of --showtargetgff / --showquerygff -- header,
+ * gene / utr / cds / exon / intron / splice features where the report side is genomic (gam.c:1224-1230:
+ * report_on_genomic = Model_Type_has_genomic_target for the target report, never for the query report), similarity line --
+ * as the reference prints it, byte for byte.  Needs the residues (identity / similarity of the gene and exon attributes:
+ * alignment.c:1382-1560, splice-site dinucleotides) and the scoring data (similarity = match calc > 0; codons through
+ * Translate_base).  The sequences are the ones that were aligned (a reverse-complemented strand as such); a strand of
+ * '-' turns the coordinates back as Alignment_display_gff_line does.  Host-only. */
+typedef struct {
+    const char    *query_id, *target_id;
+    const uint8_t *query, *target;
+    int32_t        query_len, target_len;
+    char           query_strand, target_strand;   /* '+', '-' or '.' (Sequence_get_strand_as_char) */
+    int32_t        report_on_query;               /* --showquerygff: 1; --showtargetgff: 0 */
+    int32_t        report_on_genomic;             /* gene features before the similarity line */
+    int32_t        result_id;                     /* gene_id / alignment_id */
+    const char    *date;                          /* "YYYY-MM-DD" of the ##date line; NULL: today, local time */
+    const char    *version;                       /* VERSION of the ##source-version line; NULL: "2.4.0" */
+} c4gpu_gff_request;
+/* returns the length written (without the terminating NUL), or -(length needed + 1) when buf_len is too small, or
+ * INT32_MIN for a model whose match transitions are not one of the accelerated kinds */
+int         c4gpu_alignment_format_gff(const c4gpu_model *model, const c4gpu_params *params, const c4gpu_alignment *a,
+                                       const c4gpu_gff_request *req, char *buf, size_t buf_len);
+
+/* Alignment_display (alignment.c:234-1380): the human-readable block of --showalignment yes, the reference's
+ * default output -- header, then rows of query / [translation] / match line / [translation] / target with the running
+ * coordinates, gaps, codon gaps, frameshifts, splice sites with their consensus marks, collapsed introns, split codons and
+ * the reverse-translation marks of protein-vs-DNA matches (match.c:224-236,385-417) -- byte for byte, for the models the
+ * library accelerates (1:1 DNA or protein matches, protein against DNA / genome).  Host-only. */
+typedef struct {
+    const char    *query_id, *query_def, *target_id, *target_def;    /* def: the rest of the FASTA header line, or NULL */
+    const uint8_t *query, *target;                                   /* as aligned (a reverse-complemented strand as such) */
+    int32_t        query_len, target_len;
+    char           query_strand, target_strand;
+    int32_t        width;                 /* --alignmentwidth; 0: 80 */
+    int32_t        forward_coords;        /* --forwardcoordinates (default in the reference: 1) */
+    int32_t        use_aa_tla;            /* --useaatla (default in the reference: 1): Ala / ^A^ */
+} c4gpu_display_request;
+/* returns as c4gpu_alignment_format_gff */
+int         c4gpu_alignment_display(const c4gpu_model *model, const c4gpu_params *params, const c4gpu_alignment *a,
+                                    const c4gpu_display_request *req, char *buf, size_t buf_len);
+
+/* Alignment_display_ryo (alignment.c:1781-2669): a --ryo format string printed for one alignment -- every token
+ * of the reference: %[qt][idlsSt], %[qt]a[bels], %[qt]c[bels], %s %m %r, %p[cIisS], %e[tism], %g, %S %C %V, the escapes, and
+ * the per-transition section { ... } with %P[qt][sabe] and %P[nsl] (transition scores through the calcs: match, constants,
+ * splice sites with the intron-length test on the tracked shadow, split codons; the splice predictions are computed on the
+ * host here).  Not covered: %pS for protein-against-DNA models (the reference scores the query against itself through a
+ * codon match there) -- INT32_MIN, as for an unknown token or unbalanced braces (the reference aborts). */
+typedef struct {
+    const char    *query_id, *query_def, *target_id, *target_def;
+    const uint8_t *query, *target;
+    int32_t        query_len, target_len;
+    char           query_strand, target_strand;
+    int32_t        forward_coords;        /* --forwardcoordinates */
+    int32_t        rank;                  /* %r; -1 prints the placeholder the reference's --bestn pass fills in */
+    const char    *format;
+} c4gpu_ryo_request;
+int         c4gpu_alignment_format_ryo(const c4gpu_model *model, const c4gpu_params *params, const c4gpu_alignment *a,
+                                       const c4gpu_ryo_request *req, char *buf, size_t buf_len);
+
+
+
+
 #ifdef __cplusplus
 }
 #endif
