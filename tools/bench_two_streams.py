@@ -13,7 +13,7 @@ n = int(os.environ.get("PAIRS", "4096"))
 pairs = workloads.est2genome_pairs(n, 1000, 100000)
 model = ex.Model("est2genome")
 steps = 3
-for parts in (1, 2, 4, 1, 2):
+for parts in [int(x) for x in os.environ.get("PARTS", "1,2,4,1,2").split(",")]:
     streams = [torch.cuda.Stream() for _ in range(parts)]
     engines = [ex.Engine(0, stream=s.cuda_stream) for s in streams]
     per = n // parts
