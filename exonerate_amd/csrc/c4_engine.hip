@@ -677,6 +677,16 @@ struct SeedPlan {
     int hops = 0;
 };
 
+// cooperating waves per job of the region windows (SEED 2): two where the family has that form -- a job's later windows are
+// a few hundred rows high and leave fewer waves idle than with four (north-star batch: 846 against 867 ms per step) --
+// three waves: 894-916 ms, one wave with every strip boundary through HBM: 854-872 ms, four rows per lane on two waves:
+// 851-857 ms -- C4GPU_WIN_NW=4 keeps four (read on every call: a test switches it)
+int window_waves(int family) {
+    int nw = getenv("C4GPU_WIN_NW") ? atoi(getenv("C4GPU_WIN_NW")) : 2;
+    if (nw != 2) nw = 4;
+    return get_kernel_mw(family, MODE_REGION, true, true, nw, false, 2) ? nw : 4;
+}
+
 struct Engine {
     c4gpu_ctx *ctx;
     const c4gpu_model *model;
@@ -890,7 +900,8 @@ struct Engine {
         // job (strip carry rows stay in LDS instead of HBM); C4GPU_MW=0 forces the one-wave kernels
         static const int mw_env = getenv("C4GPU_MW") ? atoi(getenv("C4GPU_MW")) : 1;
         if (seed) {
-            ki = get_kernel_mw(family, mode, true, mode == MODE_REGION, 4, false, seed->mode);
+            const int win_nw = seed->mode == 2 ? window_waves(family) : 4;
+            ki = get_kernel_mw(family, mode, true, mode == MODE_REGION, win_nw, false, seed->mode);
             if (!ki || !use_local || (mode == MODE_REGION && !pack)) { c4h::set_error("no seeded kernel for this launch"); return -1; }
             // the score pass with dumps: two jobs per lane in packed 16-bit halves where every score fits (C4GPU_PK16=0: never)
             const int pk_env = getenv("C4GPU_PK16") ? atoi(getenv("C4GPU_PK16")) : 1;      // read on every call: a test switches it
@@ -1008,6 +1019,10 @@ struct Engine {
                 if (s.dump_checkpoints) { j.ckpt_off = dump_total; dump_total += ck; }
             }
         }
+        // windows chained on the device: a later window of a job spans one dump interval plus the dumped columns, which can be
+        // more than every FIRST window of the launch: the strip carry rows are laid out for the longest window any hop can have
+        if (seed && seed->mode == 2 && seed->hops)
+            max_T = std::max<long long>(max_T, (1LL << seed->kshift) + 2LL * ki->max_at);
         lap("jobs built");
         // persistent grid: as many waves as the device keeps resident, bounded by the scratch it implies
         int blocks_per_cu = 0;
@@ -1428,7 +1443,8 @@ template <class Thr>
 int windowed_region_pass(Engine &eng, const ResidentSeqs &seqs, const std::vector<int> &pairs,
                          const std::vector<PairPlan> &plan, Thr thr, int kshift, std::vector<DevResult> &out) {
     const int n = (int)pairs.size();
-    const KernelInfo *kw = get_kernel_mw(eng.family, MODE_REGION, true, true, 4, false, 2);
+    const int win_nw = window_waves(eng.family);
+    const KernelInfo *kw = get_kernel_mw(eng.family, MODE_REGION, true, true, win_nw, false, 2);
     const long long seedw = kw->seedw;
     const int dc = kw->max_at;                           // dumped columns per dump (d*K - (dc - 1) .. d*K)
     auto nbits = [](int v) { int b = 0; while ((1LL << b) <= v) b++; return b; };
@@ -1934,12 +1950,18 @@ int find_path_lanes(Engine &eng, SideLane *side, const ResidentSeqs &seqs, int d
     int r1 = 0;
     std::string err1;
     const int device = eng.ctx->device;
+    // an exception (std::bad_alloc of a host vector) must neither leave the second thread nor skip its join
     std::thread second([&] {
-        if (hipSetDevice(device) != hipSuccess) { r1 = -1; err1 = "hipSetDevice on the second lane"; return; }
-        r1 = find_path_batch(side->eng, seqs, dpmemory_mb, threshold, alignments, nullptr, mask[1].data(), pair_thresholds, initial, false);
-        if (r1) err1 = c4h::g_error;
+        try {
+            if (hipSetDevice(device) != hipSuccess) { r1 = -1; err1 = "hipSetDevice on the second lane"; return; }
+            r1 = find_path_batch(side->eng, seqs, dpmemory_mb, threshold, alignments, nullptr, mask[1].data(), pair_thresholds, initial, false);
+            if (r1) err1 = c4h::g_error;
+        } catch (const std::exception &e) { r1 = -1; err1 = std::string("second launch lane: ") + e.what(); }
     });
-    const int r0 = find_path_batch(eng, seqs, dpmemory_mb, threshold, alignments, nullptr, mask[0].data(), pair_thresholds, initial, false);
+    int r0 = 0;
+    try {
+        r0 = find_path_batch(eng, seqs, dpmemory_mb, threshold, alignments, nullptr, mask[0].data(), pair_thresholds, initial, false);
+    } catch (const std::exception &e) { r0 = -1; c4h::set_error(std::string("first launch lane: ") + e.what()); }
     second.join();
     if (r0) return r0;
     if (r1) { c4h::set_error(err1); return r1; }
@@ -2068,39 +2090,44 @@ int c4gpu_splice_predict(c4gpu_ctx *ctx, const c4gpu_params *params, const uint8
 extern "C" int c4gpu_hsp_extend_batch(c4gpu_ctx *ctx, const c4gpu_params *params, int match_type, const c4gpu_pair *pairs,
                                       int32_t n_pairs, int32_t seedlen, int32_t dropoff, const c4gpu_hsp_seed *seeds,
                                       int32_t n_seeds, c4gpu_hsp *out) {
-    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
-    if (match_type < C4GPU_MATCH_DNA2DNA || match_type > C4GPU_MATCH_PROTEIN2DNA) { c4h::set_error("unknown match type"); return -1; }
-    if (!n_seeds) return 0;
-    const int aq = 1, at = match_type == C4GPU_MATCH_PROTEIN2DNA ? 3 : 1;
-    for (int k = 0; k < n_seeds; k++) {
-        const c4gpu_hsp_seed &sd = seeds[k];
-        if (sd.pair < 0 || sd.pair >= n_pairs || sd.query_start < 0 || sd.target_start < 0 ||
-            sd.query_start + seedlen * aq > pairs[sd.pair].query_len || sd.target_start + seedlen * at > pairs[sd.pair].target_len) {
-            c4h::set_error("an HSP seed lies outside its pair");
-            return -1;
+    try {
+        if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+        if (match_type < C4GPU_MATCH_DNA2DNA || match_type > C4GPU_MATCH_PROTEIN2DNA) { c4h::set_error("unknown match type"); return -1; }
+        if (!n_seeds) return 0;
+        const int aq = 1, at = match_type == C4GPU_MATCH_PROTEIN2DNA ? 3 : 1;
+        for (int k = 0; k < n_seeds; k++) {
+            const c4gpu_hsp_seed &sd = seeds[k];
+            if (sd.pair < 0 || sd.pair >= n_pairs || sd.query_start < 0 || sd.target_start < 0 ||
+                sd.query_start + seedlen * aq > pairs[sd.pair].query_len || sd.target_start + seedlen * at > pairs[sd.pair].target_len) {
+                c4h::set_error("an HSP seed lies outside its pair");
+                return -1;
+            }
         }
+        // the coded arrays of a protein2dna batch are exactly what PROTEIN2DNA scoring reads (row of the codon at each
+        // target position); the 1:1 matches use the plain residue rows
+        ResidentSeqs seqs;
+        if (seqs.build(ctx, match_type == C4GPU_MATCH_PROTEIN2DNA ? FAM_UNGAPPED_P2D : FAM_UNGAPPED, params, pairs, n_pairs)) return -1;
+        std::vector<HspJob> jobs(n_pairs);
+        for (int i = 0; i < n_pairs; i++) jobs[i] = HspJob{seqs.qoff[i], seqs.toff[i], seqs.qlen[i], seqs.tlen[i]};
+        DevBuf<HspJob> d_jobs;
+        DevBuf<c4gpu_hsp_seed> d_seeds;
+        DevBuf<c4gpu_hsp> d_out;
+        DevBuf<int> d_submat;
+        const int32_t *mat = match_type == C4GPU_MATCH_DNA2DNA ? &params->dna_submat[0][0] : &params->protein_submat[0][0];
+        hipStream_t s = ctx->stream;
+        if (d_jobs.upload(jobs.data(), n_pairs, s) || d_seeds.upload(seeds, n_seeds, s) || d_out.alloc(n_seeds) ||
+            d_submat.upload(mat, 24 * 24, s)) return -1;
+        const int block = 64, grid = std::min((n_seeds + block - 1) / block, 65535);
+        hipLaunchKernelGGL(hsp_extend_kernel, dim3(grid), dim3(block), 0, s, seqs.qcode.p, seqs.tcode.p, d_jobs.p, d_seeds.p,
+                           n_seeds, d_submat.p, aq, at, seedlen, dropoff, d_out.p);
+        HIP_OK(hipGetLastError());
+        if (d_out.download(out, n_seeds, s)) return -1;
+        HIP_OK(hipStreamSynchronize(s));
+        return 0;
+    } catch (const std::exception &e) {
+        c4h::set_error(std::string("c4gpu_hsp_extend_batch: ") + e.what());
+        return -1;
     }
-    // the coded arrays of a protein2dna batch are exactly what PROTEIN2DNA scoring reads (row of the codon at each
-    // target position); the 1:1 matches use the plain residue rows
-    ResidentSeqs seqs;
-    if (seqs.build(ctx, match_type == C4GPU_MATCH_PROTEIN2DNA ? FAM_UNGAPPED_P2D : FAM_UNGAPPED, params, pairs, n_pairs)) return -1;
-    std::vector<HspJob> jobs(n_pairs);
-    for (int i = 0; i < n_pairs; i++) jobs[i] = HspJob{seqs.qoff[i], seqs.toff[i], seqs.qlen[i], seqs.tlen[i]};
-    DevBuf<HspJob> d_jobs;
-    DevBuf<c4gpu_hsp_seed> d_seeds;
-    DevBuf<c4gpu_hsp> d_out;
-    DevBuf<int> d_submat;
-    const int32_t *mat = match_type == C4GPU_MATCH_DNA2DNA ? &params->dna_submat[0][0] : &params->protein_submat[0][0];
-    hipStream_t s = ctx->stream;
-    if (d_jobs.upload(jobs.data(), n_pairs, s) || d_seeds.upload(seeds, n_seeds, s) || d_out.alloc(n_seeds) ||
-        d_submat.upload(mat, 24 * 24, s)) return -1;
-    const int block = 64, grid = std::min((n_seeds + block - 1) / block, 65535);
-    hipLaunchKernelGGL(hsp_extend_kernel, dim3(grid), dim3(block), 0, s, seqs.qcode.p, seqs.tcode.p, d_jobs.p, d_seeds.p,
-                       n_seeds, d_submat.p, aq, at, seedlen, dropoff, d_out.p);
-    HIP_OK(hipGetLastError());
-    if (d_out.download(out, n_seeds, s)) return -1;
-    HIP_OK(hipStreamSynchronize(s));
-    return 0;
 }
 
 static int viterbi_jobs(Engine &eng, const ResidentSeqs &seqs, int mode, const c4gpu_viterbi_job *jobs,
@@ -2158,38 +2185,53 @@ extern "C" {
 int c4gpu_viterbi_batch(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params, int mode,
                         const c4gpu_pair *pairs, int32_t n_pairs, const c4gpu_viterbi_job *jobs, int32_t n_jobs,
                         c4gpu_viterbi_result *results) {
-    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
-    Engine eng;
-    ResidentSeqs seqs;
-    if (eng.init(ctx, model, params) || seqs.build(ctx, eng.family, params, pairs, n_pairs)) return -1;
-    return viterbi_jobs(eng, seqs, mode, jobs, n_jobs, results);
+    try {
+        if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+        Engine eng;
+        ResidentSeqs seqs;
+        if (eng.init(ctx, model, params) || seqs.build(ctx, eng.family, params, pairs, n_pairs)) return -1;
+        return viterbi_jobs(eng, seqs, mode, jobs, n_jobs, results);
+    } catch (const std::exception &e) {
+        c4h::set_error(std::string("c4gpu_viterbi_batch: ") + e.what());
+        return -1;
+    }
 }
 
 int c4gpu_batch_viterbi(c4gpu_batch *b, int mode, const c4gpu_viterbi_job *jobs, int32_t n_jobs,
                         c4gpu_viterbi_result *results) {
-    if (hipSetDevice(b->ctx->device) != hipSuccess) return -1;
-    return viterbi_jobs(b->eng, b->seqs, mode, jobs, n_jobs, results);
+    try {
+        if (hipSetDevice(b->ctx->device) != hipSuccess) return -1;
+        return viterbi_jobs(b->eng, b->seqs, mode, jobs, n_jobs, results);
+    } catch (const std::exception &e) {
+        c4h::set_error(std::string("c4gpu_batch_viterbi: ") + e.what());
+        return -1;
+    }
 }
 
 int c4gpu_batch_viterbi_model(c4gpu_batch *b, const c4gpu_model *model, int mode, const c4gpu_viterbi_job *jobs,
                               int32_t n_jobs, c4gpu_viterbi_result *results) {
-    if (hipSetDevice(b->ctx->device) != hipSuccess) return -1;
-    const std::string key(reinterpret_cast<const char *>(model), sizeof(c4gpu_model));
-    auto it = b->extra.find(key);
-    if (it == b->extra.end()) {
-        std::unique_ptr<c4gpu_batch::ExtraEngine> e(new c4gpu_batch::ExtraEngine);
-        e->model = *model;
-        if (e->eng.init(b->ctx, &e->model, &b->params)) return -1;
-        // the resident arrays were prepared for the batch's own model: the other model must read the same ones
-        if (family_is_p2d(e->eng.family) != family_is_p2d(b->eng.family) ||
-            (family_has_splice(e->eng.family) && !family_has_splice(b->eng.family)) ||
-            (family_has_phase(e->eng.family) && !family_has_phase(b->eng.family))) {
-            c4h::set_error(std::string("model [") + model->name + "] needs sequence arrays this batch was not built with");
-            return -1;
+    try {
+        if (hipSetDevice(b->ctx->device) != hipSuccess) return -1;
+        const std::string key(reinterpret_cast<const char *>(model), sizeof(c4gpu_model));
+        auto it = b->extra.find(key);
+        if (it == b->extra.end()) {
+            std::unique_ptr<c4gpu_batch::ExtraEngine> e(new c4gpu_batch::ExtraEngine);
+            e->model = *model;
+            if (e->eng.init(b->ctx, &e->model, &b->params)) return -1;
+            // the resident arrays were prepared for the batch's own model: the other model must read the same ones
+            if (family_is_p2d(e->eng.family) != family_is_p2d(b->eng.family) ||
+                (family_has_splice(e->eng.family) && !family_has_splice(b->eng.family)) ||
+                (family_has_phase(e->eng.family) && !family_has_phase(b->eng.family))) {
+                c4h::set_error(std::string("model [") + model->name + "] needs sequence arrays this batch was not built with");
+                return -1;
+            }
+            it = b->extra.emplace(key, std::move(e)).first;
         }
-        it = b->extra.emplace(key, std::move(e)).first;
+        return viterbi_jobs(it->second->eng, b->seqs, mode, jobs, n_jobs, results);
+    } catch (const std::exception &e) {
+        c4h::set_error(std::string("c4gpu_batch_viterbi_model: ") + e.what());
+        return -1;
     }
-    return viterbi_jobs(it->second->eng, b->seqs, mode, jobs, n_jobs, results);
 }
 
 void c4gpu_viterbi_result_clear(c4gpu_viterbi_result *r) {
@@ -2209,52 +2251,72 @@ static int score_pass(Engine &eng, const ResidentSeqs &seqs, int mode, std::vect
 
 int c4gpu_optimal_find_score_batch(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params,
                                    const c4gpu_pair *pairs, int32_t n_pairs, c4gpu_score *scores) {
-    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
-    Engine eng;
-    ResidentSeqs seqs;
-    std::vector<JobOut> outs;
-    if (eng.init(ctx, model, params) || seqs.build(ctx, eng.family, params, pairs, n_pairs) ||
-        score_pass(eng, seqs, MODE_SCORE, outs)) return -1;
-    for (int i = 0; i < n_pairs; i++) scores[i] = outs[i].res.score;
-    return 0;
+    try {
+        if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+        Engine eng;
+        ResidentSeqs seqs;
+        std::vector<JobOut> outs;
+        if (eng.init(ctx, model, params) || seqs.build(ctx, eng.family, params, pairs, n_pairs) ||
+            score_pass(eng, seqs, MODE_SCORE, outs)) return -1;
+        for (int i = 0; i < n_pairs; i++) scores[i] = outs[i].res.score;
+        return 0;
+    } catch (const std::exception &e) {
+        c4h::set_error(std::string("c4gpu_optimal_find_score_batch: ") + e.what());
+        return -1;
+    }
 }
 
 int c4gpu_optimal_find_path_batch(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params,
                                   const c4gpu_pair *pairs, int32_t n_pairs, int dpmemory_mb, c4gpu_score threshold,
                                   c4gpu_alignment *alignments) {
-    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
-    Engine eng;
-    ResidentSeqs seqs;
-    if (eng.init(ctx, model, params) || seqs.build(ctx, eng.family, params, pairs, n_pairs)) return -1;
-    SideLane side;
-    const bool two = lanes_wanted(seqs, nullptr, false);
-    if (two && side.init(ctx, model, params)) return -1;
-    return find_path_lanes(eng, two ? &side : nullptr, seqs, dpmemory_mb, threshold, alignments);
+    try {
+        if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+        Engine eng;
+        ResidentSeqs seqs;
+        if (eng.init(ctx, model, params) || seqs.build(ctx, eng.family, params, pairs, n_pairs)) return -1;
+        SideLane side;
+        const bool two = lanes_wanted(seqs, nullptr, false);
+        if (two && side.init(ctx, model, params)) return -1;
+        return find_path_lanes(eng, two ? &side : nullptr, seqs, dpmemory_mb, threshold, alignments);
+    } catch (const std::exception &e) {
+        c4h::set_error(std::string("c4gpu_optimal_find_path_batch: ") + e.what());
+        return -1;
+    }
 }
 
 int c4gpu_optimal_find_path_batch_subopt(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params,
                                          const c4gpu_pair *pairs, int32_t n_pairs, int dpmemory_mb,
                                          c4gpu_score threshold, const c4gpu_subopt *const *subopts,
                                          const uint8_t *active, c4gpu_alignment *alignments) {
-    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
-    Engine eng;
-    ResidentSeqs seqs;
-    if (eng.init(ctx, model, params) || seqs.build(ctx, eng.family, params, pairs, n_pairs)) return -1;
-    std::vector<const c4gpu_subopt *> subs(n_pairs, nullptr);
-    if (subopts) for (int i = 0; i < n_pairs; i++) subs[i] = subopts[i];
-    return find_path_batch(eng, seqs, dpmemory_mb, threshold, alignments, &subs, active);
+    try {
+        if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+        Engine eng;
+        ResidentSeqs seqs;
+        if (eng.init(ctx, model, params) || seqs.build(ctx, eng.family, params, pairs, n_pairs)) return -1;
+        std::vector<const c4gpu_subopt *> subs(n_pairs, nullptr);
+        if (subopts) for (int i = 0; i < n_pairs; i++) subs[i] = subopts[i];
+        return find_path_batch(eng, seqs, dpmemory_mb, threshold, alignments, &subs, active);
+    } catch (const std::exception &e) {
+        c4h::set_error(std::string("c4gpu_optimal_find_path_batch_subopt: ") + e.what());
+        return -1;
+    }
 }
 
 c4gpu_batch *c4gpu_batch_create(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params,
                                 const c4gpu_pair *pairs, int32_t n_pairs) {
-    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
-    c4gpu_batch *b = new c4gpu_batch;
-    b->ctx = ctx; b->model = *model; b->params = *params;
-    if (b->eng.init(ctx, &b->model, &b->params) || b->seqs.build(ctx, b->eng.family, &b->params, pairs, n_pairs)) {
-        delete b;
+    try {
+        if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+        c4gpu_batch *b = new c4gpu_batch;
+        b->ctx = ctx; b->model = *model; b->params = *params;
+        if (b->eng.init(ctx, &b->model, &b->params) || b->seqs.build(ctx, b->eng.family, &b->params, pairs, n_pairs)) {
+            delete b;
+            return nullptr;
+        }
+        return b;
+    } catch (const std::exception &e) {
+        c4h::set_error(std::string("c4gpu_batch_create: ") + e.what());
         return nullptr;
     }
-    return b;
 }
 
 void c4gpu_batch_destroy(c4gpu_batch *b) {
@@ -2265,58 +2327,68 @@ void c4gpu_batch_destroy(c4gpu_batch *b) {
 }
 
 int c4gpu_batch_run(c4gpu_batch *b, int what, int dpmemory_mb, c4gpu_score threshold) {
-    if (hipSetDevice(b->ctx->device) != hipSuccess) return -1;
-    const int n = b->seqs.n_pairs;
-    if (what == 0 || what == 1) {
-        std::vector<JobOut> outs;
-        if (score_pass(b->eng, b->seqs, what == 0 ? MODE_SCORE : MODE_REGION, outs)) return -1;
-        b->scores.resize(n); b->regions.resize(n);
-        for (int i = 0; i < n; i++) {
-            const DevResult &r = outs[i].res;
-            b->scores[i] = r.score;
-            b->regions[i] = c4gpu_region{r.qs, r.ts, r.qe - r.qs, r.te - r.ts};
+    try {
+        if (hipSetDevice(b->ctx->device) != hipSuccess) return -1;
+        const int n = b->seqs.n_pairs;
+        if (what == 0 || what == 1) {
+            std::vector<JobOut> outs;
+            if (score_pass(b->eng, b->seqs, what == 0 ? MODE_SCORE : MODE_REGION, outs)) return -1;
+            b->scores.resize(n); b->regions.resize(n);
+            for (int i = 0; i < n; i++) {
+                const DevResult &r = outs[i].res;
+                b->scores[i] = r.score;
+                b->regions[i] = c4gpu_region{r.qs, r.ts, r.qe - r.qs, r.te - r.ts};
+            }
+            return 0;
         }
+        for (auto &a : b->alignments) c4gpu_alignment_clear(&a);
+        b->alignments.assign(n, c4gpu_alignment{});
+        b->clear_loop();
+        if (!b->side && lanes_wanted(b->seqs, nullptr, false)) {
+            b->side.reset(new SideLane);
+            if (b->side->init(b->ctx, &b->model, &b->params)) { b->side.reset(); return -1; }
+        }
+        if (find_path_lanes(b->eng, b->side.get(), b->seqs, dpmemory_mb, threshold, b->alignments.data(), nullptr,
+                            b->pair_thresholds.empty() ? nullptr : &b->pair_thresholds)) return -1;
+        b->scores.resize(n); b->regions.resize(n);
+        for (int i = 0; i < n; i++) { b->scores[i] = b->alignments[i].score; b->regions[i] = b->alignments[i].region; }
         return 0;
+    } catch (const std::exception &e) {
+        c4h::set_error(std::string("c4gpu_batch_run: ") + e.what());
+        return -1;
     }
-    for (auto &a : b->alignments) c4gpu_alignment_clear(&a);
-    b->alignments.assign(n, c4gpu_alignment{});
-    b->clear_loop();
-    if (!b->side && lanes_wanted(b->seqs, nullptr, false)) {
-        b->side.reset(new SideLane);
-        if (b->side->init(b->ctx, &b->model, &b->params)) { b->side.reset(); return -1; }
-    }
-    if (find_path_lanes(b->eng, b->side.get(), b->seqs, dpmemory_mb, threshold, b->alignments.data(), nullptr,
-                        b->pair_thresholds.empty() ? nullptr : &b->pair_thresholds)) return -1;
-    b->scores.resize(n); b->regions.resize(n);
-    for (int i = 0; i < n; i++) { b->scores[i] = b->alignments[i].score; b->regions[i] = b->alignments[i].region; }
-    return 0;
 }
 
 int c4gpu_batch_run_regions(c4gpu_batch *b, const c4gpu_region *regions, const uint8_t *active, int dpmemory_mb,
                             c4gpu_score threshold) {
-    if (hipSetDevice(b->ctx->device) != hipSuccess) return -1;
-    const int n = b->seqs.n_pairs;
-    for (int i = 0; i < n; i++) {
-        if (active && !active[i]) continue;
-        const c4gpu_region &r = regions[i];
-        if (r.query_start < 0 || r.target_start < 0 || r.query_length < 0 || r.target_length < 0 ||
-            r.query_start + r.query_length > b->seqs.qlen[i] || r.target_start + r.target_length > b->seqs.tlen[i]) {
-            c4h::set_error("c4gpu_batch_run_regions: a region lies outside its pair");
-            return -1;
+    try {
+        if (hipSetDevice(b->ctx->device) != hipSuccess) return -1;
+        const int n = b->seqs.n_pairs;
+        for (int i = 0; i < n; i++) {
+            if (active && !active[i]) continue;
+            const c4gpu_region &r = regions[i];
+            if (r.query_start < 0 || r.target_start < 0 || r.query_length < 0 || r.target_length < 0 ||
+                r.query_start + r.query_length > b->seqs.qlen[i] || r.target_start + r.target_length > b->seqs.tlen[i]) {
+                c4h::set_error("c4gpu_batch_run_regions: a region lies outside its pair");
+                return -1;
+            }
         }
-    }
-    for (auto &a : b->alignments) c4gpu_alignment_clear(&a);
-    b->alignments.assign(n, c4gpu_alignment{});
-    b->clear_loop();
-    if (!b->side && lanes_wanted(b->seqs, active, false)) {
-        b->side.reset(new SideLane);
-        if (b->side->init(b->ctx, &b->model, &b->params)) { b->side.reset(); return -1; }
-    }
-    if (find_path_lanes(b->eng, b->side.get(), b->seqs, dpmemory_mb, threshold, b->alignments.data(), active, nullptr, regions))
+        for (auto &a : b->alignments) c4gpu_alignment_clear(&a);
+        b->alignments.assign(n, c4gpu_alignment{});
+        b->clear_loop();
+        if (!b->side && lanes_wanted(b->seqs, active, false)) {
+            b->side.reset(new SideLane);
+            if (b->side->init(b->ctx, &b->model, &b->params)) { b->side.reset(); return -1; }
+        }
+        if (find_path_lanes(b->eng, b->side.get(), b->seqs, dpmemory_mb, threshold, b->alignments.data(), active, nullptr, regions))
+            return -1;
+        b->scores.resize(n); b->regions.resize(n);
+        for (int i = 0; i < n; i++) { b->scores[i] = b->alignments[i].score; b->regions[i] = b->alignments[i].region; }
+        return 0;
+    } catch (const std::exception &e) {
+        c4h::set_error(std::string("c4gpu_batch_run_regions: ") + e.what());
         return -1;
-    b->scores.resize(n); b->regions.resize(n);
-    for (int i = 0; i < n; i++) { b->scores[i] = b->alignments[i].score; b->regions[i] = b->alignments[i].region; }
-    return 0;
+    }
 }
 
 int c4gpu_batch_set_thresholds(c4gpu_batch *b, const c4gpu_score *per_pair) {
@@ -2328,35 +2400,40 @@ int c4gpu_batch_set_thresholds(c4gpu_batch *b, const c4gpu_score *per_pair) {
 // GAM_Result_exhaustive_create's do/while (gam.c:1158-1172) for the whole batch: block what the previous
 // round found (GAM_Result_add_alignment -> SubOpt_add_alignment, gam.c:673), then the next best paths.
 int c4gpu_batch_next_paths(c4gpu_batch *b, int dpmemory_mb, c4gpu_score threshold) {
-    if (hipSetDevice(b->ctx->device) != hipSuccess) return -1;
-    const int n = b->seqs.n_pairs;
-    if ((int)b->alignments.size() != n) { c4h::set_error("c4gpu_batch_next_paths needs a c4gpu_batch_run(b, 2, ...) first"); return -1; }
-    if (b->subopts.empty()) {
-        b->subopts.resize(n);
-        for (int i = 0; i < n; i++) b->subopts[i] = c4gpu_subopt_create(b->seqs.qlen[i], b->seqs.tlen[i]);
-        b->in_loop.assign(n, 1);
-    }
-    std::vector<const c4gpu_subopt *> subs(n);
-    int still = 0;
-    for (int i = 0; i < n; i++) {
-        if (b->in_loop[i] && b->alignments[i].valid) {
-            if (c4gpu_subopt_add_alignment(b->subopts[i], &b->model, &b->alignments[i])) return -1;
-            still++;
-        } else {
-            b->in_loop[i] = 0;
+    try {
+        if (hipSetDevice(b->ctx->device) != hipSuccess) return -1;
+        const int n = b->seqs.n_pairs;
+        if ((int)b->alignments.size() != n) { c4h::set_error("c4gpu_batch_next_paths needs a c4gpu_batch_run(b, 2, ...) first"); return -1; }
+        if (b->subopts.empty()) {
+            b->subopts.resize(n);
+            for (int i = 0; i < n; i++) b->subopts[i] = c4gpu_subopt_create(b->seqs.qlen[i], b->seqs.tlen[i]);
+            b->in_loop.assign(n, 1);
         }
-        subs[i] = b->subopts[i];
+        std::vector<const c4gpu_subopt *> subs(n);
+        int still = 0;
+        for (int i = 0; i < n; i++) {
+            if (b->in_loop[i] && b->alignments[i].valid) {
+                if (c4gpu_subopt_add_alignment(b->subopts[i], &b->model, &b->alignments[i])) return -1;
+                still++;
+            } else {
+                b->in_loop[i] = 0;
+            }
+            subs[i] = b->subopts[i];
+        }
+        for (auto &a : b->alignments) c4gpu_alignment_clear(&a);
+        if (!still) return 0;
+        if (find_path_batch(b->eng, b->seqs, dpmemory_mb, threshold, b->alignments.data(), &subs, b->in_loop.data(),
+                            b->pair_thresholds.empty() ? nullptr : &b->pair_thresholds)) return -1;
+        int found = 0;
+        for (int i = 0; i < n; i++) {
+            found += b->alignments[i].valid ? 1 : 0;
+            b->scores[i] = b->alignments[i].score; b->regions[i] = b->alignments[i].region;
+        }
+        return found;
+    } catch (const std::exception &e) {
+        c4h::set_error(std::string("c4gpu_batch_next_paths: ") + e.what());
+        return -1;
     }
-    for (auto &a : b->alignments) c4gpu_alignment_clear(&a);
-    if (!still) return 0;
-    if (find_path_batch(b->eng, b->seqs, dpmemory_mb, threshold, b->alignments.data(), &subs, b->in_loop.data(),
-                        b->pair_thresholds.empty() ? nullptr : &b->pair_thresholds)) return -1;
-    int found = 0;
-    for (int i = 0; i < n; i++) {
-        found += b->alignments[i].valid ? 1 : 0;
-        b->scores[i] = b->alignments[i].score; b->regions[i] = b->alignments[i].region;
-    }
-    return found;
 }
 
 int c4gpu_batch_scores(c4gpu_batch *b, c4gpu_score *scores, c4gpu_region *regions) {

@@ -276,6 +276,30 @@ def test_windowed_region_pass_matches_oracle(eng, monkeypatch, capfd, model_type
         assert (a.as_dict() if a else None) == exp
 
 
+def test_window_kernel_on_two_and_four_waves_agree(eng, monkeypatch, capfd):
+    """The region windows run on two cooperating waves per job by default (est2genome), C4GPU_WIN_NW=4 keeps four: same
+    alignments on pairs whose windows need several super-strips in either form and whose later windows are longer than
+    the first ones (the strip carry rows are laid out for the longest window of any hop)."""
+    rng = random.Random(3131)
+    model = ex.Model("est2genome")
+    pairs = []
+    for ql, tl in [(1000, 100000), (1000, 70000), (900, 52000), (640, 41000), (1000, 33000)]:
+        pairs.append(_seeded_pairs(rng, "est2genome", ql, tl, 1)[0])
+    q = _rand(rng, 1000)                                      # an intron of 30 kb: the second window is as high as the first
+    pairs.append((q, _rand(rng, 5000) + _mutate(rng, q[:150], 0.03) + "GT" + _rand(rng, 30000) + "AG" + _mutate(rng, q[150:], 0.03) + _rand(rng, 9000)))
+    monkeypatch.setenv("C4GPU_TRACE", "1")
+    res = {}
+    for nw in ("2", "4"):
+        monkeypatch.setenv("C4GPU_WIN_NW", nw)
+        res[nw] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=32, threshold=50)]
+        err = capfd.readouterr().err
+        assert ("kernel kmw2_est2genome_region_local_pack_seed2" in err) == (nw == "2"), err[-1500:]
+        assert ("kernel kmw_est2genome_region_local_pack_seed2" in err) == (nw == "4"), err[-1500:]
+    assert res["2"] == res["4"] and all(r is not None for r in res["2"])
+    q, t = pairs[5]
+    assert res["2"][5] == oracle_lib.find_path(model.c, model.params, q.encode(), t.encode(), dpmemory=32, threshold=50)
+
+
 def test_windowed_and_one_pass_region_agree_at_full_size(eng, monkeypatch):
     """1 kb x 100 kb est2genome pairs of the north-star batch: the two-pass route (default) and the one-pass kernel
     (C4GPU_WINDOWED=0) give identical alignments; pair 0 also against the oracle."""
