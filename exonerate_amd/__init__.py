@@ -380,6 +380,21 @@ class Engine:
             raise _err("c4gpu_hsp_extend_batch")
         return [out[i].aslist() for i in range(n)]
 
+    def hsp_extend_chains(self, params, match, pairs, seedlen, dropoff, seeds, chain, horizon0):
+        """The same with the diagonal horizon applied on the device (c4gpu_hsp_extend_chains): chain[k] names the horizon
+        entry of seed k, horizon0[c] its value before the scan; a skipped seed comes back with length -1."""
+        arr, keep = _pairs(pairs)
+        kind = {"dna2dna": _abi.MATCH_DNA2DNA, "protein2protein": _abi.MATCH_PROTEIN2PROTEIN,
+                "protein2dna": _abi.MATCH_PROTEIN2DNA}[match]
+        n, nc = len(seeds), len(horizon0)
+        cs = (_abi.HspSeed * max(1, n))(*[_abi.HspSeed(*s) for s in seeds])
+        cc = (C.c_int32 * max(1, n))(*chain)
+        h0 = (C.c_int32 * max(1, nc))(*horizon0)
+        out = (_abi.Hsp * max(1, n))()
+        if _lib().c4gpu_hsp_extend_chains(self.ctx, params, kind, arr, len(pairs), seedlen, dropoff, cs, n, cc, nc, h0, out) != 0:
+            raise _err("c4gpu_hsp_extend_chains")
+        return [out[i].aslist() for i in range(n)]
+
     def sdp(self, model, pairs, hsps, query_advance=1, target_advance=1, dropoff=50, threshold=100, max_alignments=4):
         """The reference's default gapped-extension heuristic (SDP, GAM_Result_SDP_create gam.c:852) for a batch: per pair
         the list of alignments found from its HSPs ([query_start, target_start, length, score, cobs] each), both

@@ -203,6 +203,8 @@ PROTOTYPES = [
     ("c4gpu_model_device_family", C.c_int, [C.POINTER(Model)]),
     ("c4gpu_hsp_extend_batch", C.c_int, [C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(Pair), C.c_int32, C.c_int32,
                                          C.c_int32, C.POINTER(HspSeed), C.c_int32, C.POINTER(Hsp)]),
+    ("c4gpu_hsp_extend_chains", C.c_int, [C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(Pair), C.c_int32, C.c_int32, C.c_int32,
+                                 C.POINTER(HspSeed), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32), C.POINTER(Hsp)]),
     ("c4gpu_wordtab_create", C.c_void_p, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.c_int32]),
     ("c4gpu_wordtab_destroy", None, [C.c_void_p]),
     ("c4gpu_seed_scan", C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),

@@ -285,18 +285,11 @@ __global__ void splice_kernel(const uint8_t *__restrict__ seq, const long long *
 // row of the codon starting at each position), the matrix sits in LDS.  Seeds of one diagonal neighbourhood read the
 // same cache lines; the work per seed is a few hundred bytes, so the kernel is latency- and not bandwidth-bound.
 struct HspJob { long long qoff, toff; int qlen, tlen; };
-__global__ void hsp_extend_kernel(const uint8_t *__restrict__ qcode, const uint8_t *__restrict__ tcode,
-                                  const HspJob *__restrict__ jobs, const c4gpu_hsp_seed *__restrict__ seeds, int n_seeds,
-                                  const int *__restrict__ submat, int aq, int at, int seedlen, int dropoff,
-                                  c4gpu_hsp *__restrict__ out) {
-    __shared__ int sm[24 * 24];
-    for (int x = threadIdx.x; x < 24 * 24; x += blockDim.x) sm[x] = submat[x];
-    __syncthreads();
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_seeds; k += gridDim.x * blockDim.x) {
-        const HspJob jb = jobs[seeds[k].pair];
+__device__ __forceinline__ c4gpu_hsp hsp_extend_one(const uint8_t *__restrict__ qcode, const uint8_t *__restrict__ tcode, const HspJob jb,
+                                                     const c4gpu_hsp_seed sd, const int *sm, int aq, int at, int seedlen, int dropoff) {
         const uint8_t *q = qcode + jb.qoff, *t = tcode + jb.toff;
         auto sc = [&](int qp, int tp) { return sm[q[qp] * 24 + t[tp]]; };
-        int qs = seeds[k].query_start, ts = seeds[k].target_start, length = seedlen, i;
+        int qs = sd.query_start, ts = sd.target_start, length = seedlen, i;
         for (i = 0; i < length; i++) {                                   // HSP_trim_ends
             if (sc(qs, ts) > 0) break;
             qs += aq; ts += at;
@@ -332,7 +325,38 @@ __global__ void hsp_extend_kernel(const uint8_t *__restrict__ qcode, const uint8
             score += sc(qp, tp);
             if (score >= (maxscore >> 1)) break;
         }
-        out[k] = c4gpu_hsp{qs, ts, length, maxscore, i};
+        return c4gpu_hsp{qs, ts, length, maxscore, i};
+}
+
+__global__ void hsp_extend_kernel(const uint8_t *__restrict__ qcode, const uint8_t *__restrict__ tcode,
+                                  const HspJob *__restrict__ jobs, const c4gpu_hsp_seed *__restrict__ seeds, int n_seeds,
+                                  const int *__restrict__ submat, int aq, int at, int seedlen, int dropoff,
+                                  c4gpu_hsp *__restrict__ out) {
+    __shared__ int sm[24 * 24];
+    for (int x = threadIdx.x; x < 24 * 24; x += blockDim.x) sm[x] = submat[x];
+    __syncthreads();
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_seeds; k += gridDim.x * blockDim.x)
+        out[k] = hsp_extend_one(qcode, tcode, jobs[seeds[k].pair], seeds[k], sm, aq, at, seedlen, dropoff);
+}
+
+// one lane per horizon chain (c4gpu_hsp_extend_chains): its seeds in order, skipped while below the running horizon
+__global__ void hsp_chain_kernel(const uint8_t *__restrict__ qcode, const uint8_t *__restrict__ tcode,
+                                 const HspJob *__restrict__ jobs, const c4gpu_hsp_seed *__restrict__ seeds,
+                                 const int *__restrict__ order, const int *__restrict__ chain_first, int n_chains,
+                                 const int *__restrict__ horizon0, const int *__restrict__ submat, int aq, int at, int seedlen,
+                                 int dropoff, c4gpu_hsp *__restrict__ out) {
+    __shared__ int sm[24 * 24];
+    for (int x = threadIdx.x; x < 24 * 24; x += blockDim.x) sm[x] = submat[x];
+    __syncthreads();
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_chains; c += gridDim.x * blockDim.x) {
+        int horizon = horizon0[c];
+        for (int x = chain_first[c]; x < chain_first[c + 1]; x++) {
+            const int k = order[x];
+            if (seeds[k].target_start < horizon) { out[k] = c4gpu_hsp{0, 0, -1, 0, 0}; continue; }      // hspset.c:952-958
+            const c4gpu_hsp h = hsp_extend_one(qcode, tcode, jobs[seeds[k].pair], seeds[k], sm, aq, at, seedlen, dropoff);
+            out[k] = h;
+            horizon = h.target_start + h.length * at;                                                   // HSP_target_end, :990
+        }
     }
 }
 
@@ -2108,6 +2132,59 @@ int c4gpu_splice_predict(c4gpu_ctx *ctx, const c4gpu_params *params, const uint8
 }
 
 }  // extern "C"
+
+extern "C" int c4gpu_hsp_extend_batch(c4gpu_ctx *ctx, const c4gpu_params *params, int match_type, const c4gpu_pair *pairs,
+                                      int32_t n_pairs, int32_t seedlen, int32_t dropoff, const c4gpu_hsp_seed *seeds,
+                                      int32_t n_seeds, c4gpu_hsp *out);
+extern "C" int c4gpu_hsp_extend_chains(c4gpu_ctx *ctx, const c4gpu_params *params, int match_type, const c4gpu_pair *pairs,
+                                       int32_t n_pairs, int32_t seedlen, int32_t dropoff, const c4gpu_hsp_seed *seeds,
+                                       int32_t n_seeds, const int32_t *chain, int32_t n_chains, const int32_t *horizon0,
+                                       c4gpu_hsp *out) {
+    try {
+        if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+        if (match_type < C4GPU_MATCH_DNA2DNA || match_type > C4GPU_MATCH_PROTEIN2DNA) { c4h::set_error("unknown match type"); return -1; }
+        if (!n_seeds) return 0;
+        const int aq = 1, at = match_type == C4GPU_MATCH_PROTEIN2DNA ? 3 : 1;
+        std::vector<int> first((size_t)n_chains + 1, 0), order((size_t)n_seeds);
+        for (int k = 0; k < n_seeds; k++) {
+            const c4gpu_hsp_seed &sd = seeds[k];
+            if (sd.pair < 0 || sd.pair >= n_pairs || sd.query_start < 0 || sd.target_start < 0 || chain[k] < 0 || chain[k] >= n_chains ||
+                sd.query_start + seedlen * aq > pairs[sd.pair].query_len || sd.target_start + seedlen * at > pairs[sd.pair].target_len) {
+                c4h::set_error("an HSP seed lies outside its pair or names no chain");
+                return -1;
+            }
+            first[chain[k] + 1]++;
+        }
+        for (int c = 0; c < n_chains; c++) first[c + 1] += first[c];
+        {
+            std::vector<int> fill(first.begin(), first.end() - 1);
+            for (int k = 0; k < n_seeds; k++) order[fill[chain[k]]++] = k;            // index order inside every chain
+        }
+        ResidentSeqs seqs;
+        if (seqs.build(ctx, match_type == C4GPU_MATCH_PROTEIN2DNA ? FAM_UNGAPPED_P2D : FAM_UNGAPPED, params, pairs, n_pairs)) return -1;
+        std::vector<HspJob> jobs(n_pairs);
+        for (int i = 0; i < n_pairs; i++) jobs[i] = HspJob{seqs.qoff[i], seqs.toff[i], seqs.qlen[i], seqs.tlen[i]};
+        DevBuf<HspJob> d_jobs;
+        DevBuf<c4gpu_hsp_seed> d_seeds;
+        DevBuf<c4gpu_hsp> d_out;
+        DevBuf<int> d_submat, d_order, d_first, d_h0;
+        const int32_t *mat = match_type == C4GPU_MATCH_DNA2DNA ? &params->dna_submat[0][0] : &params->protein_submat[0][0];
+        hipStream_t s = ctx->stream;
+        if (d_jobs.upload(jobs.data(), n_pairs, s) || d_seeds.upload(seeds, n_seeds, s) || d_out.alloc(n_seeds) ||
+            d_submat.upload(mat, 24 * 24, s) || d_order.upload(order.data(), n_seeds, s) ||
+            d_first.upload(first.data(), (size_t)n_chains + 1, s) || d_h0.upload(horizon0, n_chains, s)) return -1;
+        const int block = 64, grid = std::min((n_chains + block - 1) / block, 65535);
+        hipLaunchKernelGGL(hsp_chain_kernel, dim3(grid), dim3(block), 0, s, seqs.qcode.p, seqs.tcode.p, d_jobs.p, d_seeds.p, d_order.p,
+                           d_first.p, n_chains, d_h0.p, d_submat.p, aq, at, seedlen, dropoff, d_out.p);
+        HIP_OK(hipGetLastError());
+        if (d_out.download(out, n_seeds, s)) return -1;
+        HIP_OK(hipStreamSynchronize(s));
+        return 0;
+    } catch (const std::exception &e) {
+        c4h::set_error(std::string("c4gpu_hsp_extend_chains: ") + e.what());
+        return -1;
+    }
+}
 
 extern "C" int c4gpu_hsp_extend_batch(c4gpu_ctx *ctx, const c4gpu_params *params, int match_type, const c4gpu_pair *pairs,
                                       int32_t n_pairs, int32_t seedlen, int32_t dropoff, const c4gpu_hsp_seed *seeds,

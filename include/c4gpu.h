@@ -13,6 +13,8 @@
  *   c4gpu_splice_predict     <->  SplicePredictor_predict_array_int  src/sequence/splice.c:383
  *   c4gpu_alignment_format   <->  Alignment_print_{sugar,cigar,vulgar}_block  src/c4/alignment.c:1622-1779
  *   c4gpu_hsp_extend_batch   <->  HSPset_seed_hsp (HSP_trim_ends/_init/_extend) src/comparison/hspset.c:933-997
+ *   c4gpu_hsp_extend_chains  <->  the same with its horizon test              src/comparison/hspset.c:939-958,990
+ *   c4gpu_alignment_display / _format_gff / _format_ryo  <->  Alignment_display / _display_gff / _display_ryo  src/c4/alignment.c:1343,3212,2659
  *   c4gpu_batch_run_regions  <->  Optimal_find_path with a region (--refine)   src/hub/gam.c:605-655
  *   c4gpu_seed_scan          <->  Seeder_add_target's automaton walk src/comparison/seeder.c:649-720,852-915
  *   c4gpu_sdp_batch          <->  GAM_Result_SDP_create's loop (SDP_Pair_next_path) src/hub/gam.c:852-890, src/sdp/sdp.c:743
@@ -374,6 +376,17 @@ typedef struct { int32_t query_start, target_start, length, score, cobs; } c4gpu
 int         c4gpu_hsp_extend_batch(c4gpu_ctx *ctx, const c4gpu_params *params, int match_type,
                                    const c4gpu_pair *pairs, int32_t n_pairs, int32_t seedlen, int32_t dropoff,
                                    const c4gpu_hsp_seed *seeds, int32_t n_seeds, c4gpu_hsp *out);
+/* The same with the diagonal horizon applied on the device (hspset.c:952-958,990): chain[k] names the horizon entry seed k
+ * is tested against and updates -- one per (HSPset, diagonal section, query frame, target frame) -- and horizon0[c] is that
+ * entry's value before the scan.  The seeds of a chain are taken in index order by one lane: a seed whose target_start lies
+ * below the chain's horizon is NOT extended (out[k].length = -1), every other one is, and moves the horizon to its HSP's
+ * target end, exactly as HSPset_seed_hsp does seed by seed.  A long identical diagonal then costs one extension instead of one
+ * per word hit.  The caller's replay makes the same decisions from the same numbers and never reads a skipped entry. */
+int         c4gpu_hsp_extend_chains(c4gpu_ctx *ctx, const c4gpu_params *params, int match_type,
+                                    const c4gpu_pair *pairs, int32_t n_pairs, int32_t seedlen, int32_t dropoff,
+                                    const c4gpu_hsp_seed *seeds, int32_t n_seeds, const int32_t *chain, int32_t n_chains,
+                                    const int32_t *horizon0, c4gpu_hsp *out);
+
 
 /* The seeder's word scan (Seeder_add_target -> FSM_traverse / Seeder_VFSM_traverse_single -> Seeder_FSM_traverse_func,
  * src/comparison/seeder.c:649-720,852-915; src/struct/fsm.c:186-198).  A word table holds the words the queries put into

@@ -124,6 +124,8 @@ static void hsp_flush(void){
     c4gpu_hsp_seed *seeds;
     c4gpu_hsp *hsps;
     gint *set_pair, *set_first;
+    gint32 *chain_of = NULL, *horizon0 = NULL, *gc = NULL;
+    gint n_chains = 0;
     gboolean ok = TRUE;
     gint64 t0 = g_get_monotonic_time();
     if(!n_sets)
@@ -161,6 +163,46 @@ static void hsp_flush(void){
             }
         }
     set_first[n_sets] = total;
+    /* the horizon entry every seed is tested against (hspset.c:939-958): one chain per (set, section, frames); on the
+     * device a chain's seeds are taken in order and the ones below the running horizon are not extended at all
+     * (c4gpu_hsp_extend_chains): a long identical diagonal costs one extension instead of one per word hit.
+     * C4GPU_HSP_CHAIN=0: every seed is extended and the replay alone applies the horizon */
+    if(!g_getenv("C4GPU_HSP_HOST") && !(g_getenv("C4GPU_HSP_CHAIN") && !atoi(g_getenv("C4GPU_HSP_CHAIN")))){
+        register GArray *h0 = g_array_new(FALSE, FALSE, sizeof(gint32));
+        chain_of = g_new(gint32, total + 1);
+        for(i = 0; i < n_sets; i++){
+            register ShimSeedSet *ss = hsp_order->pdata[i];
+            register HSPset *set = ss->set;
+            register gint aq = set->param->match->query->advance, at = set->param->match->target->advance;
+            register gint qlen = set->query->len, slots = qlen * aq * at, x;
+            register gint32 *slot = g_new(gint32, slots > 0 ? slots : 1);
+            for(x = 0; x < slots; x++)
+                slot[x] = -1;
+            for(k = 0; k < ss->seeds->len; k++){
+                register guint *seed = &g_array_index(ss->seeds, guint, 2 * k);
+                register gint diag_pos = (seed[1] * aq) - (seed[0] * at);
+                register gint qf = seed[0] % aq, tf = seed[1] % at;
+                register gint section_pos = (diag_pos + qlen) % qlen;
+                gint32 h;
+                if(section_pos < 0){                          /* no horizon entry (see hsp_replay): never skipped */
+                    h = G_MININT32;
+                    chain_of[set_first[i] + k] = h0->len;
+                    g_array_append_val(h0, h);
+                    continue;
+                    }
+                x = (section_pos * aq + qf) * at + tf;
+                if(slot[x] < 0){
+                    slot[x] = h0->len;
+                    h = set->horizon[0][section_pos][qf][tf];
+                    g_array_append_val(h0, h);
+                    }
+                chain_of[set_first[i] + k] = slot[x];
+                }
+            g_free(slot);
+            }
+        n_chains = h0->len;
+        horizon0 = (gint32*)g_array_free(h0, FALSE);
+        }
     if(g_getenv("C4GPU_HSP_HOST")){
         /* the reference's own extension, one scratch HSPset per seed (nothing in its way) */
         for(i = 0; i < n_sets; i++){
@@ -193,6 +235,7 @@ static void hsp_flush(void){
                 continue;
             gs = g_new(c4gpu_hsp_seed, total + 1);
             go = g_new(c4gpu_hsp, total + 1);
+            gc = chain_of ? g_new(gint32, total + 1) : NULL;
             for(k = i; k < n_sets; k++){
                 register ShimSeedSet *sk = hsp_order->pdata[k];
                 if(done[k] || (hsp_match_kind(sk->set) != kind) || (sk->set->param->seedlen != si->set->param->seedlen)
@@ -200,10 +243,16 @@ static void hsp_flush(void){
                     continue;
                 done[k] = TRUE;
                 memcpy(gs + count, seeds + set_first[k], sizeof(c4gpu_hsp_seed) * (set_first[k+1] - set_first[k]));
+                if(gc)
+                    memcpy(gc + count, chain_of + set_first[k], sizeof(gint32) * (set_first[k+1] - set_first[k]));
                 count += set_first[k+1] - set_first[k];
                 (void)first;
                 }
-            if(c4gpu_hsp_extend_batch(shim_get_ctx(), &params, kind, pairs, n_sets, si->set->param->seedlen,
+            if(gc){
+                if(c4gpu_hsp_extend_chains(shim_get_ctx(), &params, kind, pairs, n_sets, si->set->param->seedlen,
+                                           si->set->param->dropoff, gs, count, gc, n_chains, horizon0, go) != 0)
+                    ok = FALSE;
+            } else if(c4gpu_hsp_extend_batch(shim_get_ctx(), &params, kind, pairs, n_sets, si->set->param->seedlen,
                                       si->set->param->dropoff, gs, count, go) != 0)
                 ok = FALSE;
             for(k = i, count = 0; ok && (k < n_sets); k++){            /* scatter back in the same order */
@@ -214,7 +263,7 @@ static void hsp_flush(void){
                 memcpy(hsps + set_first[k], go + count, sizeof(c4gpu_hsp) * (set_first[k+1] - set_first[k]));
                 count += set_first[k+1] - set_first[k];
                 }
-            g_free(gs); g_free(go);
+            g_free(gs); g_free(go); g_free(gc);
             }
         g_free(done);
         }
@@ -239,7 +288,7 @@ static void hsp_flush(void){
         g_free(strs->pdata[i]);
     g_ptr_array_free(strs, TRUE);
     g_hash_table_destroy(seq_index);
-    g_free(pairs); g_free(seeds); g_free(hsps); g_free(set_pair); g_free(set_first);
+    g_free(pairs); g_free(seeds); g_free(hsps); g_free(set_pair); g_free(set_first); g_free(chain_of); g_free(horizon0);
     hst.flushes++;
     hst.device_ms += (g_get_monotonic_time() - t0) / 1e3;
     return;

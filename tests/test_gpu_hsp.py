@@ -52,6 +52,44 @@ def test_device_hsps_match_reference_vectors(eng, name):
         assert kept == r["set"], r["id"]
 
 
+@pytest.mark.parametrize("name", HSP_SETS)
+def test_horizon_chains_on_the_device_give_the_reference_sets(eng, name):
+    """c4gpu_hsp_extend_chains: one lane per horizon entry takes its seeds in order and does not extend the ones below the
+    running horizon (hspset.c:952-958,990).  The HSPs it does extend, kept by the threshold, are the reference's whole-set
+    lists; every extended seed equals the unconditional extension; a chain that starts from a non-zero horizon skips what
+    the reference would skip."""
+    recs = load_set(name)
+    par, recs = recs[0]["params"], recs[1:]
+    params = ex.default_params()
+    at = par["target_advance"]
+    pairs = [(r["query"], r["target"]) for r in recs]
+    seeds, chain, keys = [], [], {}
+    for k, r in enumerate(recs):
+        for qs, ts in r["seeds"]:
+            key = (k, (ts - qs * at + len(r["query"])) % len(r["query"]), ts % at)
+            chain.append(keys.setdefault(key, len(keys)))
+            seeds.append((k, qs, ts))
+    plain = eng.hsp_extend(params, par["match"], pairs, par["seedlen"], par["dropoff"], seeds)
+    got = eng.hsp_extend_chains(params, par["match"], pairs, par["seedlen"], par["dropoff"], seeds, chain, [0] * len(keys))
+    skipped = 0
+    kept = [[] for _ in recs]
+    for (k, qs, ts), g, p in zip(seeds, got, plain):
+        if g[2] < 0:
+            skipped += 1
+            continue
+        assert g == p
+        if g[3] >= par["threshold"]:
+            kept[k].append(g)
+    assert skipped > 0
+    for r, ks in zip(recs, kept):
+        assert ks == r["set"], r["id"]
+    # a horizon that is already far to the right: nothing of those chains is extended
+    far = [10 ** 9 if c % 2 else 0 for c in range(len(keys))]
+    got2 = eng.hsp_extend_chains(params, par["match"], pairs, par["seedlen"], par["dropoff"], seeds, chain, far)
+    for c, g, g0 in zip(chain, got2, got):
+        assert (g[2] < 0) if c % 2 else (g == g0)
+
+
 def test_all_word_hits_of_north_star_pairs(eng):
     """1 kb cDNAs against 100 kb windows: every shared 12-mer of every pair as a seed (tens of thousands per launch),
     against the oracle."""
