@@ -1506,7 +1506,12 @@ int windowed_region_pass(Engine &eng, const ResidentSeqs &seqs, const std::vecto
         want.push_back(x);
     }
     const size_t wanted = want.size();
-    const int max_hops = getenv("C4GPU_WINDOW_HOPS") ? atoi(getenv("C4GPU_WINDOW_HOPS")) : 12;
+    // hop budget: enough windows for the longest way back any wanted pair can have (a path that starts in the first dump
+    // interval: reverse strands of the north-star batch, 289 of 1 024 pairs at 12 hops -- the one-pass kernel that finished
+    // them cost 127 ms per 1 024 pairs, the extra hops cost nothing: profiles/r03_step.md), at least 12, at most 64
+    int need_hops = 12;
+    for (int x : want) need_hops = std::max(need_hops, ((outs[x].res.te - 1) >> kshift) + 2);
+    const int max_hops = getenv("C4GPU_WINDOW_HOPS") ? atoi(getenv("C4GPU_WINDOW_HOPS")) : std::min(need_hops, 64);
     std::vector<int> open;                                       // pairs whose path runs back further than the hop budget
     long long windows = 0;
     if (!want.empty()) {

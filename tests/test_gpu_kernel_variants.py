@@ -313,6 +313,34 @@ def test_windowed_and_one_pass_region_agree_at_full_size(eng, monkeypatch):
     assert two[0].as_dict() == oracle_lib.find_path(model.c, model.params, q, t, dpmemory=32)
 
 
+def test_window_hop_budget_covers_paths_across_the_whole_window(eng, monkeypatch, capfd):
+    """Paths that run back over the whole 100 kb window (a 90 kb intron; reverse-complemented cDNAs, whose chance alignments
+    chain hits over 93 kb) need 13-14 windows at 8 192 columns per dump: the hop budget follows the longest way back, no
+    pair is left to the one-pass kernel, and the alignments are the ones a budget of ONE hop gives (every pair finished by
+    the one-pass kernel then)."""
+    rng = random.Random(4242)
+    model = ex.Model("est2genome")
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    pairs = []
+    for k in range(3):
+        q = _rand(rng, 1000 - 7 * k)
+        pairs.append((q.encode(), (_rand(rng, 1500 + 300 * k) + _mutate(rng, q[:400], 0.03) + "GT" + _rand(rng, 90000) + "AG" +
+                                   _mutate(rng, q[400:], 0.03) + _rand(rng, 2000)).encode()))
+    for q, t in workloads.est2genome_pairs(5, 1000, 100000, first=200):
+        pairs.append((q.translate(comp)[::-1], t))
+    monkeypatch.setenv("C4GPU_TRACE", "1")
+    monkeypatch.setenv("C4GPU_SEED_KSHIFT", "13")         # the default spacing, and the two-pass route whatever earlier tests measured
+    full = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=32, threshold=100)]
+    err = capfd.readouterr().err
+    assert "windowed region pass" in err and " 0 of %d paths left to the one-pass kernel" % len(pairs) in err, err[-1500:]
+    assert all(a is not None for a in full[:3]) and all(a["region"][3] > 90000 for a in full[:3])
+    monkeypatch.setenv("C4GPU_WINDOW_HOPS", "1")
+    one = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=32, threshold=100)]
+    err = capfd.readouterr().err
+    assert " 0 of" not in err.split("windowed region pass")[-1].split("\n")[0], err[-1500:]
+    assert full == one
+
+
 def test_packed_16_bit_score_pass_agrees_with_the_32_bit_pass(eng, monkeypatch, capfd):
     """The score pass with column dumps runs two jobs per lane in packed 16-bit halves (c4_viterbi16_kernel.h) where every
     score fits; C4GPU_PK16=0 keeps the 32-bit kernel.  Same alignments either way on a ragged batch with an odd number of
