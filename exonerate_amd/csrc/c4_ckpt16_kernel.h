@@ -1,0 +1,499 @@
+// c4_ckpt16_kernel.h — the FIND_CHECKPOINTS continuation pass (viterbi.c:605-631, optimal.c:160-230) with TWO jobs per
+// lane in packed 16-bit halves: the form the score pass took in c4_viterbi16_kernel.h, now with the two payloads a
+// checkpoint cell carries beside its score.
+//
+// What a cell holds per state, low half = job A, high half = job B:
+//   sc   the score (v_pk_add_i16 clamp / v_pk_max_i16; "unset" = -32 768, adds saturate);
+//   srp  the checkpoint payload ((row x states) + state) x max_target_advance + k of viterbi.c:515-522 — an unsigned
+//        16-bit number (queries up to 3 275 rows for est2genome), moved with the winner by v_bfi_b32;
+//   il   for the states whose intron-start shadow something can still read (the two intron states of est2genome): the
+//        length of the open intron so far, the saturating counter of the packed score pass; shadow = column - il - 2.
+// A transition is: candidate = source + calc (one packed add), mask = candidate beats the holder (v_pk_sub_i16 clamp +
+// v_pk_ashrrev_i16, strict <: the first transition into a state assigns, later ones replace on strict <,
+// viterbi.c:766-775), score = packed max, payloads = v_bfi_b32 under the mask — six instructions for two cells where
+// the 32-bit kernel spends add, compare and one select per slot on one.
+//
+// Which jobs: top-level checkpoint passes of Optimal_find_path_reduced_space (first state START with the zero cell,
+// final state END: what fused_reduced_paths launches) under the continuation kernels' row-0 shortcut (CONT && LOCAL of
+// c4_viterbi_kernel.h).  START is valid in the origin cell only and END in the far corner only (CORNER scopes,
+// viterbi.c:68-76): the START transitions are evaluated in the one cell that can hold the origin, END is evaluated once
+// per job, in 32-bit arithmetic on the halves of the corner cell, and neither state occupies registers in the column loop.
+//
+// Exactness.  Every cell ON the optimal path holds its reference value: the path is a local optimum, so every prefix
+// of it scores at least minus one gap/intron opening (dropping a negative prefix would score higher), and a prefix is
+// at most the best score; both are far inside 16 bits under the host's guard ((Q + 1) x largest substitution score
+// plus what introns can gain <= 16 000).  A cell OFF the path may saturate at -32 768 (its reference value lies below
+// that); a saturated or unset value plus everything a path can gain stays below -16 000 and loses against the real
+// candidate of every path cell, exactly as the -987 654 321 candidates of the 32-bit kernels do.  Winner, payload and
+// tie-break of every path cell are therefore the reference's, which is all the checkpoint traceback reads
+// (viterbi.c:537-601 follows the payloads from the corner cell; cells it does not visit never leave the kernel:
+// calls whose checkpoint cells go to the caller keep the 32-bit kernels).
+// The length counter saturates at 32 767 columns: an intron that long passes the minimum test either way, the maximum
+// cannot fail (T + 4 <= max_intron, checked by the host), and the shadow written into a checkpoint cell is then
+// "at least 32 767 columns back" — the host and the stitch kernel compare such shadows as equivalent (shadow_equiv in
+// c4_engine.hip): a continuation seeded with either computes the same scores and the same path.
+#pragma once
+#include "c4_viterbi16_kernel.h"
+
+namespace c4k {
+
+__device__ __forceinline__ int bfi32(int mask, int a, int b) {       // (mask & a) | (~mask & b): one v_bfi_b32
+    return (mask & a) | (~mask & b);
+}
+
+template <class M, int R>
+struct WaveCK16 {
+    using F = Facts<M>;
+    using W32 = WaveDP<M, R, MODE_CKPT, true, true>;
+    static constexpr int NS = M::NS, NCOL = M::MAXAT + 1, W = 64 * R, MAXAT = M::MAXAT;
+    static constexpr int CS = W32::CS;                    // the reference's cell: score, designations, checkpoint slot
+    static constexpr bool live(int s) { return M::NDES > 0 && W32::slot_live(s, 0); }
+    static constexpr bool inner(int s) { return s != M::START && s != M::END; }
+    static constexpr int n_live() { int n = 0; for (int s = 0; s < NS; s++) n += (inner(s) && live(s)); return n; }
+    static constexpr int n_inner() { int n = 0; for (int s = 0; s < NS; s++) n += inner(s); return n; }
+    // a checkpoint row in the job's slab: one word (score | payload << 16) per inner state, then the live lengths two per word
+    static constexpr int word_of(int s) { int n = 0; for (int x = 0; x < s; x++) n += inner(x); return n; }
+    static constexpr int live_index(int s) { int n = 0; for (int x = 0; x < s; x++) n += (inner(x) && live(x)); return n; }
+    static constexpr int CKW = n_inner() + (n_live() + 1) / 2;
+    static constexpr int NEXP = F::n_exported();
+    static constexpr int n_exp_live() { int n = 0; for (int s = 0; s < NS; s++) n += (F::exported(s) && live(s)); return n; }
+    static constexpr int BND = NEXP * 2 + n_exp_live();   // ints per column between strips
+    static_assert(!F::has_phase(), "split-codon calcs are not packed");
+    static_assert(M::NDES <= 1, "one shadow designation");
+    static_assert(M::START == 0 && M::END == 1, "state numbering of the closed model");
+    static_assert(!F::exported(M::START), "START advances nothing");
+    struct C16 { int sc[NS]; int il[NS]; int srp[NS]; };
+
+    const KParams *kp;
+    int lane;
+    const uint8_t *qc[2], *tc[2];
+    const uint2 *ss16[2];
+    int Q[2], T[2], q0[2], t0[2], tlast[2], cp_count[2], section[2];
+    int *ckp[2];                                          // each job's checkpoint rows
+    int cp_next_j[2], cp_next_i[2];
+    int Qm, Tm, Tmin;
+    int min_len_pk, at_pk[4], cv_pk[16];
+    C16 col[NCOL][R], nbr[NCOL], expo, nx_carry;
+    int qrow[2][R];
+    int nx_tcode[2];
+    uint2 nx_sp16[2];
+    bool carry_cols;
+    int corner_sc[2], corner_srp[2];
+    bool corner_set[2];
+
+    template <class Fn>
+    __device__ __forceinline__ static void for_exported(Fn &&fn) {
+        int slot = 0;
+        static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+            if constexpr (F::exported(S)) { fn(S_, slot); slot += 2 + (live(S) ? 1 : 0); }
+        });
+    }
+    __device__ __forceinline__ static void write_empty_column(int *colp) {
+        for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
+            colp[slot] = NEG16; colp[slot + 1] = 0;
+            if constexpr (live(S)) colp[slot + 2] = 0;
+        });
+    }
+    __device__ __forceinline__ void prefetch_carry(int s_next, const int *bnd_in) {
+        const int jx = s_next < 0 ? 0 : (s_next > Tm ? Tm : s_next);
+        const int jc = carry_cols ? jx : 0;
+        for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
+            const int *p = bnd_in + (long long)jc * BND + slot;
+            nx_carry.sc[S] = p[0];
+            nx_carry.srp[S] = p[1];
+            if constexpr (live(S)) nx_carry.il[S] = p[2];
+        });
+    }
+    __device__ __forceinline__ void prefetch_column(int j) {
+        constexpr int mat = F::match_at();
+        static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
+            int ti = t0[H] + j - mat;
+            ti = ti < 0 ? 0 : (ti > tlast[H] ? tlast[H] : ti);
+            nx_tcode[H] = tc[H][(unsigned)ti];
+            if constexpr (F::has_splice()) {
+                int tp = t0[H] + j - 2;
+                tp = tp < 0 ? 0 : (tp > tlast[H] ? tlast[H] : tp);
+                nx_sp16[H] = ss16[H][(unsigned)tp];
+            }
+        });
+    }
+
+    // one cell of both jobs; ORIGIN: this instantiation can hold the origin cell (row 0 of the lane, steps before the
+    // main loop), the only cell a transition out of START is valid in
+    template <int RR, int PH, bool JINT>
+    __device__ __forceinline__ void eval_cell(int j, bool origin, int ms, const int (&sp)[4]) {
+        C16 &c = col[PH][RR];
+        static_for<M::NT>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
+            constexpr TrDesc t = M::tr[K];
+            if constexpr (t.out == M::END) return;                            // once per job, in the corner cell (step)
+            if constexpr (t.in == M::START && (RR > 0 || JINT)) return;       // cannot be the origin cell
+            static_assert(!(t.in == M::START && F::code(K) == 1), "a state's first transition is never the one out of START");
+            constexpr int PD = (PH - t.at + NCOL) % NCOL;
+            const C16 &src = (t.aq == 0) ? col[PD][RR] : (RR > 0 ? col[PD][RR > 0 ? RR - 1 : 0] : nbr[PD]);
+            int cand, srpc = 0, ilc = 0;
+            if constexpr (t.in == M::START) {
+                static_assert(t.in != M::START || (t.aq == 0 && t.at == 0 && t.calc < 0), "START leaves silently");
+                cand = origin ? 0 : NEG16;                                    // the zero cell (viterbi.c:705-714)
+            } else {
+                cand = src.sc[t.in];
+                srpc = src.srp[t.in];
+                if constexpr (t.calc >= 0) {
+                    constexpr CalcDesc cd = M::calc[t.calc];
+                    if constexpr (cd.kind == CALC_CONST) cand = pk_add<1>(cand, cv_pk[t.calc]);
+                    else if constexpr (cd.kind >= CALC_MATCH_DNA && cd.kind <= CALC_MATCH_P2D) cand = pk_add<1>(cand, ms);
+                    else if constexpr (cd.kind == CALC_SPLICE_PRE) cand = pk_add<1>(cand, sp[cd.param]);
+                    else if constexpr (cd.kind == CALC_SPLICE_POST) {
+                        static_assert(live(t.in), "post-splice calc without a length");
+                        const int bad = pk_lt_mask<1>(src.il[t.in], min_len_pk, 0);      // length so far < min - at - 2
+                        const int sv = bfi32(bad, NEG16, sp[cd.param]);
+                        cand = pk_add<1>(cand, sv);
+                    }
+                }
+                if constexpr (!JINT && t.at > 0) cand = (j >= t.at) ? cand : NEG16;
+                if constexpr (live(t.out)) {
+                    if constexpr (F::owns_shadow(t.in, 0)) ilc = 0;
+                    else if constexpr (live(t.in)) ilc = pk_add<1>(src.il[t.in], at_pk[t.at]);
+                }
+            }
+            if constexpr (F::code(K) == 1) {                     // the first transition into this state assigns
+                c.sc[t.out] = cand;
+                c.srp[t.out] = srpc;
+                if constexpr (live(t.out)) c.il[t.out] = ilc;
+            } else {
+                const int win = pk_lt_mask<1>(c.sc[t.out], cand, 0);                  // strict <: the newcomer wins
+                c.srp[t.out] = bfi32(win, srpc, c.srp[t.out]);
+                if constexpr (live(t.out)) c.il[t.out] = bfi32(win, ilc, c.il[t.out]);
+                c.sc[t.out] = pk_max<1>(c.sc[t.out], cand);
+            }
+        });
+    }
+
+    template <bool JINT, int PH>
+    __device__ __forceinline__ void step(int s, int i0, bool first_strip, bool last_strip, const int *bnd_in, int *bnd_out) {
+        const int j = s - lane;
+        int ms[R];
+        static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+            ms[RR] = pk_pack(kp->submat[qrow[0][RR] + nx_tcode[0]], kp->submat[qrow[1][RR] + nx_tcode[1]]);
+        });
+        int sp[4] = {0, 0, 0, 0};
+        if constexpr (F::has_splice()) {
+            sp[0] = (int)__builtin_amdgcn_perm(nx_sp16[1].x, nx_sp16[0].x, 0x05040100u);
+            sp[1] = (int)__builtin_amdgcn_perm(nx_sp16[1].x, nx_sp16[0].x, 0x07060302u);
+            sp[2] = (int)__builtin_amdgcn_perm(nx_sp16[1].y, nx_sp16[0].y, 0x05040100u);
+            sp[3] = (int)__builtin_amdgcn_perm(nx_sp16[1].y, nx_sp16[0].y, 0x07060302u);
+        }
+        for_exported([&](auto S_, int) __attribute__((always_inline)) { constexpr int S = S_;
+            nbr[PH].sc[S] = dpp_shr1(nx_carry.sc[S], expo.sc[S]);
+            nbr[PH].srp[S] = dpp_shr1(nx_carry.srp[S], expo.srp[S]);
+            if constexpr (live(S)) nbr[PH].il[S] = dpp_shr1(nx_carry.il[S], expo.il[S]);
+        });
+        prefetch_carry(s + 1, bnd_in);
+        prefetch_column(j + 1);
+        const bool origin = first_strip & (lane == 0) & (s == 0);
+        static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+            eval_cell<RR, PH, JINT>(j, origin, ms[RR], sp);
+        });
+        // the bottom row for the lane below, BEFORE any checkpoint edit (that lane still needs column j as it was)
+        for_exported([&](auto S_, int) __attribute__((always_inline)) { constexpr int S = S_;
+            expo.sc[S] = col[PH][R - 1].sc[S];
+            expo.srp[S] = col[PH][R - 1].srp[S];
+            if constexpr (live(S)) expo.il[S] = col[PH][R - 1].il[S];
+        });
+        if (!last_strip && lane == 63 && j >= 0 && j <= Tm) {
+            for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
+                int *p = bnd_out + (long long)j * BND + slot;
+                p[0] = expo.sc[S];
+                p[1] = expo.srp[S];
+                if constexpr (live(S)) p[2] = expo.il[S];
+            });
+        }
+        // the corner cell (Q, T) of each job: END is entered here and nowhere else (viterbi.c:813-832).  Its
+        // transitions in id order on the 32-bit halves: the first assigns, later ones replace on strict <.
+        if (s >= Tmin) {
+            static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
+                const bool mine = (j == T[H]) & (Q[H] >= i0) & (Q[H] < i0 + R);
+                if (__builtin_amdgcn_ballot_w64(mine)) {
+                    static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                        if (mine & (i0 + RR == Q[H])) {
+                            bool set = false;
+                            int e_sc = 0, e_srp = 0;
+                            static_for<M::NT>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
+                                constexpr TrDesc t = M::tr[K];
+                                if constexpr (t.out == M::END) {
+                                    static_assert(t.out != M::END || (t.aq == 0 && t.at == 0 && t.calc < 0 && t.in != M::START),
+                                                  "END is entered silently from an inner state");
+                                    const int v = pk_half(col[PH][RR].sc[t.in], H);
+                                    const int p = (int)(((unsigned)col[PH][RR].srp[t.in] >> (16 * H)) & 0xffffu);
+                                    const bool win = !set | (e_sc < v);
+                                    e_sc = win ? v : e_sc;
+                                    e_srp = win ? p : e_srp;
+                                    set = true;
+                                }
+                            });
+                            corner_sc[H] = e_sc; corner_srp[H] = e_srp; corner_set[H] = set;
+                        }
+                    });
+                }
+            });
+        }
+        // checkpoint rows (Viterbi_Checkpoint_process, viterbi.c:605-631): at checkpoint column c the reference copies rows
+        // c, c-1, .. and then stamps their payload slots.  Each of those columns is copied out at the step that computes it
+        // (c4_viterbi_kernel.h, step (7)); the stamp stays at column c.  The two jobs have their own columns.
+        {
+            unsigned stamp = 0;
+            static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
+                const bool cp_live = (j >= 0) & (j <= T[H]) & (cp_next_i[H] < cp_count[H]);
+                const unsigned ahead = (unsigned)(cp_next_j[H] - j);            // 0 .. MAXAT-1: a column the checkpoint keeps
+                if (__builtin_amdgcn_ballot_w64(cp_live & (ahead < (unsigned)MAXAT))) {
+                    if (cp_live & (ahead < (unsigned)MAXAT)) {
+                        static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                            const int i = i0 + RR;
+                            if (i <= Q[H]) {
+                                int *p = ckp[H] + ((((long long)cp_next_i[H] * MAXAT + ahead) * (Q[H] + 1) + i)) * CKW;
+                                constexpr unsigned sel = H ? 0x07060302u : 0x05040100u;
+                                int lw[(n_live() + 1) / 2 > 0 ? (n_live() + 1) / 2 : 1] = {0};
+                                static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                                    if constexpr (inner(S)) {
+                                        p[word_of(S)] = (int)__builtin_amdgcn_perm((unsigned)col[PH][RR].srp[S], (unsigned)col[PH][RR].sc[S], sel);
+                                        if constexpr (live(S)) {
+                                            constexpr int li = live_index(S);
+                                            const unsigned h = ((unsigned)col[PH][RR].il[S] >> (16 * H)) & 0xffffu;
+                                            lw[li / 2] |= (int)(h << (16 * (li & 1)));
+                                        }
+                                    }
+                                });
+                                static_for<(n_live() + 1) / 2>([&](auto L_) __attribute__((always_inline)) { constexpr int L = L_; p[n_inner() + L] = lw[L]; });
+                            }
+                        });
+                    }
+                    stamp |= (cp_live & (ahead == 0u)) ? (H ? 0xffff0000u : 0x0000ffffu) : 0u;
+                }
+            });
+            if (__builtin_amdgcn_ballot_w64(stamp != 0u)) {
+                // the stamps only depend on the lane's rows: keep the compiler from hoisting them out of the column loop
+                int i0v = i0;
+                asm volatile("" : "+v"(i0v));
+                static_for<MAXAT>([&](auto ROW_) __attribute__((always_inline)) { constexpr int ROW = ROW_;
+                    constexpr int PR = (PH - ROW + NCOL) % NCOL;
+                    static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                        const int rowid = (i0v + RR) * (NS * MAXAT);
+                        static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                            if constexpr (inner(S)) {
+                                const int id = (rowid + S * MAXAT + ROW) & 0xffff;              // viterbi.c:515-522
+                                col[PR][RR].srp[S] = bfi32((int)stamp, id | (id << 16), col[PR][RR].srp[S]);
+                            }
+                        });
+                    });
+                    // our copies of row i0-1 at these columns get the same edit
+                    const int rowid = (i0v - 1) * (NS * MAXAT);
+                    static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                        if constexpr (inner(S) && F::exported(S)) {
+                            const int id = (rowid + S * MAXAT + ROW) & 0xffff;
+                            nbr[PR].srp[S] = bfi32((int)stamp, id | (id << 16), nbr[PR].srp[S]);
+                        }
+                    });
+                });
+                static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
+                    const bool mine = (stamp & (H ? 0xffff0000u : 0x0000ffffu)) != 0u;
+                    cp_next_i[H] += mine ? 1 : 0;
+                    cp_next_j[H] += mine ? section[H] : 0;
+                });
+            }
+        }
+    }
+
+    __device__ __forceinline__ void run(const DevJob &ja, const DevJob &jb, const DevSeqs &seqs, int *bnd, int *ckpt_a, int *ckpt_b) {
+        const DevJob *jp[2] = {&ja, &jb};
+        ckp[0] = ckpt_a; ckp[1] = ckpt_b;
+        static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
+            const DevJob &jx = *jp[H];
+            Q[H] = jx.Q; T[H] = jx.T; q0[H] = jx.q0; t0[H] = jx.t0;
+            tlast[H] = seqs.tlen[jx.pair] > 0 ? seqs.tlen[jx.pair] - 1 : 0;
+            qc[H] = seqs.qcode + seqs.qoff[jx.pair];
+            tc[H] = seqs.tcode + seqs.toff[jx.pair];
+            ss16[H] = F::has_splice() ? seqs.ss16 + seqs.toff[jx.pair] : nullptr;
+            cp_count[H] = jx.cp_count;
+            section[H] = jx.T / (jx.cp_count + 1);
+            corner_sc[H] = LOW; corner_srp[H] = 0; corner_set[H] = false;
+        });
+        Qm = Q[0] > Q[1] ? Q[0] : Q[1]; Tm = T[0] > T[1] ? T[0] : T[1]; Tmin = T[0] < T[1] ? T[0] : T[1];
+        static_for<M::NC>([&](auto CI_) __attribute__((always_inline)) { constexpr int CI = CI_;
+            const int v = clamp16(kp->calc_value[CI]);
+            cv_pk[CI] = pk_pack(v, v);
+        });
+        static_for<4>([&](auto A_) __attribute__((always_inline)) { constexpr int A = A_; at_pk[A] = pk_pack(A, A); });
+        {
+            const int lim = clamp16(kp->min_intron - 4);
+            min_len_pk = pk_pack(lim, lim);
+        }
+        const int nstrips = (Qm + 1 + W - 1) / W;
+        const int nsteps = Tm + 64;
+        const int main_lo = 63 + MAXAT, main_hi = Tm;
+        const int nsteps_r = (nsteps + NCOL - 1) / NCOL * NCOL;
+        const int main_lo_r = (main_lo + NCOL - 1) / NCOL * NCOL;
+        for (int b = 0; b < nstrips; b++) {
+            const int i0 = b * W + lane * R;
+            static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
+                static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                    const int i = i0 + RR;
+                    qrow[H][RR] = 24 * ((i >= 1 && i <= Q[H]) ? (int)qc[H][q0[H] + i - 1] : 0);
+                });
+                cp_next_j[H] = section[H] > 0 ? section[H] : 0x7fffffff; cp_next_i[H] = 0;
+            });
+            static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                expo.sc[S] = NEG16; expo.il[S] = 0; expo.srp[S] = 0;
+                static_for<NCOL>([&](auto D_) __attribute__((always_inline)) { constexpr int D = D_;
+                    nbr[D].sc[S] = NEG16; nbr[D].il[S] = 0; nbr[D].srp[S] = 0;
+                    static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                        col[D][RR].sc[S] = NEG16; col[D][RR].il[S] = 0; col[D][RR].srp[S] = 0;
+                    });
+                });
+            });
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const bool first = (b == 0), last = (b == nstrips - 1);
+            // slab layout: [empty column][carry row A (Tm + 1 columns)][carry row B]
+            carry_cols = !first;
+            const int *bnd_in = first ? bnd : bnd + BND + (long long)((b + 1) & 1) * (Tm + 1) * BND;
+            int *bnd_out = bnd + BND + (long long)(b & 1) * (Tm + 1) * BND;
+            auto group = [&](auto JI_, int s0) __attribute__((always_inline)) {
+                constexpr bool JI = decltype(JI_)::value != 0;
+                static_for<NCOL>([&](auto P_) __attribute__((always_inline)) { constexpr int P = P_;
+                    step<JI, P>(s0 + P, i0, first, last, bnd_in, bnd_out);
+                });
+            };
+            prefetch_column(0 - lane);
+            prefetch_carry(0, bnd_in);
+            int s = 0;
+            for (; s < main_lo_r && s < nsteps_r; s += NCOL) group(IC<0>{}, s);
+            for (; s + NCOL - 1 <= main_hi; s += NCOL) group(IC<1>{}, s);
+            for (; s < nsteps_r; s += NCOL) group(IC<0>{}, s);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // carry row visible to the next strip
+        }
+    }
+
+    // Viterbi_Checkpoint_traceback (viterbi.c:537-601) over the packed rows of one job; the list is written last section
+    // first, cells in the reference's layout (score, intron-start shadow, payload)
+    struct Cell3 { int sc, shadow, srp; };
+    __device__ static Cell3 cell_at(const int *ck, const DevJob &job, int section_length, int cp, int row, int qpos, int state) {
+        const int *p = ck + (((long long)cp * MAXAT + row) * (job.Q + 1) + qpos) * CKW;
+        Cell3 c; c.sc = 0; c.shadow = 0; c.srp = 0;
+        static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+            if constexpr (inner(S)) {
+                if (state == S) {
+                    const unsigned w = (unsigned)p[word_of(S)];
+                    c.sc = (int)(short)(w & 0xffffu);
+                    c.srp = (int)(w >> 16);
+                    if constexpr (live(S)) {
+                        constexpr int li = live_index(S);
+                        const int il = (int)(((unsigned)p[n_inner() + li / 2] >> (16 * (li & 1))) & 0xffffu);
+                        c.shadow = job.t0 + (section_length * (cp + 1) - row) - il - 2;
+                    }
+                }
+            }
+        });
+        return c;
+    }
+    __device__ __noinline__ static void checkpoint_traceback(const int *ck, const DevJob &job, DevVsa *vsa, DevResult &res) {
+        const int q0 = job.q0, t0 = job.t0;
+        const int cpn = job.cp_count, section_length = job.T / (cpn + 1);
+        auto decode = [&](int srp, int &state, int &row, int &pos) {
+            row = srp % MAXAT;
+            const int rem = srp / MAXAT;
+            state = rem % NS;
+            pos = rem / NS;
+        };
+        int state, row, pos, n = 0;
+        decode(res.last_srp, state, row, pos);
+        int query_start = q0 + pos, target_start = t0 + section_length * cpn - row;
+        DevVsa v;
+        v.qs = query_start; v.ts = target_start;
+        v.ql = (q0 + job.Q) - query_start; v.tl = (t0 + job.T) - target_start;
+        v.first_state = state;
+        for (int l = 0; l < CELL_MAX; l++) v.final_cell[l] = l < CS ? res.final_cell[l] : 0;
+        vsa[n++] = v;
+        for (int c = cpn - 1; c >= 1; c--) {
+            const DevVsa p = v;
+            const int prev_row = row;
+            const Cell3 cell = cell_at(ck, job, section_length, c, prev_row, p.qs - q0, p.first_state);
+            decode(cell.srp, state, row, pos);
+            query_start = q0 + pos;
+            target_start = p.ts - section_length - row + prev_row;
+            v.qs = query_start; v.ts = target_start; v.ql = p.qs - query_start; v.tl = p.ts - target_start;
+            v.first_state = state;
+            for (int l = 0; l < CELL_MAX; l++) v.final_cell[l] = 0;
+            v.final_cell[0] = cell.sc; v.final_cell[1] = cell.shadow; v.final_cell[CS - 1] = cell.srp;
+            vsa[n++] = v;
+        }
+        {
+            const DevVsa p = v;
+            const Cell3 cell = cell_at(ck, job, section_length, 0, row, p.qs - q0, p.first_state);
+            v.qs = q0; v.ts = t0; v.ql = query_start - q0; v.tl = target_start - t0;
+            v.first_state = job.first_state;
+            for (int l = 0; l < CELL_MAX; l++) v.final_cell[l] = 0;
+            v.final_cell[0] = cell.sc; v.final_cell[1] = cell.shadow; v.final_cell[CS - 1] = cell.srp;
+            vsa[n++] = v;
+        }
+        res.n_vsa = n;
+    }
+};
+
+// persistent waves; workgroup p of the queue runs jobs 2p and 2p + 1 (the last one alone when the launch holds an odd
+// number: its high half repeats it).  scratch.ckpt holds two job slabs per wave (ckpt_stride ints each).
+template <class M, int R, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
+void ckpt16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, int n_jobs, DevResult *results, DevVsa *vsas,
+                   DevScratch scratch, int *queue) {
+    using DP = WaveCK16<M, R>;
+    __shared__ KParams kp_lds;
+    __shared__ int next_job;
+    {
+        const int *src = reinterpret_cast<const int *>(kparams);
+        int *dst = reinterpret_cast<int *>(&kp_lds);
+        for (int x = threadIdx.x; x < (int)(sizeof(KParams) / sizeof(int)); x += 64) dst[x] = src[x];
+    }
+    __syncthreads();
+    int *bnd = scratch.bnd + (long long)blockIdx.x * scratch.bnd_stride;
+    if (threadIdx.x == 0) DP::write_empty_column(bnd);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    int *ck_a = scratch.ckpt + (long long)blockIdx.x * 2 * scratch.ckpt_stride, *ck_b = ck_a + scratch.ckpt_stride;
+    const int n_pairs = (n_jobs + 1) / 2;
+    for (;;) {
+        if (threadIdx.x == 0) next_job = atomicAdd(queue, 1);
+        __syncthreads();
+        const int pid = next_job;
+        __syncthreads();
+        if (pid >= n_pairs) break;
+        const int ia = 2 * pid, ib = (2 * pid + 1 < n_jobs) ? 2 * pid + 1 : 2 * pid;
+        DP dp;
+        dp.kp = &kp_lds;
+        dp.lane = threadIdx.x;
+        dp.run(jobs[ia], jobs[ib], seqs, bnd, ck_a, ck_b);
+        // the lane that owned a job's corner cell hands it to the lane that walks the job's checkpoints
+        int sc[2], srp[2];
+        bool set[2];
+        for (int h = 0; h < 2; h++) {
+            const unsigned long long owners = __ballot(dp.corner_set[h]);
+            const int owner = owners ? __ffsll((long long)owners) - 1 : 0;
+            sc[h] = __shfl(dp.corner_sc[h], owner); srp[h] = __shfl(dp.corner_srp[h], owner);
+            set[h] = owners != 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __syncthreads();
+        if (threadIdx.x < 2 && (threadIdx.x == 0 || ib != ia)) {
+            const int h = threadIdx.x;
+            const DevJob &job = jobs[h ? ib : ia];
+            DevResult res;
+            res.flags = set[h] ? 0 : FLAG_NO_END; res.n_ops = 0; res.n_vsa = 0; res.pad = 0; res.qs = res.ts = 0;
+            res.cell_size = DP::CS; res.ops_off = 0;
+            for (int l = 0; l < CELL_MAX; l++) res.final_cell[l] = 0;
+            res.final_cell[0] = sc[h]; res.final_cell[DP::CS - 1] = srp[h];
+            res.score = sc[h]; res.end_set = set[h]; res.qe = job.Q; res.te = job.T; res.last_srp = srp[h];
+            if (set[h]) DP::checkpoint_traceback(h ? ck_b : ck_a, job, vsas + job.vsa_off, res);
+            results[h ? ib : ia] = res;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace c4k

@@ -466,11 +466,25 @@ __global__ void memrule_probe_kernel(c4h::MemRule rule, int dpmemory_mb, const i
 
 struct FusePair { long long off; int count, status; };      // merged (transition, length) pairs at out[2 * off ..]; status 0 = done
 
+// Is the final cell a sub-alignment computed the one its successor was seeded with?  Exactly, except for cells predicted by the
+// packed checkpoint pass (c4_ckpt16_kernel.h), whose intron-length counter saturates: a shadow slot (the target position an
+// open intron started at) that lies 32 767 columns or more behind the cell is known there only as "that far back", and two
+// such positions are interchangeable — the one thing ever computed from a shadow is the intron's length at its 3' site
+// (intron.c:150-160), which passes the minimum either way and cannot exceed the maximum (Engine::pk16_fits).
+__host__ __device__ inline bool final_cell_equiv(const int *computed, const int *predicted, int n_slots, int target_end, bool packed) {
+    if (computed[0] != predicted[0]) return false;
+    for (int l = 1; l < n_slots; l++) {
+        if (computed[l] == predicted[l]) continue;
+        if (!(packed && (long long)target_end - predicted[l] - 2 >= 32767 && (long long)target_end - computed[l] - 2 >= 32767)) return false;
+    }
+    return true;
+}
+
 // one thread per checkpoint job: verify the chain of final cells, then Alignment_add (alignment.c:75-102) over the runs
 // of its sub-alignments in path order (each job's walk wrote its runs END -> START)
 __global__ void fuse_stitch_kernel(const DevJob *parents, const DevVsa *vsa, const int *first, int n_parents,
                                    const DevResult *sub, const uint32_t *runs, int path_cs, const int *flags,
-                                   unsigned long long *out_used, int *out, FusePair *pairs) {
+                                   unsigned long long *out_used, int *out, FusePair *pairs, int n_packed) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= n_parents) return;
     FusePair fp; fp.off = 0; fp.count = 0; fp.status = 1;
@@ -485,8 +499,8 @@ __global__ void fuse_stitch_kernel(const DevJob *parents, const DevVsa *vsa, con
         total += r.n_ops;
         // the next sub-alignment was seeded with the predicted cell: it must be the one this one produced
         if (k + 1 < cnt) {
-            const int *pred = vsa[pj.vsa_off + (cnt - 1 - k)].final_cell;
-            for (int l = 0; l < path_cs; l++) bad |= (r.final_cell[l] != pred[l]);
+            const DevVsa &dv = vsa[pj.vsa_off + (cnt - 1 - k)];
+            bad |= !final_cell_equiv(r.final_cell, dv.final_cell, path_cs, dv.ts + dv.tl, x < n_packed);
             if (bad) break;
         }
     }
@@ -686,6 +700,7 @@ struct JobOut {
     RunList runs;                 // PATH: (transition << 24 | length) runs, START -> END
     std::vector<DevVsa> vsa;      // CKPT: sub-alignments, last section first
     std::vector<int> checkpoints; // CKPT + dump_checkpoints
+    bool packed = false;          // CKPT: the cells come from the packed 16-bit pass (final_cell_equiv)
 };
 
 // The windowed region pass (c4_viterbi_kernel.h, SEED): what a launch needs to know about the column dumps.
@@ -726,6 +741,10 @@ struct Engine {
     // what the continuation kernels without the row-0 mask need to stay exact (cont_free_ok)
     double calc_bound = 0;
     int pk16_match_max = 1, pk16_max_intron = 0;
+    // what ONE intron can add to a path (best 5' sum + best 3' sum + the opening constant; 0 when that is negative, as with
+    // the default parameters: 13 + 16 - 30) and the fewest target columns it takes: a path gains at most
+    // (Q + 1) x pk16_match_max + (T / pk16_intron_cols + 1) x pk16_intron_gain (pk16_fits)
+    int pk16_intron_gain = 0, pk16_intron_cols = 4;
     DevBuf<KParams> kparams;
     // reusable device buffers
     DevBuf<DevJob> d_jobs;
@@ -813,6 +832,29 @@ struct Engine {
             pk16_params_ok = pmax <= 16000.0 && smax <= 16000.0 && params->min_intron >= 0 && params->min_intron <= 30000 &&
                              params->max_intron >= params->min_intron;
             pk16_max_intron = params->max_intron;
+            if (family_has_splice(family)) {
+                // largest value a site of each kind can score: every PSSM row at its best, rounded as the predictor rounds
+                int best[4] = {0, 0, 0, 0};
+                for (int k = 0; k < 4; k++) {
+                    const c4gpu_splice_model &sp = params->splice[k];
+                    double sum = 0;
+                    for (int r = 0; r < sp.model_length && r < C4GPU_SPLICE_MAX_LEN; r++) {
+                        double mx = 0;
+                        for (int c = 0; c < 5; c++) mx = std::max(mx, (double)sp.data[r][c]);
+                        sum += mx;
+                    }
+                    best[k] = (int)std::floor(sum + 0.5) + 1;
+                }
+                int pre = -0x40000000, post = -0x40000000;
+                for (int i = 0; i < m->n_calcs; i++) {
+                    const int prm = m->calcs[i].param & 3;
+                    if (m->calcs[i].kind == C4GPU_CALC_SPLICE_PRE) pre = std::max(pre, m->calcs[i].value + best[prm]);
+                    if (m->calcs[i].kind == C4GPU_CALC_SPLICE_POST) post = std::max(post, m->calcs[i].value + best[prm]);
+                }
+                const long long gain = (long long)pre + post;
+                pk16_intron_gain = (int)std::max<long long>(0, std::min<long long>(gain, 1 << 20));
+                pk16_intron_cols = std::max(4, params->min_intron);
+            }
             if (getenv("C4GPU_LOCAL_EXACT") && atoi(getenv("C4GPU_LOCAL_EXACT")) == 0) local_exact = false;   // test hook
         }
         for (int c = 0; c < 4096; c++) {
@@ -829,6 +871,29 @@ struct Engine {
     bool cont_free_ok(long long q_plus_t) const {
         if (getenv("C4GPU_CONT_FREE") && atoi(getenv("C4GPU_CONT_FREE")) == 0) return false;
         return (double)(q_plus_t + 2) * std::max(calc_bound, 1.0) < 4.0e8;
+    }
+
+    // The packed 16-bit passes (c4_viterbi16_kernel.h, c4_ckpt16_kernel.h) are exact while everything a path can gain stays
+    // inside 16 000: the substitution scores of its query rows plus, where an intron's two sites can outweigh its opening
+    // penalty (a small --intronpenalty), that net gain once per intron the target has room for; and the intron length test
+    // must not be able to fail on the upper side (the packed length counter saturates).
+    bool pk16_fits(int query_length, int target_length) const {
+        const double gain = (double)(query_length + 1) * pk16_match_max +
+                            (double)(target_length / pk16_intron_cols + 1) * pk16_intron_gain;
+        return gain <= 16000.0 && (!family_has_splice(family) || (long long)target_length + 4 <= (long long)pk16_max_intron);
+    }
+    // the four splice values of every target position as the packed passes add them (ss16_kernel): built once per batch,
+    // finished before the lock is released (the other lane launches on another stream)
+    int ensure_ss16(const ResidentSeqs &seqs) {
+        if (!family_has_splice(family)) return 0;
+        std::lock_guard<std::mutex> hold(seqs.ss16_lock);
+        if (!seqs.ss16_built) {
+            if (seqs.ss16.alloc((size_t)seqs.ss_len)) return -1;
+            HIP_OK(pk16_build_splice(family, kparams.p, seqs.dev.ss, seqs.dev.ss_stride, seqs.ss_len, seqs.ss16.p, ctx->stream));
+            HIP_OK(hipStreamSynchronize(ctx->stream));
+            seqs.ss16_built = true;
+        }
+        return 0;
     }
 
     // Runs `specs` in `mode`; out[i] corresponds to specs[i].  Calls whose region holds blocked cells
@@ -932,20 +997,9 @@ struct Engine {
             const KernelInfo *kpk = (seed->mode == 1 && pk_env && pk16_params_ok && n >= 2) ? get_kernel_pk16(family, pk_env == 3 ? 0 : pk_env == 4 ? 2 : 1) : nullptr;      // 3: the all-asm form (c4_viterbi16_kernel.h, VAR 0)
             if (kpk) {
                 bool fits = true;
-                for (int i = 0; i < n && fits; i++)
-                    fits = (double)(specs[i].region.query_length + 1) * pk16_match_max <= 16000.0 &&
-                           (!family_has_splice(family) || (long long)specs[i].region.target_length + 4 <= (long long)pk16_max_intron);
-                if (fits && pk_env != 3) {
-                    // variant 1 reads the four splice values of a column as one packed 8-byte entry: built once per batch
-                    // (finished before the lock is released: the other lane launches on another stream)
-                    std::lock_guard<std::mutex> hold(seqs.ss16_lock);
-                    if (!seqs.ss16_built) {
-                        if (seqs.ss16.alloc((size_t)seqs.ss_len)) return -1;
-                        HIP_OK(pk16_build_splice(family, kparams.p, seqs.dev.ss, seqs.dev.ss_stride, seqs.ss_len, seqs.ss16.p, ctx->stream));
-                        HIP_OK(hipStreamSynchronize(ctx->stream));
-                        seqs.ss16_built = true;
-                    }
-                }
+                for (int i = 0; i < n && fits; i++) fits = pk16_fits(specs[i].region.query_length, specs[i].region.target_length);
+                // variant 1 reads the four splice values of a column as one packed 8-byte entry
+                if (fits && pk_env != 3 && ensure_ss16(seqs)) return -1;
                 if (fits) ki = kpk;
             }
         } else if (mw_env && !cont && (mode == MODE_SCORE || mode == MODE_REGION)) {
@@ -1290,35 +1344,66 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
     if (!kc) kc = get_kernel(eng.family, MODE_CKPT, true, false, false, wpe_env, false, 0);
     if (!kp) kp = get_kernel(eng.family, MODE_PATH, true, false, false, wpe_env, false, 0);
     if (!kc || !kp) return 0;
-    if (getenv("C4GPU_TRACE")) fprintf(stderr, "c4gpu trace:   fused: kernels %s, %s\n", kc->name, kp->name);
+    // the packed 16-bit checkpoint kernel (c4_ckpt16_kernel.h: two jobs per lane) for every job whose scores, checkpoint
+    // payloads and intron lengths fit its halves; C4GPU_CK16=0: never, 2..: the other shapes kept for measurement (read on
+    // every call: a test switches it)
+    const int ck_env = getenv("C4GPU_CK16") ? atoi(getenv("C4GPU_CK16")) : 1;
+    const KernelInfo *kc16 = (ck_env > 0 && cont_free && eng.pk16_params_ok) ? get_kernel_ck16(eng.family, ck_env - 1) : nullptr;
+    const int ck16_tmax = getenv("C4GPU_CK16_TMAX") ? atoi(getenv("C4GPU_CK16_TMAX")) : 0x7fffffff;      // test hook
     hipStream_t s = ctx->stream;
     const c4h::MemRule rule{m->max_query_advance, m->max_target_advance, m->n_states, m->total_shadow_designations};
-    // -- the checkpoint jobs, longest first (persistent waves pull from the queue head)
-    std::vector<int> order(n);
+    // -- the checkpoint jobs: the packed kernel's first, each group longest first (persistent waves pull from the queue head)
+    std::vector<int> order(n), cpn(n);
+    std::vector<char> fits16(n, 0);
     std::iota(order.begin(), order.end(), 0);
     auto cells = [&](int x) { const c4gpu_region &r = plan[red[x]].ar; return (long long)(r.query_length + 1) * (r.target_length + 1); };
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cells(a) > cells(b); });
+    int n16 = 0;
+    for (int x = 0; x < n; x++) {
+        const c4gpu_region &r = plan[red[x]].ar;
+        cpn[x] = c4h::checkpoint_rows(m, &r, dpmemory_mb);
+        if (!kc16) continue;
+        // payload ((row x states) + state) x max_target_advance + k in 16 bits; checkpoint columns max_target_advance apart at least
+        const bool ok = eng.pk16_fits(r.query_length, r.target_length) && r.target_length <= ck16_tmax &&
+                        ((long long)r.query_length + 2) * kc16->n_states * kc16->max_at <= 65535 && cpn[x] >= 1 &&
+                        r.target_length / (cpn[x] + 1) >= kc16->max_at;
+        fits16[x] = ok ? 1 : 0;
+        n16 += ok ? 1 : 0;
+    }
+    if (n16 < 2) { n16 = 0; std::fill(fits16.begin(), fits16.end(), 0); kc16 = nullptr; }
+    if (kc16 && eng.ensure_ss16(seqs)) return -1;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        return fits16[a] != fits16[b] ? fits16[a] > fits16[b] : cells(a) > cells(b);
+    });
+    if (getenv("C4GPU_TRACE"))
+        fprintf(stderr, "c4gpu trace:   fused: kernels %s, %s\nc4gpu trace:   fused: packed checkpoint kernel %s for %d of %d jobs\n", kc->name, kp->name,
+                kc16 ? kc16->name : "-", n16, n);
     std::vector<DevJob> &jobs = eng.hf_jobs;
     jobs.resize(n);
-    long long vsa_total = 0, max_ckpt = 0, max_T = 0, ckpt_cells = 0;
-    bool carry = false;
+    long long vsa_total = 0, max_ckpt = 0, max_T = 0, ckpt_cells = 0, max_ckpt16 = 0, max_T16 = 0;
+    bool carry = false, carry16 = false;
     for (int x = 0; x < n; x++) {
         const c4gpu_region &r = plan[red[order[x]]].ar;
         DevJob &j = jobs[x];
         memset(&j, 0, sizeof j);
         j.pair = red[order[x]]; j.q0 = r.query_start; j.t0 = r.target_start; j.Q = r.query_length; j.T = r.target_length;
         j.first_state = m->start_state; j.final_state = m->end_state;
-        j.cp_count = c4h::checkpoint_rows(m, &r, dpmemory_mb);
+        j.cp_count = cpn[order[x]];
         int tb = 0;
         while ((1LL << tb) <= j.T) tb++;
         j.tshift = tb;
         j.ckpt_off = -1; j.seed_off = -1;
         j.vsa_off = (int)vsa_total;
         vsa_total += j.cp_count + 1;
-        max_ckpt = std::max(max_ckpt, (long long)j.cp_count * kc->max_at * (j.Q + 1) * kc->n_states * kc->cs);
-        max_T = std::max<long long>(max_T, j.T);
         ckpt_cells += (long long)(j.Q + 1) * (j.T + 1);
-        if ((j.Q + 1 + 64 * kc->R - 1) / (64 * kc->R) > kc->waves) carry = true;
+        if (x < n16) {
+            max_ckpt16 = std::max(max_ckpt16, (long long)j.cp_count * kc16->max_at * (j.Q + 1) * kc16->ckw);
+            max_T16 = std::max<long long>(max_T16, j.T);
+            if ((j.Q + 1 + 64 * kc16->R - 1) / (64 * kc16->R) > 1) carry16 = true;
+        } else {
+            max_ckpt = std::max(max_ckpt, (long long)j.cp_count * kc->max_at * (j.Q + 1) * kc->n_states * kc->cs);
+            max_T = std::max<long long>(max_T, j.T);
+            if ((j.Q + 1 + 64 * kc->R - 1) / (64 * kc->R) > kc->waves) carry = true;
+        }
     }
     if (vsa_total > 0x7fffffffLL) return 0;
     auto grid_for = [&](const KernelInfo *ki, long long jobs_n, long long bytes_per_wave) -> long long {
@@ -1333,23 +1418,39 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
     int zero = 0;
     unsigned long long zero64 = 0;
     {
+        // two launches on the lane's stream, one after the other: they share the carry rows and the checkpoint slabs
+        const int zeros[2] = {0, 0};
+        const int n32 = n - n16;
         const long long bnd_per_wave = (2 * ((carry ? max_T : 0) + 1) + 1) * (long long)std::max(kc->bnd, 1);
-        const long long grid = grid_for(kc, n, bnd_per_wave * 4 + max_ckpt * 4);
-        if (eng.d_fjobs.upload(jobs.data(), n, s) || eng.d_fres.alloc(n) || eng.d_queue.upload(&zero, 1, s) ||
-            eng.d_bnd.alloc(bnd_per_wave * grid) || eng.d_fvsa.alloc(vsa_total) || eng.d_ckpt.alloc(max_ckpt * grid) ||
-            eng.d_ckpt_dump.alloc(1))
+        const long long grid = n32 ? grid_for(kc, n32, bnd_per_wave * 4 + max_ckpt * 4) : 0;
+        const long long bnd16_per_wave = kc16 ? (2 * ((carry16 ? max_T16 : 0) + 1) + 1) * (long long)std::max(kc16->bnd, 1) : 0;
+        const long long grid16 = kc16 ? grid_for(kc16, (n16 + 1) / 2, bnd16_per_wave * 4 + 2 * max_ckpt16 * 4) : 0;
+        if (eng.d_fjobs.upload(jobs.data(), n, s) || eng.d_fres.alloc(n) || eng.d_queue.upload(zeros, 2, s) ||
+            eng.d_bnd.alloc(std::max(bnd_per_wave * grid, bnd16_per_wave * grid16)) || eng.d_fvsa.alloc(vsa_total) ||
+            eng.d_ckpt.alloc(std::max(max_ckpt * grid, 2 * max_ckpt16 * grid16)) || eng.d_ckpt_dump.alloc(1))
             return -1;
         LaunchArgs a;
         memset(&a.scratch, 0, sizeof a.scratch);
-        a.kp = eng.kparams.p; a.seqs = seqs.dev; a.jobs = eng.d_fjobs.p; a.n_jobs = n; a.results = eng.d_fres.p;
+        a.kp = eng.kparams.p; a.seqs = seqs.dev;
         a.seqs.sub_colptr = nullptr; a.seqs.sub_rows = nullptr; a.seqs.span_in = nullptr; a.seqs.span_out = nullptr;
         a.seqs.seed = nullptr;
-        a.vsas = eng.d_fvsa.p; a.ops = nullptr; a.queue = eng.d_queue.p; a.grid = (int)grid; a.stream = s;
-        a.scratch.bnd = eng.d_bnd.p; a.scratch.bnd_stride = bnd_per_wave; a.scratch.carry = carry ? 1 : 0;
-        a.scratch.ckpt = max_ckpt ? eng.d_ckpt.p : nullptr; a.scratch.ckpt_stride = max_ckpt;
+        a.seqs.ss16 = seqs.ss16_built ? seqs.ss16.p : nullptr;
+        a.vsas = eng.d_fvsa.p; a.ops = nullptr; a.stream = s;
+        a.scratch.bnd = eng.d_bnd.p;
         a.scratch.ckpt_dump = eng.d_ckpt_dump.p;
         if (ctx->timing) HIP_OK(hipEventRecord(ctx->ev0, s));
-        HIP_OK(kc->launch(a));
+        if (kc16) {
+            a.jobs = eng.d_fjobs.p; a.n_jobs = n16; a.results = eng.d_fres.p; a.queue = eng.d_queue.p; a.grid = (int)grid16;
+            a.scratch.bnd_stride = bnd16_per_wave; a.scratch.carry = carry16 ? 1 : 0;
+            a.scratch.ckpt = eng.d_ckpt.p; a.scratch.ckpt_stride = max_ckpt16;
+            HIP_OK(kc16->launch(a));
+        }
+        if (n32) {
+            a.jobs = eng.d_fjobs.p + n16; a.n_jobs = n32; a.results = eng.d_fres.p + n16; a.queue = eng.d_queue.p + 1; a.grid = (int)grid;
+            a.scratch.bnd_stride = bnd_per_wave; a.scratch.carry = carry ? 1 : 0;
+            a.scratch.ckpt = max_ckpt ? eng.d_ckpt.p : nullptr; a.scratch.ckpt_stride = max_ckpt;
+            HIP_OK(kc->launch(a));
+        }
         if (ctx->timing) HIP_OK(hipEventRecord(ctx->ev1, s));
     }
     std::vector<DevResult> &res = eng.hf_res;
@@ -1423,7 +1524,7 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
         return -1;
     hipLaunchKernelGGL(fuse_stitch_kernel, dim3((n + 63) / 64), dim3(64), 0, s, eng.d_fjobs.p, eng.d_fvsa.p, eng.d_ffirst.p, n,
                        eng.d_fsub_res.p, eng.d_runs_out.p, 1 + m->total_shadow_designations, eng.d_fflags.p, eng.d_runs_used.p,
-                       eng.d_fout.p, eng.d_fpairs.p);
+                       eng.d_fout.p, eng.d_fpairs.p, n16);
     HIP_OK(hipGetLastError());
     std::vector<FusePair> &fps = eng.hf_pairs;
     fps.resize(n);
@@ -1464,6 +1565,7 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
             JobOut o;
             o.res = res[x];
             o.runs.n = 0;
+            o.packed = x < n16;
             if (!(res[x].flags & FLAG_NO_END)) o.vsa.assign(vsa.begin() + jobs[x].vsa_off, vsa.begin() + jobs[x].vsa_off + res[x].n_vsa);
             unfinished[red[order[x]]] = std::move(o);
         }
@@ -1765,7 +1867,8 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
         lap("device route done");
     }
     std::vector<c4gpu_score> red_score(n, 0);
-    std::vector<char> redo(n, 0);
+    std::vector<char> redo(n, 0), packed_pair(n, 0);        // packed_pair: predicted cells from the packed checkpoint pass
+    for (const auto &kv : ckpt_done) packed_pair[kv.first] = kv.second.packed ? 1 : 0;
     bool first_round = true;
     for (;;) {
         struct Ref { int pair, seg; };
@@ -1821,7 +1924,8 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
             // optimal.c:214-217 passes vsa->final_cell as the buffer the recursive pass overwrites; siblings
             // scheduled in the same round used the old value: it must not have changed
             if (!first_round && !children.empty() &&
-                memcmp(children.back().final_cell, sg[k].final_cell, sizeof(int) * (1 + m->total_shadow_designations)) != 0) {
+                !final_cell_equiv(children.back().final_cell, sg[k].final_cell, 1 + m->total_shadow_designations,
+                                  sg[k].region.target_start + sg[k].region.target_length, packed_pair[refs[x].pair] != 0)) {
                 if (getenv("C4GPU_TRACE"))
                     fprintf(stderr, "c4gpu trace: pair %d nested segment %d: final cell %d/%d after the nested pass, %d/%d predicted\n",
                             refs[x].pair, k, children.back().final_cell[0], children.back().final_cell[1], sg[k].final_cell[0], sg[k].final_cell[1]);
@@ -1886,7 +1990,8 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
             }
             if (redo[i] || repairing[i] >= 0) continue;     // redone below from the first stale sub-alignment
             for (uint32_t r : outs[x].runs) c4h::alignment_add(&a, &cap[i], (int)(r >> 24), (int)(r & 0xffffff));
-            if (memcmp(outs[x].res.final_cell, sg[k].final_cell, sizeof(int) * path_cs) != 0) {
+            if (!final_cell_equiv(outs[x].res.final_cell, sg[k].final_cell, path_cs,
+                                  sg[k].region.target_start + sg[k].region.target_length, packed_pair[i] != 0)) {
                 if (getenv("C4GPU_TRACE"))
                     fprintf(stderr, "c4gpu trace: pair %d sub-alignment %d: final cell %d/%d computed, %d/%d predicted\n", i,
                             k, outs[x].res.final_cell[0], outs[x].res.final_cell[1], sg[k].final_cell[0], sg[k].final_cell[1]);

@@ -45,6 +45,7 @@ struct KernelInfo {
     int n_states, max_at;
     int waves;                // waves per job (workgroup = 64 * waves threads)
     int seedw;                // ints per row of a dumped column (SEED kernels)
+    int ckw;                  // the packed checkpoint pass: ints per row of a checkpoint column in a job's slab
 };
 
 // family x mode x continuation x local-scope specialisation; NULL launch = not compiled
@@ -61,6 +62,9 @@ const KernelInfo *get_kernel_mw(int family, int mode, bool local, bool pack, int
 // the packed 16-bit score pass with column dumps (c4_viterbi16_kernel.h): two jobs per lane; NULL = not compiled for the family.
 // Launched over the same job / result arrays as the 32-bit kernel (workgroup p runs jobs 2p and 2p + 1).
 const KernelInfo *get_kernel_pk16(int family, int variant = 0);
+// the packed 16-bit checkpoint pass (c4_ckpt16_kernel.h): two jobs per lane, one wave per pair of jobs; scratch.ckpt holds two
+// slabs of ckpt_stride ints per wave; variant: rows per lane / register cap shapes kept for measurement (0 = the default)
+const KernelInfo *get_kernel_ck16(int family, int variant = 0);
 hipError_t pk16_build_splice(int family, const KParams *kp, const int *ss, long long ss_stride, long long n, void *out, hipStream_t s);
 
 #define C4K_DEFINE_KERNEL_SPAN(SYMBOL, M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV, SPANV)                                          \

@@ -430,6 +430,58 @@ def test_device_route_of_the_sub_alignments_gives_the_host_route_results(eng, mo
     assert res["1"][k] == oracle_lib.find_path(model.c, model.params, enc(q), enc(t), dpmemory=dpm, threshold=30)
 
 
+@pytest.mark.parametrize("dpm", [32, 1, 0])
+def test_packed_16_bit_checkpoint_pass_agrees_with_the_32_bit_pass(eng, monkeypatch, capfd, dpm):
+    """The checkpoint pass of the device route (Viterbi_Checkpoint_process viterbi.c:605-631, traceback :537-601) runs two jobs
+    per lane in packed 16-bit halves (c4_ckpt16_kernel.h) wherever score, checkpoint payload and intron length fit;
+    C4GPU_CK16=0 keeps the 32-bit kernel.  Same alignments either way on a ragged batch with an odd number of jobs (the two
+    jobs of a lane differ in rows, columns and checkpoint columns; queries of one to seven strips), with an intron longer than
+    the 15-bit length counter (45 000 columns: its saturated shadow is "equivalent", final_cell_equiv) and with every
+    shape of the packed kernel; pairs also against the oracle.  C4GPU_CK16_TMAX keeps some jobs of the launch on the 32-bit
+    kernel: both kernels then serve one call."""
+    rng = random.Random(4100 + dpm)
+    model = ex.Model("est2genome")
+    pairs = []
+    sizes = [(900, 30000), (400, 52000), (1000, 9000), (640, 30000), (130, 20000), (777, 41000), (1300, 7000), (190, 2500),
+             (64, 3000), (1000, 100000)]
+    if dpm == 0:
+        sizes = [(300, 5000), (77, 900), (640, 2000), (1000, 1300), (1000, 12000), (150, 600), (450, 3000)]
+    for ql, tl in sizes:
+        pairs += _seeded_pairs(rng, "est2genome", ql, tl, 1)
+    q = _rand(rng, 800)
+    pairs.append((q, _rand(rng, 3000) + _mutate(rng, q[:400], 0.03) + "GT" + _rand(rng, 45000) + "AG" + _mutate(rng, q[400:], 0.03) + _rand(rng, 2000)))
+    pairs.append((_rand(rng, 500), _rand(rng, 25000)))                          # unrelated: below the threshold
+    monkeypatch.setenv("C4GPU_TRACE", "1")
+    res, fin = {}, {}
+    for ck, tmax in (("1", None), ("2", None), ("3", None), ("4", None), ("5", None), ("1", "20000"), ("0", None)):
+        monkeypatch.setenv("C4GPU_CK16", ck)
+        if tmax: monkeypatch.setenv("C4GPU_CK16_TMAX", tmax)
+        else: monkeypatch.delenv("C4GPU_CK16_TMAX", raising=False)
+        res[ck + (tmax or "")] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=dpm, threshold=30)]
+        err = capfd.readouterr().err
+        fused = [ln for ln in err.splitlines() if "fused: packed checkpoint kernel" in ln]
+        assert fused, err[-2000:]
+        words = fused[0].split("packed checkpoint kernel")[1].split()          # "<kernel> for <n16> of <n> jobs"
+        n16, n32 = int(words[2]), int(words[4]) - int(words[2])
+        if ck == "0":
+            assert words[0] == "-" and n16 == 0
+        else:
+            assert words[0].startswith("kck16_est2genome") and n16 >= 2, fused[0]
+            assert (n32 > 0) == (tmax is not None), fused[0]
+        finished = [ln for ln in err.splitlines() if "pairs finished on the device route" in ln][0].split("fused:")[1].split()
+        fin[ck + (tmax or "")] = (finished[0], finished[2])                 # "N of M pairs finished ..."
+    for k, v in res.items():
+        assert v == res["0"], k
+        assert fin[k] == fin["0"], (k, fin)            # the packed pass sends no pair to the host route that the 32-bit pass keeps
+    long_pair = len(pairs) - 2
+    ops = [model.c.transitions[t].label for t, n in res["1"][long_pair]["ops"] if n >= 45000]
+    assert ops == [6], "the long intron is not in the alignment"              # C4_Label_INTRON
+    for k in (2, 6, 7):
+        if k < len(pairs) and res["1"][k] is not None and len(pairs[k][1]) <= 12000:
+            q, t = pairs[k]
+            assert res["1"][k] == oracle_lib.find_path(model.c, model.params, q.encode(), t.encode(), dpmemory=dpm, threshold=30)
+
+
 @pytest.mark.parametrize("model_type", ["est2genome", "affine:local", "protein2genome"])
 def test_two_launch_lanes_give_the_one_lane_results(eng, monkeypatch, model_type):
     """A large batch is cut into two halves of equal work that walk through the passes of Optimal_find_path on two streams
