@@ -37,27 +37,38 @@
 
 namespace c4k {
 
-__device__ __forceinline__ int bfi32(int mask, int a, int b) {       // (mask & a) | (~mask & b): one v_bfi_b32
-    return (mask & a) | (~mask & b);
+// (mask & a) | (~mask & b) as ONE instruction (v_bitop3_b32 with the bit-select truth table): written with & | ~ the compiler
+// merges the masks of a chain of selects and shares them between the payloads of a state, which comes to three logic
+// instructions per select instead of one (117 against 64 per step of the packed region windows at four rows per lane)
+__device__ __forceinline__ int bfi32(int mask, int a, int b) {
+    return __builtin_amdgcn_bitop3_b32(mask, a, b, 0xCA);
 }
 
-template <class M, int R>
+// ROOT: the state the path's END is entered from where the caller knows it (the region pass reports it), -1 otherwise.  The
+// pass then computes the states that can reach ROOT and no others (Roots, c4_viterbi16_kernel.h): the checkpoint pass runs
+// from the region's start to its end cell, the optimal path there is the one the region pass found, its END is entered
+// from ROOT (a corner-to-corner path of another component is also a local path ending in that cell, so it scores no more
+// than that component's state did in the region pass, which lost against — or, behind it in transition order, did not beat —
+// ROOT's), and every cell, payload and checkpoint the traceback follows lies in ROOT's component.
+template <class M, int R, int ROOT = -1>
 struct WaveCK16 {
     using F = Facts<M>;
+    using RT = Roots<M>;
     using W32 = WaveDP<M, R, MODE_CKPT, true, true>;
     static constexpr int NS = M::NS, NCOL = M::MAXAT + 1, W = 64 * R, MAXAT = M::MAXAT;
     static constexpr int CS = W32::CS;                    // the reference's cell: score, designations, checkpoint slot
     static constexpr bool live(int s) { return M::NDES > 0 && W32::slot_live(s, 0); }
-    static constexpr bool inner(int s) { return s != M::START && s != M::END; }
+    static constexpr bool inner(int s) { return RT::member(ROOT, s); }       // the states this pass computes
+    static constexpr bool exported(int s) { return inner(s) && F::exported(s); }
     static constexpr int n_live() { int n = 0; for (int s = 0; s < NS; s++) n += (inner(s) && live(s)); return n; }
     static constexpr int n_inner() { int n = 0; for (int s = 0; s < NS; s++) n += inner(s); return n; }
     // a checkpoint row in the job's slab: one word (score | payload << 16) per inner state, then the live lengths two per word
     static constexpr int word_of(int s) { int n = 0; for (int x = 0; x < s; x++) n += inner(x); return n; }
     static constexpr int live_index(int s) { int n = 0; for (int x = 0; x < s; x++) n += (inner(x) && live(x)); return n; }
     static constexpr int CKW = n_inner() + (n_live() + 1) / 2;
-    static constexpr int NEXP = F::n_exported();
-    static constexpr int n_exp_live() { int n = 0; for (int s = 0; s < NS; s++) n += (F::exported(s) && live(s)); return n; }
-    static constexpr int BND = NEXP * 2 + n_exp_live();   // ints per column between strips
+    static constexpr int n_exp() { int n = 0; for (int s = 0; s < NS; s++) n += exported(s); return n; }
+    static constexpr int n_exp_live() { int n = 0; for (int s = 0; s < NS; s++) n += (exported(s) && live(s)); return n; }
+    static constexpr int BND = n_exp() * 2 + n_exp_live();   // ints per column between strips
     static_assert(!F::has_phase(), "split-codon calcs are not packed");
     static_assert(M::NDES <= 1, "one shadow designation");
     static_assert(M::START == 0 && M::END == 1, "state numbering of the closed model");
@@ -85,7 +96,7 @@ struct WaveCK16 {
     __device__ __forceinline__ static void for_exported(Fn &&fn) {
         int slot = 0;
         static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
-            if constexpr (F::exported(S)) { fn(S_, slot); slot += 2 + (live(S) ? 1 : 0); }
+            if constexpr (exported(S)) { fn(S_, slot); slot += 2 + (live(S) ? 1 : 0); }
         });
     }
     __device__ __forceinline__ static void write_empty_column(int *colp) {
@@ -125,7 +136,8 @@ struct WaveCK16 {
         C16 &c = col[PH][RR];
         static_for<M::NT>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
             constexpr TrDesc t = M::tr[K];
-            if constexpr (t.out == M::END) return;                            // once per job, in the corner cell (step)
+            if constexpr (!inner(t.out)) return;                              // END: once per job, in the corner cell (step); or a state
+                                                                              // that cannot reach the root
             if constexpr (t.in == M::START && (RR > 0 || JINT)) return;       // cannot be the origin cell
             static_assert(!(t.in == M::START && F::code(K) == 1), "a state's first transition is never the one out of START");
             constexpr int PD = (PH - t.at + NCOL) % NCOL;
@@ -219,7 +231,7 @@ struct WaveCK16 {
                             int e_sc = 0, e_srp = 0;
                             static_for<M::NT>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
                                 constexpr TrDesc t = M::tr[K];
-                                if constexpr (t.out == M::END) {
+                                if constexpr (t.out == M::END && inner(t.in)) {
                                     static_assert(t.out != M::END || (t.aq == 0 && t.at == 0 && t.calc < 0 && t.in != M::START),
                                                   "END is entered silently from an inner state");
                                     const int v = pk_half(col[PH][RR].sc[t.in], H);
@@ -279,7 +291,7 @@ struct WaveCK16 {
                         const int rowid = (i0v + RR) * (NS * MAXAT);
                         static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
                             if constexpr (inner(S)) {
-                                const int id = (rowid + S * MAXAT + ROW) & 0xffff;              // viterbi.c:515-522
+                                const int id = (rowid + S * MAXAT + ROW) & 0xffff;              // viterbi.c:515-522 (the full model's state count)
                                 col[PR][RR].srp[S] = bfi32((int)stamp, id | (id << 16), col[PR][RR].srp[S]);
                             }
                         });
@@ -287,7 +299,7 @@ struct WaveCK16 {
                     // our copies of row i0-1 at these columns get the same edit
                     const int rowid = (i0v - 1) * (NS * MAXAT);
                     static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
-                        if constexpr (inner(S) && F::exported(S)) {
+                        if constexpr (exported(S)) {
                             const int id = (rowid + S * MAXAT + ROW) & 0xffff;
                             nbr[PR].srp[S] = bfi32((int)stamp, id | (id << 16), nbr[PR].srp[S]);
                         }
@@ -437,13 +449,53 @@ struct WaveCK16 {
     }
 };
 
-// persistent waves; workgroup p of the queue runs jobs 2p and 2p + 1 (the last one alone when the launch holds an odd
-// number: its high half repeats it).  scratch.ckpt holds two job slabs per wave (ckpt_stride ints each).
-template <class M, int R, int WPE>
+// One pair of jobs (both with root ROOT; jb = ja where the pair holds one job) on one wave
+template <class M, int R, int ROOT>
+__device__ __forceinline__ void ckpt16_pair(const KParams *kp_lds, const DevSeqs &seqs, const DevJob *jobs, int ia, int ib,
+                                            DevResult *results, DevVsa *vsas, int *bnd, int *ck_a, int *ck_b) {
+    using DP = WaveCK16<M, R, ROOT>;
+    if (threadIdx.x == 0) DP::write_empty_column(bnd);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    DP dp;
+    dp.kp = kp_lds;
+    dp.lane = threadIdx.x;
+    dp.run(jobs[ia], jobs[ib], seqs, bnd, ck_a, ck_b);
+    // the lane that owned a job's corner cell hands it to the lane that walks the job's checkpoints
+    int sc[2], srp[2];
+    bool set[2];
+    for (int h = 0; h < 2; h++) {
+        const unsigned long long owners = __ballot(dp.corner_set[h]);
+        const int owner = owners ? __ffsll((long long)owners) - 1 : 0;
+        sc[h] = __shfl(dp.corner_sc[h], owner); srp[h] = __shfl(dp.corner_srp[h], owner);
+        set[h] = owners != 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __syncthreads();
+    if (threadIdx.x < 2 && (threadIdx.x == 0 || ib != ia)) {
+        const int h = threadIdx.x;
+        const DevJob &job = jobs[h ? ib : ia];
+        DevResult res;
+        res.flags = set[h] ? 0 : FLAG_NO_END; res.n_ops = 0; res.n_vsa = 0; res.pad = 0; res.qs = res.ts = 0;
+        res.cell_size = DP::CS; res.ops_off = 0;
+        for (int l = 0; l < CELL_MAX; l++) res.final_cell[l] = 0;
+        res.final_cell[0] = sc[h]; res.final_cell[DP::CS - 1] = srp[h];
+        res.score = sc[h]; res.end_set = set[h]; res.qe = job.Q; res.te = job.T; res.last_srp = srp[h];
+        if (set[h]) DP::checkpoint_traceback(h ? ck_b : ck_a, job, vsas + job.vsa_off, res);
+        results[h ? ib : ia] = res;
+    }
+    __syncthreads();
+}
+
+// persistent waves; workgroup p of the queue runs the p-th pair of the host's list (LaunchArgs::aux: two job indices, the second
+// -1 where a job runs alone: its high half repeats it).  scratch.ckpt holds two job slabs per wave (ckpt_stride ints each).
+// ROOTED: the jobs name their root (DevJob::root) and both jobs of a pair have the same one; else every inner state is computed.
+template <class M, int R, int WPE, bool ROOTED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
-void ckpt16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, int n_jobs, DevResult *results, DevVsa *vsas,
-                   DevScratch scratch, int *queue) {
-    using DP = WaveCK16<M, R>;
+void ckpt16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, const int *pairs, int n_pairs, DevResult *results,
+                   DevVsa *vsas, DevScratch scratch, int *queue) {
+    using RT = Roots<M>;
+    static_assert(!ROOTED || RT::disjoint(), "a rooted pass needs components to choose from");
     __shared__ KParams kp_lds;
     __shared__ int next_job;
     {
@@ -453,46 +505,34 @@ void ckpt16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, int
     }
     __syncthreads();
     int *bnd = scratch.bnd + (long long)blockIdx.x * scratch.bnd_stride;
-    if (threadIdx.x == 0) DP::write_empty_column(bnd);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
     int *ck_a = scratch.ckpt + (long long)blockIdx.x * 2 * scratch.ckpt_stride, *ck_b = ck_a + scratch.ckpt_stride;
-    const int n_pairs = (n_jobs + 1) / 2;
     for (;;) {
         if (threadIdx.x == 0) next_job = atomicAdd(queue, 1);
         __syncthreads();
         const int pid = next_job;
         __syncthreads();
         if (pid >= n_pairs) break;
-        const int ia = 2 * pid, ib = (2 * pid + 1 < n_jobs) ? 2 * pid + 1 : 2 * pid;
-        DP dp;
-        dp.kp = &kp_lds;
-        dp.lane = threadIdx.x;
-        dp.run(jobs[ia], jobs[ib], seqs, bnd, ck_a, ck_b);
-        // the lane that owned a job's corner cell hands it to the lane that walks the job's checkpoints
-        int sc[2], srp[2];
-        bool set[2];
-        for (int h = 0; h < 2; h++) {
-            const unsigned long long owners = __ballot(dp.corner_set[h]);
-            const int owner = owners ? __ffsll((long long)owners) - 1 : 0;
-            sc[h] = __shfl(dp.corner_sc[h], owner); srp[h] = __shfl(dp.corner_srp[h], owner);
-            set[h] = owners != 0;
+        const int ia = pairs[2 * pid], ib = pairs[2 * pid + 1] >= 0 ? pairs[2 * pid + 1] : ia;
+        if constexpr (ROOTED) {
+            const int root = jobs[ia].root;
+            bool ran = false;
+            static_for<RT::count()>([&](auto X_) __attribute__((always_inline)) { constexpr int X = X_;
+                constexpr int ROOT = RT::root(X);
+                if (!ran && root == ROOT) {
+                    ckpt16_pair<M, R, ROOT>(&kp_lds, seqs, jobs, ia, ib, results, vsas, bnd, ck_a, ck_b);
+                    ran = true;
+                }
+            });
+            if (!ran && threadIdx.x < 2 && (threadIdx.x == 0 || ib != ia)) {      // a root the model does not have
+                DevResult res;
+                res.flags = FLAG_NO_END; res.n_ops = 0; res.n_vsa = 0; res.pad = 0; res.qs = res.ts = res.qe = res.te = 0;
+                res.cell_size = 0; res.ops_off = 0; res.score = LOW; res.end_set = 0; res.last_srp = 0;
+                for (int l = 0; l < CELL_MAX; l++) res.final_cell[l] = 0;
+                results[threadIdx.x ? ib : ia] = res;
+            }
+        } else {
+            ckpt16_pair<M, R, -1>(&kp_lds, seqs, jobs, ia, ib, results, vsas, bnd, ck_a, ck_b);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __syncthreads();
-        if (threadIdx.x < 2 && (threadIdx.x == 0 || ib != ia)) {
-            const int h = threadIdx.x;
-            const DevJob &job = jobs[h ? ib : ia];
-            DevResult res;
-            res.flags = set[h] ? 0 : FLAG_NO_END; res.n_ops = 0; res.n_vsa = 0; res.pad = 0; res.qs = res.ts = 0;
-            res.cell_size = DP::CS; res.ops_off = 0;
-            for (int l = 0; l < CELL_MAX; l++) res.final_cell[l] = 0;
-            res.final_cell[0] = sc[h]; res.final_cell[DP::CS - 1] = srp[h];
-            res.score = sc[h]; res.end_set = set[h]; res.qe = job.Q; res.te = job.T; res.last_srp = srp[h];
-            if (set[h]) DP::checkpoint_traceback(h ? ck_b : ck_a, job, vsas + job.vsa_off, res);
-            results[h ? ib : ia] = res;
-        }
-        __syncthreads();
     }
 }
 

@@ -672,6 +672,8 @@ struct JobSpec {                  // host description of one Viterbi call
     int pair;
     c4gpu_region region;
     int first_state = 0, final_state = 1, cp_count = 0;
+    int root = 0;                        // the state the path's END is entered from, for the kernels that only compute that state's
+                                         // component (Roots, c4_viterbi16_kernel.h); 0: not known
     int first_cell[CELL_MAX] = {0};
     bool dump_checkpoints = false;
     const c4gpu_subopt *sub = nullptr;   // sub-optimal blocking for this call (else the engine's per-pair table)
@@ -707,6 +709,9 @@ struct JobOut {
 struct SeedPlan {
     int mode = 0;                  // 1: the score pass writes dumps; 2: the region windows start from them
     int kshift = 11;               // a dump every 1 << kshift columns
+    bool fmt16 = false;            // the dumps are the packed score pass's 16-bit rows (Dump16), read by the packed windows
+                                   // (c4_win16_kernel.h): set by the mode 1 run, handed on to the mode 2 run
+    int seedw = 0, dc = 0;         // ints per dumped row, dumped columns per dump: of the kernel the mode 1 run took
     std::vector<long long> off;    // per spec: mode 1 (out) start of the job's dumps; mode 2 (in) the dump to start from, -1 = none
     std::vector<int> rows;         // per spec, mode 2: rows of a dumped column (Q + 1 of the score pass)
     // mode 2, windows chained on the device (DevJob::seed_base ..): per spec the pair's first dump, the dump the first
@@ -755,7 +760,7 @@ struct Engine {
     DevBuf<uint8_t> d_ops;
     DevBuf<int> d_bnd, d_ckpt, d_ckpt_dump, d_queue;
     DevBuf<uint32_t> d_tb;
-    DevBuf<int> d_sub_t, d_sub_q, d_sub_colptr, d_span, d_seed;
+    DevBuf<int> d_sub_t, d_sub_q, d_sub_colptr, d_span, d_seed, d_pairs;
     // fused_reduced_paths: checkpoint jobs, their results and sub-alignment lists, the sub-alignment jobs built from them
     DevBuf<DevJob> d_fjobs, d_fsub_jobs;
     DevBuf<DevResult> d_fres, d_fsub_res;
@@ -1001,6 +1006,21 @@ struct Engine {
                 // variant 1 reads the four splice values of a column as one packed 8-byte entry
                 if (fits && pk_env != 3 && ensure_ss16(seqs)) return -1;
                 if (fits) ki = kpk;
+                // ... and with the packed region windows behind it (c4_win16_kernel.h; C4GPU_WIN16=0: the 32-bit windows) it
+                // writes its dumps as 16-bit rows: window rows and columns must fit 15 / 16 bits
+                const int w16_env = getenv("C4GPU_WIN16") ? atoi(getenv("C4GPU_WIN16")) : 1;     // read on every call: a test switches it
+                const KernelInfo *kd = (fits && pk_env == 1 && w16_env) ? get_kernel_pk16(family, 3) : nullptr;
+                if (kd && get_kernel_win16(family, 0) && seed->kshift <= 15) {
+                    bool rows_ok = true;
+                    for (int i = 0; i < n && rows_ok; i++) rows_ok = specs[i].region.query_length < 32000;
+                    if (rows_ok) { ki = kd; seed->fmt16 = true; }
+                }
+            }
+            if (seed->mode == 1) { seed->seedw = ki->seedw; seed->dc = ki->max_at; }
+            if (seed->mode == 2 && seed->fmt16) {
+                const int w16_env = getenv("C4GPU_WIN16") ? atoi(getenv("C4GPU_WIN16")) : 1;     // 2..: the other shapes, for measurement
+                ki = get_kernel_win16(family, w16_env > 1 ? w16_env - 1 : 0);
+                if (!ki || !seqs.ss16_built) { c4h::set_error("no packed window kernel for this launch"); return -1; }
             }
         } else if (mw_env && !cont && (mode == MODE_SCORE || mode == MODE_REGION)) {
             const KernelInfo *kmw = get_kernel_mw(family, mode, use_local, pack, 4, pts != nullptr);
@@ -1027,7 +1047,11 @@ struct Engine {
             key.resize(n);
             long long biggest = 0;
             for (int i = 0; i < n; i++) { key[i] = cells(i); biggest = std::max(biggest, key[i]); }
-            if (!(n > 32768 && biggest < (1 << 20)))
+            if (ki->pairs)         // two jobs per lane, paired by the host: jobs of one root together, each group longest first
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+                    return specs[a].root != specs[b].root ? specs[a].root < specs[b].root : key[a] > key[b];
+                });
+            else if (!(n > 32768 && biggest < (1 << 20)))
                 std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] > key[b]; });
         }
         std::vector<DevJob> &jobs = h_jobs;
@@ -1047,6 +1071,7 @@ struct Engine {
                 j.pair = s.pair; j.q0 = s.region.query_start; j.t0 = s.region.target_start;
                 j.Q = s.region.query_length; j.T = s.region.target_length;
                 j.first_state = s.first_state; j.final_state = s.final_state; j.cp_count = s.cp_count;
+                j.root = s.root;
                 j.tshift = nbits(j.T);
                 memcpy(j.first_cell, s.first_cell, sizeof j.first_cell);
                 j.ckpt_off = -1;
@@ -1106,7 +1131,15 @@ struct Engine {
         int blocks_per_cu = 0;
         HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, ki->func, 64 * ki->waves, 0));
         if (blocks_per_cu < 1) blocks_per_cu = 1;
-        long long grid = std::min<long long>(n, (long long)blocks_per_cu * ctx->prop.multiProcessorCount);
+        // the kernels that run two jobs per lane in pairs the host lists: neighbours of the same root
+        std::vector<int> pair_list;
+        if (ki->pairs)
+            for (int x = 0; x < n;) {
+                const bool two = x + 1 < n && jobs[x + 1].root == jobs[x].root;
+                pair_list.push_back(x); pair_list.push_back(two ? x + 1 : -1);
+                x += two ? 2 : 1;
+            }
+        long long grid = std::min<long long>(ki->pairs ? (long long)pair_list.size() / 2 : n, (long long)blocks_per_cu * ctx->prop.multiProcessorCount);
         // strip carry rows in HBM are only needed when a job has more strips than one workgroup holds at once
         // (one for the single-wave kernels, `waves` for the cooperating ones)
         long long carry_T = 0;
@@ -1168,6 +1201,10 @@ struct Engine {
                 a.seqs.seed = d_seed.p;
             }
             a.vsas = d_vsa.p; a.ops = nullptr; a.queue = d_queue.p; a.grid = (int)grid; a.stream = s;
+            if (ki->pairs) {
+                if (d_pairs.upload(pair_list.data(), pair_list.size(), s)) return -1;
+                a.aux = d_pairs.p; a.n_aux = (int)(pair_list.size() / 2);
+            }
             a.scratch.bnd = d_bnd.p; a.scratch.bnd_stride = bnd_per_wave; a.scratch.carry = carry_T ? 1 : 0;
             a.scratch.tb = max_tb ? d_tb.p : nullptr; a.scratch.tb_stride = max_tb;
             a.scratch.ckpt = max_ckpt ? d_ckpt.p : nullptr; a.scratch.ckpt_stride = max_ckpt;
@@ -1245,6 +1282,7 @@ struct PairPlan {
     bool active = false, reduced = false;
     c4gpu_score region_score = 0;
     c4gpu_region ar;
+    int end_from = 0;            // the state END was entered from in the region pass's best end cell (0: that pass did not say)
     std::vector<Segment> segs;   // reduced-space: the flattened vsa_list
 };
 
@@ -1345,19 +1383,26 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
     if (!kp) kp = get_kernel(eng.family, MODE_PATH, true, false, false, wpe_env, false, 0);
     if (!kc || !kp) return 0;
     // the packed 16-bit checkpoint kernel (c4_ckpt16_kernel.h: two jobs per lane) for every job whose scores, checkpoint
-    // payloads and intron lengths fit its halves; C4GPU_CK16=0: never, 2..: the other shapes kept for measurement (read on
-    // every call: a test switches it)
+    // payloads and intron lengths fit its halves — in its rooted form (the component of the state the path's END is entered
+    // from: one strand of est2genome) where the region pass reported that state, else over every inner state;
+    // C4GPU_CK16=0: never, 2..: the other shapes kept for measurement, C4GPU_CK16_ROOT=0: never the rooted form (read on every
+    // call: a test switches them)
     const int ck_env = getenv("C4GPU_CK16") ? atoi(getenv("C4GPU_CK16")) : 1;
-    const KernelInfo *kc16 = (ck_env > 0 && cont_free && eng.pk16_params_ok) ? get_kernel_ck16(eng.family, ck_env - 1) : nullptr;
+    const bool ck_root_env = !(getenv("C4GPU_CK16_ROOT") && atoi(getenv("C4GPU_CK16_ROOT")) == 0);
+    const bool ck16_on = ck_env > 0 && cont_free && eng.pk16_params_ok;
+    const KernelInfo *kc16 = ck16_on ? get_kernel_ck16(eng.family, 0, false) : nullptr;
+    const KernelInfo *kc16r = (ck16_on && ck_root_env) ? get_kernel_ck16(eng.family, ck_env - 1, true) : nullptr;
     const int ck16_tmax = getenv("C4GPU_CK16_TMAX") ? atoi(getenv("C4GPU_CK16_TMAX")) : 0x7fffffff;      // test hook
     hipStream_t s = ctx->stream;
     const c4h::MemRule rule{m->max_query_advance, m->max_target_advance, m->n_states, m->total_shadow_designations};
-    // -- the checkpoint jobs: the packed kernel's first, each group longest first (persistent waves pull from the queue head)
+    // -- the checkpoint jobs: the rooted packed kernel's first (root by root), then the packed kernel's, then the 32-bit kernel's,
+    // each group longest first (persistent waves pull from the queue head)
     std::vector<int> order(n), cpn(n);
-    std::vector<char> fits16(n, 0);
+    std::vector<char> group(n, 0);                   // 2: packed, rooted; 1: packed; 0: 32-bit
     std::iota(order.begin(), order.end(), 0);
     auto cells = [&](int x) { const c4gpu_region &r = plan[red[x]].ar; return (long long)(r.query_length + 1) * (r.target_length + 1); };
-    int n16 = 0;
+    auto root_of = [&](int x) { return plan[red[x]].end_from; };
+    int count_g[3] = {0, 0, 0};
     for (int x = 0; x < n; x++) {
         const c4gpu_region &r = plan[red[x]].ar;
         cpn[x] = c4h::checkpoint_rows(m, &r, dpmemory_mb);
@@ -1366,21 +1411,30 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
         const bool ok = eng.pk16_fits(r.query_length, r.target_length) && r.target_length <= ck16_tmax &&
                         ((long long)r.query_length + 2) * kc16->n_states * kc16->max_at <= 65535 && cpn[x] >= 1 &&
                         r.target_length / (cpn[x] + 1) >= kc16->max_at;
-        fits16[x] = ok ? 1 : 0;
-        n16 += ok ? 1 : 0;
+        group[x] = !ok ? 0 : (kc16r && root_of(x) > 1) ? 2 : 1;
+        count_g[(int)group[x]]++;
     }
-    if (n16 < 2) { n16 = 0; std::fill(fits16.begin(), fits16.end(), 0); kc16 = nullptr; }
-    if (kc16 && eng.ensure_ss16(seqs)) return -1;
+    for (int g = 2; g >= 1; g--)
+        if (count_g[g] == 1) {                          // a lone packed job gains nothing: the group below takes it
+            for (int x = 0; x < n; x++) if (group[x] == g) group[x] = (char)(g - 1);
+            count_g[g - 1]++; count_g[g] = 0;
+        }
+    if (!count_g[1] && !count_g[2]) { kc16 = nullptr; kc16r = nullptr; }
+    const int n16r = count_g[2], n16a = count_g[1], n16 = n16r + n16a;
+    if (n16 && eng.ensure_ss16(seqs)) return -1;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-        return fits16[a] != fits16[b] ? fits16[a] > fits16[b] : cells(a) > cells(b);
+        if (group[a] != group[b]) return group[a] > group[b];
+        if (group[a] == 2 && root_of(a) != root_of(b)) return root_of(a) < root_of(b);
+        return cells(a) > cells(b);
     });
     if (getenv("C4GPU_TRACE"))
-        fprintf(stderr, "c4gpu trace:   fused: kernels %s, %s\nc4gpu trace:   fused: packed checkpoint kernel %s for %d of %d jobs\n", kc->name, kp->name,
-                kc16 ? kc16->name : "-", n16, n);
+        fprintf(stderr, "c4gpu trace:   fused: kernels %s, %s\nc4gpu trace:   fused: packed checkpoint kernels %s for %d, %s for %d of %d jobs\n",
+                kc->name, kp->name, (kc16r && n16r) ? kc16r->name : "-", n16r, (kc16 && n16a) ? kc16->name : "-", n16a, n);
     std::vector<DevJob> &jobs = eng.hf_jobs;
     jobs.resize(n);
     long long vsa_total = 0, max_ckpt = 0, max_T = 0, ckpt_cells = 0, max_ckpt16 = 0, max_T16 = 0;
     bool carry = false, carry16 = false;
+    int bnd16 = 0;
     for (int x = 0; x < n; x++) {
         const c4gpu_region &r = plan[red[order[x]]].ar;
         DevJob &j = jobs[x];
@@ -1388,6 +1442,7 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
         j.pair = red[order[x]]; j.q0 = r.query_start; j.t0 = r.target_start; j.Q = r.query_length; j.T = r.target_length;
         j.first_state = m->start_state; j.final_state = m->end_state;
         j.cp_count = cpn[order[x]];
+        j.root = x < n16r ? root_of(order[x]) : 0;
         int tb = 0;
         while ((1LL << tb) <= j.T) tb++;
         j.tshift = tb;
@@ -1396,9 +1451,11 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
         vsa_total += j.cp_count + 1;
         ckpt_cells += (long long)(j.Q + 1) * (j.T + 1);
         if (x < n16) {
-            max_ckpt16 = std::max(max_ckpt16, (long long)j.cp_count * kc16->max_at * (j.Q + 1) * kc16->ckw);
+            const KernelInfo *k16 = x < n16r ? kc16r : kc16;
+            max_ckpt16 = std::max(max_ckpt16, (long long)j.cp_count * k16->max_at * (j.Q + 1) * (x < n16r ? k16->ckw_root : k16->ckw));
             max_T16 = std::max<long long>(max_T16, j.T);
-            if ((j.Q + 1 + 64 * kc16->R - 1) / (64 * kc16->R) > 1) carry16 = true;
+            bnd16 = std::max(bnd16, k16->bnd);
+            if ((j.Q + 1 + 64 * k16->R - 1) / (64 * k16->R) > 1) carry16 = true;
         } else {
             max_ckpt = std::max(max_ckpt, (long long)j.cp_count * kc->max_at * (j.Q + 1) * kc->n_states * kc->cs);
             max_T = std::max<long long>(max_T, j.T);
@@ -1406,6 +1463,16 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
         }
     }
     if (vsa_total > 0x7fffffffLL) return 0;
+    // the packed kernels' pairs: neighbours of the same kernel and root
+    std::vector<int> pair_list;
+    int pairs_r = 0, pairs_a = 0;
+    for (int x = 0; x < n16;) {
+        const int lim = x < n16r ? n16r : n16;
+        const bool two = x + 1 < lim && jobs[x + 1].root == jobs[x].root;
+        pair_list.push_back(x); pair_list.push_back(two ? x + 1 : -1);
+        (x < n16r ? pairs_r : pairs_a)++;
+        x += two ? 2 : 1;
+    }
     auto grid_for = [&](const KernelInfo *ki, long long jobs_n, long long bytes_per_wave) -> long long {
         int blocks_per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, ki->func, 64 * ki->waves, 0) != hipSuccess || blocks_per_cu < 1)
@@ -1418,14 +1485,17 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
     int zero = 0;
     unsigned long long zero64 = 0;
     {
-        // two launches on the lane's stream, one after the other: they share the carry rows and the checkpoint slabs
-        const int zeros[2] = {0, 0};
+        // up to three launches on the lane's stream, one after the other: they share the carry rows and the checkpoint slabs
+        const int zeros[3] = {0, 0, 0};
         const int n32 = n - n16;
         const long long bnd_per_wave = (2 * ((carry ? max_T : 0) + 1) + 1) * (long long)std::max(kc->bnd, 1);
         const long long grid = n32 ? grid_for(kc, n32, bnd_per_wave * 4 + max_ckpt * 4) : 0;
-        const long long bnd16_per_wave = kc16 ? (2 * ((carry16 ? max_T16 : 0) + 1) + 1) * (long long)std::max(kc16->bnd, 1) : 0;
-        const long long grid16 = kc16 ? grid_for(kc16, (n16 + 1) / 2, bnd16_per_wave * 4 + 2 * max_ckpt16 * 4) : 0;
-        if (eng.d_fjobs.upload(jobs.data(), n, s) || eng.d_fres.alloc(n) || eng.d_queue.upload(zeros, 2, s) ||
+        const long long bnd16_per_wave = n16 ? (2 * ((carry16 ? max_T16 : 0) + 1) + 1) * (long long)std::max(bnd16, 1) : 0;
+        const long long grid16r = pairs_r ? grid_for(kc16r, pairs_r, bnd16_per_wave * 4 + 2 * max_ckpt16 * 4) : 0;
+        const long long grid16a = pairs_a ? grid_for(kc16, pairs_a, bnd16_per_wave * 4 + 2 * max_ckpt16 * 4) : 0;
+        const long long grid16 = std::max(grid16r, grid16a);
+        if (eng.d_fjobs.upload(jobs.data(), n, s) || eng.d_fres.alloc(n) || eng.d_queue.upload(zeros, 3, s) ||
+            eng.d_pairs.upload(pair_list.data(), pair_list.size(), s) ||
             eng.d_bnd.alloc(std::max(bnd_per_wave * grid, bnd16_per_wave * grid16)) || eng.d_fvsa.alloc(vsa_total) ||
             eng.d_ckpt.alloc(std::max(max_ckpt * grid, 2 * max_ckpt16 * grid16)) || eng.d_ckpt_dump.alloc(1))
             return -1;
@@ -1439,14 +1509,21 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
         a.scratch.bnd = eng.d_bnd.p;
         a.scratch.ckpt_dump = eng.d_ckpt_dump.p;
         if (ctx->timing) HIP_OK(hipEventRecord(ctx->ev0, s));
-        if (kc16) {
-            a.jobs = eng.d_fjobs.p; a.n_jobs = n16; a.results = eng.d_fres.p; a.queue = eng.d_queue.p; a.grid = (int)grid16;
-            a.scratch.bnd_stride = bnd16_per_wave; a.scratch.carry = carry16 ? 1 : 0;
-            a.scratch.ckpt = eng.d_ckpt.p; a.scratch.ckpt_stride = max_ckpt16;
+        // the packed kernels index the whole job / result arrays through their pair lists
+        a.jobs = eng.d_fjobs.p; a.n_jobs = n16; a.results = eng.d_fres.p;
+        a.scratch.bnd_stride = bnd16_per_wave; a.scratch.carry = carry16 ? 1 : 0;
+        a.scratch.ckpt = eng.d_ckpt.p; a.scratch.ckpt_stride = max_ckpt16;
+        if (pairs_r) {
+            a.queue = eng.d_queue.p; a.grid = (int)grid16r; a.aux = eng.d_pairs.p; a.n_aux = pairs_r;
+            HIP_OK(kc16r->launch(a));
+        }
+        if (pairs_a) {
+            a.queue = eng.d_queue.p + 1; a.grid = (int)grid16a; a.aux = eng.d_pairs.p + 2 * pairs_r; a.n_aux = pairs_a;
             HIP_OK(kc16->launch(a));
         }
         if (n32) {
-            a.jobs = eng.d_fjobs.p + n16; a.n_jobs = n32; a.results = eng.d_fres.p + n16; a.queue = eng.d_queue.p + 1; a.grid = (int)grid;
+            a.jobs = eng.d_fjobs.p + n16; a.n_jobs = n32; a.results = eng.d_fres.p + n16; a.queue = eng.d_queue.p + 2; a.grid = (int)grid;
+            a.aux = nullptr; a.n_aux = 0;
             a.scratch.bnd_stride = bnd_per_wave; a.scratch.carry = carry ? 1 : 0;
             a.scratch.ckpt = max_ckpt ? eng.d_ckpt.p : nullptr; a.scratch.ckpt_stride = max_ckpt;
             HIP_OK(kc->launch(a));
@@ -1585,10 +1662,6 @@ template <class Thr>
 int windowed_region_pass(Engine &eng, const ResidentSeqs &seqs, const std::vector<int> &pairs,
                          const std::vector<PairPlan> &plan, Thr thr, int kshift, std::vector<DevResult> &out) {
     const int n = (int)pairs.size();
-    const int win_nw = window_waves(eng.family);
-    const KernelInfo *kw = get_kernel_mw(eng.family, MODE_REGION, true, true, win_nw, false, 2);
-    const long long seedw = kw->seedw;
-    const int dc = kw->max_at;                           // dumped columns per dump (d*K - (dc - 1) .. d*K)
     auto nbits = [](int v) { int b = 0; while ((1LL << b) <= v) b++; return b; };
     std::vector<JobSpec> specs(n);
     std::vector<JobOut> outs;
@@ -1596,6 +1669,8 @@ int windowed_region_pass(Engine &eng, const ResidentSeqs &seqs, const std::vecto
     SeedPlan sp1;
     sp1.mode = 1; sp1.kshift = kshift;
     if (eng.run(seqs, MODE_SCORE, false, specs, outs, &sp1)) return -1;
+    const long long seedw = sp1.seedw;                   // ints per dumped row: the score kernel's format (32-bit cells or Dump16)
+    const int dc = sp1.dc;                               // dumped columns per dump (d*K - (dc - 1) .. d*K)
     out.assign(n, DevResult());
     // the windows of a pair follow each other inside one workgroup (viterbi_kernel_mw, SEED 2): ONE launch over the first
     // windows of all wanted pairs; a job walks left from the end cell, one dump interval per window, until its payload is a
@@ -1619,7 +1694,7 @@ int windowed_region_pass(Engine &eng, const ResidentSeqs &seqs, const std::vecto
     if (!want.empty()) {
         std::vector<JobSpec> hs(want.size());
         SeedPlan sp2;
-        sp2.mode = 2; sp2.kshift = kshift; sp2.hops = std::max(1, max_hops);
+        sp2.mode = 2; sp2.kshift = kshift; sp2.hops = std::max(1, max_hops); sp2.fmt16 = sp1.fmt16;
         sp2.off.resize(want.size()); sp2.rows.resize(want.size()); sp2.base.resize(want.size());
         sp2.d.resize(want.size()); sp2.t0w.resize(want.size()); sp2.t0_base.resize(want.size());
         for (size_t h = 0; h < want.size(); h++) {
@@ -1630,6 +1705,12 @@ int windowed_region_pass(Engine &eng, const ResidentSeqs &seqs, const std::vecto
             hs[h].pair = pairs[x];
             hs[h].region = c4gpu_region{ar.query_start, ar.target_start + t0w, outs[x].res.qe, outs[x].res.te - t0w};
             hs[h].final_state = eng.model->end_state;
+            if (sp1.fmt16) {
+                // the packed windows compute the component of the state END was entered from, and end in that state
+                // (the score pass reports it: DevResult::last_srp)
+                hs[h].final_state = hs[h].root = outs[x].res.last_srp;
+                if (outs[x].res.last_srp <= 1) { c4h::set_error("windowed region pass: the score pass did not say where END was entered from"); return -1; }
+            }
             sp2.rows[h] = ar.query_length + 1;
             sp2.base[h] = sp1.off[x];
             sp2.off[h] = d >= 1 ? sp1.off[x] + (long long)(d - 1) * dc * (ar.query_length + 1) * seedw : -1;
@@ -1807,6 +1888,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
         const DevResult &r = pr.second;
         if (r.score < thr(pr.first)) { p.active = false; continue; }
         p.region_score = r.score;
+        p.end_from = r.last_srp;                 // the windowed pass's packed score kernel reports it (c4_viterbi16_kernel.h); else 0
         // Viterbi_Data_finalise, viterbi.c:633-653 (curr_*_start are relative to the region the pass ran over)
         if (m->start_scope != C4GPU_SCOPE_QUERY) p.ar.query_start += r.qs;
         if (m->start_scope != C4GPU_SCOPE_TARGET) p.ar.target_start += r.ts;

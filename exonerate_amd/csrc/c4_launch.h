@@ -33,6 +33,10 @@ struct LaunchArgs {
     int *queue;
     int grid;
     hipStream_t stream;
+    // the two-jobs-per-lane kernels that take their pairing from the host (c4_win16_kernel.h, c4_ckpt16_kernel.h): n_aux pairs of
+    // job indices (second = -1: the job runs alone); the two jobs of a pair have the same root (Roots, c4_viterbi16_kernel.h)
+    const int *aux = nullptr;
+    int n_aux = 0;
 };
 
 struct KernelInfo {
@@ -45,7 +49,9 @@ struct KernelInfo {
     int n_states, max_at;
     int waves;                // waves per job (workgroup = 64 * waves threads)
     int seedw;                // ints per row of a dumped column (SEED kernels)
-    int ckw;                  // the packed checkpoint pass: ints per row of a checkpoint column in a job's slab
+    int ckw;                  // the packed checkpoint pass: ints per row of a checkpoint column in a job's slab (root -1; see ckw_root)
+    int pairs = 0;            // 1: the kernel reads LaunchArgs::aux (pairs of jobs with a common root, DevJob::pad0)
+    int ckw_root = 0;         // the packed checkpoint pass restricted to one root's component: ints per row
 };
 
 // family x mode x continuation x local-scope specialisation; NULL launch = not compiled
@@ -62,9 +68,13 @@ const KernelInfo *get_kernel_mw(int family, int mode, bool local, bool pack, int
 // the packed 16-bit score pass with column dumps (c4_viterbi16_kernel.h): two jobs per lane; NULL = not compiled for the family.
 // Launched over the same job / result arrays as the 32-bit kernel (workgroup p runs jobs 2p and 2p + 1).
 const KernelInfo *get_kernel_pk16(int family, int variant = 0);
-// the packed 16-bit checkpoint pass (c4_ckpt16_kernel.h): two jobs per lane, one wave per pair of jobs; scratch.ckpt holds two
-// slabs of ckpt_stride ints per wave; variant: rows per lane / register cap shapes kept for measurement (0 = the default)
-const KernelInfo *get_kernel_ck16(int family, int variant = 0);
+// the packed 16-bit checkpoint pass (c4_ckpt16_kernel.h): two jobs per lane, one wave per pair of jobs (LaunchArgs::aux);
+// scratch.ckpt holds two slabs of ckpt_stride ints per wave; rooted: the form that computes the component of DevJob::root only
+// (NULL where the family's components overlap); variant: rows per lane / register cap shapes kept for measurement (0 = the default)
+const KernelInfo *get_kernel_ck16(int family, int variant = 0, bool rooted = false);
+// the packed 16-bit region windows (c4_win16_kernel.h): two windows per lane, one wave per pair of window chains, started from
+// the 16-bit dumps of get_kernel_pk16(family, 3); variant: rows per lane / register cap shapes (0 = the default)
+const KernelInfo *get_kernel_win16(int family, int variant = 0);
 hipError_t pk16_build_splice(int family, const KParams *kp, const int *ss, long long ss_stride, long long n, void *out, hipStream_t s);
 
 #define C4K_DEFINE_KERNEL_SPAN(SYMBOL, M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV, SPANV)                                          \

@@ -63,11 +63,86 @@ __device__ __forceinline__ int clamp16(int x) { return x < -32768 ? -32768 : (x 
 
 constexpr int NEG16 = (int)0x80008000u;          // -32 768 in both halves
 
-template <class M, int R, int VAR = 0>
+// The components of a model as seen from END.  A path ends with a transition into END from one state (its "root"); every
+// state of the path can reach that root, so a pass that only has to reproduce ONE path whose root is known (the region
+// windows, the checkpoint pass: the whole-rectangle score pass has already decided which transition into END won, and a
+// pass restricted to the path's region can only confirm it: c4_win16_kernel.h, c4_ckpt16_kernel.h) needs the states from
+// which the root can be reached and no others.  est2genome: the forward-strand states {2, 3, 4, 8} and the reverse-strand
+// states {5, 6, 7, 9} never feed each other (they only share START and END), so such a pass computes half the model.
+// ROOT = -1 stands for "every inner state" (a model with one component, or a root that is not known).
+template <class M>
+struct Roots {
+    static constexpr bool inner(int s) { return s != M::START && s != M::END; }
+    static constexpr int count() {
+        int n = 0;
+        for (int k = 0; k < M::NT; k++) {
+            if (M::tr[k].out != M::END || !inner(M::tr[k].in)) continue;
+            bool seen = false;
+            for (int x = 0; x < k; x++) if (M::tr[x].out == M::END && M::tr[x].in == M::tr[k].in) seen = true;
+            n += seen ? 0 : 1;
+        }
+        return n;
+    }
+    static constexpr int root(int idx) {           // the idx-th distinct source state of END, in transition order
+        int n = 0;
+        for (int k = 0; k < M::NT; k++) {
+            if (M::tr[k].out != M::END || !inner(M::tr[k].in)) continue;
+            bool seen = false;
+            for (int x = 0; x < k; x++) if (M::tr[x].out == M::END && M::tr[x].in == M::tr[k].in) seen = true;
+            if (seen) continue;
+            if (n == idx) return M::tr[k].in;
+            n++;
+        }
+        return -1;
+    }
+    static constexpr bool member(int rt, int s) {  // can inner state s reach rt (rt itself included)?  rt < 0: every inner state
+        if (!inner(s)) return false;
+        if (rt < 0) return true;
+        bool in[M::NS] = {};
+        in[rt] = true;
+        for (int it = 0; it < M::NS; it++)
+            for (int k = 0; k < M::NT; k++)
+                if (in[M::tr[k].out] && inner(M::tr[k].in)) in[M::tr[k].in] = true;
+        return in[s];
+    }
+    // the first root whose component holds s (-1: none)
+    static constexpr int root_of(int s) { for (int r = 0; r < count(); r++) if (member(root(r), s)) return root(r); return -1; }
+    // do the components of the roots overlap?  (then restricting a pass to one of them saves nothing worth a kernel)
+    static constexpr bool disjoint() {
+        for (int s = 0; s < M::NS; s++) { int n = 0; for (int r = 0; r < count(); r++) n += member(root(r), s); if (n > 1) return false; }
+        return count() >= 2;
+    }
+};
+
+// The column dumps in 16-bit form (DUMP16: what the packed region windows of c4_win16_kernel.h start from): per dumped row
+// the scores of the inner states (START is never set and nothing reads END), then the intron lengths something can still
+// read, one 16-bit half each in that order, two halves per int.  est2genome: 8 + 2 halves = 5 ints per row (the 32-bit
+// format: 12).  The length is stored as the packed passes carry it (saturating counter), not as a target position.
+template <class M>
+struct Dump16 {
+    using W1 = WaveDP<M, 1, MODE_SCORE, false, true, false, false, 0, 1>;
+    static constexpr bool live(int s) { return M::NDES > 0 && W1::slot_live(s, 0); }
+    static constexpr bool inner(int s) { return s != M::START && s != M::END; }
+    static constexpr int n_inner() { int n = 0; for (int s = 0; s < M::NS; s++) n += inner(s); return n; }
+    static constexpr int n_live() { int n = 0; for (int s = 0; s < M::NS; s++) n += (inner(s) && live(s)); return n; }
+    static constexpr int NH = n_inner() + n_live();                 // halves per row
+    static constexpr int SEEDW16 = (NH + 1) / 2;                    // ints per row
+    static constexpr int half_of_sc(int s) { int n = 0; for (int x = 0; x < s; x++) n += inner(x); return n; }
+    static constexpr int half_of_il(int s) { int n = n_inner(); for (int x = 0; x < s; x++) n += (inner(x) && live(x)); return n; }
+    // the state whose score (h < n_inner()) or length sits in half h; -1: padding
+    static constexpr int state_of_half(int h) {
+        if (h < n_inner()) { for (int s = 0; s < M::NS; s++) if (inner(s) && half_of_sc(s) == h) return s; return -1; }
+        for (int s = 0; s < M::NS; s++) if (inner(s) && live(s) && half_of_il(s) == h) return s;
+        return -1;
+    }
+};
+
+template <class M, int R, int VAR = 0, bool DUMP16 = false>
 struct WaveDP16 {
     using F = Facts<M>;
     using W32 = WaveDP<M, R, MODE_SCORE, false, true, false, false, 0, 1>;     // the 32-bit score pass: dump layout
-    static constexpr int NS = M::NS, NCOL = M::MAXAT + 1, W = 64 * R, DC = M::MAXAT, SEEDW = W32::SEEDW;
+    using D16 = Dump16<M>;
+    static constexpr int NS = M::NS, NCOL = M::MAXAT + 1, W = 64 * R, DC = M::MAXAT, SEEDW = DUMP16 ? D16::SEEDW16 : W32::SEEDW;
     static constexpr bool live(int s) { return M::NDES > 0 && W32::slot_live(s, 0); }
     static constexpr int NEXP = F::n_exported();
     static constexpr int BND = NEXP * 2;                 // ints per column between strips: score pair + length pair per exported state
@@ -96,6 +171,9 @@ struct WaveDP16 {
     lds_int *ring_in, *ring_out;
     bool use_ring_in, use_ring_out, carry_ok, carry_cols;
     int best[2], best_i[2], best_j[2], best_pk;
+    // best_i: (query row << 4) | the state the cell's END was entered from (Roots): the row-major order of the rows is
+    // that of these numbers, and no register is spent on the state
+    static_assert(M::NS <= 16, "state in four bits");
     bool best_set[2];
     int sbest[2], sbest_i[2], sbest_j[2];
     bool sbest_set[2];
@@ -234,8 +312,19 @@ struct WaveDP16 {
                     static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
                         const int tsc = pk_half(col[PH][RR].sc[M::END], H);
                         const bool upd = jact & (i0 + RR <= Q[H]) & (!best_set[H] | (best[H] < tsc));
+                        // which transition into END holds it: the first assigns, later ones replace on strict < (viterbi.c:766-775)
+                        int from = -1, fsc = 0;
+                        static_for<M::NT>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
+                            constexpr TrDesc t = M::tr[K];
+                            if constexpr (t.out == M::END && t.in != M::START) {
+                                const int v = pk_half(col[PH][RR].sc[t.in], H);
+                                const bool win = (from < 0) | (fsc < v);
+                                fsc = win ? v : fsc;
+                                from = win ? t.in : from;
+                            }
+                        });
                         best[H] = upd ? tsc : best[H];
-                        best_i[H] = upd ? i0 + RR : best_i[H];
+                        best_i[H] = upd ? (((i0 + RR) << 4) | from) : best_i[H];
                         best_j[H] = upd ? j : best_j[H];
                         best_set[H] = best_set[H] | upd;
                     });
@@ -272,11 +361,25 @@ struct WaveDP16 {
                         const int i = i0 + RR;
                         if (i <= Q[H]) {
                             int *p = seed_wr[H] + (((long long)(d - 1) * DC + which) * seed_rows[H] + i) * SEEDW;
-                            static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
-                                store_dword<S * 4>(p, pk_half(col[PH][RR].sc[S], H));
-                                if constexpr (live(S))
-                                    store_dword<W32::dump_pos(S, 0) * 4>(p, t0[H] + j - pk_half(col[PH][RR].il[S], H) - 2);
-                            });
+                            if constexpr (DUMP16) {
+                                // this job's halves of two values per word (Dump16)
+                                auto half_reg = [&](auto HI_) __attribute__((always_inline)) -> int { constexpr int HI = HI_;
+                                    constexpr int S = D16::state_of_half(HI);
+                                    if constexpr (S < 0) return 0;
+                                    else if constexpr (HI < D16::n_inner()) return col[PH][RR].sc[S];
+                                    else return col[PH][RR].il[S];
+                                };
+                                static_for<D16::SEEDW16>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
+                                    const int va = half_reg(IC<2 * K>{}), vb = half_reg(IC<2 * K + 1>{});
+                                    store_dword<K * 4>(p, (int)__builtin_amdgcn_perm((unsigned)vb, (unsigned)va, H ? 0x07060302u : 0x05040100u));
+                                });
+                            } else {
+                                static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                                    store_dword<S * 4>(p, pk_half(col[PH][RR].sc[S], H));
+                                    if constexpr (live(S))
+                                        store_dword<W32::dump_pos(S, 0) * 4>(p, t0[H] + j - pk_half(col[PH][RR].il[S], H) - 2);
+                                });
+                            }
                         }
                     });
                 }
@@ -460,11 +563,11 @@ __global__ void ss16_kernel(const KParams *kp, const int *ss, long long ss_strid
 
 // NW cooperating waves per PAIR of jobs: workgroup p of the queue runs jobs 2p and 2p + 1 (the last one alone when the
 // launch holds an odd number: its high half repeats it)
-template <class M, int R, int NW, int WPE, int VAR = 0>
+template <class M, int R, int NW, int WPE, int VAR = 0, bool DUMP16 = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
 void viterbi16_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, int n_jobs, DevResult *results,
                          DevScratch scratch, int *queue) {
-    using DP = WaveDP16<M, R, VAR>;
+    using DP = WaveDP16<M, R, VAR, DUMP16>;
     __shared__ KParams kp_lds;
     __shared__ int next_job;
     __shared__ int rings[(NW > 1 ? NW - 1 : 1) * DP::RING * DP::BND];
@@ -512,10 +615,11 @@ void viterbi16_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *job
                 bs = bs || os;
             }
             DevResult res;
-            res.flags = bs ? 0 : FLAG_NO_END; res.n_ops = 0; res.n_vsa = 0; res.last_srp = 0; res.pad = 0;
+            res.flags = bs ? 0 : FLAG_NO_END; res.n_ops = 0; res.n_vsa = 0; res.pad = 0;
+            res.last_srp = bs ? (bi & 15) : -1;          // the state END was entered from in the best end cell (-1: no end cell)
             res.cell_size = 1 + M::NDES; res.ops_off = 0;
             for (int l = 0; l < CELL_MAX; l++) res.final_cell[l] = 0;
-            res.score = b; res.end_set = bs; res.qe = bi; res.te = bj; res.qs = 0; res.ts = 0;
+            res.score = b; res.end_set = bs; res.qe = bi >> 4; res.te = bj; res.qs = 0; res.ts = 0;
             results[h ? ib : ia] = res;
         }
         __syncthreads();

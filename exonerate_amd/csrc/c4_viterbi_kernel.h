@@ -73,7 +73,8 @@ struct DevSeqs {
 struct DevJob {
     int pair, q0, t0, Q, T;
     int first_state, final_state, cp_count;
-    int tshift, pad0;                    // packed region start: (query_start << tshift) | target_start
+    int tshift, root;                    // packed region start: (query_start << tshift) | target_start; root: the state the path's END
+                                         // is entered from where a pass restricted to that state's component wants it (Roots; 0: not known)
     int first_cell[CELL_MAX];
     long long ops_off;                   // into the ops byte array (PATH)
     int ops_cap, vsa_off;                // vsa_off: into the DevVsa array (CKPT)

@@ -5,17 +5,19 @@
 #include "../c4_launch.h"
 #include "../c4_viterbi16_kernel.h"
 namespace c4k {
-#define PK16_KERNEL(NAME, M, RV, NWV, WPEV, VARV)                                                                      \
+#define PK16_KERNEL(NAME, M, RV, NWV, WPEV, VARV, D16V)                                                                \
     static hipError_t NAME##_launch(const LaunchArgs &a) {                                                            \
-        hipLaunchKernelGGL((viterbi16_kernel_mw<M, RV, NWV, WPEV, VARV>), dim3(a.grid), dim3(64 * NWV), 0, a.stream,   \
+        hipLaunchKernelGGL((viterbi16_kernel_mw<M, RV, NWV, WPEV, VARV, D16V>), dim3(a.grid), dim3(64 * NWV), 0, a.stream,   \
                            a.kp, a.seqs, a.jobs, a.n_jobs, a.results, a.scratch, a.queue);                             \
         return hipGetLastError();                                                                                      \
     }                                                                                                                  \
-    static const KernelInfo NAME = {NAME##_launch, (const void *)viterbi16_kernel_mw<M, RV, NWV, WPEV, VARV>, #NAME, RV, 2,  \
-                                    WaveDP16<M, RV>::BND, M::NS, M::MAXAT, NWV, WaveDP16<M, RV>::SEEDW};
-PK16_KERNEL(kpk16_est2genome, Est2GenomeDesc, 4, 4, 3, 0)
-PK16_KERNEL(kpk16b_est2genome, Est2GenomeDesc, 4, 4, 3, 1)
-PK16_KERNEL(kpk16c_est2genome, Est2GenomeDesc, 4, 4, 3, 2)
+    static const KernelInfo NAME = {NAME##_launch, (const void *)viterbi16_kernel_mw<M, RV, NWV, WPEV, VARV, D16V>, #NAME, RV, 2,  \
+                                    WaveDP16<M, RV, VARV, D16V>::BND, M::NS, M::MAXAT, NWV, WaveDP16<M, RV, VARV, D16V>::SEEDW};
+PK16_KERNEL(kpk16_est2genome, Est2GenomeDesc, 4, 4, 3, 0, false)
+PK16_KERNEL(kpk16b_est2genome, Est2GenomeDesc, 4, 4, 3, 1, false)
+PK16_KERNEL(kpk16c_est2genome, Est2GenomeDesc, 4, 4, 3, 2, false)
+// variant 3: variant 1 with its column dumps in 16-bit form (Dump16), what the packed region windows (c4_win16_kernel.h) read
+PK16_KERNEL(kpk16d_est2genome, Est2GenomeDesc, 4, 4, 3, 1, true)
 // the packed splice array of variant 1 (ss16_kernel): n positions of the batch's concatenated targets
 hipError_t pk16_build_splice(int family, const KParams *kp, const int *ss, long long ss_stride, long long n, void *out, hipStream_t s) {
     if (family != FAM_EST2GENOME) return hipErrorInvalidValue;
@@ -24,6 +26,6 @@ hipError_t pk16_build_splice(int family, const KParams *kp, const int *ss, long 
 }
 const KernelInfo *get_kernel_pk16(int family, int variant) {
     if (family != FAM_EST2GENOME) return nullptr;
-    return variant == 2 ? &kpk16c_est2genome : variant == 1 ? &kpk16b_est2genome : &kpk16_est2genome;
+    return variant == 3 ? &kpk16d_est2genome : variant == 2 ? &kpk16c_est2genome : variant == 1 ? &kpk16b_est2genome : &kpk16_est2genome;
 }
 }

@@ -288,6 +288,7 @@ def test_window_kernel_on_two_and_four_waves_agree(eng, monkeypatch, capfd):
     q = _rand(rng, 1000)                                      # an intron of 30 kb: the second window is as high as the first
     pairs.append((q, _rand(rng, 5000) + _mutate(rng, q[:150], 0.03) + "GT" + _rand(rng, 30000) + "AG" + _mutate(rng, q[150:], 0.03) + _rand(rng, 9000)))
     monkeypatch.setenv("C4GPU_TRACE", "1")
+    monkeypatch.setenv("C4GPU_WIN16", "0")                # the 32-bit windows (the packed ones: test_packed_16_bit_region_windows_..)
     res = {}
     for nw in ("2", "4"):
         monkeypatch.setenv("C4GPU_WIN_NW", nw)
@@ -364,7 +365,9 @@ def test_packed_16_bit_score_pass_agrees_with_the_32_bit_pass(eng, monkeypatch, 
         res[pk] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=32, threshold=20)]
         err = capfd.readouterr().err
         assert "windowed region pass" in err
-        assert ("kpk16b_est2genome" in err) == (pk == "1") and ("kpk16_est2genome" in err) == (pk == "3"), err[-1500:]
+        # the default form writes its dumps as 16-bit rows for the packed windows behind it (kpk16d; C4GPU_WIN16=0: kpk16b)
+        assert ("kpk16d_est2genome" in err) == (pk == "1") and ("kpk16_est2genome" in err) == (pk == "3"), err[-1500:]
+        assert ("kwin16_est2genome" in err) == (pk == "1"), err[-1500:]
         assert ("kpk16c_est2genome" in err) == (pk == "4"), err[-1500:]
     assert res["1"] == res["0"] and res["3"] == res["0"] and res["4"] == res["0"]
     ops = [model.c.transitions[t].label for t, n in res["1"][7]["ops"] if n >= 45000]
@@ -382,6 +385,65 @@ def test_packed_16_bit_score_pass_agrees_with_the_32_bit_pass(eng, monkeypatch, 
     monkeypatch.setenv("C4GPU_PK16", "0")
     b = [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=20)]
     assert a == b and a2 == b and a4 == b
+
+
+def test_packed_16_bit_region_windows_agree_with_the_32_bit_windows(eng, monkeypatch, capfd):
+    """The region windows run two windows per lane in packed 16-bit halves (c4_win16_kernel.h) behind the packed score pass,
+    from its 16-bit dumps, each chain over the component of the state its END was entered from (one strand of est2genome);
+    C4GPU_WIN16=0 keeps the 32-bit windows.  Same alignments either way, in every shape of the packed kernel, on a ragged
+    batch with an odd number of jobs on either strand (reverse-complemented pairs: the gene on the other strand, introns
+    CT..AC, END entered from the reverse match state), chains of one to thirteen windows, an intron longer than the 15-bit
+    length counter, a pair below the threshold; then with tiny dump intervals (a path crosses dozens of dumps, introns jump
+    over dumped columns); pairs also against the oracle."""
+    rng = random.Random(1606)
+    model = ex.Model("est2genome")
+    comp = str.maketrans("ACGTN", "TGCAN")
+    pairs = []
+    for k, (ql, tl) in enumerate([(900, 36000), (400, 52000), (1000, 9000 + 33000), (640, 33000), (1000, 100000), (450, 34000),
+                                  (777, 41000), (1000, 70000), (520, 66000)]):
+        q, t = _seeded_pairs(rng, "est2genome", ql, tl, 1)[0]
+        if k % 3 == 1: q, t = q.translate(comp)[::-1], t.translate(comp)[::-1]       # the gene on the reverse strand
+        pairs.append((q, t))
+    q = _rand(rng, 800)
+    pairs.append((q, _rand(rng, 3000) + _mutate(rng, q[:400], 0.03) + "GT" + _rand(rng, 45000) + "AG" + _mutate(rng, q[400:], 0.03) + _rand(rng, 2000)))
+    q = _rand(rng, 990)                                    # a 90 kb intron on the reverse strand: thirteen windows back
+    t = _rand(rng, 1500) + _mutate(rng, q[:400], 0.03) + "GT" + _rand(rng, 90000) + "AG" + _mutate(rng, q[400:], 0.03) + _rand(rng, 2000)
+    pairs.append((q.translate(comp)[::-1], t.translate(comp)[::-1]))
+    pairs.append((_rand(rng, 500), _rand(rng, 35000)))                         # unrelated: below the threshold
+    monkeypatch.setenv("C4GPU_TRACE", "1")
+    monkeypatch.setenv("C4GPU_SEED_KSHIFT", "13")
+    res = {}
+    for w in ("1", "2", "3", "4", "0"):
+        monkeypatch.setenv("C4GPU_WIN16", w)
+        res[w] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=32, threshold=100)]
+        err = capfd.readouterr().err
+        assert "windowed region pass" in err and " 0 of " in err.split("windowed region pass")[-1].split("\n")[0], err[-1500:]
+        assert ("kwin16_est2genome" in err) == (w != "0") and ("kpk16d_est2genome" in err) == (w != "0"), err[-1500:]
+        assert ("kmw2_est2genome_region_local_pack_seed2" in err) == (w == "0"), err[-1500:]
+    for w in ("1", "2", "3", "4"):
+        assert res[w] == res["0"], w
+    assert all(r is not None for r in res["0"][:-1])          # (the unrelated pair has a chance alignment above the threshold or not)
+    # both strands were there: an intron-labelled run of a reverse-strand pair goes through the reverse intron state
+    strands = set()
+    for r in res["1"][:-1]:
+        if r is None: continue
+        states = {model.c.transitions[t].output for t, n in r["ops"]}
+        strands.add("rev" if 9 in states or 5 in states else "fwd")
+    assert strands == {"fwd", "rev"}, strands
+    assert res["1"][10]["region"][3] > 90000 and res["1"][9]["region"][3] > 45000
+    for k in (2, 3):
+        q, t = pairs[k]
+        assert res["1"][k] == oracle_lib.find_path(model.c, model.params, q.encode(), t.encode(), dpmemory=32, threshold=100)
+    for kshift in ("6", "9"):
+        monkeypatch.setenv("C4GPU_SEED_KSHIFT", kshift)
+        small = [pairs[0], pairs[1], pairs[3], pairs[5], pairs[11]]
+        got = {}
+        for w in ("1", "3", "0"):
+            monkeypatch.setenv("C4GPU_WIN16", w)
+            got[w] = [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=100)]
+            err = capfd.readouterr().err
+            assert ("kwin16_est2genome" in err) == (w != "0"), err[-1500:]
+        assert got["1"] == got["0"] and got["3"] == got["0"], kshift
 
 
 @pytest.mark.parametrize("model_type,dpm", [("affine:local", 32), ("affine:local", 1), ("affine:local", 0),
@@ -453,23 +515,34 @@ def test_packed_16_bit_checkpoint_pass_agrees_with_the_32_bit_pass(eng, monkeypa
     pairs.append((_rand(rng, 500), _rand(rng, 25000)))                          # unrelated: below the threshold
     monkeypatch.setenv("C4GPU_TRACE", "1")
     res, fin = {}, {}
-    for ck, tmax in (("1", None), ("2", None), ("3", None), ("4", None), ("5", None), ("1", "20000"), ("0", None)):
+    # C4GPU_CK16 = 1..4: the shapes of the rooted form (one strand's states: the jobs whose region pass said where END was
+    # entered from); C4GPU_CK16_ROOT=0: every job on the form that computes all inner states
+    rooted_seen = 0
+    for ck, tmax, root in (("1", None, "1"), ("2", None, "1"), ("3", None, "1"), ("4", None, "1"), ("1", None, "0"),
+                           ("1", "20000", "1"), ("0", None, "1")):
         monkeypatch.setenv("C4GPU_CK16", ck)
+        monkeypatch.setenv("C4GPU_CK16_ROOT", root)
         if tmax: monkeypatch.setenv("C4GPU_CK16_TMAX", tmax)
         else: monkeypatch.delenv("C4GPU_CK16_TMAX", raising=False)
-        res[ck + (tmax or "")] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=dpm, threshold=30)]
+        key = ck + (tmax or "") + ("" if root == "1" else "a")
+        res[key] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=dpm, threshold=30)]
         err = capfd.readouterr().err
-        fused = [ln for ln in err.splitlines() if "fused: packed checkpoint kernel" in ln]
+        fused = [ln for ln in err.splitlines() if "fused: packed checkpoint kernels" in ln]
         assert fused, err[-2000:]
-        words = fused[0].split("packed checkpoint kernel")[1].split()          # "<kernel> for <n16> of <n> jobs"
-        n16, n32 = int(words[2]), int(words[4]) - int(words[2])
+        words = fused[0].split("packed checkpoint kernels")[1].replace(",", " ").split()   # "<rooted> for <n> <all> for <n> of <n> jobs"
+        n16r, n16a, n_all = int(words[2]), int(words[5]), int(words[7])
+        n32 = n_all - n16r - n16a
         if ck == "0":
-            assert words[0] == "-" and n16 == 0
+            assert words[0] == "-" and words[3] == "-" and n16r + n16a == 0
         else:
-            assert words[0].startswith("kck16_est2genome") and n16 >= 2, fused[0]
+            assert n16r + n16a >= 2, fused[0]
+            assert (words[0].startswith("kck16r_est2genome")) == (n16r > 0) and (words[3].startswith("kck16_est2genome")) == (n16a > 0), fused[0]
             assert (n32 > 0) == (tmax is not None), fused[0]
+            if root == "0": assert n16r == 0, fused[0]
+            rooted_seen += n16r
         finished = [ln for ln in err.splitlines() if "pairs finished on the device route" in ln][0].split("fused:")[1].split()
-        fin[ck + (tmax or "")] = (finished[0], finished[2])                 # "N of M pairs finished ..."
+        fin[key] = (finished[0], finished[2])                 # "N of M pairs finished ..."
+    assert (rooted_seen > 0) == (dpm != 0), "the 100 kb targets take the windowed region pass, which names the root"
     for k, v in res.items():
         assert v == res["0"], k
         assert fin[k] == fin["0"], (k, fin)            # the packed pass sends no pair to the host route that the 32-bit pass keeps
