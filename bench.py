@@ -187,6 +187,47 @@ def spawn_ranks(n, argv):
     return rc
 
 
+def other_configs(ex, eng):
+    """BASELINE.json's configurations 2, 3 and 5 at their full sizes on this GPU (exonerate_amd.workloads.bench_config): one
+    warm-up and one timed pass of Optimal_find_path (-D 32) each; cells/s on first-pass cells, the device time of each kind of
+    kernel, and every 64th alignment checked — score, region and operations — against tests/golden/bench_configs.json
+    (generated by tools/make_bench_golden.py from the CPU oracle; tests/test_bench_golden.py keeps the file honest).  The
+    headline `value` is configuration 4; these are reported beside it so that every configuration's number is the driver's."""
+    from exonerate_amd import workloads
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_configs.json")))
+    names = {0: "score", 1: "path", 2: "region", 3: "checkpoint"}
+    out = {}
+    for name, label in (("c2", "config 2: affine:local, 4096 DNA pairs of 1 kb x 1 kb"),
+                        ("c3", "config 3: protein2dna, 1024 proteins of 500 aa x one 1 Mb contig"),
+                        ("c5", "config 5 (exhaustive shape): protein2genome, 256 proteins of 300 aa x one 10 Mb chromosome")):
+        model_name, pairs, _ = workloads.bench_config(name)
+        model = ex.Model(model_name)
+        b = ex.ResidentBatch(eng, model, pairs)
+        b.run(2)                                                          # warm-up
+        for m in range(4):
+            b.kernel_stats(m, reset=True)
+        t0 = time.perf_counter()
+        b.run(2)
+        dt = time.perf_counter() - t0
+        ks = {m: b.kernel_stats(m) for m in range(4)}
+        cells = sum((len(q) + 1) * (len(t) + 1) for q, t in pairs)
+        checked = 0
+        for rec in want[name]["sample"]:
+            a = b.alignment(rec["pair"])
+            ok = a is not None and a.score == rec["score"] and list(a.region) == rec["region"] and [list(o) for o in a.ops] == rec["ops"]
+            assert ok, "%s: pair %d differs from tests/golden/bench_configs.json" % (name, rec["pair"])
+            checked += 1
+        dom = max(range(4), key=lambda m_: ks[m_]["ms"])
+        out[name] = {"workload": label, "pairs": len(pairs), "first_pass_cells": cells, "ms_per_pass": dt * 1e3,
+                     "value": cells / dt, "unit": "cells/s", "alignments_per_s": len(pairs) / dt,
+                     "kernel_ms": {names[m]: ks[m]["ms"] for m in range(4)},
+                     "dominant_kernel": {"pass": names[dom], "ms": ks[dom]["ms"], "launches": ks[dom]["launches"]},
+                     "checked": "%d alignments (every %dth pair: score, region, operations) equal to tests/golden/bench_configs.json"
+                                % (checked, want[name]["every"])}
+        b.close()
+    return out
+
+
 def revcomp(seq):
     return seq.translate(bytes.maketrans(b"ACGTacgt", b"TGCAtgca"))[::-1]
 
@@ -202,6 +243,7 @@ def main():
     ap.add_argument("--tlen", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-revcomp", action="store_true", help="skip the extra both-strands measurement")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE's other configurations (the `configs` block)")
     args = ap.parse_args()
 
     stub = os.environ.get("C4_BENCH_STUB") == "1"
@@ -285,12 +327,14 @@ def main():
     if use_dist:
         from exonerate_amd import parallel
         cdev = parallel.collective_device()
-    work = {"delivered": 0, "gathered_ints": 0}
+    work = {"delivered": 0, "gathered_ints": 0, "queue_s": 0.0, "align_s": 0.0, "gather_s": 0.0}
+    per_rank = {}
 
     def one_step(b, n_local):
         """One pass of the hot path over this rank's batch, as a work-queue step: rank 0 broadcasts the job
         header and scatters the work items (global pair ids; the residues are resident), every rank aligns its shard,
         the results (score, region, operations of every pair: c4gpu_batch_export) are gathered — tensors over RCCL/xGMI."""
+        c0 = time.perf_counter()
         if use_dist:
             head = torch.tensor([n_local, world, 2, 32] if rank == 0 else [0, 0, 0, 0], dtype=torch.int64, device=cdev)
             dist.broadcast(head, src=0)                                   # job header: items per rank, ranks, mode, -D
@@ -301,8 +345,12 @@ def main():
             else:
                 dist.scatter(mine, None, src=0)
             assert int(head[0].item()) == n_local and int(mine[0].item()) == rank * n_local, "work items do not match the resident shard"
+        work["queue_s"] += time.perf_counter() - c0                       # header broadcast + work-item scatter (incl. waiting for rank 0)
+        c0 = time.perf_counter()
         b.run(2)
         flat = b.export()                                                 # host copy of this rank's results, one stream
+        work["align_s"] += time.perf_counter() - c0                       # this rank's own alignment work
+        c0 = time.perf_counter()
         if use_dist:
             got = parallel.all_gather_ragged(torch.from_numpy(flat).to(cdev), cdev)
             if rank == 0:
@@ -316,6 +364,7 @@ def main():
         else:
             work["delivered"] += int(flat[:7 * n_local].reshape(n_local, 7)[:, 0].sum())
             work["gathered_ints"] += int(flat.size)
+        work["gather_s"] += time.perf_counter() - c0                      # result gather (incl. waiting for the slowest rank)
 
     def timed(b, steps, warmup, n_local=None):
         """W untimed + exactly K timed steps between barriers; max over ranks."""
@@ -326,21 +375,37 @@ def main():
         for m in range(4):
             b.kernel_stats(m, reset=True)
         work["delivered"] = work["gathered_ints"] = 0
+        work["queue_s"] = work["align_s"] = work["gather_s"] = 0.0
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             one_step(b, n_local)
+        t_own = time.perf_counter() - t0                                  # before the closing barrier: this rank's own K steps
         barrier()
         el = time.perf_counter() - t0
+        mine = [el, t_own, work["align_s"], work["queue_s"], work["gather_s"]]
+        rows = [mine]
         if use_dist:
             tmax = torch.tensor([el], dtype=torch.float64, device="cpu" if stub else "cuda")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el = float(tmax.item())
+            # every rank's own clock, for the reader of a scaling run: which rank was slow, and was it its alignment work,
+            # the work-queue collectives or the wait for the others
+            tl = [torch.zeros(len(mine), dtype=torch.float64, device="cpu" if stub else "cuda") for _ in range(world)]
+            dist.all_gather(tl, torch.tensor(mine, dtype=torch.float64, device="cpu" if stub else "cuda"))
+            rows = [[float(x) for x in t.tolist()] for t in tl]
+        per_rank["ms_per_step"] = [r[1] / steps * 1e3 for r in rows]
+        per_rank["align_ms_per_step"] = [r[2] / steps * 1e3 for r in rows]
+        per_rank["queue_ms_per_step"] = [r[3] / steps * 1e3 for r in rows]
+        per_rank["gather_ms_per_step"] = [r[4] / steps * 1e3 for r in rows]
+        a = per_rank["align_ms_per_step"]
+        per_rank["align_imbalance_max_over_min"] = max(a) / min(a) if min(a) > 0 else None
         return el
 
     flush_c_stdio()
     elapsed = timed(batch, args.steps, args.warmup)
     stats = {m: batch.kernel_stats(m) for m in range(4)}
+    ranks_report = dict(per_rank)                                         # of the headline run (the both-strands leg overwrites it)
     n_aligned = sum(1 for i in range(min(args.pairs, 64)) if batch.alignment(i) is not None)
 
     # both strands ("once with revcomp on, doubling cells"): what the reference does for DNA queries by
@@ -457,9 +522,14 @@ def main():
                            "alignments_delivered_per_step": work["delivered"] / max(1, args.steps),
                            "result_ints_per_step": work["gathered_ints"] / max(1, args.steps),
                            "probe_pair_identical_on_all_ranks": probe_same},
+            # every rank's own clock over the K timed steps (before the closing barrier), split into its alignment work, the
+            # work-queue collectives in front of it and the result gather behind it (both include waiting for other ranks)
+            "ranks": ranks_report,
         }
         if rc:
             out["revcomp"] = rc
+        if not args.no_configs and not use_dist and not stub:
+            out["configs"] = other_configs(ex, eng)
         # the all-cores leg runs at N=1 only; at N>1 the one-core leg ran before the process group was formed (early_cpu)
         if early_cpu is not None:
             rec, ref_line = early_cpu

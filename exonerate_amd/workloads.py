@@ -131,3 +131,20 @@ def protein_vs_contig(n_proteins, plen=500, contig_len=1000000, seed=20260931, i
             full[i] = pl
         places = full
     return [p.tobytes() for p in proteins], contig, places
+
+
+def bench_config(name):
+    """BASELINE.json's other configurations at their full sizes, as bench.py's `configs` block, tests/test_gpu_configs.py and
+    tools/make_bench_golden.py use them: (model name, pairs, place of each pair's planted gene in the shared contig or None).
+    c2: affine:local, 4 096 DNA pairs of 1 kb x 1 kb; c3: protein2dna, 1 024 proteins of 500 aa against ONE 1 Mb contig
+    (every fourth protein has its gene there); c5: protein2genome, exhaustive, 256 proteins of 300 aa against ONE 10 Mb
+    chromosome (every protein's intron-split gene is there)."""
+    if name == "c2":
+        return "affine:local", affine_dna_pairs(4096, 1000), None
+    if name == "c3":
+        proteins, contig, places = protein_vs_contig(1024, 500, 1000000, plant_every=4)
+        return "protein2dna", [(p, contig) for p in proteins], places
+    if name == "c5":
+        proteins, contig, places = protein_vs_contig(256, 300, 10000000, seed=20260935, introns=True)
+        return "protein2genome", [(p, contig) for p in proteins], places
+    raise ValueError("bench_config: c2, c3 or c5")
