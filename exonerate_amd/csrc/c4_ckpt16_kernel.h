@@ -509,7 +509,7 @@ void ckpt16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, con
     for (;;) {
         if (threadIdx.x == 0) next_job = atomicAdd(queue, 1);
         __syncthreads();
-        const int pid = next_job;
+        const int pid = __builtin_amdgcn_readfirstlane(next_job);      // wave-uniform: job descriptions and pointers in scalar registers
         __syncthreads();
         if (pid >= n_pairs) break;
         const int ia = pairs[2 * pid], ib = pairs[2 * pid + 1] >= 0 ? pairs[2 * pid + 1] : ia;

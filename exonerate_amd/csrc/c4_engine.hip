@@ -203,12 +203,19 @@ struct PrepTables {
 };
 
 // residue bytes -> substitution matrix row (Submat_lookup's index step, submat.h:54-56)
+// (codes, when given: the set of rows that occur, one bit each -- what the staged packed score pass sizes its query profile by)
 __global__ void encode_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, long long n,
-                              const PrepTables *__restrict__ tab, int *bad) {
+                              const PrepTables *__restrict__ tab, int *bad, int *codes = nullptr) {
+    int seen = 0;
     for (long long x = blockIdx.x * (long long)blockDim.x + threadIdx.x; x < n; x += (long long)gridDim.x * blockDim.x) {
         const uint8_t c = tab->submat_index[in[x]];
         if (c >= 24) atomicExch(bad, 1);
         out[x] = c >= 24 ? 0 : c;
+        seen |= 1 << (c >= 24 ? 0 : c);
+    }
+    if (codes) {
+        for (int off = 32; off > 0; off >>= 1) seen |= __shfl_xor(seen, off);
+        if ((threadIdx.x & 63) == 0 && seen) atomicOr(codes, seen);
     }
 }
 
@@ -537,6 +544,10 @@ struct ResidentSeqs {
     mutable DevBuf<uint2> ss16;            // the packed score pass's splice values (built on its first launch over this batch)
     mutable bool ss16_built = false;
     mutable std::mutex ss16_lock;          // two lanes may reach the first packed launch together
+    // the residue codes the targets hold, for the staged packed score pass (c4_viterbi16_kernel.h, IO 1): [0, 24) code -> dense
+    // index (0xff: absent), [24, 32) dense index -> code; tdense_n = 0: not known (codon-coded targets)
+    DevBuf<uint8_t> tdense;
+    int tdense_n = 0;
     long long ss_len = 0;                 // positions per splice array
     DevBuf<PrepTables> tables;
     DevBuf<c4gpu_splice_model> splice_models;
@@ -620,8 +631,8 @@ struct ResidentSeqs {
             d_utoff.upload(utoff.data(), n_utargets, s) || d_utlen.upload(utlen.data(), n_utargets, s))
             return -1;
         if (trace) { HIP_OK(hipStreamSynchronize(s)); lap("uploaded"); }
-        int zero = 0;
-        if (bad.upload(&zero, 1, s)) return -1;
+        int zero[2] = {0, 0};
+        if (bad.upload(zero, 2, s)) return -1;
         const int blocks = 1024;
         hipLaunchKernelGGL(encode_kernel, dim3(blocks), dim3(256), 0, s, qraw.p, qcode.p, (long long)hq.size(), tables.p, bad.p);
         int max_t = 1;
@@ -630,7 +641,7 @@ struct ResidentSeqs {
         if (family_is_p2d(family)) {
             hipLaunchKernelGGL(codon_kernel, dim3(xb, yb), dim3(256), 0, s, traw.p, tcode.p, d_utoff.p, d_utlen.p, n_utargets, tables.p, bad.p);
         } else {
-            hipLaunchKernelGGL(encode_kernel, dim3(blocks), dim3(256), 0, s, traw.p, tcode.p, (long long)ht.size(), tables.p, bad.p);
+            hipLaunchKernelGGL(encode_kernel, dim3(blocks), dim3(256), 0, s, traw.p, tcode.p, (long long)ht.size(), tables.p, bad.p, bad.p + 1);
         }
         dev.ss = nullptr;
         dev.ss16 = nullptr;
@@ -652,9 +663,24 @@ struct ResidentSeqs {
         }
         HIP_OK(hipGetLastError());
         lap("kernels queued");
-        int hbad = 0;
-        if (bad.download(&hbad, 1, s)) return -1;
+        int hbad2[2] = {0, 0};
+        if (bad.download(hbad2, 2, s)) return -1;
         HIP_OK(hipStreamSynchronize(s));
+        const int hbad = hbad2[0];
+        tdense_n = 0;
+        if (!family_is_p2d(family) && hbad2[1]) {
+            uint8_t tab[32];
+            memset(tab, 0xff, 24);
+            memset(tab + 24, 0, 8);
+            int nd = 0;
+            for (int c = 0; c < 24; c++)
+                if (hbad2[1] >> c & 1) { if (nd < 8) { tab[c] = (uint8_t)nd; tab[24 + nd] = (uint8_t)c; } nd++; }
+            if (nd <= 8) {
+                if (tdense.upload(tab, 32, s)) return -1;
+                HIP_OK(hipStreamSynchronize(s));
+                tdense_n = nd;
+            }
+        }
         lap("coded, splice arrays built");
         if (hbad) {
             c4h::set_error(hbad == 2 ? "a target codon translates outside the substitution matrix alphabet (non-IUPAC base?)"
@@ -986,6 +1012,7 @@ struct Engine {
             }
             cont_free = !cells_leave && cont_free_ok(worst);
         }
+        const uint8_t *staged_codes = nullptr;         // set with the staged packed score pass: its residue-code table
         const KernelInfo *ki = get_kernel(family, mode, cont, cont ? cont_free : use_local, pack, pts ? 0 : wpe_env, pts != nullptr, span);
         if (!ki && cont_free) ki = get_kernel(family, mode, cont, false, pack, pts ? 0 : wpe_env, pts != nullptr, span);
         if (!ki) { c4h::set_error("no compiled kernel for this model/mode"); return -1; }
@@ -1014,6 +1041,15 @@ struct Engine {
                     bool rows_ok = true;
                     for (int i = 0; i < n && rows_ok; i++) rows_ok = specs[i].region.query_length < 32000;
                     if (rows_ok) { ki = kd; seed->fmt16 = true; }
+                    // ... and with its column loop fed from LDS alone (IO 1) where every query fits the strips of one workgroup
+                    // and the targets hold few enough residue codes for the query profile (C4GPU_PK16_IO=0: never)
+                    const int io_env = getenv("C4GPU_PK16_IO") ? atoi(getenv("C4GPU_PK16_IO")) : 1;
+                    const KernelInfo *ke = (rows_ok && io_env) ? get_kernel_pk16(family, 4) : nullptr;
+                    if (ke && seqs.tdense_n > 0 && seqs.tdense_n <= pk16_staged_codes()) {
+                        bool strips_ok = true;
+                        for (int i = 0; i < n && strips_ok; i++) strips_ok = specs[i].region.query_length + 1 <= pk16_staged_rows();
+                        if (strips_ok) { ki = ke; staged_codes = seqs.tdense.p; }
+                    }
                 }
             }
             if (seed->mode == 1) { seed->seedw = ki->seedw; seed->dc = ki->max_at; }
@@ -1131,6 +1167,7 @@ struct Engine {
         int blocks_per_cu = 0;
         HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, ki->func, 64 * ki->waves, 0));
         if (blocks_per_cu < 1) blocks_per_cu = 1;
+        if (seed && getenv("C4GPU_TRACE")) fprintf(stderr, "c4gpu trace:   kernel %s: %d workgroups per CU\n", ki->name, blocks_per_cu);
         // the kernels that run two jobs per lane in pairs the host lists: neighbours of the same root
         std::vector<int> pair_list;
         if (ki->pairs)
@@ -1205,6 +1242,7 @@ struct Engine {
                 if (d_pairs.upload(pair_list.data(), pair_list.size(), s)) return -1;
                 a.aux = d_pairs.p; a.n_aux = (int)(pair_list.size() / 2);
             }
+            if (staged_codes) a.aux = reinterpret_cast<const int *>(staged_codes);
             a.scratch.bnd = d_bnd.p; a.scratch.bnd_stride = bnd_per_wave; a.scratch.carry = carry_T ? 1 : 0;
             a.scratch.tb = max_tb ? d_tb.p : nullptr; a.scratch.tb_stride = max_tb;
             a.scratch.ckpt = max_ckpt ? d_ckpt.p : nullptr; a.scratch.ckpt_stride = max_ckpt;
@@ -1722,6 +1760,9 @@ int windowed_region_pass(Engine &eng, const ResidentSeqs &seqs, const std::vecto
             const DevResult &r = wouts[h].res;
             DevResult &o = out[want[h]];
             if (!r.end_set || r.score != o.score) {
+                if (getenv("C4GPU_TRACE"))
+                    fprintf(stderr, "c4gpu trace:   pair %d: score pass %d at (%d, %d), window corner %d (set %d)\n", pairs[want[h]],
+                            o.score, o.qe, o.te, r.score, (int)r.end_set);
                 c4h::set_error("windowed region pass: a window's corner cell differs from the score pass");
                 return -1;
             }
@@ -1740,6 +1781,9 @@ int windowed_region_pass(Engine &eng, const ResidentSeqs &seqs, const std::vecto
             const DevResult &r = outs[h].res;
             DevResult &o = out[open[h]];
             if (r.score != o.score || r.qe != o.qe || r.te != o.te) {
+                if (getenv("C4GPU_TRACE"))
+                    fprintf(stderr, "c4gpu trace:   pair %d: score pass %d at (%d, %d), one-pass kernel %d at (%d, %d)\n", pairs[open[h]],
+                            o.score, o.qe, o.te, r.score, r.qe, r.te);
                 c4h::set_error("windowed region pass: the one-pass kernel disagrees with the score pass");
                 return -1;
             }

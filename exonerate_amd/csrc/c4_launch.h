@@ -75,6 +75,10 @@ const KernelInfo *get_kernel_ck16(int family, int variant = 0, bool rooted = fal
 // the packed 16-bit region windows (c4_win16_kernel.h): two windows per lane, one wave per pair of window chains, started from
 // the 16-bit dumps of get_kernel_pk16(family, 3); variant: rows per lane / register cap shapes (0 = the default)
 const KernelInfo *get_kernel_win16(int family, int variant = 0);
+// the staged form of the packed score pass (get_kernel_pk16(family, 4)): residue codes its query profile holds, query rows
+// (Q + 1) a workgroup covers
+int pk16_staged_codes();
+int pk16_staged_rows();
 hipError_t pk16_build_splice(int family, const KParams *kp, const int *ss, long long ss_stride, long long n, void *out, hipStream_t s);
 
 #define C4K_DEFINE_KERNEL_SPAN(SYMBOL, M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV, SPANV)                                          \

@@ -137,7 +137,19 @@ struct Dump16 {
     }
 };
 
-template <class M, int R, int VAR = 0, bool DUMP16 = false>
+// IO 1 (the launch's queries fit ONE super-strip of the cooperating waves and its targets hold at most NCODE different
+// residue codes): nothing of the column loop goes through vector memory or a wave-uniform branch.
+//   * every strip boundary is an LDS ring (the first wave reads a constant empty column, the last one writes a column
+//     nobody reads): no HBM carry row, no "ring or memory" branch around the carry reads and writes;
+//   * the column inputs -- the four splice values of both jobs, already interleaved into packed halves, and the residue
+//     codes -- come from a per-wave LDS stage of 128 columns that the wave refills every chunk (64 coalesced columns,
+//     clamped once there): a step reads its column with two LDS reads instead of four global loads, their clamps, address
+//     arithmetic and the four v_perm;
+//   * the substitution scores of a lane's R query rows against each residue code sit in LDS as one 8-byte entry per
+//     (job, code, lane) -- a query profile, rebuilt per strip: a step reads two entries (conflict-free: the bank depends on
+//     the lane only) instead of 2 R table words at computed addresses.
+// 301 -> ~225 instructions per step of 8 cells (profiles/r04_score_budget.md).
+template <class M, int R, int VAR = 0, bool DUMP16 = false, int IO = 0>
 struct WaveDP16 {
     using F = Facts<M>;
     using W32 = WaveDP<M, R, MODE_SCORE, false, true, false, false, 0, 1>;     // the 32-bit score pass: dump layout
@@ -145,13 +157,24 @@ struct WaveDP16 {
     static constexpr int NS = M::NS, NCOL = M::MAXAT + 1, W = 64 * R, DC = M::MAXAT, SEEDW = DUMP16 ? D16::SEEDW16 : W32::SEEDW;
     static constexpr bool live(int s) { return M::NDES > 0 && W32::slot_live(s, 0); }
     static constexpr int NEXP = F::n_exported();
-    static constexpr int BND = NEXP * 2;                 // ints per column between strips: score pair + length pair per exported state
+    static constexpr int n_exported_live() { int n = 0; for (int x = 0; x < NS; x++) n += (F::exported(x) && live(x)); return n; }
+    // ints per column between strips: score pair + length pair per exported state (IO 1: a length pair only where one is live)
+    static constexpr int BND = IO ? (NEXP + n_exported_live() + 3) / 4 * 4 : NEXP * 2;
     static constexpr int RING = 256;
-    static constexpr int CH = (64 + NCOL - 1) / NCOL * NCOL;
+    // steps between two meetings of the cooperating waves; IO 1: also between two refills of the column stage, whose 128
+    // columns hold the 63 + 64 columns the lanes of a wave read during a chunk
+    static constexpr int CH = IO ? 63 / NCOL * NCOL : (64 + NCOL - 1) / NCOL * NCOL;
+    static constexpr int NCODE = 6;                      // IO 1: residue codes a launch's targets may hold
+    static constexpr int STAGE_COLS = 128, STAGE_INTS = 8;        // column stage: 32 bytes per column
+    static constexpr int PROF_INTS = NCODE * 128;                 // query profile: ints per (wave, job): [code][lane] of 8 bytes
+    static_assert(!IO || (VAR >= 1 && F::has_splice() && R == 4), "the staged form is built for the packed splice entries and 4 rows per lane");
     static_assert(!F::has_phase(), "split-codon calcs are not packed");
     static_assert(M::NDES <= 1, "one shadow designation");
     typedef __attribute__((address_space(3))) int lds_int;
     struct C16 { int sc[NS]; int il[NS]; };
+    // an LDS byte address kept as a number (it is advanced and masked like one) back to a pointer
+    __device__ __forceinline__ static lds_int *lds_at(int a) { return (lds_int *)(size_t)(unsigned)a; }
+    __device__ __forceinline__ static int lds_addr(const lds_int *p) { return (int)(unsigned)(size_t)p; }
 
     const KParams *kp;
     int lane;
@@ -170,7 +193,16 @@ struct WaveDP16 {
     uint2 nx_sp16[2];
     lds_int *ring_in, *ring_out;
     bool use_ring_in, use_ring_out, carry_ok, carry_cols;
+    // IO 1
+    int ring_in_mask, ring_out_mask;                    // 255, or 0 for the constant column of the first / last wave
+    int nx_sp4[4], nx_off[2];                           // next column: packed splice values; profile byte offsets of its two codes
+    int nx_prof[4];                                     // ... and the profile entries of those codes: job A rows 0-1, 2-3, job B rows 0-1, 2-3
+    int prof_a[2];                                      // LDS byte address of this lane's profile entry of code 0, per job
+    int stage_a, stage_base;                            // LDS byte address of the next column's stage entry; of the wave's stage (4 KB-aligned)
+    const uint8_t *tdense;                              // [24] code -> dense index (0xff: not in the launch), [24 + d] code of index d
     int best[2], best_i[2], best_j[2], best_pk;
+    int unset_pk;                       // what best_pk holds for a job without an end cell yet: -32 768; IO 1, a lane none of whose rows
+                                        // belongs to the job: 32 767 (nothing of it can be an end cell, nothing beats it)
     // best_i: (query row << 4) | the state the cell's END was entered from (Roots): the row-major order of the rows is
     // that of these numbers, and no register is spent on the state
     static_assert(M::NS <= 16, "state in four bits");
@@ -182,14 +214,26 @@ struct WaveDP16 {
     __device__ __forceinline__ static void for_exported(Fn &&fn) {
         int slot = 0;
         static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
-            if constexpr (F::exported(S)) { fn(S_, slot); slot += 2; }
+            if constexpr (F::exported(S)) { fn(S_, slot); slot += IO ? (live(S) ? 2 : 1) : 2; }
         });
     }
-    __device__ __forceinline__ static void write_empty_column(int *colp) {
-        for_exported([&](auto S_, int slot) __attribute__((always_inline)) { colp[slot] = NEG16; colp[slot + 1] = 0; });
+    template <class P>
+    __device__ __forceinline__ static void write_empty_column(P colp) {
+        for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
+            colp[slot] = NEG16;
+            if constexpr (!IO || live(S)) colp[slot + 1] = 0;
+        });
     }
     __device__ __forceinline__ void prefetch_carry(int s_next, const int *bnd_in) {
         const int jx = s_next < 0 ? 0 : (s_next > Tm ? Tm : s_next);
+        if constexpr (IO == 1) {
+            const lds_int *p = ring_in + (jx & ring_in_mask) * BND;
+            for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
+                nx_carry.sc[S] = p[slot];
+                if constexpr (live(S)) nx_carry.il[S] = p[slot + 1];
+            });
+            return;
+        }
         const int jc = (carry_cols | use_ring_in) ? jx : 0;
         if (use_ring_in) {
             for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
@@ -205,7 +249,67 @@ struct WaveDP16 {
             });
         }
     }
+    // IO 1: the next column's entry of the stage (the lane's columns follow each other: a running address)
+    __device__ __forceinline__ void prefetch_staged() {
+        const lds_int *p = lds_at(stage_a);
+        static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; nx_sp4[K] = p[K]; });
+        nx_off[0] = p[4]; nx_off[1] = p[5];
+        stage_a = ((stage_a + STAGE_INTS * 4) & (STAGE_COLS * STAGE_INTS * 4 - 1)) | stage_base;
+    }
+    // IO 1: the profile entries of the next column's codes; issued in the middle of a step, when the stage entry has arrived
+    __device__ __forceinline__ void prefetch_profile() {
+        const lds_int *pa = lds_at(prof_a[0] + nx_off[0]), *pb = lds_at(prof_a[1] + nx_off[1]);
+        nx_prof[0] = pa[0]; nx_prof[1] = pa[1]; nx_prof[2] = pb[0]; nx_prof[3] = pb[1];
+    }
+    // IO 1: columns c0 + lane of both jobs into the stage -- clamped as prefetch_column clamps them, the splice values of the two
+    // jobs interleaved into packed halves (what step() did with four v_perm per step), the residue codes as profile offsets
+    __device__ __forceinline__ void fill_stage(lds_int *stage, int c0) {
+        constexpr int mat = F::match_at();
+        const int c = c0 + lane;
+        uint2 sv[2]; int off[2];
+        static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
+            int ti = t0[H] + c - mat;
+            ti = ti < 0 ? 0 : (ti > tlast[H] ? tlast[H] : ti);
+            int tp = t0[H] + c - 2;
+            tp = tp < 0 ? 0 : (tp > tlast[H] ? tlast[H] : tp);
+            sv[H] = ss16[H][(unsigned)tp];
+            off[H] = (int)tdense[tc[H][(unsigned)ti]] * 512;
+        });
+        lds_int *p = stage + (c & (STAGE_COLS - 1)) * STAGE_INTS;
+        p[0] = (int)__builtin_amdgcn_perm(sv[1].x, sv[0].x, 0x05040100u);
+        p[1] = (int)__builtin_amdgcn_perm(sv[1].x, sv[0].x, 0x07060302u);
+        p[2] = (int)__builtin_amdgcn_perm(sv[1].y, sv[0].y, 0x05040100u);
+        p[3] = (int)__builtin_amdgcn_perm(sv[1].y, sv[0].y, 0x07060302u);
+        p[4] = off[0]; p[5] = off[1];
+    }
+    // IO 1: the substitution scores of this lane's R rows against every residue code of the launch: one 8-byte entry per
+    // (job, code, lane), four 16-bit scores.  Rows below a job's last one (the rest of the last strip; nothing above reads
+    // them, nothing of them is dumped or reported) score DEAD_ROW against everything: their match state then never leaves the 0
+    // START gives it, and their END never beats a best score -- without that the lanes that hold such rows would send their
+    // wave through the end-cell bookkeeping in every step (counters of round 4: 131 instructions, a quarter of the waves).
+    static constexpr int DEAD_ROW = -16000;
+    __device__ __forceinline__ void build_profile(int i0) {
+        static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
+            int qr[R];
+            static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                const int i = i0 + RR;
+                qr[RR] = 24 * ((i >= 1 && i <= Q[H]) ? (int)qc[H][q0[H] + i - 1] : 0);
+            });
+            for (int d = 0; d < NCODE; d++) {
+                const int code = tdense[24 + d];
+                int v[R];
+                static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                    v[RR] = (i0 + RR > Q[H]) ? DEAD_ROW : clamp16(kp->submat[qr[RR] + code]);
+                });
+                lds_int *p = lds_at(prof_a[H] + d * 512);
+                p[0] = pk_pack(v[0], v[1]);
+                p[1] = pk_pack(v[2], v[3]);
+            }
+        });
+    }
+
     __device__ __forceinline__ void prefetch_column(int j) {
+        if constexpr (IO == 1) { prefetch_staged(); return; }
         constexpr int mat = F::match_at();
         static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
             int ti = t0[H] + j - mat;
@@ -272,11 +376,21 @@ struct WaveDP16 {
     __device__ __forceinline__ void step(int s, int i0, bool last_strip, const int *bnd_in, int *bnd_out) {
         const int j = s - lane;
         int ms[R];
-        static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
-            ms[RR] = pk_pack(kp->submat[qrow[0][RR] + nx_tcode[0]], kp->submat[qrow[1][RR] + nx_tcode[1]]);
-        });
+        if constexpr (IO == 1) {
+            const int a0 = nx_prof[0], a1 = nx_prof[1], b0 = nx_prof[2], b1 = nx_prof[3];
+            ms[0] = (int)__builtin_amdgcn_perm((unsigned)b0, (unsigned)a0, 0x05040100u);
+            ms[1] = (int)__builtin_amdgcn_perm((unsigned)b0, (unsigned)a0, 0x07060302u);
+            ms[2] = (int)__builtin_amdgcn_perm((unsigned)b1, (unsigned)a1, 0x05040100u);
+            ms[3] = (int)__builtin_amdgcn_perm((unsigned)b1, (unsigned)a1, 0x07060302u);
+        } else {
+            static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                ms[RR] = pk_pack(kp->submat[qrow[0][RR] + nx_tcode[0]], kp->submat[qrow[1][RR] + nx_tcode[1]]);
+            });
+        }
         int sp[4] = {0, 0, 0, 0};
-        if constexpr (F::has_splice() && VAR >= 1) {
+        if constexpr (IO == 1) {
+            static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; sp[K] = nx_sp4[K]; });
+        } else if constexpr (F::has_splice() && VAR >= 1) {
             // the values arrive clamped, with the calc constant of a pre-splice transition folded in (ss16_kernel): job A's
             // four in the halves of nx_sp16[0], job B's in nx_sp16[1]; one v_perm each puts a value of both into one register
             sp[0] = (int)__builtin_amdgcn_perm(nx_sp16[1].x, nx_sp16[0].x, 0x05040100u);
@@ -300,6 +414,9 @@ struct WaveDP16 {
         prefetch_column(j + 1);
         static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
             eval_cell<RR, PH, JINT>(j, ms[RR], sp);
+            // IO 1: half-way through the step the stage entry read above has arrived; the profile entries it points to are then
+            // there when the next step starts
+            if constexpr (IO == 1 && RR == R / 2 - 1) prefetch_profile();
         });
         // end cell (viterbi.c:778-791): a new maximum is rare; one packed maximum over the lane's cells decides
         {
@@ -329,14 +446,23 @@ struct WaveDP16 {
                         best_set[H] = best_set[H] | upd;
                     });
                 });
-                best_pk = pk_pack(best_set[0] ? best[0] : -32768, best_set[1] ? best[1] : -32768);
+                best_pk = pk_pack(best_set[0] ? best[0] : pk_half(unset_pk, 0), best_set[1] ? best[1] : pk_half(unset_pk, 1));
             }
         }
         for_exported([&](auto S_, int) __attribute__((always_inline)) { constexpr int S = S_;
             expo.sc[S] = col[PH][R - 1].sc[S];
             if constexpr (live(S)) expo.il[S] = col[PH][R - 1].il[S];
         });
-        if (!last_strip && lane == 63 && j >= 0 && j <= Tm) {
+        if constexpr (IO == 1) {
+            // the last wave's ring is one column nobody reads; inside the rectangle's columns (JINT) lane 63 is always on a column
+            if (lane == 63 && (JINT || (j >= 0 && j <= Tm))) {
+                lds_int *p = ring_out + (j & ring_out_mask) * BND;
+                for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
+                    p[slot] = expo.sc[S];
+                    if constexpr (live(S)) p[slot + 1] = expo.il[S];
+                });
+            }
+        } else if (!last_strip && lane == 63 && j >= 0 && j <= Tm) {
             if (use_ring_out) {
                 for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
                     lds_int *p = ring_out + (j & (RING - 1)) * BND + slot;
@@ -392,7 +518,7 @@ struct WaveDP16 {
             sbest[H] = best[H]; sbest_i[H] = best_i[H]; sbest_j[H] = best_j[H]; sbest_set[H] = best_set[H];
             best_set[H] = false; best[H] = LOW;
         });
-        best_pk = NEG16;
+        best_pk = unset_pk;
     }
     __device__ __forceinline__ void strip_end() {
         static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
@@ -420,9 +546,15 @@ struct WaveDP16 {
     // barriers) and wave w+1 has finished chunk k-4 (the ring slots it is about to overwrite have been read: a ring holds
     // 256 columns, a chunk 66, lane 63 writes 63 columns behind the step) -- up to two chunks of slack per neighbour
     // instead of lock-step.
+    // (IO 1: `stage` is this wave's column stage, `edge` the two constant columns -- the empty one the first wave reads and the
+    // one the last wave writes; prof_a and tdense are set by the kernel)
     template <int NW>
     __device__ __forceinline__ void run_mw(const DevJob &ja, const DevJob &jb, const DevSeqs &seqs, int *bnd, lds_int *rings, int wid,
-                                           lds_int *prog = nullptr) {
+                                           lds_int *prog = nullptr, lds_int *stage = nullptr, lds_int *edge = nullptr) {
+        static_assert(!(IO == 1 && VAR == 2), "the staged form keeps the chunk barriers");
+        // chunks a wave runs behind the wave above it: the row above must be there one column ahead of the step that reads it,
+        // i.e. SKEW * CH - 1 - 63 >= CH
+        constexpr int SKEW = (CH >= 64) ? 2 : 3;
         const DevJob *jp[2] = {&ja, &jb};
         static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
             const DevJob &jx = *jp[H];
@@ -458,12 +590,18 @@ struct WaveDP16 {
         for (int sb = 0; sb < nsuper; sb++) {
             const int b = sb * NW + wid;
             const int i0 = b * W + lane * R;
-            static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
-                static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
-                    const int i = i0 + RR;
-                    qrow[H][RR] = 24 * ((i >= 1 && i <= Q[H]) ? (int)qc[H][q0[H] + i - 1] : 0);
+            unset_pk = NEG16;
+            if constexpr (IO == 1) {
+                build_profile(i0);
+                unset_pk = pk_pack(i0 > Q[0] ? 32767 : -32768, i0 > Q[1] ? 32767 : -32768);
+            } else {
+                static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
+                    static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+                        const int i = i0 + RR;
+                        qrow[H][RR] = 24 * ((i >= 1 && i <= Q[H]) ? (int)qc[H][q0[H] + i - 1] : 0);
+                    });
                 });
-            });
+            }
             static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
                 expo.sc[S] = NEG16; expo.il[S] = 0;
                 static_for<NCOL>([&](auto D_) __attribute__((always_inline)) { constexpr int D = D_;
@@ -479,6 +617,14 @@ struct WaveDP16 {
             use_ring_in = wid > 0; use_ring_out = wid < NW - 1;
             ring_in = rings + (wid > 0 ? wid - 1 : 0) * RING * BND;
             ring_out = rings + (wid < NW - 1 ? wid : 0) * RING * BND;
+            if constexpr (IO == 1) {
+                if (wid == 0) ring_in = edge;
+                if (wid == NW - 1) ring_out = edge + BND;
+                ring_in_mask = wid > 0 ? RING - 1 : 0;
+                ring_out_mask = wid < NW - 1 ? RING - 1 : 0;
+                stage_base = lds_addr(stage);
+                stage_a = lds_addr(stage) + ((0 - lane) & (STAGE_COLS - 1)) * STAGE_INTS * 4;
+            }
             const bool last = (b >= nstrips - 1), idle = (b >= nstrips);
             auto group = [&](auto JI_, int s0) __attribute__((always_inline)) {
                 constexpr bool JI = decltype(JI_)::value != 0;
@@ -496,6 +642,7 @@ struct WaveDP16 {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             };
             auto before = [&](int k) __attribute__((always_inline)) {
+                if constexpr (IO == 1) fill_stage(stage, k * CH + 1);           // columns k CH + 1 ... k CH + 64: what this chunk's steps read ahead
                 if constexpr (FLAGS) {
                     if (wid > 0) wait_for(wid - 1, k + 2 < nchunks ? k + 2 : nchunks);
                     if (wid < NW - 1 && k >= 4) wait_for(wid + 1, k - 3);
@@ -509,13 +656,15 @@ struct WaveDP16 {
                 if (lane == 0) __hip_atomic_store(prog + wid, idle ? 0x40000000 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __syncthreads();
             } else {
-                for (int t = 0; t < 2 * wid; t++) __syncthreads();
+                for (int t = 0; t < SKEW * wid; t++) __syncthreads();
             }
             if (idle) {
                 if constexpr (!FLAGS) for (int k = 0; k < nchunks; k++) __syncthreads();
             } else {
-                before(0);                           // the first carry column is read ahead of the first step
+                if constexpr (IO == 1) fill_stage(stage, -63);         // columns -63 ... 0: what the first steps of the lanes read
+                else before(0);                      // the first carry column is read ahead of the first step
                 prefetch_column(0 - lane);
+                if constexpr (IO == 1) prefetch_profile();
                 prefetch_carry(0, bnd_in);
                 int k = 0;
                 for (; k < nchunks && k * CH < main_lo; k++) {
@@ -534,7 +683,7 @@ struct WaveDP16 {
                     after(k);
                 }
             }
-            if constexpr (!FLAGS) for (int t = 0; t < 2 * (NW - 1 - wid); t++) __syncthreads();
+            if constexpr (!FLAGS) for (int t = 0; t < SKEW * (NW - 1 - wid); t++) __syncthreads();
             strip_end();
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
@@ -563,23 +712,35 @@ __global__ void ss16_kernel(const KParams *kp, const int *ss, long long ss_strid
 
 // NW cooperating waves per PAIR of jobs: workgroup p of the queue runs jobs 2p and 2p + 1 (the last one alone when the
 // launch holds an odd number: its high half repeats it)
-template <class M, int R, int NW, int WPE, int VAR = 0, bool DUMP16 = false>
+// (IO 1: `tdense` is the launch's residue-code table -- [0, 24) code -> dense index, [24, 24 + NCODE) dense index -> code; the
+// host takes this kernel only when every query fits NW strips and the targets hold at most NCODE codes)
+template <class M, int R, int NW, int WPE, int VAR = 0, bool DUMP16 = false, int IO = 0>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
 void viterbi16_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, int n_jobs, DevResult *results,
-                         DevScratch scratch, int *queue) {
-    using DP = WaveDP16<M, R, VAR, DUMP16>;
-    __shared__ KParams kp_lds;
+                         DevScratch scratch, int *queue, const uint8_t *tdense = nullptr) {
+    using DP = WaveDP16<M, R, VAR, DUMP16, IO>;
+    // IO 1 leaves the launch constants in memory (a strip reads them once) and spends the LDS on the column stages (4 KB per
+    // wave, 4 KB-aligned: the running stage address wraps with one v_and_or), the query profiles and the rings: 52.2 KB per
+    // workgroup, three workgroups per CU
+    __shared__ __attribute__((aligned(4096))) int stage_mem[IO ? NW * DP::STAGE_COLS * DP::STAGE_INTS : 1];
+    __shared__ __attribute__((aligned(16))) int prof_mem[IO ? NW * 2 * DP::PROF_INTS : 1];
+    __shared__ __attribute__((aligned(16))) int edge_cols[IO ? 2 * DP::BND : 1];
+    __shared__ __attribute__((aligned(16))) int kp_stage[IO ? 1 : (sizeof(KParams) + 3) / 4];
     __shared__ int next_job;
-    __shared__ int rings[(NW > 1 ? NW - 1 : 1) * DP::RING * DP::BND];
+    __shared__ __attribute__((aligned(16))) int rings[(NW > 1 ? NW - 1 : 1) * DP::RING * DP::BND];
     __shared__ int wave_best[NW][2][4];
     __shared__ int progress[NW];
-    {
+    if constexpr (IO == 0) {
         const int *src = reinterpret_cast<const int *>(kparams);
-        int *dst = reinterpret_cast<int *>(&kp_lds);
+        int *dst = kp_stage;
         for (int x = threadIdx.x; x < (int)(sizeof(KParams) / sizeof(int)); x += 64 * NW) dst[x] = src[x];
+    } else {
+        if (threadIdx.x == 0) DP::write_empty_column((typename DP::lds_int *)edge_cols);
     }
     __syncthreads();
-    const int wid = threadIdx.x >> 6;
+    // wave-uniform by construction: said to the compiler, so that what follows from them (job descriptions, sequence and ring
+    // pointers, strip bounds) lives in scalar registers
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int *bnd = scratch.bnd + (long long)blockIdx.x * scratch.bnd_stride;
     if (threadIdx.x == 0) DP::write_empty_column(bnd);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -588,15 +749,25 @@ void viterbi16_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *job
     for (;;) {
         if (threadIdx.x == 0) next_job = atomicAdd(queue, 1);
         __syncthreads();
-        const int pid = next_job;
+        const int pid = __builtin_amdgcn_readfirstlane(next_job);
         __syncthreads();
         if (pid >= n_pairs) break;
         const int ia = 2 * pid, ib = (2 * pid + 1 < n_jobs) ? 2 * pid + 1 : 2 * pid;
         DP dp;
-        dp.kp = &kp_lds;
         dp.lane = threadIdx.x & 63;
         dp.carry_ok = scratch.carry != 0;
-        dp.template run_mw<NW>(jobs[ia], jobs[ib], seqs, bnd, (typename DP::lds_int *)rings, wid, (typename DP::lds_int *)progress);
+        if constexpr (IO == 1) {
+            dp.kp = kparams;
+            dp.tdense = tdense;
+            static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
+                dp.prof_a[H] = DP::lds_addr((typename DP::lds_int *)prof_mem + (wid * 2 + H) * DP::PROF_INTS) + dp.lane * 8;
+            });
+            dp.template run_mw<NW>(jobs[ia], jobs[ib], seqs, bnd, (typename DP::lds_int *)rings, wid, (typename DP::lds_int *)progress,
+                                   (typename DP::lds_int *)stage_mem + wid * DP::STAGE_COLS * DP::STAGE_INTS, (typename DP::lds_int *)edge_cols);
+        } else {
+            dp.kp = reinterpret_cast<const KParams *>(kp_stage);
+            dp.template run_mw<NW>(jobs[ia], jobs[ib], seqs, bnd, (typename DP::lds_int *)rings, wid, (typename DP::lds_int *)progress);
+        }
         dp.reduce_best();
         if (dp.lane == 0)
             for (int h = 0; h < 2; h++) {

@@ -1224,7 +1224,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
     for (;;) {
         if (threadIdx.x == 0) next_job = atomicAdd(queue, 1);
         __syncthreads();
-        const int jid = next_job;
+        const int jid = __builtin_amdgcn_readfirstlane(next_job);      // wave-uniform: job descriptions and pointers in scalar registers
         __syncthreads();
         if (jid >= n_jobs) break;
         const DevJob &job = jobs[jid];
@@ -1306,7 +1306,7 @@ void viterbi_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *jobs,
         for (int x = threadIdx.x; x < (int)(sizeof(KParams) / sizeof(int)); x += 64 * NW) dst[x] = src[x];
     }
     __syncthreads();
-    const int wid = threadIdx.x >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int *bnd = scratch.bnd + (long long)blockIdx.x * scratch.bnd_stride;
     if (threadIdx.x == 0) DP::write_empty_column(bnd);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1314,7 +1314,7 @@ void viterbi_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *jobs,
     for (;;) {
         if (threadIdx.x == 0) next_job = atomicAdd(queue, 1);
         __syncthreads();
-        const int jid = next_job;
+        const int jid = __builtin_amdgcn_readfirstlane(next_job);      // wave-uniform: job descriptions and pointers in scalar registers
         __syncthreads();
         if (jid >= n_jobs) break;
         if constexpr (SEED == 2) {

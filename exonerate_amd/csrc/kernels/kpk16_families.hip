@@ -18,6 +18,19 @@ PK16_KERNEL(kpk16b_est2genome, Est2GenomeDesc, 4, 4, 3, 1, false)
 PK16_KERNEL(kpk16c_est2genome, Est2GenomeDesc, 4, 4, 3, 2, false)
 // variant 3: variant 1 with its column dumps in 16-bit form (Dump16), what the packed region windows (c4_win16_kernel.h) read
 PK16_KERNEL(kpk16d_est2genome, Est2GenomeDesc, 4, 4, 3, 1, true)
+// variant 4: variant 3 with its column loop fed from LDS only (c4_viterbi16_kernel.h, IO 1: column stage, query profile, every strip
+// boundary a ring); for launches whose queries fit the four strips of a workgroup and whose targets hold at most six residue
+// codes; the launch's code table arrives in LaunchArgs::aux
+static hipError_t kpk16e_est2genome_launch(const LaunchArgs &a) {
+    hipLaunchKernelGGL((viterbi16_kernel_mw<Est2GenomeDesc, 4, 4, 3, 1, true, 1>), dim3(a.grid), dim3(64 * 4), 0, a.stream,
+                       a.kp, a.seqs, a.jobs, a.n_jobs, a.results, a.scratch, a.queue, reinterpret_cast<const uint8_t *>(a.aux));
+    return hipGetLastError();
+}
+static const KernelInfo kpk16e_est2genome = {kpk16e_est2genome_launch, (const void *)viterbi16_kernel_mw<Est2GenomeDesc, 4, 4, 3, 1, true, 1>,
+                                             "kpk16e_est2genome", 4, 2, WaveDP16<Est2GenomeDesc, 4, 1, true, 1>::BND, Est2GenomeDesc::NS,
+                                             Est2GenomeDesc::MAXAT, 4, WaveDP16<Est2GenomeDesc, 4, 1, true, 1>::SEEDW};
+int pk16_staged_codes() { return WaveDP16<Est2GenomeDesc, 4, 1, true, 1>::NCODE; }
+int pk16_staged_rows() { return 4 * 64 * 4; }
 // the packed splice array of variant 1 (ss16_kernel): n positions of the batch's concatenated targets
 hipError_t pk16_build_splice(int family, const KParams *kp, const int *ss, long long ss_stride, long long n, void *out, hipStream_t s) {
     if (family != FAM_EST2GENOME) return hipErrorInvalidValue;
@@ -26,6 +39,6 @@ hipError_t pk16_build_splice(int family, const KParams *kp, const int *ss, long 
 }
 const KernelInfo *get_kernel_pk16(int family, int variant) {
     if (family != FAM_EST2GENOME) return nullptr;
-    return variant == 3 ? &kpk16d_est2genome : variant == 2 ? &kpk16c_est2genome : variant == 1 ? &kpk16b_est2genome : &kpk16_est2genome;
+    return variant == 4 ? &kpk16e_est2genome : variant == 3 ? &kpk16d_est2genome : variant == 2 ? &kpk16c_est2genome : variant == 1 ? &kpk16b_est2genome : &kpk16_est2genome;
 }
 }

@@ -366,7 +366,8 @@ def test_packed_16_bit_score_pass_agrees_with_the_32_bit_pass(eng, monkeypatch, 
         err = capfd.readouterr().err
         assert "windowed region pass" in err
         # the default form writes its dumps as 16-bit rows for the packed windows behind it (kpk16d; C4GPU_WIN16=0: kpk16b)
-        assert ("kpk16d_est2genome" in err) == (pk == "1") and ("kpk16_est2genome" in err) == (pk == "3"), err[-1500:]
+        # (... from LDS-fed column loops where queries and residue codes allow it: kpk16e, the test below)
+        assert ("kpk16e_est2genome" in err) == (pk == "1") and ("kpk16_est2genome" in err) == (pk == "3"), err[-1500:]
         assert ("kwin16_est2genome" in err) == (pk == "1"), err[-1500:]
         assert ("kpk16c_est2genome" in err) == (pk == "4"), err[-1500:]
     assert res["1"] == res["0"] and res["3"] == res["0"] and res["4"] == res["0"]
@@ -385,6 +386,69 @@ def test_packed_16_bit_score_pass_agrees_with_the_32_bit_pass(eng, monkeypatch, 
     monkeypatch.setenv("C4GPU_PK16", "0")
     b = [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=20)]
     assert a == b and a2 == b and a4 == b
+
+
+def test_staged_packed_score_pass_agrees_with_the_plain_one(eng, monkeypatch, capfd):
+    """The packed score pass feeds its column loop from LDS alone (c4_viterbi16_kernel.h, IO 1: column stage refilled per chunk,
+    query profile per strip, every strip boundary a ring, the waves three chunks apart) where every query fits the four strips
+    of a workgroup and the targets hold at most six residue codes; C4GPU_PK16_IO=0 keeps the form that loads per step.  Same
+    alignments either way and as the 32-bit pass on a ragged batch with an odd number of jobs (two jobs of a lane with
+    different target lengths and offsets: the stage clamps each), N in queries and targets (five codes), a 45 000-column
+    intron, queries of 1 to 1 023 rows (one to four strips, idle waves), with the default and with tiny dump intervals; a
+    seventh residue code in a target or a query of 1 024 rows sends the launch to the plain form."""
+    rng = random.Random(4242)
+    model = ex.Model("est2genome")
+    pairs = []
+    for k, (ql, tl) in enumerate([(1023, 30000), (400, 52000), (1000, 9000), (640, 30011), (1000, 100000), (130, 20000), (777, 41000),
+                                  (64, 5000), (257, 12345), (1, 3000)]):
+        q, t = _seeded_pairs(rng, "est2genome", ql, tl, 1)[0]
+        if k % 2:                                            # N in the target and in the query
+            i, j = rng.randrange(len(t) - 40), rng.randrange(max(1, len(q) - 3))
+            t = t[:i] + "N" * 7 + t[i + 7:]
+            q = q[:j] + "N" + q[j + 1:]
+        pairs.append((q, t))
+    q = _rand(rng, 800)
+    pairs.append((q, _rand(rng, 3000) + _mutate(rng, q[:400], 0.03) + "GT" + _rand(rng, 45000) + "AG" + _mutate(rng, q[400:], 0.03) + _rand(rng, 2000)))
+    monkeypatch.setenv("C4GPU_TRACE", "1")
+    res = {}
+    for io, pk in (("1", "1"), ("0", "1"), ("1", "0")):
+        monkeypatch.setenv("C4GPU_PK16_IO", io)
+        monkeypatch.setenv("C4GPU_PK16", pk)
+        res[io, pk] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=32, threshold=20)]
+        err = capfd.readouterr().err
+        assert ("kpk16e_est2genome" in err) == (io == "1" and pk == "1"), err[-1500:]
+        assert ("kpk16d_est2genome" in err) == (io == "0"), err[-1500:]
+        if io == "1" and pk == "1":
+            assert "kernel kpk16e_est2genome: 3 workgroups per CU" in err, err[-1500:]
+    assert res["1", "1"] == res["0", "1"] == res["1", "0"]
+    assert sum(1 for a in res["1", "1"] if a) >= 9
+    for k in (2, 7, 9):
+        q, t = pairs[k]
+        assert res["1", "1"][k] == oracle_lib.find_path(model.c, model.params, q.encode(), t.encode(), dpmemory=32, threshold=20)
+    monkeypatch.setenv("C4GPU_SEED_KSHIFT", "6")
+    small = pairs[:4] + pairs[5:10]
+    monkeypatch.setenv("C4GPU_PK16_IO", "1"); monkeypatch.setenv("C4GPU_PK16", "1")
+    a = [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=20)]
+    assert "kpk16e_est2genome" in capfd.readouterr().err
+    monkeypatch.setenv("C4GPU_PK16", "0")
+    b = [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=20)]
+    assert a == b
+    monkeypatch.delenv("C4GPU_SEED_KSHIFT")
+    monkeypatch.setenv("C4GPU_PK16", "1")
+    # seven residue codes (A C G T N R Y): no profile for them; a query of 1 024 rows: five strips
+    q, t = pairs[3]
+    many = pairs[:3] + [(q, t[:100] + "RY" + t[102:])] + pairs[4:]
+    c = [x.as_dict() if x else None for x in eng.find_path(model, many, dpmemory=32, threshold=20)]
+    err = capfd.readouterr().err
+    assert "kpk16d_est2genome" in err and "kpk16e_est2genome" not in err, err[-1500:]
+    q, t = _seeded_pairs(rng, "est2genome", 1024, 20000, 1)[0]
+    tall = pairs + [(q, t)]
+    d = [x.as_dict() if x else None for x in eng.find_path(model, tall, dpmemory=32, threshold=20)]
+    err = capfd.readouterr().err
+    assert "kpk16d_est2genome" in err and "kpk16e_est2genome" not in err, err[-1500:]
+    monkeypatch.setenv("C4GPU_PK16", "0")
+    assert c == [x.as_dict() if x else None for x in eng.find_path(model, many, dpmemory=32, threshold=20)]
+    assert d == [x.as_dict() if x else None for x in eng.find_path(model, tall, dpmemory=32, threshold=20)]
 
 
 def test_packed_16_bit_region_windows_agree_with_the_32_bit_windows(eng, monkeypatch, capfd):

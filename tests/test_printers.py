@@ -13,6 +13,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CPU_EXE = os.path.join(ROOT, "oracle", "_ref", "exonerate-compiled")
 pytestmark = pytest.mark.skipif(not os.path.exists(CPU_EXE), reason="the reference binary is built in the build container")
 
+
+
+def _align(model, qq, tt, threshold):
+    """The alignment the printers are given: here the oracle's (the formatter needs no device); tests/test_gpu_printers.py runs
+    the same cases with the alignments the MI355X makes."""
+    exp = oracle_lib.find_path(model.c, model.params, qq.encode(), tt.encode(), dpmemory=32, threshold=threshold)
+    assert exp is not None
+    return ex.Alignment.from_parts(model, exp["score"], exp["region"], exp["ops"], len(qq), len(tt))
+
+
 AA = "ARNDCQEGHILKMFPSTWYV"
 TABLE = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"
 CODON = {}
@@ -94,9 +104,7 @@ def test_gff_dump_is_the_reference_s(tmp_path, model_type, flip):
         qq = _revcomp(q) if qstrand == "-" else q
         tt = _revcomp(t) if tstrand == "-" else t
         seen_reverse |= tstrand == "-" or qstrand == "-"
-        exp = oracle_lib.find_path(model.c, model.params, qq.encode(), tt.encode(), dpmemory=32, threshold=int(f[9]))
-        assert exp is not None
-        a = ex.Alignment.from_parts(model, exp["score"], exp["region"], exp["ops"], len(qq), len(tt))
+        a = _align(model, qq, tt, int(f[9]))
         assert a.vulgar("qy", "tg", qstrand, tstrand) == vulgar
         got = vulgar + "\n" + a.gff(qq, tt, "qy", "tg", qstrand, tstrand, on_query=True, date=date) + \
             a.gff(qq, tt, "qy", "tg", qstrand, tstrand, on_query=False, date=date)
@@ -138,8 +146,7 @@ def test_alignment_display_is_the_reference_s(tmp_path, model_type, flip, width)
         qstrand, tstrand = f[4], f[8]
         qq = _revcomp(q) if qstrand == "-" else q
         tt = _revcomp(t) if tstrand == "-" else t
-        exp = oracle_lib.find_path(model.c, model.params, qq.encode(), tt.encode(), dpmemory=32, threshold=int(f[9]))
-        a = ex.Alignment.from_parts(model, exp["score"], exp["region"], exp["ops"], len(qq), len(tt))
+        a = _align(model, qq, tt, int(f[9]))
         assert a.vulgar("qy", "tg", qstrand, tstrand) == vulgar
         # Sequence_revcomp (sequence.c:405-410) marks the description of the strand it makes
         qdef = "some text:[revcomp]" if qstrand == "-" else "some text"
@@ -187,8 +194,7 @@ def test_printers_on_random_cases(tmp_path, model_type):
                 date = re.search(r"##date (\S+)", b).group(1)
                 qq = _revcomp(q) if qstrand == "-" else q
                 tt = _revcomp(t) if tstrand == "-" else t
-                exp = oracle_lib.find_path(model.c, model.params, qq.encode(), tt.encode(), dpmemory=32, threshold=int(f[9]))
-                a = ex.Alignment.from_parts(model, exp["score"], exp["region"], exp["ops"], len(qq), len(tt))
+                a = _align(model, qq, tt, int(f[9]))
                 assert a.vulgar("q%d" % k, "t%d" % k, qstrand, tstrand, forward_coords=fwd) == vulgar
                 qdef = "[revcomp]" if qstrand == "-" else None
                 tdef = "a target:[revcomp]" if tstrand == "-" else "a target"
@@ -242,8 +248,7 @@ def test_ryo_is_the_reference_s(tmp_path, model_type):
                 qstrand, tstrand = f[4], f[8]
                 qq = _revcomp(q) if qstrand == "-" else q
                 tt = _revcomp(t) if tstrand == "-" else t
-                exp = oracle_lib.find_path(model.c, model.params, qq.encode(), tt.encode(), dpmemory=32, threshold=int(f[9]))
-                a = ex.Alignment.from_parts(model, exp["score"], exp["region"], exp["ops"], len(qq), len(tt))
+                a = _align(model, qq, tt, int(f[9]))
                 qdef = "a query:[revcomp]" if qstrand == "-" else "a query"
                 tdef = "[revcomp]" if tstrand == "-" else None
                 full = sep + "\\n" + fmt + "\\n##\\n"
@@ -251,3 +256,29 @@ def test_ryo_is_the_reference_s(tmp_path, model_type):
                 assert got == b, (fmt, "\n".join(_diff(got, b)))
                 n_blocks += 1
     assert n_blocks >= 4 * len(formats)
+
+
+@pytest.mark.parametrize("model_type", ["protein2dna", "protein2genome"])
+def test_percent_self_on_a_codon_match_is_an_error_where_the_reference_crashes(tmp_path, model_type):
+    """`%pS` (Alignment_get_percent_self, alignment.c:1586-1618) scores the query against itself through self_data =
+    Model_Type_create_data(type, query, query) (gam.c:599): for a protein-vs-DNA model that reads the PROTEIN query as the DNA
+    side of a codon match (Match_3_translate_self_func, match.c:186-197, three residues past each position), and the
+    reference binary dies of SIGSEGV there -- there is no output to reproduce.  The library says so instead of printing a
+    number: c4gpu_alignment_format_ryo returns INT32_MIN (include/c4gpu.h), the Python mirror raises; every other token of the
+    same string still prints for these models (test_ryo_is_the_reference_s)."""
+    rng = random.Random(7 + len(model_type))
+    q, t = _case(rng, model_type, flip=False)
+    qf, tf = tmp_path / "q.fa", tmp_path / "t.fa"
+    qf.write_text(">qy\n%s\n" % q)
+    tf.write_text(">tg\n%s\n" % t)
+    r = subprocess.run([CPU_EXE, "-m", model_type, "-E", "yes", "-S", "no", "--showalignment", "no", "--showvulgar", "yes",
+                        "--ryo", "self %pS\\n", "-V", "0", str(qf), str(tf)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == -11 and b"self" not in r.stdout, (r.returncode, r.stdout[-300:])       # SIGSEGV before a byte of it
+    r = subprocess.run([CPU_EXE, "-m", model_type, "-E", "yes", "-S", "no", "--showalignment", "no", "--showvulgar", "yes",
+                        "-V", "0", str(qf), str(tf)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    f = [l for l in r.stdout.decode().splitlines() if l.startswith("vulgar: ")][0].split()
+    model = ex.Model(model_type)
+    a = _align(model, q, t, int(f[9]))
+    assert a.ryo("id %pi\\n", q, t) .startswith("id ")
+    with pytest.raises(ex.C4GpuError, match="pS"):
+        a.ryo("self %pS\\n", q, t)

@@ -1,21 +1,18 @@
-# round 4: profiles of the library with the packed windows and the rooted checkpoint pass: one launch lane first (per-kernel
-# times and counters add up to the step), then the default two lanes; dump spacing experiment; the configs block
+#!/bin/bash
+# round 4, call e: the staged packed score pass with its profile reads in mid-step: timing, SQ counter breakdown (one launch lane), tests
 set -u
-mkdir -p gpurun_out/r4e
-C4GPU_LANES=1 BENCH_EXTRA="--no-configs --no-revcomp --no-cpu-baseline" bash tools/profile_round.sh r04_a_lanes1 > gpurun_out/r4e/prof_lanes1.log 2>&1
-bash tools/profile_round.sh r04_a > gpurun_out/r4e/prof.log 2>&1
-tail -1 gpurun_out/prof_r04_a/bench.json | python -c "
-import json,sys
-d=json.loads(sys.stdin.read())
-print(d['ms_per_step'], d['value'], d.get('revcomp',{}).get('value'))
-print(json.dumps(d.get('configs'), indent=1)[:3000])
-print(d.get('ranks'))
-"
-for k in 12 11; do
-  echo "== C4GPU_SEED_KSHIFT=$k"
-  C4GPU_SEED_KSHIFT=$k timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-revcomp --no-configs > gpurun_out/r4e/bench_k$k.json 2> gpurun_out/r4e/bench_k$k.err
-  tail -1 gpurun_out/r4e/bench_k$k.json | python -c "
-import json,sys
-d=json.loads(sys.stdin.read())
-print(d['ms_per_step'], d['value'], d['kernel_ms'])"
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/r4e; mkdir -p $OUT
+B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-revcomp --no-configs"
+C4GPU_LANES=1 timeout 600 $B > $OUT/io1_lanes1.json 2> $OUT/io1_lanes1.err
+timeout 600 $B > $OUT/io1.json 2> $OUT/io1.err
+for f in io1_lanes1 io1; do python - <<P
+import json
+try:
+    d=json.load(open("$OUT/$f.json")); print("$f", round(d["ms_per_step"],1), {k: round(v,1) for k,v in d["kernel_ms"].items()})
+except Exception as e: print("$f", "failed", e)
+P
 done
+C4GPU_LANES=1 bash tools/profile_sq_breakdown.sh r04_b > $OUT/sq.log 2>&1
+cd $ROOT
+timeout 1500 python -m pytest tests/test_gpu_kernel_variants.py -m gpu -x -q > $OUT/pytest.log 2>&1
+tail -5 $OUT/pytest.log

@@ -7,7 +7,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_${TAG}_sq
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-revcomp"
+BENCH="python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-revcomp --no-configs"
 cd /tmp
 i=0
 for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH" \

@@ -18,7 +18,7 @@ with open(os.path.join(root, "profiles", tag + "_sq.csv"), "w") as o:
             "# the dispatches of a kernel in the run; SQ_WAVES / SQ_WAVE_CYCLES are repeated in every pass (@pass)\n")
     o.write("kernel," + ",".join(names) + "\n")
     for k, v in sorted(agg.items(), key=lambda kv: -max(kv[1].get("SQ_WAVE_CYCLES@1", 0), 0)):
-        if "viterbi" not in k:
+        if not any(t in k for t in ("viterbi", "win16", "ckpt16")):
             continue
         o.write('"%s",' % k + ",".join("%.0f" % v.get(n, 0) for n in names) + "\n")
 print(open(os.path.join(root, "profiles", tag + "_sq.csv")).read()[:3000])
