@@ -154,6 +154,7 @@ PROTOTYPES = [
     ("c4gpu_ctx_create", C.c_void_p, [C.c_int]),
     ("c4gpu_ctx_destroy", None, [C.c_void_p]),
     ("c4gpu_ctx_warm", None, [C.c_void_p]),
+    ("c4gpu_ctx_warm_cancel", None, []),
     ("c4gpu_ctx_set_stream", None, [C.c_void_p, C.c_void_p]),
     ("c4gpu_ctx_device_info", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int),
                                         C.POINTER(C.c_int64)]),

@@ -1021,7 +1021,12 @@ struct Engine {
         // job (strip carry rows stay in LDS instead of HBM); C4GPU_MW=0 forces the one-wave kernels
         static const int mw_env = getenv("C4GPU_MW") ? atoi(getenv("C4GPU_MW")) : 1;
         if (seed) {
-            const int win_nw = seed->mode == 2 ? window_waves(family) : 4;
+            int win_nw = seed->mode == 2 ? window_waves(family) : 4;
+            // the score pass of a launch with too few jobs to occupy the device on four waves each (256 proteins against one
+            // chromosome): eight waves of half the rows (C4GPU_MW=4 keeps four)
+            if (seed->mode == 1 && mw_env != 4 && (long long)n * 8 <= 2LL * 4 * ctx->prop.multiProcessorCount &&
+                get_kernel_mw(family, mode, true, false, 8, false, 1))
+                win_nw = 8;
             ki = get_kernel_mw(family, mode, true, mode == MODE_REGION, win_nw, false, seed->mode);
             if (!ki || !use_local || (mode == MODE_REGION && !pack)) { c4h::set_error("no seeded kernel for this launch"); return -1; }
             // the score pass with dumps: two jobs per lane in packed 16-bit halves where every score fits (C4GPU_PK16=0: never)
@@ -2326,13 +2331,23 @@ int c4gpu_memrule_device(c4gpu_ctx *ctx, const c4gpu_model *model, int dpmemory_
 // Load the code objects a heuristic run touches first (sequence preparation, HSP extension, word scan; the SDP passes of
 // every family) without launching anything: hipFuncGetAttributes resolves a kernel, which loads its translation unit's
 // code object.  Meant for a background thread while the host still reads sequences (the drop-in: c4gpu_shim.c).
+// c4gpu_ctx_warm_cancel(): a warm-up that is running (on whatever thread) returns before its next load, one that has not
+// started loads nothing -- so that a caller that is about to leave can join its warm-up thread within one load (the drop-in's
+// way out, integration/c4gpu_shim.c: no thread is inside the HIP runtime when the exit handlers run).
+static std::atomic<int> g_warm_cancel{0};
+void c4gpu_ctx_warm_cancel(void) { g_warm_cancel.store(1, std::memory_order_relaxed); }
 void c4gpu_ctx_warm(c4gpu_ctx *ctx) {
-    if (!ctx || hipSetDevice(ctx->device) != hipSuccess) return;
+    if (!ctx || g_warm_cancel.load(std::memory_order_relaxed) || hipSetDevice(ctx->device) != hipSuccess) return;
     hipFuncAttributes a;
     (void)hipFuncGetAttributes(&a, (const void *)encode_kernel);
     const c4sdp::SdpKernels *ks[4] = {c4sdp::sdp_kernels_affine(), c4sdp::sdp_kernels_protein2dna(), c4sdp::sdp_kernels_est2genome(),
                                       c4sdp::sdp_kernels_protein2genome()};
-    for (const c4sdp::SdpKernels *k : ks) { (void)hipFuncGetAttributes(&a, k->rev_func); (void)hipFuncGetAttributes(&a, k->fwd_func); }
+    for (const c4sdp::SdpKernels *k : ks) {
+        if (g_warm_cancel.load(std::memory_order_relaxed)) break;
+        (void)hipFuncGetAttributes(&a, k->rev_func);
+        if (g_warm_cancel.load(std::memory_order_relaxed)) break;
+        (void)hipFuncGetAttributes(&a, k->fwd_func);
+    }
     (void)hipGetLastError();
 }
 

@@ -186,7 +186,9 @@ struct WaveDP16 {
     int Q[2], T[2], q0[2], t0[2], tlast[2], seed_rows[2], seed_kshift;
     int *seed_wr[2];
     int Qm, Tm;                                         // the larger of the two
-    int min_len_pk, at_pk[4], cv_pk[16], fifteen;
+    // the intron length counter is kept as (length so far) - (min_intron - 4), saturating: an intron opens at open_il_pk =
+    // -(min_intron - 4) and "long enough for the 3' site" is "not negative"; the dumps hold the length itself (lim_pk is added)
+    int open_il_pk, lim_pk, at_pk[4], cv_pk[16], fifteen;
     C16 col[NCOL][R], nbr[NCOL], expo, nx_carry;
     int qrow[2][R];
     int nx_tcode[2], nx_sp[2][4];
@@ -348,7 +350,9 @@ struct WaveDP16 {
                     // intron length = length so far + this advance + 2 (c4_viterbi_kernel.h: (t0 + j - at) - shadow + 2); too
                     // short: the transition scores -987654321 (intron.c:150-160); too long cannot happen (T + 4 <= max_intron)
                     static_assert(live(t.in), "post-splice calc without a length");
-                    const int bad = pk_lt_mask<VAR>(src.il[t.in], min_len_pk, fifteen);      // length so far < min - at - 2
+                    // length so far < min - at - 2: the counter starts at -(min - at - 2) (open_il_pk), so that is its sign -- one
+                    // instruction where a comparison with the limit is two
+                    const int bad = pk_neg_mask(src.il[t.in], fifteen);
                     const int sv = (bad & NEG16) | (~bad & sp[cd.param]);
                     cand = pk_add<VAR>(cand, sv);
                 }
@@ -356,7 +360,7 @@ struct WaveDP16 {
             if constexpr (!JINT && t.at > 0) cand = (j >= t.at) ? cand : NEG16;
             int ilc = 0;
             if constexpr (live(t.out)) {
-                if constexpr (F::owns_shadow(t.in, 0)) ilc = 0;
+                if constexpr (F::owns_shadow(t.in, 0)) ilc = open_il_pk;
                 else if constexpr (live(t.in)) ilc = pk_add<VAR>(src.il[t.in], at_pk[t.at]);
             }
             if constexpr (F::code(K) == 1) {                     // the first transition into this state
@@ -493,7 +497,7 @@ struct WaveDP16 {
                                     constexpr int S = D16::state_of_half(HI);
                                     if constexpr (S < 0) return 0;
                                     else if constexpr (HI < D16::n_inner()) return col[PH][RR].sc[S];
-                                    else return col[PH][RR].il[S];
+                                    else return pk_add<VAR>(col[PH][RR].il[S], lim_pk);
                                 };
                                 static_for<D16::SEEDW16>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
                                     const int va = half_reg(IC<2 * K>{}), vb = half_reg(IC<2 * K + 1>{});
@@ -503,7 +507,7 @@ struct WaveDP16 {
                                 static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
                                     store_dword<S * 4>(p, pk_half(col[PH][RR].sc[S], H));
                                     if constexpr (live(S))
-                                        store_dword<W32::dump_pos(S, 0) * 4>(p, t0[H] + j - pk_half(col[PH][RR].il[S], H) - 2);
+                                        store_dword<W32::dump_pos(S, 0) * 4>(p, t0[H] + j - pk_half(pk_add<VAR>(col[PH][RR].il[S], lim_pk), H) - 2);
                                 });
                             }
                         }
@@ -580,7 +584,8 @@ struct WaveDP16 {
         {
             // "length so far < min_intron - at - 2" for the post-splice transitions (all advance the target by 2)
             const int lim = clamp16(kp->min_intron - 4);
-            min_len_pk = pk_pack(lim, lim);
+            lim_pk = pk_pack(lim, lim);
+            open_il_pk = pk_pack(-lim, -lim);
         }
         const int nstrips = (Qm + 1 + W - 1) / W;
         const int nsuper = (nstrips + NW - 1) / NW;

@@ -215,6 +215,10 @@ void        c4gpu_ctx_destroy(c4gpu_ctx *ctx);
  * launching anything; thread-safe beside other calls on the context: meant for a background thread of a caller that still
  * has host work to do before its first batch (integration/c4gpu_shim.c starts the context that way). */
 void        c4gpu_ctx_warm(c4gpu_ctx *ctx);
+/* Ends a warm-up that is running on another thread before its next code-object load and turns later ones into no-ops: a caller
+ * that is about to leave the process joins its warm-up thread after this and runs its exit handlers with no thread inside the
+ * HIP runtime (integration/c4gpu_shim.c, shim_quiesce). */
+void        c4gpu_ctx_warm_cancel(void);
 /* Use an externally owned HIP stream (e.g. torch's current stream) for all launches; NULL = default. */
 void        c4gpu_ctx_set_stream(c4gpu_ctx *ctx, void *hip_stream);
 int         c4gpu_ctx_device_info(c4gpu_ctx *ctx, char *name, size_t name_len, int *n_cu, int64_t *mem_bytes);

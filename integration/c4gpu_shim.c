@@ -82,13 +82,35 @@ static GCond shim_ctx_cond;
 static gboolean shim_ctx_ready = FALSE;
 static gchar *shim_ctx_error = NULL;
 
-/* Process exit with the device open: the HIP runtime's own teardown (static destructors of the libraries the lazy front
- * loaded) costs tens of milliseconds and has nothing left to do for a process that is about to end.  Registered when the
- * device thread starts, i.e. after everything the program registered itself, so it runs first: flush, then leave.
- * C4GPU_SLOW_EXIT keeps the ordinary exit. */
-static void shim_fast_exit(int status, void *arg){
-    fflush(NULL);
-    _exit(status);
+/* The way out.  The device thread may still be loading code objects (c4gpu_ctx_warm) when a short run is over; the HIP
+ * runtime registers its exit handlers while that thread loads it, so an ordinary exit would run them -- tearing the runtime
+ * down -- under a thread that is still inside it (SIGSEGV at the end of a 0.2 s run, seen once in ~10 in round 3, then
+ * papered over with _exit).  Now every way out first QUIESCES the device thread: the warm-up is told to stop before its next
+ * load (c4gpu_ctx_warm_cancel), the thread is joined, and only then do the exit handlers run, with no thread left inside
+ * the runtime.  Both ways out come through here: main()'s return (the wrapper below) and every exit() call of the
+ * reference's own objects (general/argument.c's error handler among them), which the Makefile points at shim_exit with
+ * objcopy --redefine-sym.  C4GPU_FAST_EXIT=1: after the join, skip the runtime's teardown (tens of milliseconds that a
+ * process about to end has no use for) with _exit -- an option now, not the fix. */
+static gboolean shim_joined = FALSE;
+static void shim_quiesce(void){
+    register GThread *t;
+    g_mutex_lock(&shim_ctx_lock);
+    t = shim_joined ? NULL : shim_ctx_thread;
+    shim_joined = TRUE;
+    g_mutex_unlock(&shim_ctx_lock);
+    if(!t)
+        return;
+    c4gpu_ctx_warm_cancel();
+    g_thread_join(t);
+    return;
+    }
+void shim_exit(int status){
+    shim_quiesce();
+    if(shim_ctx_thread && g_getenv("C4GPU_FAST_EXIT")){
+        fflush(NULL);
+        _exit(status);
+        }
+    exit(status);
     }
 
 static gpointer shim_ctx_open(gpointer data){
@@ -123,21 +145,18 @@ static void shim_start_ctx(void){
     shim_verbose = (g_getenv("C4GPU_VERBOSE") != NULL);
     if((!shim_args.use_gpu) || g_getenv("C4GPU_DISABLE"))
         return;
-    if(!g_getenv("C4GPU_SLOW_EXIT"))
-        on_exit(shim_fast_exit, NULL);
+    g_mutex_lock(&shim_ctx_lock);
     shim_ctx_thread = g_thread_new("c4gpu-ctx", shim_ctx_open, NULL);
+    g_mutex_unlock(&shim_ctx_lock);
     return;
     }
 
-/* The program's main() (general/argument.c:319, renamed by the Makefile).  A run that started the device thread leaves
- * without running exit handlers at all: the HIP runtime registers its own while the background thread loads it -- later
- * than shim_fast_exit, so they would run BEFORE it and tear the runtime down under a thread that may still be loading
- * code objects (a run that is over before the device is warm: SIGSEGV at exit, seen once in ~10 runs of the 0.2 s BSDP
- * case).  shim_fast_exit stays for exit() calls from inside the run. */
+/* The program's main() (general/argument.c:319, renamed by the Makefile): its return is a way out like any other. */
 extern int exonerate_main_cpu(int argc, char **argv);
 int main(int argc, char **argv){
     register int rc = exonerate_main_cpu(argc, argv);
-    if(shim_ctx_thread && !g_getenv("C4GPU_SLOW_EXIT")){
+    shim_quiesce();
+    if(shim_ctx_thread && g_getenv("C4GPU_FAST_EXIT")){
         fflush(NULL);
         _exit(rc);
         }
@@ -145,21 +164,26 @@ int main(int argc, char **argv){
     }
 
 c4gpu_ctx *shim_get_ctx(void){
+    register gchar *why = NULL;
+    register c4gpu_ctx *ctx;
     shim_start_ctx();
+    /* ready, error and the context itself are the device thread's to write: read under its lock */
+    g_mutex_lock(&shim_ctx_lock);
     if(shim_ctx_thread && !shim_ctx_ready){
         gint64 w0 = g_get_monotonic_time();
-        g_mutex_lock(&shim_ctx_lock);
         while(!shim_ctx_ready)
             g_cond_wait(&shim_ctx_cond, &shim_ctx_lock);
-        g_mutex_unlock(&shim_ctx_lock);
         shim_waited += g_get_monotonic_time() - w0;
         }
-    if(shim_ctx_error){
-        g_warning("c4gpu: %s -- using the CPU Viterbi", shim_ctx_error);
-        g_free(shim_ctx_error);
-        shim_ctx_error = NULL;
+    why = shim_ctx_error;
+    shim_ctx_error = NULL;
+    ctx = shim_ctx;
+    g_mutex_unlock(&shim_ctx_lock);
+    if(why){
+        g_warning("c4gpu: %s -- using the CPU Viterbi", why);
+        g_free(why);
         }
-    return shim_ctx;
+    return ctx;
     }
 
 /* The seams in front of SMALL pieces of work (word scan, HSP extension, BSDP's sub-DPs, SDP) ask this way: the context if
@@ -797,11 +821,16 @@ void GAM_report(GAM *gam){        /* analysis.c:1421: after the last pair */
     shim_sdp_report();
     shim_seed_report();
     shim_hsp_report();
-    /* with the ordinary exit the background code-object loads must be over before the process winds down; the fast exit
-     * (shim_fast_exit) needs nobody to wait */
-    if(shim_ctx_thread && (shim_verbose || g_getenv("C4GPU_SLOW_EXIT"))){
-        g_thread_join(shim_ctx_thread);
-        shim_ctx_thread = NULL;
+    /* the start-up line of C4GPU_VERBOSE wants the device thread's last clock: wait for it (a run without the line leaves its
+     * warm-up to shim_quiesce, which cuts it short) */
+    if(shim_ctx_thread && shim_verbose){
+        register gboolean mine;
+        g_mutex_lock(&shim_ctx_lock);
+        mine = !shim_joined;
+        shim_joined = TRUE;
+        g_mutex_unlock(&shim_ctx_lock);
+        if(mine)
+            g_thread_join(shim_ctx_thread);
         if(shim_verbose)
             g_message("c4gpu start-up: device opened on its own thread from %.0f to %.0f ms after process start, code objects loaded "
                       "by %.0f ms; the main thread waited %.0f ms for it; end of the run at %.0f ms", (shim_t_open - shim_t0) / 1e3,

@@ -441,7 +441,7 @@ def test_staged_packed_score_pass_agrees_with_the_plain_one(eng, monkeypatch, ca
     c = [x.as_dict() if x else None for x in eng.find_path(model, many, dpmemory=32, threshold=20)]
     err = capfd.readouterr().err
     assert "kpk16d_est2genome" in err and "kpk16e_est2genome" not in err, err[-1500:]
-    q, t = _seeded_pairs(rng, "est2genome", 1024, 20000, 1)[0]
+    q, t = _seeded_pairs(rng, "est2genome", 1024, 100000, 1)[0]           # a target long enough for the windowed route
     tall = pairs + [(q, t)]
     d = [x.as_dict() if x else None for x in eng.find_path(model, tall, dpmemory=32, threshold=20)]
     err = capfd.readouterr().err
@@ -482,7 +482,8 @@ def test_packed_16_bit_region_windows_agree_with_the_32_bit_windows(eng, monkeyp
         res[w] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=32, threshold=100)]
         err = capfd.readouterr().err
         assert "windowed region pass" in err and " 0 of " in err.split("windowed region pass")[-1].split("\n")[0], err[-1500:]
-        assert ("kwin16_est2genome" in err) == (w != "0") and ("kpk16d_est2genome" in err) == (w != "0"), err[-1500:]
+        # (the score pass behind them writes 16-bit dumps: kpk16e, its LDS-fed form, for these queries and residue codes)
+        assert ("kwin16_est2genome" in err) == (w != "0") and ("kpk16e_est2genome" in err) == (w != "0"), err[-1500:]
         assert ("kmw2_est2genome_region_local_pack_seed2" in err) == (w == "0"), err[-1500:]
     for w in ("1", "2", "3", "4"):
         assert res[w] == res["0"], w

@@ -438,3 +438,39 @@ def test_small_work_does_not_wait_for_the_device(tmp_path, extra):
         assert r.stdout.decode() == ref_out and ref_out.count("vulgar:") >= 4
     ldd = subprocess.run(["ldd", GPU_EXE], stdout=subprocess.PIPE).stdout.decode()
     assert "libc4gpu" not in ldd and "amdhip" not in ldd
+
+
+@pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
+                    reason="reference binaries are built in the build container (make -C integration)")
+def test_short_runs_leave_through_the_ordinary_exit(tmp_path):
+    """The way out of the drop-in (integration/c4gpu_shim.c, shim_quiesce): a run that is over while the device thread still
+    loads code objects stops that warm-up (c4gpu_ctx_warm_cancel), joins the thread and THEN runs the exit handlers -- the
+    HIP runtime's own among them -- instead of skipping them with _exit as round 3 did after a SIGSEGV in the runtime's
+    teardown.  The 0.2 s heuristic est2genome run fifty times through the ordinary exit, ten times through the optional
+    fast one (C4GPU_FAST_EXIT=1: _exit AFTER the join), and the error path (exit(1) from general/argument.c's handler,
+    pointed at shim_exit by the Makefile) with the device thread started: exit status and output as the reference's every time."""
+    from exonerate_amd import workloads
+    pairs = workloads.est2genome_pairs(8, 400, 40000, seed=123)
+    qf, tf = str(tmp_path / "q.fa"), str(tmp_path / "t.fa")
+    _fasta(qf, [("q%d" % k, q.decode()) for k, (q, t) in enumerate(pairs)])
+    _fasta(tf, [("t%d" % k, t.decode()) for k, (q, t) in enumerate(pairs)])
+    args = ["-m", "est2genome", "--showalignment", "no", "--showvulgar", "yes", "-V", "0", qf, tf]
+    ref_out, _ = _run(CPU_EXE, args)
+    assert ref_out.count("vulgar:") >= 4
+    env = {k: v for k, v in os.environ.items() if k not in ("C4GPU_WAIT", "C4GPU_FAST_EXIT")}
+    for rep in range(60):
+        e = dict(env)
+        if rep >= 50:
+            e["C4GPU_FAST_EXIT"] = "1"
+        r = subprocess.run([GPU_EXE] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=300)
+        assert r.returncode == 0, (rep, r.returncode, r.stderr.decode()[-2000:])
+        assert r.stdout.decode() == ref_out, rep
+    # the error path: a protein query for a DNA model is refused after the options were parsed and the device thread started
+    pf = str(tmp_path / "p.fa")
+    _fasta(pf, [("p", "MKVLAAGIVGLLLAQWERTYHSAAPPKKLMNDE")])
+    bad = ["-m", "est2genome", "-V", "0", pf, tf]
+    rr = subprocess.run([CPU_EXE] + bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    for rep in range(10):
+        r = subprocess.run([GPU_EXE] + bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+        assert r.returncode == rr.returncode == 1, (rep, r.returncode, r.stderr.decode()[-1000:])
+        assert r.stdout == rr.stdout
