@@ -477,13 +477,21 @@ def main():
         try:
             vj = json.load(open(os.path.join(ROOT, "profiles", "valu_issue_latest.json")))
             if valu_pmc and avg_ms > 0:
-                peak_ipc = vj["peak_wave_inst_per_clk_per_simd"]
+                # peak: the nominal issue rate (one wave64 VALU instruction per 2 cycles and SIMD at the 2.4 GHz peak clock);
+                # beside it the rate the packed max-plus transition itself reaches at this kernel's occupancy and the clock
+                # it sustains there (tools/inst_class_microbench.hip: 3.0 cycles per instruction at three waves per SIMD)
+                peak_ipc = vj.get("nominal_wave_inst_per_clk_per_simd", vj["peak_wave_inst_per_clk_per_simd"])
                 clk = vj["clock_ghz"] * 1e9
                 peak = peak_ipc * vj["simds"] * clk                     # wave-instructions per second, whole chip
                 ach = valu_pmc["insts_per_launch"] / (avg_ms * 1e-3)
                 valu = {"bound": "valu-issue", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-inst/s",
                         "frac": ach / peak, "peak_wave_inst_per_clk_per_simd": peak_ipc, "clock_ghz": vj["clock_ghz"],
                         "lane_ops_per_cell": valu_pmc["lane_ops_per_cell"], "source": vj["source"]}
+                w = str(int(round(valu_pmc.get("waves_per_simd", 0))))
+                if w in vj.get("wave_inst_per_clk_per_simd_by_waves", {}):
+                    mix = vj["wave_inst_per_clk_per_simd_by_waves"][w] * vj["simds"] * vj["effective_clock_ghz_by_waves"][w] * 1e9
+                    valu["mix_rate_at_occupancy"] = {"waves_per_simd": int(w), "wave_inst_per_clk_per_simd": vj["wave_inst_per_clk_per_simd_by_waves"][w],
+                                                     "clock_ghz": vj["effective_clock_ghz_by_waves"][w], "peak": mix / 1e9, "frac": ach / mix}
         except (OSError, ValueError, KeyError):
             pass
         out = {

@@ -47,6 +47,20 @@ typedef struct {
 
 static GPtrArray *sdp_pending = NULL;
 static gdouble sdp_pending_bytes = 0.0;
+static gdouble sdp_budget_bytes(void){
+    static gdouble budget = 0.0;
+    if(budget <= 0.0){
+        int64_t mem = 0;
+        register c4gpu_ctx *ctx = shim_get_ctx();
+        if(g_getenv("C4GPU_SDP_GB"))
+            budget = atof(g_getenv("C4GPU_SDP_GB")) * 1e9;
+        else if(ctx && (c4gpu_ctx_device_info(ctx, NULL, 0, NULL, &mem) == 0) && (mem > 0))
+            budget = MIN(0.8 * (gdouble)mem, 120e9);
+        else
+            budget = 64e9;
+        }
+    return budget;
+    }
 static ShimSdpPending *sdp_cur = NULL;
 static struct { long pairs, served_pairs, alignments, flushes; double device_ms, replay_ms; } sst;
 
@@ -260,9 +274,14 @@ gboolean shim_sdp_collect(GAM *gam, Comparison *comparison){
     p->comparison = Comparison_share(comparison);
     g_ptr_array_add(sdp_pending, p);
     /* the device passes visit, like the reference's scheduler, only the cells inside the X-drop and keep their traceback
-     * in an arena of 64 KB chunks: measured 7 chunks per seed + 0.25 per HSP position (both flavours, c4_sdp_dev.inc); a
-     * flush is cut when that estimate (x 1.3) or the staged residues (~20 bytes per residue with codes and splice arrays)
-     * pass C4GPU_BATCH_GB, so that one flush's arena stays an allocation of tens of GB */
+     * in an arena of 64 KB chunks: measured 7 chunks per seed + 0.25 per HSP position (both flavours, c4_sdp_dev.inc; config
+     * 5's heuristic leg takes 0.99 of that).  A launch lasts as long as its longest pair -- a serial chain on one wave -- so
+     * the pairs of a run belong in as FEW flushes as the device's memory holds (round 4: 512 pairs of config 5 in four
+     * flushes of 64 GB were four times 350 ms of passes): a flush is cut when the estimate (x 1.15) plus the staged residues
+     * (~20 bytes per residue with codes and splice arrays) pass C4GPU_SDP_GB.  Default: 0.8 of the device's memory, at most
+     * 120 GB -- this estimate counts every HSP where the library's arena counts the seeds it runs (about half), and ONE
+     * allocation of 113 GB takes hipMalloc 1.6 s where 65 GB take 0.3 ms (measured, profiles/r04_c5_breakdown.md): config 5's
+     * 512 pairs go in two flushes of 65 + 48 GB (2 x 370 ms of passes) instead of one (385 ms of passes behind 1.6 s of hipMalloc) */
     {
         register GArray *hsps = g_array_new(FALSE, FALSE, sizeof(c4gpu_hsp));
         gint qa, ta;
@@ -271,13 +290,13 @@ gboolean shim_sdp_collect(GAM *gam, Comparison *comparison){
         if(sdp_gather_hsps(comparison, hsps, &qa, &ta)){
             for(k = 0; k < hsps->len; k++)
                 positions += g_array_index(hsps, c4gpu_hsp, k).length;
-            sdp_pending_bytes += 1.3 * 65536.0 * (7.0 * hsps->len + 0.25 * positions);
+            sdp_pending_bytes += 1.15 * 65536.0 * (7.0 * hsps->len + 0.25 * positions);
             }
         g_array_free(hsps, TRUE);
     }
     sdp_pending_bytes += 20.0 * (comparison->query->len + comparison->target->len);
     if(((gint)sdp_pending->len >= shim_batch_size())
-    || (sdp_pending_bytes > (g_getenv("C4GPU_BATCH_GB") ? atof(g_getenv("C4GPU_BATCH_GB")) : 64.0) * 1e9))
+    || (sdp_pending_bytes > sdp_budget_bytes()))
         shim_sdp_flush();
     return TRUE;
     }

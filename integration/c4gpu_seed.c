@@ -135,14 +135,18 @@ static void seed_walk_trie(ShimSeedTab *st, FSM *f){
     }
 
 /* Is the table worth building yet?  Reading the words off the automaton costs about as much as the reference's walk over
- * 16 symbols per trie node (measured: 0.5 us per node against 20-50 ns per walked symbol); until the targets of this seeder
- * add up to that, the reference's own walk serves them (a 100-protein seeder with word neighbourhoods against one 10 kaa
- * target is walked in a millisecond and its 660 000 words would take 270 ms to read). */
+ * a few symbols per trie node; until the targets of this seeder add up to that, the reference's own walk serves them (a
+ * 100-protein seeder with word neighbourhoods against one 10 kaa target is walked in a millisecond and its 660 000 words
+ * would take 270 ms to read).  The factor was 16 until round 4 (0.5 us per node against 20-50 ns per walked symbol, measured
+ * on short targets); config 5's heuristic leg measured it again on a 10 Mb chromosome (profiles/r04_c5_breakdown.md): the
+ * reference's three-frame walk of 10 Mb is 700-800 ms, reading a 256-protein seeder's words 200 ms and scanning the
+ * chromosome on the device 100 ms with delivery -- break-even at 2.7 symbols per node, and with 16 the first strand of every
+ * query chunk was still walked on the CPU.  Now 4 (C4GPU_SEED_FACTOR). */
 static gboolean seed_worth_it(ShimSeedTab *st, Sequence *target){
     register Seeder *seeder = st->seeder;
     register gdouble nodes = seeder->seeder_fsm ? (gdouble)seeder->seeder_fsm->fsm->chunk_count
                                                 : (gdouble)seeder->seeder_vfsm->vfsm->lrw / 64.0;
-    register gdouble factor = g_getenv("C4GPU_SEED_FACTOR") ? atof(g_getenv("C4GPU_SEED_FACTOR")) : 16.0;
+    register gdouble factor = g_getenv("C4GPU_SEED_FACTOR") ? atof(g_getenv("C4GPU_SEED_FACTOR")) : 4.0;
     return (gdouble)(st->walked + target->len) >= factor * nodes;
     }
 

@@ -607,7 +607,9 @@ def test_packed_16_bit_checkpoint_pass_agrees_with_the_32_bit_pass(eng, monkeypa
             rooted_seen += n16r
         finished = [ln for ln in err.splitlines() if "pairs finished on the device route" in ln][0].split("fused:")[1].split()
         fin[key] = (finished[0], finished[2])                 # "N of M pairs finished ..."
-    assert (rooted_seen > 0) == (dpm != 0), "the 100 kb targets take the windowed region pass, which names the root"
+    # the 100 kb targets take the windowed region pass, which names the root (the short batch of -D 0 only where the context's
+    # earlier batches left the windowed form switched on: c4gpu_ctx::window_rate)
+    if dpm != 0: assert rooted_seen > 0
     for k, v in res.items():
         assert v == res["0"], k
         assert fin[k] == fin["0"], (k, fin)            # the packed pass sends no pair to the host route that the 32-bit pass keeps
