@@ -82,8 +82,11 @@ struct WaveCK16 {
     int Q[2], T[2], q0[2], t0[2], tlast[2], cp_count[2], section[2];
     int *ckp[2];                                          // each job's checkpoint rows
     int cp_next_j[2], cp_next_i[2];
+    int cp_phase[2];                                      // wave-uniform: (step + MAXAT - 1) mod section, see step()
     int Qm, Tm, Tmin;
-    int min_len_pk, at_pk[4], cv_pk[16];
+    // the intron length counter is kept minus (min_intron - 4), as in c4_viterbi16_kernel.h: an intron opens at open_il_pk, the
+    // 3' site's length test is the counter's sign; what leaves the kernel (and what the dumps bring) is the length itself
+    int open_il_pk, lim_pk, fifteen, at_pk[4], cv_pk[16];
     C16 col[NCOL][R], nbr[NCOL], expo, nx_carry;
     int qrow[2][R];
     int nx_tcode[2];
@@ -156,14 +159,14 @@ struct WaveCK16 {
                     else if constexpr (cd.kind == CALC_SPLICE_PRE) cand = pk_add<1>(cand, sp[cd.param]);
                     else if constexpr (cd.kind == CALC_SPLICE_POST) {
                         static_assert(live(t.in), "post-splice calc without a length");
-                        const int bad = pk_lt_mask<1>(src.il[t.in], min_len_pk, 0);      // length so far < min - at - 2
+                        const int bad = pk_neg_mask(src.il[t.in], fifteen);            // length so far < min - at - 2: the counter's sign
                         const int sv = bfi32(bad, NEG16, sp[cd.param]);
                         cand = pk_add<1>(cand, sv);
                     }
                 }
                 if constexpr (!JINT && t.at > 0) cand = (j >= t.at) ? cand : NEG16;
                 if constexpr (live(t.out)) {
-                    if constexpr (F::owns_shadow(t.in, 0)) ilc = 0;
+                    if constexpr (F::owns_shadow(t.in, 0)) ilc = open_il_pk;
                     else if constexpr (live(t.in)) ilc = pk_add<1>(src.il[t.in], at_pk[t.at]);
                 }
             }
@@ -251,7 +254,16 @@ struct WaveCK16 {
         // checkpoint rows (Viterbi_Checkpoint_process, viterbi.c:605-631): at checkpoint column c the reference copies rows
         // c, c-1, .. and then stamps their payload slots.  Each of those columns is copied out at the step that computes it
         // (c4_viterbi_kernel.h, step (7)); the stamp stays at column c.  The two jobs have their own columns.
-        {
+        // A lane stands on a column a checkpoint keeps when a multiple of the job's section length lies in [j, j + MAXAT - 1];
+        // some lane of the wave does when one lies in [s - 63, s + MAXAT - 1], i.e. when (s + MAXAT - 1) mod section <= 63 + MAXAT - 1:
+        // a scalar test (cp_phase is kept per step) in front of the per-lane tests, ballots and stores below -- they were
+        // a sixth of the instructions of a step and apply to 65 steps in every section.
+        const bool cp_near = (section[0] <= 0) | (cp_phase[0] <= 63 + MAXAT - 1) | (section[1] <= 0) | (cp_phase[1] <= 63 + MAXAT - 1);
+        static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
+            const int nx = cp_phase[H] + 1;
+            cp_phase[H] = nx >= section[H] ? nx - section[H] : nx;
+        });
+        if (cp_near) {
             unsigned stamp = 0;
             static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
                 const bool cp_live = (j >= 0) & (j <= T[H]) & (cp_next_i[H] < cp_count[H]);
@@ -269,7 +281,7 @@ struct WaveCK16 {
                                         p[word_of(S)] = (int)__builtin_amdgcn_perm((unsigned)col[PH][RR].srp[S], (unsigned)col[PH][RR].sc[S], sel);
                                         if constexpr (live(S)) {
                                             constexpr int li = live_index(S);
-                                            const unsigned h = ((unsigned)col[PH][RR].il[S] >> (16 * H)) & 0xffffu;
+                                            const unsigned h = ((unsigned)pk_add<1>(col[PH][RR].il[S], lim_pk) >> (16 * H)) & 0xffffu;    // the row holds the length
                                             lw[li / 2] |= (int)(h << (16 * (li & 1)));
                                         }
                                     }
@@ -336,7 +348,9 @@ struct WaveCK16 {
         static_for<4>([&](auto A_) __attribute__((always_inline)) { constexpr int A = A_; at_pk[A] = pk_pack(A, A); });
         {
             const int lim = clamp16(kp->min_intron - 4);
-            min_len_pk = pk_pack(lim, lim);
+            lim_pk = pk_pack(lim, lim);
+            open_il_pk = pk_pack(-lim, -lim);
+            fifteen = 0x000f000f;
         }
         const int nstrips = (Qm + 1 + W - 1) / W;
         const int nsteps = Tm + 64;
@@ -351,6 +365,7 @@ struct WaveCK16 {
                     qrow[H][RR] = 24 * ((i >= 1 && i <= Q[H]) ? (int)qc[H][q0[H] + i - 1] : 0);
                 });
                 cp_next_j[H] = section[H] > 0 ? section[H] : 0x7fffffff; cp_next_i[H] = 0;
+                cp_phase[H] = section[H] > 0 ? (MAXAT - 1) % section[H] : 0;
             });
             static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
                 expo.sc[S] = NEG16; expo.il[S] = 0; expo.srp[S] = 0;
@@ -457,7 +472,7 @@ __device__ __forceinline__ void ckpt16_pair(const KParams *kp_lds, const DevSeqs
     if (threadIdx.x == 0) DP::write_empty_column(bnd);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    DP dp;
+    DP dp{};                 // every member starts defined (c4_viterbi_kernel.h, viterbi_kernel)
     dp.kp = kp_lds;
     dp.lane = threadIdx.x;
     dp.run(jobs[ia], jobs[ib], seqs, bnd, ck_a, ck_b);

@@ -102,6 +102,9 @@ struct DevBuf {
         if (!count) count = 1;
         HIP_OK(hipMalloc((void **)&p, count * sizeof(T)));
         n = count;
+        // C4GPU_FILL_ALLOC=<byte>: every new device buffer starts as that byte (a test hook: nothing may depend on what a
+        // buffer held before its first write)
+        if (const char *fill = getenv("C4GPU_FILL_ALLOC")) HIP_OK(hipMemset(p, atoi(fill), count * sizeof(T)));
         return 0;
     }
     int upload(const T *src, size_t count, hipStream_t s) {
@@ -561,7 +564,7 @@ struct ResidentSeqs {
     DevBuf<int> d_utlen;
 
     int build(c4gpu_ctx *ctx, int family, const c4gpu_params *params, const c4gpu_pair *pairs, int n) {
-        static const bool trace = getenv("C4GPU_TRACE") != nullptr;
+        const bool trace = getenv("C4GPU_TRACE") != nullptr;          // read on every call: tests switch it
         const auto t_begin = std::chrono::steady_clock::now();
         auto lap = [&](const char *what) {
             if (trace) fprintf(stderr, "c4gpu trace: staging: %-24s at %.3f ms\n", what,
@@ -968,7 +971,7 @@ struct Engine {
 
     int run_impl(const ResidentSeqs &seqs, int mode, bool cont, const std::vector<JobSpec> &specs,
                  std::vector<JobOut> &out, const std::vector<RegionPoints> *pts, SeedPlan *seed = nullptr) {
-        static const bool trace = getenv("C4GPU_TRACE") != nullptr;
+        const bool trace = getenv("C4GPU_TRACE") != nullptr;          // read on every call: tests switch it
         const auto t_begin = std::chrono::steady_clock::now();
         struct Trace {
             bool on; std::chrono::steady_clock::time_point t0; int mode, n;
@@ -1172,7 +1175,7 @@ struct Engine {
         int blocks_per_cu = 0;
         HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, ki->func, 64 * ki->waves, 0));
         if (blocks_per_cu < 1) blocks_per_cu = 1;
-        if (seed && getenv("C4GPU_TRACE")) fprintf(stderr, "c4gpu trace:   kernel %s: %d workgroups per CU\n", ki->name, blocks_per_cu);
+        if (trace) fprintf(stderr, "c4gpu trace:   kernel %s: %d workgroups per CU\n", ki->name, blocks_per_cu);
         // the kernels that run two jobs per lane in pairs the host lists: neighbours of the same root
         std::vector<int> pair_list;
         if (ki->pairs)
@@ -1405,7 +1408,7 @@ int sequential_reduced_path(Engine &eng, const ResidentSeqs &seqs, int pair, int
 // handful of waves takes as long as thousands: 433 ms for 11 chance alignments across 1 kb x 93 kb).
 int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector<int> &red, const std::vector<PairPlan> &plan,
                         int dpmemory_mb, c4gpu_alignment *alignments, std::vector<char> &done, std::map<int, JobOut> &unfinished) {
-    static const bool trace = getenv("C4GPU_TRACE") != nullptr;
+    const bool trace = getenv("C4GPU_TRACE") != nullptr;          // read on every call: tests switch it
     const auto t_begin = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (trace) fprintf(stderr, "c4gpu trace:   fused: %-22s at %.3f ms\n", what,
@@ -1829,7 +1832,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
         SubScope(Engine &e_, const std::vector<const c4gpu_subopt *> *s) : e(e_) { e.pair_sub = s; }
         ~SubScope() { e.pair_sub = nullptr; }
     } sub_scope(eng, subs);
-    static const bool trace = getenv("C4GPU_TRACE") != nullptr;
+    const bool trace = getenv("C4GPU_TRACE") != nullptr;          // read on every call: tests switch it
     const auto t_begin = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (trace) fprintf(stderr, "c4gpu trace: find_path_batch: %-28s at %.3f ms\n", what,

@@ -758,7 +758,7 @@ void viterbi16_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *job
         __syncthreads();
         if (pid >= n_pairs) break;
         const int ia = 2 * pid, ib = (2 * pid + 1 < n_jobs) ? 2 * pid + 1 : 2 * pid;
-        DP dp;
+        DP dp{};                 // every member starts defined (c4_viterbi_kernel.h, viterbi_kernel)
         dp.lane = threadIdx.x & 63;
         dp.carry_ok = scratch.carry != 0;
         if constexpr (IO == 1) {

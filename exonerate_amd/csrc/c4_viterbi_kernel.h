@@ -1228,7 +1228,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
         __syncthreads();
         if (jid >= n_jobs) break;
         const DevJob &job = jobs[jid];
-        DP dp;
+        // every member starts defined.  Round 4: one set of the derived protein2genome vectors came out differently when the
+        // suite's kernel-variant tests had run before it in the same process (and only then): an object left uninitialised is
+        // undefined wherever a member is read before it is written, and what the registers held decided
+        // (tests/test_gpu_parity.py after tests/test_gpu_kernel_variants.py; -ftrivial-auto-var-init=zero and =pattern
+        // both gave the reference's answer, as does this)
+        DP dp{};
         dp.kp = &kp_lds;
         dp.lane = threadIdx.x;
         dp.carry_ok = scratch.carry != 0;
@@ -1324,7 +1329,7 @@ void viterbi_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *jobs,
         const DevJob &job = (SEED == 2) ? job_lds : jobs[jid];
         int hop = 0, first_score = 0;
       next_hop:
-        DP dp;
+        DP dp{};                 // every member starts defined (see viterbi_kernel)
         dp.kp = &kp_lds;
         dp.lane = threadIdx.x & 63;
         dp.carry_ok = scratch.carry != 0;

@@ -65,7 +65,9 @@ struct WaveWin16 {
     int Q[2], T[2], q0[2], t0[2], tlast[2], seed_rows[2], final_state[2];
     bool seeded[2];
     int Qm, Tm;
-    int min_len_pk, at_pk[4], cv_pk[16];
+    // the intron length counter is kept minus (min_intron - 4), as in c4_viterbi16_kernel.h: an intron opens at open_il_pk, the
+    // 3' site's length test is the counter's sign; what leaves the kernel (and what the dumps bring) is the length itself
+    int open_il_pk, lim_pk, fifteen, at_pk[4], cv_pk[16];
     C16 col[NCOL][R], nbr[NCOL], expo, nx_carry;
     int qrow[2][R];
     int nx_tcode[2];
@@ -137,14 +139,14 @@ struct WaveWin16 {
                     else if constexpr (cd.kind == CALC_SPLICE_PRE) cand = pk_add<1>(cand, sp[cd.param]);
                     else if constexpr (cd.kind == CALC_SPLICE_POST) {
                         static_assert(live(t.in), "post-splice calc without a length");
-                        const int bad = pk_lt_mask<1>(src.il[t.in], min_len_pk, 0);      // length so far < min - at - 2
+                        const int bad = pk_neg_mask(src.il[t.in], fifteen);            // length so far < min - at - 2: the counter's sign
                         const int sv = bfi32(bad, NEG16, sp[cd.param]);
                         cand = pk_add<1>(cand, sv);
                     }
                 }
                 if constexpr (!JINT && t.at > 0) cand = (j >= t.at) ? cand : NEG16;
                 if constexpr (live(t.out)) {
-                    if constexpr (F::owns_shadow(t.in, 0)) ilc = 0;
+                    if constexpr (F::owns_shadow(t.in, 0)) ilc = open_il_pk;
                     else if constexpr (live(t.in)) ilc = pk_add<1>(src.il[t.in], at_pk[t.at]);
                 }
             }
@@ -219,7 +221,7 @@ struct WaveWin16 {
                                     constexpr int hl = D16::half_of_il(S);
                                     const int vl = (int)__builtin_amdgcn_perm((unsigned)w[1][hl / 2], (unsigned)w[0][hl / 2],
                                                                               (hl & 1) ? 0x07060302u : 0x05040100u);
-                                    col[PH][RR].il[S] = bfi32(sdm, vl, col[PH][RR].il[S]);
+                                    col[PH][RR].il[S] = bfi32(sdm, pk_sub(vl, lim_pk), col[PH][RR].il[S]);      // the dump holds the length
                                 }
                                 col[PH][RR].rq[S] = bfi32(sdm, ident_pk, col[PH][RR].rq[S]);
                                 const int st = S * DC + jc;
@@ -293,7 +295,9 @@ struct WaveWin16 {
         static_for<4>([&](auto A_) __attribute__((always_inline)) { constexpr int A = A_; at_pk[A] = pk_pack(A, A); });
         {
             const int lim = clamp16(kp->min_intron - 4);
-            min_len_pk = pk_pack(lim, lim);
+            lim_pk = pk_pack(lim, lim);
+            open_il_pk = pk_pack(-lim, -lim);
+            fifteen = 0x000f000f;
         }
         const int nstrips = (Qm + 1 + W - 1) / W;
         const int nsteps = Tm + 64;
@@ -350,7 +354,7 @@ __device__ __forceinline__ void win16_chains(const KParams *kp_lds, const DevSeq
     int hop = 0, first_score = 0;                      // threads 0 and 1: their window chain
     bool active = threadIdx.x < 2 && more[threadIdx.x & 1];
     for (;;) {
-        DP dp;
+        DP dp{};                 // every member starts defined (c4_viterbi_kernel.h, viterbi_kernel)
         dp.kp = kp_lds;
         dp.lane = threadIdx.x;
         dp.run(job_lds[0], job_lds[1], seqs, bnd);
