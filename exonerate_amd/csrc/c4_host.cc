@@ -280,11 +280,16 @@ struct GffCtx {
         return (((float)mt) / ((float)tt)) * 100;
     }
     void printf_out(const char *fmt, ...) __attribute__((format(printf, 2, 3))) {
-        char tmp[512];
-        va_list ap;
+        // two passes: sequence identifiers of any length (the reference prints through g_strdup_printf)
+        va_list ap, ap2;
         va_start(ap, fmt);
-        vsnprintf(tmp, sizeof tmp, fmt, ap);
+        va_copy(ap2, ap);
+        const int n = vsnprintf(nullptr, 0, fmt, ap);
         va_end(ap);
+        std::string tmp((size_t)(n < 0 ? 0 : n) + 1, '\0');
+        vsnprintf(&tmp[0], tmp.size(), fmt, ap2);
+        va_end(ap2);
+        tmp.resize((size_t)(n < 0 ? 0 : n));
         out += tmp;
     }
     // Alignment_display_gff_line (alignment.c:2732-2794)
@@ -310,11 +315,15 @@ struct GffCtx {
         out += "\n";
     }
     static std::string fmt(const char *f, ...) __attribute__((format(printf, 1, 2))) {
-        char tmp[512];
-        va_list ap;
+        va_list ap, ap2;
         va_start(ap, f);
-        vsnprintf(tmp, sizeof tmp, f, ap);
+        va_copy(ap2, ap);
+        const int n = vsnprintf(nullptr, 0, f, ap);
         va_end(ap);
+        std::string tmp((size_t)(n < 0 ? 0 : n) + 1, '\0');
+        vsnprintf(&tmp[0], tmp.size(), f, ap2);
+        va_end(ap2);
+        tmp.resize((size_t)(n < 0 ? 0 : n));
         return tmp;
     }
     // Alignment_display_gff_exon (alignment.c:2804-2858)

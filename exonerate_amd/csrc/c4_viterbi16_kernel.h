@@ -165,7 +165,10 @@ struct WaveDP16 {
     // columns hold the 63 + 64 columns the lanes of a wave read during a chunk
     static constexpr int CH = IO ? 63 / NCOL * NCOL : (64 + NCOL - 1) / NCOL * NCOL;
     static constexpr int NCODE = 6;                      // IO 1: residue codes a launch's targets may hold
-    static constexpr int STAGE_COLS = 128, STAGE_INTS = 8;        // column stage: 32 bytes per column
+    // column stage: 128 columns x 8 planes of one int (six used), plane-major -- the lanes of a wave read consecutive columns, so a
+    // plane read is 64 consecutive words: no bank conflict (column-major entries of 32 bytes put 64 lanes on 8 banks: 72 % of the
+    // LDS-active cycles of the first LDS-fed form were conflicts, profiles/r04_c_sq.csv)
+    static constexpr int STAGE_COLS = 128, STAGE_INTS = 8;
     static constexpr int PROF_INTS = NCODE * 128;                 // query profile: ints per (wave, job): [code][lane] of 8 bytes
     static_assert(!IO || (VAR >= 1 && F::has_splice() && R == 4), "the staged form is built for the packed splice entries and 4 rows per lane");
     static_assert(!F::has_phase(), "split-codon calcs are not packed");
@@ -254,9 +257,9 @@ struct WaveDP16 {
     // IO 1: the next column's entry of the stage (the lane's columns follow each other: a running address)
     __device__ __forceinline__ void prefetch_staged() {
         const lds_int *p = lds_at(stage_a);
-        static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; nx_sp4[K] = p[K]; });
-        nx_off[0] = p[4]; nx_off[1] = p[5];
-        stage_a = ((stage_a + STAGE_INTS * 4) & (STAGE_COLS * STAGE_INTS * 4 - 1)) | stage_base;
+        static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; nx_sp4[K] = p[K * STAGE_COLS]; });
+        nx_off[0] = p[4 * STAGE_COLS]; nx_off[1] = p[5 * STAGE_COLS];
+        stage_a = ((stage_a + 4) & (STAGE_COLS * 4 - 1)) | stage_base;
     }
     // IO 1: the profile entries of the next column's codes; issued in the middle of a step, when the stage entry has arrived
     __device__ __forceinline__ void prefetch_profile() {
@@ -277,12 +280,12 @@ struct WaveDP16 {
             sv[H] = ss16[H][(unsigned)tp];
             off[H] = (int)tdense[tc[H][(unsigned)ti]] * 512;
         });
-        lds_int *p = stage + (c & (STAGE_COLS - 1)) * STAGE_INTS;
-        p[0] = (int)__builtin_amdgcn_perm(sv[1].x, sv[0].x, 0x05040100u);
-        p[1] = (int)__builtin_amdgcn_perm(sv[1].x, sv[0].x, 0x07060302u);
-        p[2] = (int)__builtin_amdgcn_perm(sv[1].y, sv[0].y, 0x05040100u);
-        p[3] = (int)__builtin_amdgcn_perm(sv[1].y, sv[0].y, 0x07060302u);
-        p[4] = off[0]; p[5] = off[1];
+        lds_int *p = stage + (c & (STAGE_COLS - 1));
+        p[0 * STAGE_COLS] = (int)__builtin_amdgcn_perm(sv[1].x, sv[0].x, 0x05040100u);
+        p[1 * STAGE_COLS] = (int)__builtin_amdgcn_perm(sv[1].x, sv[0].x, 0x07060302u);
+        p[2 * STAGE_COLS] = (int)__builtin_amdgcn_perm(sv[1].y, sv[0].y, 0x05040100u);
+        p[3 * STAGE_COLS] = (int)__builtin_amdgcn_perm(sv[1].y, sv[0].y, 0x07060302u);
+        p[4 * STAGE_COLS] = off[0]; p[5 * STAGE_COLS] = off[1];
     }
     // IO 1: the substitution scores of this lane's R rows against every residue code of the launch: one 8-byte entry per
     // (job, code, lane), four 16-bit scores.  Rows below a job's last one (the rest of the last strip; nothing above reads
@@ -628,7 +631,7 @@ struct WaveDP16 {
                 ring_in_mask = wid > 0 ? RING - 1 : 0;
                 ring_out_mask = wid < NW - 1 ? RING - 1 : 0;
                 stage_base = lds_addr(stage);
-                stage_a = lds_addr(stage) + ((0 - lane) & (STAGE_COLS - 1)) * STAGE_INTS * 4;
+                stage_a = lds_addr(stage) + ((0 - lane) & (STAGE_COLS - 1)) * 4;
             }
             const bool last = (b >= nstrips - 1), idle = (b >= nstrips);
             auto group = [&](auto JI_, int s0) __attribute__((always_inline)) {

@@ -248,13 +248,21 @@ static void seed_deliver(Seeder *seeder, Sequence *target, ShimEmit *e, gint tar
     return;
     }
 
-/* one walk: `seq` as the reference would hand it to FSM_traverse, frame 0 (untranslated) or 1 .. 3 */
-static gboolean seed_scan_string(ShimSeedTab *st, Sequence *target, gchar *seq, gint frame, GArray *mine){
+/* one walk: `seq` as the reference would hand it to FSM_traverse, frame 0 (untranslated) or 1 .. 3.  The hits of a frame are
+ * only written down here; Seeder_add_target delivers them once every frame of the target has been scanned, so that a scan
+ * that fails (no device memory for the hit buffer, a HIP error) leaves nothing half done and the target goes to the
+ * reference's own walk */
+typedef struct {
+    c4gpu_word_hit *hits;
+    gint64 n_hits;
+    gint frame;
+    } ShimFrameHits;
+
+static gboolean seed_scan_string(ShimSeedTab *st, gchar *seq, gint frame, ShimFrameHits *out){
     register gint n = strlen(seq), i;
     register guchar *sym = g_new(guchar, n + 1);
     register c4gpu_word_hit *hits = NULL;
     int64_t n_hits = 0, cap;
-    register gint64 k;
     gint64 t0 = g_get_monotonic_time();
     for(i = 0; i < n; i++)
         sym[i] = st->column[(guchar)seq[i]];
@@ -301,16 +309,23 @@ static gboolean seed_scan_string(ShimSeedTab *st, Sequence *target, gchar *seq, 
         }
     sdst.scans++; sdst.symbols += n; sdst.hits += n_hits;
     sdst.scan_ms += (g_get_monotonic_time() - t0) / 1e3;
-    t0 = g_get_monotonic_time();
-    for(k = 0; k < n_hits; k++){
-        register ShimEmit *e = &g_array_index(st->emits, ShimEmit, hits[k].emit);
-        register gint tpos = frame ? (hits[k].pos * 3) + frame - 1 : hits[k].pos;       /* seeder.c:657-660 */
+    out->hits = hits; out->n_hits = n_hits; out->frame = frame;
+    g_free(sym);
+    return TRUE;
+    }
+
+static void seed_deliver_frame(ShimSeedTab *st, Sequence *target, ShimFrameHits *fh, GArray *mine){
+    register gint64 k;
+    gint64 t0 = g_get_monotonic_time();
+    for(k = 0; k < fh->n_hits; k++){
+        register ShimEmit *e = &g_array_index(st->emits, ShimEmit, fh->hits[k].emit);
+        register gint tpos = fh->frame ? (fh->hits[k].pos * 3) + fh->frame - 1 : fh->hits[k].pos;       /* seeder.c:657-660 */
         seed_deliver(st->seeder, target, e, tpos - e->loader->tpos_modifier, mine);
         }
     sdst.host_ms += (g_get_monotonic_time() - t0) / 1e3;
-    g_free(hits);
-    g_free(sym);
-    return TRUE;
+    g_free(fh->hits);
+    fh->hits = NULL;
+    return;
     }
 
 void Seeder_add_target(Seeder *seeder, Sequence *target){
@@ -319,6 +334,8 @@ void Seeder_add_target(Seeder *seeder, Sequence *target){
     register gint i;
     register Seeder_QueryInfo *query_info;
     register GArray *mine = NULL, *theirs = NULL;
+    ShimFrameHits frames[3];
+    gint n_frames = 0;
     gboolean ok = TRUE;
     static gint off = -1;
     if(off < 0)
@@ -361,19 +378,38 @@ void Seeder_add_target(Seeder *seeder, Sequence *target){
             register gchar *seq = Sequence_get_str(masked);
             Sequence_destroy(aa_seq);
             Sequence_destroy(masked);
-            ok = seed_scan_string(st, target, seq, i + 1, mine);
+            ok = seed_scan_string(st, seq, i + 1, &frames[n_frames]);
+            if(ok)
+                n_frames++;
             g_free(seq);
             }
     } else {
         register Sequence *masked = Sequence_mask(target);
         register gchar *seq = Sequence_get_str(masked);
         Sequence_destroy(masked);
-        ok = seed_scan_string(st, target, seq, 0, mine);
+        ok = seed_scan_string(st, seq, 0, &frames[0]);
+        if(ok)
+            n_frames = 1;
         g_free(seq);
         }
+    if(!ok){
+        /* nothing has been delivered yet: this target (and the rest of this seeder's) keeps the reference's walk */
+        for(i = 0; i < n_frames; i++)
+            g_free(frames[i].hits);
+        st->hopeless = TRUE;
+        sdst.targets--;
+        sdst.cpu_targets++;
+        if(theirs){                                   /* check mode: the reference's walk has already run, its seeds only written down */
+            g_array_free(theirs, TRUE);
+            g_array_free(mine, TRUE);
+            }
+        Seeder_add_target_cpu(seeder, target);
+        Sequence_destroy(target);
+        return;
+        }
+    for(i = 0; i < n_frames; i++)
+        seed_deliver_frame(st, target, &frames[i], mine);
     Sequence_destroy(target);
-    if(!ok)
-        g_error("c4gpu: the device word scan failed in the middle of a target");
     if(theirs){
         if(theirs->len != mine->len)
             g_error("c4gpu seed check: the reference's walk finds %u seeds, the device scan %u", theirs->len, mine->len);

@@ -51,12 +51,12 @@ def _inputs(rng, model, n):
     return qs, ts
 
 
-# C4_FUZZ_SEED / C4_FUZZ_REPS: longer one-off campaigns with other seeds (default: the 32 committed cases)
+# C4_FUZZ_SEED / C4_FUZZ_REPS: longer one-off campaigns with other seeds (default: 24 + 12 committed cases; round 4 cut a rep of each model: the GPU suite's time)
 CASES = []
 _rng = random.Random(int(os.environ.get("C4_FUZZ_SEED", "20260928")))
 for _model in ("affine:local", "affine:global", "affine:bestfit", "affine:overlap", "est2genome", "protein2dna",
                "protein2genome", "ungapped"):
-    for _rep in range(int(os.environ.get("C4_FUZZ_REPS", "4"))):
+    for _rep in range(int(os.environ.get("C4_FUZZ_REPS", "3"))):
         flags = ["-S", _rng.choice(["yes", "no"])]
         if _rng.random() < 0.5:
             flags += ["-D", _rng.choice(["0", "1"])]
@@ -120,7 +120,7 @@ def test_random_inputs_and_flags(tmp_path, model, flags, batch, seed):
 HCASES = []
 _hr = random.Random(int(os.environ.get("C4_FUZZ_SEED", "20260929")))
 for _model in ("affine:local", "protein2dna", "est2genome", "protein2genome"):
-    for _rep in range(int(os.environ.get("C4_FUZZ_REPS", "4"))):
+    for _rep in range(int(os.environ.get("C4_FUZZ_REPS", "3"))):
         hflags = ["--gappedextension", _hr.choice(["yes", "no"])]
         if _hr.random() < 0.4:
             hflags += ["-S", "no"]

@@ -49,7 +49,8 @@ def test_exonerate_gpu_output_is_byte_identical(tmp_path, model, extra, batch):
             for k, c in enumerate("TCAG"):
                 codon.setdefault(table[i * 16 + j * 4 + k], []).append(a + b + c)
     qs, ts = [], []
-    for n in range(3):
+    # (the sub-optimal loop over est2genome pairs is the reference's slowest case here: two sequences a side instead of three)
+    for n in range(2 if (model == "est2genome" and "-S" in extra) else 3):
         if model.startswith("protein"):
             q = aa(120 + 30 * n)
             coding = "".join(rng.choice(codon[x]) for x in q)

@@ -282,3 +282,26 @@ def test_percent_self_on_a_codon_match_is_an_error_where_the_reference_crashes(t
     assert a.ryo("id %pi\\n", q, t) .startswith("id ")
     with pytest.raises(ex.C4GpuError, match="pS"):
         a.ryo("self %pS\\n", q, t)
+
+
+def test_gff_lines_with_identifiers_longer_than_any_fixed_buffer(tmp_path):
+    """The GFF printers build their lines with sequence identifiers in them ("Target %s %d %d", "sequence %s"): identifiers of
+    700 bytes print whole, as the reference's g_strdup_printf does (round 3 cut them at 512 bytes)."""
+    rng = random.Random(99)
+    q, t = _case(rng, "est2genome", False)
+    qid, tid = "q" * 700, "t" * 650
+    qf, tf = tmp_path / "q.fa", tmp_path / "t.fa"
+    qf.write_text(">%s\n%s\n" % (qid, q))
+    tf.write_text(">%s\n%s\n" % (tid, t))
+    args = ["-m", "est2genome", "-E", "yes", "-S", "no", "--showalignment", "no", "--showvulgar", "yes", "--showquerygff", "yes",
+            "--showtargetgff", "yes", "-V", "0", str(qf), str(tf)]
+    r = subprocess.run([CPU_EXE] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-1000:]
+    b = [x for x in re.split(r"(?m)^(?=vulgar: )", r.stdout.decode()) if x.startswith("vulgar: ")][0]
+    vulgar = b.splitlines()[0]
+    f = vulgar.split()
+    date = re.search(r"##date (\S+)", b).group(1)
+    model = ex.Model("est2genome")
+    a = _align(model, q, t, int(f[9]))
+    got = vulgar + "\n" + a.gff(q, t, qid, tid, f[4], f[8], on_query=True, date=date) + a.gff(q, t, qid, tid, f[4], f[8], on_query=False, date=date)
+    assert got == b, "\n".join(_diff(got, b))
