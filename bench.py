@@ -15,6 +15,7 @@ Prints ONE JSON line on rank 0:
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -225,7 +226,39 @@ def other_configs(ex, eng):
                      "checked": "%d alignments (every %dth pair: score, region, operations) equal to tests/golden/bench_configs.json"
                                 % (checked, want[name]["every"])}
         b.close()
+    out.update(c5_heuristic_leg())
     return out
+
+
+def c5_heuristic_leg():
+    """BASELINE config 5's heuristic leg through the drop-in binary (integration/_build/exonerate-gpu: the reference's own
+    objects with libc4gpu.so behind its seams -- word scan, HSP extension and SDP on the device): 256 proteins of 300 aa against
+    one 10 Mb chromosome, -m protein2genome, default mode; wall time of the second of two runs, stdout compared by SHA-256 with
+    what the reference binary printed for the same input (tests/golden/bench_c5_heuristic.json, tools/make_c5_heuristic_golden.py:
+    the reference needs 66 s on one core of the GPU box, too long for the bench).  Skipped where the binary is not built."""
+    import hashlib, tempfile
+    from exonerate_amd import workloads
+    exe = os.path.join(ROOT, "integration", "_build", "exonerate-gpu")
+    gold = os.path.join(ROOT, "tests", "golden", "bench_c5_heuristic.json")
+    if not (os.path.exists(exe) and os.path.exists(gold)):
+        return {}
+    want = json.load(open(gold))
+    with tempfile.TemporaryDirectory() as d:
+        qf, tf = workloads.write_c5_heuristic_input(d)
+        env = dict(os.environ, C4GPU_VERBOSE="1")
+        dt, r = 0.0, None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            r = subprocess.run([exe] + want["args"] + [qf, tf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            dt = time.perf_counter() - t0
+            assert r.returncode == 0, r.stderr.decode()[-800:]
+    assert hashlib.sha256(r.stdout).hexdigest() == want["sha256"], "c5 heuristic leg: output differs from the reference's"
+    served = [l.split("c4gpu ", 1)[1].strip() for l in r.stderr.decode().splitlines() if "c4gpu sdp:" in l or "c4gpu seed:" in l]
+    return {"c5_heuristic": {"workload": "config 5 (heuristic leg): exonerate-gpu -m protein2genome, 256 proteins of 300 aa x one 10 Mb "
+                                         "chromosome, seeding + SDP on the device", "wall_s": dt, "alignments": want["alignments"],
+                             "reference_wall_s_one_core": 66.3,
+                             "checked": "stdout (%d vulgar lines) SHA-256 equal to the reference binary's, tests/golden/bench_c5_heuristic.json"
+                                        % want["alignments"], "device": served}}
 
 
 def revcomp(seq):

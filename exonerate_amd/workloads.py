@@ -148,3 +148,17 @@ def bench_config(name):
         proteins, contig, places = protein_vs_contig(256, 300, 10000000, seed=20260935, introns=True)
         return "protein2genome", [(p, contig) for p in proteins], places
     raise ValueError("bench_config: c2, c3 or c5")
+
+
+def write_c5_heuristic_input(directory, n=256, seed=20260935):
+    """BASELINE config 5's heuristic leg as FASTA files: n proteins of 300 aa and one 10 Mb chromosome that holds their
+    intron-split genes (tools/bench_c5_heuristic.py, tools/make_c5_heuristic_golden.py, bench.py)."""
+    import os
+    proteins, contig, _ = protein_vs_contig(n, 300, 10000000, seed=seed, introns=True)
+    qf, tf = os.path.join(directory, "q.fa"), os.path.join(directory, "t.fa")
+    with open(qf, "w") as f:
+        for i, p in enumerate(proteins):
+            f.write(">p%d\n%s\n" % (i, p.decode()))
+    with open(tf, "w") as f:
+        f.write(">chr\n%s\n" % contig.decode())
+    return qf, tf
