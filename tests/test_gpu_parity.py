@@ -438,3 +438,21 @@ def test_span_seam_matches_reference_vectors(eng, name, mtype, qa, match_state, 
                 else:
                     rle.append([o, 1])
             assert rle == r["ops"], r["id"]
+
+
+@pytest.mark.parametrize("fill", ["90", "255"])
+def test_nothing_depends_on_what_a_new_buffer_held(eng, monkeypatch, fill):
+    """C4GPU_FILL_ALLOC=<byte> starts every device buffer of the library as that byte (DevBuf::alloc): the reference's vector
+    sets of the four families, the derived models and a reduced-space set come out as with fresh (zeroed) memory -- no kernel
+    reads a buffer before something wrote it.  (The companion for registers is the value-initialised per-wave DP object,
+    c4_viterbi_kernel.h: round 4 found one derived protein2genome set depending on what the registers held.)"""
+    monkeypatch.setenv("C4GPU_FILL_ALLOC", fill)
+    for name in ("affine_local_dna", "est2genome", "protein2dna", "protein2genome", "derived_protein2genome_end",
+                 "derived_est2genome_fwd_join", "est2genome_D0", "est2genome_big"):
+        model = _model(name)
+        recs = load_set(name)
+        pairs = [(r["query"], r["target"]) for r in recs]
+        assert eng.find_score(model, pairs) == [r["score"] for r in recs], name
+        for rec, aln in zip(recs, eng.find_path(model, pairs, dpmemory=recs[0]["dpmemory"])):
+            if "path_score" in rec:
+                assert aln is not None and aln.as_dict(rec["id"]) == expected(rec), (name, rec["id"])
