@@ -435,6 +435,15 @@ def test_staged_packed_score_pass_agrees_with_the_plain_one(eng, monkeypatch, ca
     assert a == b
     monkeypatch.delenv("C4GPU_SEED_KSHIFT")
     monkeypatch.setenv("C4GPU_PK16", "1")
+    # six residue codes (A C G T N R): the profile is full
+    q, t = pairs[4]
+    six = pairs[:4] + [(q, t[:2000] + "RRAR" + t[2004:])] + pairs[5:]
+    e = [x.as_dict() if x else None for x in eng.find_path(model, six, dpmemory=32, threshold=20)]
+    assert "kpk16e_est2genome" in capfd.readouterr().err
+    monkeypatch.setenv("C4GPU_PK16", "0")
+    assert e == [x.as_dict() if x else None for x in eng.find_path(model, six, dpmemory=32, threshold=20)]
+    monkeypatch.setenv("C4GPU_PK16", "1")
+    capfd.readouterr()
     # seven residue codes (A C G T N R Y): no profile for them; a query of 1 024 rows: five strips
     q, t = pairs[3]
     many = pairs[:3] + [(q, t[:100] + "RY" + t[102:])] + pairs[4:]
