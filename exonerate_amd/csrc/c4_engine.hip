@@ -1050,9 +1050,9 @@ struct Engine {
                     for (int i = 0; i < n && rows_ok; i++) rows_ok = specs[i].region.query_length < 32000;
                     if (rows_ok) { ki = kd; seed->fmt16 = true; }
                     // ... and with its column loop fed from LDS alone (IO 1) where every query fits the strips of one workgroup
-                    // and the targets hold few enough residue codes for the query profile (C4GPU_PK16_IO=0: never)
-                    const int io_env = getenv("C4GPU_PK16_IO") ? atoi(getenv("C4GPU_PK16_IO")) : 1;
-                    const KernelInfo *ke = (rows_ok && io_env) ? get_kernel_pk16(family, 4) : nullptr;
+                    // and the targets hold few enough residue codes for the query profile (C4GPU_PK16_IO=0: never; 1: with a barrier per chunk instead of progress counters)
+                    const int io_env = getenv("C4GPU_PK16_IO") ? atoi(getenv("C4GPU_PK16_IO")) : 2;
+                    const KernelInfo *ke = (rows_ok && io_env) ? get_kernel_pk16(family, io_env == 2 ? 5 : 4) : nullptr;     // 2 (default): progress counters between the cooperating waves; 1: a barrier per chunk
                     if (ke && seqs.tdense_n > 0 && seqs.tdense_n <= pk16_staged_codes()) {
                         bool strips_ok = true;
                         for (int i = 0; i < n && strips_ok; i++) strips_ok = specs[i].region.query_length + 1 <= pk16_staged_rows();

@@ -558,7 +558,6 @@ struct WaveDP16 {
     template <int NW>
     __device__ __forceinline__ void run_mw(const DevJob &ja, const DevJob &jb, const DevSeqs &seqs, int *bnd, lds_int *rings, int wid,
                                            lds_int *prog = nullptr, lds_int *stage = nullptr, lds_int *edge = nullptr) {
-        static_assert(!(IO == 1 && VAR == 2), "the staged form keeps the chunk barriers");
         // chunks a wave runs behind the wave above it: the row above must be there one column ahead of the step that reads it,
         // i.e. SKEW * CH - 1 - 63 >= CH
         constexpr int SKEW = (CH >= 64) ? 2 : 3;
@@ -652,8 +651,11 @@ struct WaveDP16 {
             auto before = [&](int k) __attribute__((always_inline)) {
                 if constexpr (IO == 1) fill_stage(stage, k * CH + 1);           // columns k CH + 1 ... k CH + 64: what this chunk's steps read ahead
                 if constexpr (FLAGS) {
-                    if (wid > 0) wait_for(wid - 1, k + 2 < nchunks ? k + 2 : nchunks);
-                    if (wid < NW - 1 && k >= 4) wait_for(wid + 1, k - 3);
+                    // the row above: its chunk k + SKEW - 1 done; the ring slots this chunk overwrites (columns up to (k + 1) CH - 64 - RING):
+                    // read by the wave below, i.e. its chunk floor(((k + 1) CH - 65 - RING) / CH) = k + 1 - BACK done
+                    constexpr int BACK = (RING + 65 + CH - 1) / CH;
+                    if (wid > 0) wait_for(wid - 1, k + SKEW < nchunks ? k + SKEW : nchunks);
+                    if (wid < NW - 1 && k + 1 >= BACK) wait_for(wid + 1, k + 2 - BACK);
                 }
             };
             auto after = [&](int k) __attribute__((always_inline)) {
@@ -669,8 +671,10 @@ struct WaveDP16 {
             if (idle) {
                 if constexpr (!FLAGS) for (int k = 0; k < nchunks; k++) __syncthreads();
             } else {
-                if constexpr (IO == 1) fill_stage(stage, -63);         // columns -63 ... 0: what the first steps of the lanes read
-                else before(0);                      // the first carry column is read ahead of the first step
+                if constexpr (IO == 1) {
+                    fill_stage(stage, -63);          // columns -63 ... 0: what the first steps of the lanes read
+                    if constexpr (FLAGS) { if (wid > 0) wait_for(wid - 1, SKEW < nchunks ? SKEW : nchunks); }
+                } else before(0);                    // the first carry column is read ahead of the first step
                 prefetch_column(0 - lane);
                 if constexpr (IO == 1) prefetch_profile();
                 prefetch_carry(0, bnd_in);

@@ -366,8 +366,8 @@ def test_packed_16_bit_score_pass_agrees_with_the_32_bit_pass(eng, monkeypatch, 
         err = capfd.readouterr().err
         assert "windowed region pass" in err
         # the default form writes its dumps as 16-bit rows for the packed windows behind it (kpk16d; C4GPU_WIN16=0: kpk16b)
-        # (... from LDS-fed column loops where queries and residue codes allow it: kpk16e, the test below)
-        assert ("kpk16e_est2genome" in err) == (pk == "1") and ("kpk16_est2genome" in err) == (pk == "3"), err[-1500:]
+        # (... from LDS-fed column loops where queries and residue codes allow it: kpk16f, the test below)
+        assert ("kpk16f_est2genome" in err) == (pk == "1") and ("kpk16_est2genome" in err) == (pk == "3"), err[-1500:]
         assert ("kwin16_est2genome" in err) == (pk == "1"), err[-1500:]
         assert ("kpk16c_est2genome" in err) == (pk == "4"), err[-1500:]
     assert res["1"] == res["0"] and res["3"] == res["0"] and res["4"] == res["0"]
@@ -411,25 +411,28 @@ def test_staged_packed_score_pass_agrees_with_the_plain_one(eng, monkeypatch, ca
     pairs.append((q, _rand(rng, 3000) + _mutate(rng, q[:400], 0.03) + "GT" + _rand(rng, 45000) + "AG" + _mutate(rng, q[400:], 0.03) + _rand(rng, 2000)))
     monkeypatch.setenv("C4GPU_TRACE", "1")
     res = {}
-    for io, pk in (("1", "1"), ("0", "1"), ("1", "0")):
+    # C4GPU_PK16_IO: 2 (the default) = the LDS-fed form with progress counters between its cooperating waves (kpk16f), 1 = the same
+    # with a barrier per chunk (kpk16e), 0 = the form that loads per step (kpk16d)
+    for io, pk in (("1", "1"), ("2", "1"), ("0", "1"), ("1", "0")):
         monkeypatch.setenv("C4GPU_PK16_IO", io)
         monkeypatch.setenv("C4GPU_PK16", pk)
         res[io, pk] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=32, threshold=20)]
         err = capfd.readouterr().err
         assert ("kpk16e_est2genome" in err) == (io == "1" and pk == "1"), err[-1500:]
+        assert ("kpk16f_est2genome" in err) == (io == "2"), err[-1500:]
         assert ("kpk16d_est2genome" in err) == (io == "0"), err[-1500:]
-        if io == "1" and pk == "1":
-            assert "kernel kpk16e_est2genome: 3 workgroups per CU" in err, err[-1500:]
-    assert res["1", "1"] == res["0", "1"] == res["1", "0"]
+        if io in ("1", "2") and pk == "1":
+            assert "kernel kpk16%s_est2genome: 3 workgroups per CU" % ("e" if io == "1" else "f") in err, err[-1500:]
+    assert res["1", "1"] == res["2", "1"] == res["0", "1"] == res["1", "0"]
     assert sum(1 for a in res["1", "1"] if a) >= 9
     for k in (2, 7, 9):
         q, t = pairs[k]
         assert res["1", "1"][k] == oracle_lib.find_path(model.c, model.params, q.encode(), t.encode(), dpmemory=32, threshold=20)
     monkeypatch.setenv("C4GPU_SEED_KSHIFT", "6")
     small = pairs[:4] + pairs[5:10]
-    monkeypatch.setenv("C4GPU_PK16_IO", "1"); monkeypatch.setenv("C4GPU_PK16", "1")
+    monkeypatch.delenv("C4GPU_PK16_IO"); monkeypatch.setenv("C4GPU_PK16", "1")
     a = [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=20)]
-    assert "kpk16e_est2genome" in capfd.readouterr().err
+    assert "kpk16f_est2genome" in capfd.readouterr().err
     monkeypatch.setenv("C4GPU_PK16", "0")
     b = [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=20)]
     assert a == b
@@ -439,7 +442,7 @@ def test_staged_packed_score_pass_agrees_with_the_plain_one(eng, monkeypatch, ca
     q, t = pairs[4]
     six = pairs[:4] + [(q, t[:2000] + "RRAR" + t[2004:])] + pairs[5:]
     e = [x.as_dict() if x else None for x in eng.find_path(model, six, dpmemory=32, threshold=20)]
-    assert "kpk16e_est2genome" in capfd.readouterr().err
+    assert "kpk16f_est2genome" in capfd.readouterr().err
     monkeypatch.setenv("C4GPU_PK16", "0")
     assert e == [x.as_dict() if x else None for x in eng.find_path(model, six, dpmemory=32, threshold=20)]
     monkeypatch.setenv("C4GPU_PK16", "1")
@@ -449,12 +452,12 @@ def test_staged_packed_score_pass_agrees_with_the_plain_one(eng, monkeypatch, ca
     many = pairs[:3] + [(q, t[:100] + "RY" + t[102:])] + pairs[4:]
     c = [x.as_dict() if x else None for x in eng.find_path(model, many, dpmemory=32, threshold=20)]
     err = capfd.readouterr().err
-    assert "kpk16d_est2genome" in err and "kpk16e_est2genome" not in err, err[-1500:]
+    assert "kpk16d_est2genome" in err and "kpk16e_est2genome" not in err and "kpk16f_est2genome" not in err, err[-1500:]
     q, t = _seeded_pairs(rng, "est2genome", 1024, 100000, 1)[0]           # a target long enough for the windowed route
     tall = pairs + [(q, t)]
     d = [x.as_dict() if x else None for x in eng.find_path(model, tall, dpmemory=32, threshold=20)]
     err = capfd.readouterr().err
-    assert "kpk16d_est2genome" in err and "kpk16e_est2genome" not in err, err[-1500:]
+    assert "kpk16d_est2genome" in err and "kpk16e_est2genome" not in err and "kpk16f_est2genome" not in err, err[-1500:]
     monkeypatch.setenv("C4GPU_PK16", "0")
     assert c == [x.as_dict() if x else None for x in eng.find_path(model, many, dpmemory=32, threshold=20)]
     assert d == [x.as_dict() if x else None for x in eng.find_path(model, tall, dpmemory=32, threshold=20)]
@@ -491,8 +494,8 @@ def test_packed_16_bit_region_windows_agree_with_the_32_bit_windows(eng, monkeyp
         res[w] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=32, threshold=100)]
         err = capfd.readouterr().err
         assert "windowed region pass" in err and " 0 of " in err.split("windowed region pass")[-1].split("\n")[0], err[-1500:]
-        # (the score pass behind them writes 16-bit dumps: kpk16e, its LDS-fed form, for these queries and residue codes)
-        assert ("kwin16_est2genome" in err) == (w != "0") and ("kpk16e_est2genome" in err) == (w != "0"), err[-1500:]
+        # (the score pass behind them writes 16-bit dumps: kpk16f, its LDS-fed form, for these queries and residue codes)
+        assert ("kwin16_est2genome" in err) == (w != "0") and ("kpk16f_est2genome" in err) == (w != "0"), err[-1500:]
         assert ("kmw2_est2genome_region_local_pack_seed2" in err) == (w == "0"), err[-1500:]
     for w in ("1", "2", "3", "4"):
         assert res[w] == res["0"], w
