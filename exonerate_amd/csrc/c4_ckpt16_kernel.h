@@ -326,7 +326,11 @@ struct WaveCK16 {
         }
     }
 
-    __device__ __forceinline__ void run(const DevJob &ja, const DevJob &jb, const DevSeqs &seqs, int *bnd, int *ckpt_a, int *ckpt_b) {
+    // NW cooperating waves: wave `wid` runs the strips wid, wid + NW, ...; carry rows through the workgroup's slab, a strip starts a
+    // chunk of steps once the strip above has finished the columns it reads (progress counters in LDS: c4_win16_kernel.h, run)
+    template <int NW>
+    __device__ __forceinline__ void run(const DevJob &ja, const DevJob &jb, const DevSeqs &seqs, int *bnd, int *ckpt_a, int *ckpt_b,
+                                        int wid, int *prog) {
         const DevJob *jp[2] = {&ja, &jb};
         ckp[0] = ckpt_a; ckp[1] = ckpt_b;
         static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
@@ -357,7 +361,9 @@ struct WaveCK16 {
         const int main_lo = 63 + MAXAT, main_hi = Tm;
         const int nsteps_r = (nsteps + NCOL - 1) / NCOL * NCOL;
         const int main_lo_r = (main_lo + NCOL - 1) / NCOL * NCOL;
-        for (int b = 0; b < nstrips; b++) {
+        constexpr int CHK = (64 / NCOL) * NCOL;             // steps per chunk of the progress protocol
+        const int PS = nsteps_r + 1;
+        for (int b = wid; b < nstrips; b += NW) {
             const int i0 = b * W + lane * R;
             static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
                 static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
@@ -388,12 +394,38 @@ struct WaveCK16 {
                     step<JI, P>(s0 + P, i0, first, last, bnd_in, bnd_out);
                 });
             };
-            prefetch_column(0 - lane);
-            prefetch_carry(0, bnd_in);
-            int s = 0;
-            for (; s < main_lo_r && s < nsteps_r; s += NCOL) group(IC<0>{}, s);
-            for (; s + NCOL - 1 <= main_hi; s += NCOL) group(IC<1>{}, s);
-            for (; s < nsteps_r; s += NCOL) group(IC<0>{}, s);
+            if constexpr (NW == 1) {
+                prefetch_column(0 - lane);
+                prefetch_carry(0, bnd_in);
+                int s = 0;
+                for (; s < main_lo_r && s < nsteps_r; s += NCOL) group(IC<0>{}, s);
+                for (; s + NCOL - 1 <= main_hi; s += NCOL) group(IC<1>{}, s);
+                for (; s < nsteps_r; s += NCOL) group(IC<0>{}, s);
+            } else {
+                const int above = (wid + NW - 1) % NW, above_base = ((b - 1) / NW) * PS, my_base = (b / NW) * PS;
+                // the steps before c1 read carry columns up to c1 (one step ahead): written by the strip above in its step c1 + 63
+                auto wait_above = [&](int c1) __attribute__((always_inline)) {
+                    if (first) return;
+                    const int need = above_base + (c1 + 64 < nsteps_r ? c1 + 64 : nsteps_r);
+                    while (__hip_atomic_load(prog + above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                };
+                wait_above(CHK < nsteps_r ? CHK : nsteps_r);
+                prefetch_column(0 - lane);
+                prefetch_carry(0, bnd_in);
+                for (int c0 = 0; c0 < nsteps_r; c0 += CHK) {
+                    const int c1 = c0 + CHK < nsteps_r ? c0 + CHK : nsteps_r;
+                    if (c0) wait_above(c1);
+                    int s = c0;
+                    for (; s < main_lo_r && s < c1; s += NCOL) group(IC<0>{}, s);
+                    for (; s + NCOL - 1 <= main_hi && s < c1; s += NCOL) group(IC<1>{}, s);
+                    for (; s < c1; s += NCOL) group(IC<0>{}, s);
+                    if (!last) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) __hip_atomic_store(prog + wid, my_base + c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // carry row visible to the next strip
         }
     }
@@ -465,28 +497,41 @@ struct WaveCK16 {
 };
 
 // One pair of jobs (both with root ROOT; jb = ja where the pair holds one job) on one wave
-template <class M, int R, int ROOT>
+template <class M, int R, int ROOT, int NW>
 __device__ __forceinline__ void ckpt16_pair(const KParams *kp_lds, const DevSeqs &seqs, const DevJob *jobs, int ia, int ib,
-                                            DevResult *results, DevVsa *vsas, int *bnd, int *ck_a, int *ck_b) {
+                                            DevResult *results, DevVsa *vsas, int *bnd, int *ck_a, int *ck_b, int *prog,
+                                            int (*corner_lds)[4]) {
     using DP = WaveCK16<M, R, ROOT>;
     if (threadIdx.x == 0) DP::write_empty_column(bnd);
+    if constexpr (NW > 1) {
+        if (threadIdx.x < NW) prog[threadIdx.x] = 0;
+        if (threadIdx.x < 2) corner_lds[threadIdx.x][3] = 0;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     DP dp{};                 // every member starts defined (c4_viterbi_kernel.h, viterbi_kernel)
     dp.kp = kp_lds;
-    dp.lane = threadIdx.x;
-    dp.run(jobs[ia], jobs[ib], seqs, bnd, ck_a, ck_b);
+    dp.lane = threadIdx.x & 63;
+    dp.template run<NW>(jobs[ia], jobs[ib], seqs, bnd, ck_a, ck_b, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), prog);
     // the lane that owned a job's corner cell hands it to the lane that walks the job's checkpoints
     int sc[2], srp[2];
     bool set[2];
-    for (int h = 0; h < 2; h++) {
-        const unsigned long long owners = __ballot(dp.corner_set[h]);
-        const int owner = owners ? __ffsll((long long)owners) - 1 : 0;
-        sc[h] = __shfl(dp.corner_sc[h], owner); srp[h] = __shfl(dp.corner_srp[h], owner);
-        set[h] = owners != 0;
+    if constexpr (NW == 1) {
+        for (int h = 0; h < 2; h++) {
+            const unsigned long long owners = __ballot(dp.corner_set[h]);
+            const int owner = owners ? __ffsll((long long)owners) - 1 : 0;
+            sc[h] = __shfl(dp.corner_sc[h], owner); srp[h] = __shfl(dp.corner_srp[h], owner);
+            set[h] = owners != 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __syncthreads();
+    } else {                                               // ... through LDS: the corner's strip ran on one of the waves
+        for (int h = 0; h < 2; h++)
+            if (dp.corner_set[h]) { corner_lds[h][0] = dp.corner_sc[h]; corner_lds[h][1] = dp.corner_srp[h]; corner_lds[h][3] = 1; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __syncthreads();
+        for (int h = 0; h < 2; h++) { sc[h] = corner_lds[h][0]; srp[h] = corner_lds[h][1]; set[h] = corner_lds[h][3] != 0; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __syncthreads();
     if (threadIdx.x < 2 && (threadIdx.x == 0 || ib != ia)) {
         const int h = threadIdx.x;
         const DevJob &job = jobs[h ? ib : ia];
@@ -505,18 +550,20 @@ __device__ __forceinline__ void ckpt16_pair(const KParams *kp_lds, const DevSeqs
 // persistent waves; workgroup p of the queue runs the p-th pair of the host's list (LaunchArgs::aux: two job indices, the second
 // -1 where a job runs alone: its high half repeats it).  scratch.ckpt holds two job slabs per wave (ckpt_stride ints each).
 // ROOTED: the jobs name their root (DevJob::root) and both jobs of a pair have the same one; else every inner state is computed.
-template <class M, int R, int WPE, bool ROOTED>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
+template <class M, int R, int WPE, bool ROOTED, int NW = 1>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
 void ckpt16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, const int *pairs, int n_pairs, DevResult *results,
                    DevVsa *vsas, DevScratch scratch, int *queue) {
     using RT = Roots<M>;
     static_assert(!ROOTED || RT::disjoint(), "a rooted pass needs components to choose from");
     __shared__ KParams kp_lds;
     __shared__ int next_job;
+    __shared__ int prog[NW];
+    __shared__ int corner_lds[2][4];
     {
         const int *src = reinterpret_cast<const int *>(kparams);
         int *dst = reinterpret_cast<int *>(&kp_lds);
-        for (int x = threadIdx.x; x < (int)(sizeof(KParams) / sizeof(int)); x += 64) dst[x] = src[x];
+        for (int x = threadIdx.x; x < (int)(sizeof(KParams) / sizeof(int)); x += 64 * NW) dst[x] = src[x];
     }
     __syncthreads();
     int *bnd = scratch.bnd + (long long)blockIdx.x * scratch.bnd_stride;
@@ -534,7 +581,7 @@ void ckpt16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, con
             static_for<RT::count()>([&](auto X_) __attribute__((always_inline)) { constexpr int X = X_;
                 constexpr int ROOT = RT::root(X);
                 if (!ran && root == ROOT) {
-                    ckpt16_pair<M, R, ROOT>(&kp_lds, seqs, jobs, ia, ib, results, vsas, bnd, ck_a, ck_b);
+                    ckpt16_pair<M, R, ROOT, NW>(&kp_lds, seqs, jobs, ia, ib, results, vsas, bnd, ck_a, ck_b, prog, corner_lds);
                     ran = true;
                 }
             });
@@ -546,7 +593,7 @@ void ckpt16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, con
                 results[threadIdx.x ? ib : ia] = res;
             }
         } else {
-            ckpt16_pair<M, R, -1>(&kp_lds, seqs, jobs, ia, ib, results, vsas, bnd, ck_a, ck_b);
+            ckpt16_pair<M, R, -1, NW>(&kp_lds, seqs, jobs, ia, ib, results, vsas, bnd, ck_a, ck_b, prog, corner_lds);
         }
     }
 }

@@ -1062,8 +1062,14 @@ struct Engine {
             }
             if (seed->mode == 1) { seed->seedw = ki->seedw; seed->dc = ki->max_at; }
             if (seed->mode == 2 && seed->fmt16) {
-                const int w16_env = getenv("C4GPU_WIN16") ? atoi(getenv("C4GPU_WIN16")) : 1;     // 2..: the other shapes, for measurement
-                ki = get_kernel_win16(family, w16_env > 1 ? w16_env - 1 : 0);
+                const int w16_env = getenv("C4GPU_WIN16") ? atoi(getenv("C4GPU_WIN16")) : 1;     // 2..9: one shape whatever the jobs (tests, measurement)
+                int shape = w16_env == 9 ? 0 : w16_env - 1;
+                if (w16_env <= 1) {          // the strips of a window on two cooperating waves where the first windows have two strips and more
+                    long long strips = 0;
+                    for (int i = 0; i < n; i++) strips += (specs[i].region.query_length + 1 + 255) / 256;
+                    shape = strips >= 2LL * n ? 7 : 0;
+                }
+                ki = get_kernel_win16(family, shape);
                 if (!ki || !seqs.ss16_built) { c4h::set_error("no packed window kernel for this launch"); return -1; }
             }
         } else if (mw_env && !cont && (mode == MODE_SCORE || mode == MODE_REGION)) {
@@ -1189,7 +1195,7 @@ struct Engine {
         // (one for the single-wave kernels, `waves` for the cooperating ones)
         long long carry_T = 0;
         for (int x = 0; x < n; x++)
-            if ((jobs[x].Q + 1 + 64 * ki->R - 1) / (64 * ki->R) > ki->waves) carry_T = max_T;
+            if ((jobs[x].Q + 1 + 64 * ki->R - 1) / (64 * ki->R) > (ki->hbm_carry ? 1 : ki->waves)) carry_T = max_T;
         // per workgroup: one "empty" column (what the first strip reads as its row above) + two carry rows
         const long long bnd_per_wave = (2 * ((carry_T ? carry_T : 0) + 1) + 1) * (long long)std::max(ki->bnd, 1);
         const long long bytes_per_wave = bnd_per_wave * 4 + max_tb * 4 + max_ckpt * 4 + max_runs * 4;
@@ -1431,13 +1437,13 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
     // the packed 16-bit checkpoint kernel (c4_ckpt16_kernel.h: two jobs per lane) for every job whose scores, checkpoint
     // payloads and intron lengths fit its halves — in its rooted form (the component of the state the path's END is entered
     // from: one strand of est2genome) where the region pass reported that state, else over every inner state;
-    // C4GPU_CK16=0: never, 2..: the other shapes kept for measurement, C4GPU_CK16_ROOT=0: never the rooted form (read on every
+    // C4GPU_CK16=0: never, 2..8: one shape whatever the jobs (tests, measurement), C4GPU_CK16_ROOT=0: never the rooted form (read on every
     // call: a test switches them)
     const int ck_env = getenv("C4GPU_CK16") ? atoi(getenv("C4GPU_CK16")) : 1;
     const bool ck_root_env = !(getenv("C4GPU_CK16_ROOT") && atoi(getenv("C4GPU_CK16_ROOT")) == 0);
     const bool ck16_on = ck_env > 0 && cont_free && eng.pk16_params_ok;
     const KernelInfo *kc16 = ck16_on ? get_kernel_ck16(eng.family, 0, false) : nullptr;
-    const KernelInfo *kc16r = (ck16_on && ck_root_env) ? get_kernel_ck16(eng.family, ck_env - 1, true) : nullptr;
+    const KernelInfo *kc16r = (ck16_on && ck_root_env) ? get_kernel_ck16(eng.family, ck_env == 8 ? 0 : ck_env - 1, true) : nullptr;   // 1: chosen below, 8: variant 0
     const int ck16_tmax = getenv("C4GPU_CK16_TMAX") ? atoi(getenv("C4GPU_CK16_TMAX")) : 0x7fffffff;      // test hook
     hipStream_t s = ctx->stream;
     const c4h::MemRule rule{m->max_query_advance, m->max_target_advance, m->n_states, m->total_shadow_designations};
@@ -1467,6 +1473,14 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
         }
     if (!count_g[1] && !count_g[2]) { kc16 = nullptr; kc16r = nullptr; }
     const int n16r = count_g[2], n16a = count_g[1], n16 = n16r + n16a;
+    if (kc16r && n16r && ck_env == 1) {
+        // the shape by the strips of 256 rows the rooted jobs have: four (two) cooperating waves per pair of jobs where the
+        // jobs fill them -- the launch then lasts as long as its work, not as its longest job's strips one after the other
+        // (north-star batch, two lanes: 481 -> 446 ms per step; gpurun_out/ck16) --, one wave per pair of short queries
+        long long strips = 0;
+        for (int x = 0; x < n; x++) if (group[x] == 2) strips += (plan[red[x]].ar.query_length + 1 + 255) / 256;
+        kc16r = get_kernel_ck16(eng.family, strips >= 3LL * n16r ? 4 : strips >= 2LL * n16r ? 5 : 0, true);
+    }
     if (n16 && eng.ensure_ss16(seqs)) return -1;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
         if (group[a] != group[b]) return group[a] > group[b];

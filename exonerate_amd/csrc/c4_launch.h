@@ -52,6 +52,7 @@ struct KernelInfo {
     int ckw;                  // the packed checkpoint pass: ints per row of a checkpoint column in a job's slab (root -1; see ckw_root)
     int pairs = 0;            // 1: the kernel reads LaunchArgs::aux (pairs of jobs with a common root, DevJob::pad0)
     int ckw_root = 0;         // the packed checkpoint pass restricted to one root's component: ints per row
+    int hbm_carry = 0;        // 1: cooperating waves that hand the strip carry rows on through the workgroup's slab (not LDS rings)
 };
 
 // family x mode x continuation x local-scope specialisation; NULL launch = not compiled

@@ -272,7 +272,13 @@ struct WaveWin16 {
         });
     }
 
-    __device__ __forceinline__ void run(const DevJob &ja, const DevJob &jb, const DevSeqs &seqs, int *bnd) {
+    // NW cooperating waves: wave `wid` runs the strips wid, wid + NW, ... of the window; a strip's carry row goes through the
+    // workgroup's slab as with one wave, and a strip starts a chunk of steps once the strip above has finished the columns that
+    // chunk reads (progress counters in LDS, prog[wave] = pass x PS + steps finished; c4_viterbi16_kernel.h, VAR 2).  The slab
+    // of strip b + 1 is the one strip b - 1 wrote and strip b reads: b + 1 is at least 64 steps behind b, which has then read
+    // (one step ahead) every column b + 1 overwrites.
+    template <int NW>
+    __device__ __forceinline__ void run(const DevJob &ja, const DevJob &jb, const DevSeqs &seqs, int *bnd, int wid, int *prog) {
         const DevJob *jp[2] = {&ja, &jb};
         static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
             const DevJob &jx = *jp[H];
@@ -304,7 +310,9 @@ struct WaveWin16 {
         const int main_lo = 63 + (MAXAT > DC ? MAXAT : DC), main_hi = Tm;
         const int nsteps_r = (nsteps + NCOL - 1) / NCOL * NCOL;
         const int main_lo_r = (main_lo + NCOL - 1) / NCOL * NCOL;
-        for (int b = 0; b < nstrips; b++) {
+        constexpr int CHK = (64 / NCOL) * NCOL;             // steps per chunk of the progress protocol
+        const int PS = nsteps_r + 1;
+        for (int b = wid; b < nstrips; b += NW) {
             const int i0 = b * W + lane * R;
             static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
                 static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
@@ -333,12 +341,38 @@ struct WaveWin16 {
                     step<JI, P>(s0 + P, i0, last, bnd_in, bnd_out);
                 });
             };
-            prefetch_column(0 - lane);
-            prefetch_carry(0, bnd_in);
-            int s = 0;
-            for (; s < main_lo_r && s < nsteps_r; s += NCOL) group(IC<0>{}, s);
-            for (; s + NCOL - 1 <= main_hi; s += NCOL) group(IC<1>{}, s);
-            for (; s < nsteps_r; s += NCOL) group(IC<0>{}, s);
+            if constexpr (NW == 1) {
+                prefetch_column(0 - lane);
+                prefetch_carry(0, bnd_in);
+                int s = 0;
+                for (; s < main_lo_r && s < nsteps_r; s += NCOL) group(IC<0>{}, s);
+                for (; s + NCOL - 1 <= main_hi; s += NCOL) group(IC<1>{}, s);
+                for (; s < nsteps_r; s += NCOL) group(IC<0>{}, s);
+            } else {
+                const int above = (wid + NW - 1) % NW, above_base = ((b - 1) / NW) * PS, my_base = (b / NW) * PS;
+                // the steps before c1 read carry columns up to c1 (one step ahead): written by the strip above in its step c1 + 63
+                auto wait_above = [&](int c1) __attribute__((always_inline)) {
+                    if (first) return;
+                    const int need = above_base + (c1 + 64 < nsteps_r ? c1 + 64 : nsteps_r);
+                    while (__hip_atomic_load(prog + above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                };
+                wait_above(CHK < nsteps_r ? CHK : nsteps_r);
+                prefetch_column(0 - lane);
+                prefetch_carry(0, bnd_in);
+                for (int c0 = 0; c0 < nsteps_r; c0 += CHK) {
+                    const int c1 = c0 + CHK < nsteps_r ? c0 + CHK : nsteps_r;
+                    if (c0) wait_above(c1);
+                    int s = c0;
+                    for (; s < main_lo_r && s < c1; s += NCOL) group(IC<0>{}, s);
+                    for (; s + NCOL - 1 <= main_hi && s < c1; s += NCOL) group(IC<1>{}, s);
+                    for (; s < c1; s += NCOL) group(IC<0>{}, s);
+                    if (!last) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) __hip_atomic_store(prog + wid, my_base + c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // carry row visible to the next strip
         }
     }
@@ -347,27 +381,45 @@ struct WaveWin16 {
 // The window chains of a pair of jobs (both with root ROOT) on one wave: results in the 32-bit window kernel's form — score
 // of the chain's first corner, end_set, n_vsa = windows run, pad >= 0 with (qs, ts) where the chain found the start, pad < 0
 // where the hop budget ran out.  job_lds[1] is an idle window when the pair holds one job.
-template <class M, int R, int ROOT>
+template <class M, int R, int ROOT, int NW>
 __device__ __forceinline__ void win16_chains(const KParams *kp_lds, const DevSeqs &seqs, DevJob *job_lds, int *more, int ia, int ib,
-                                             DevResult *results, int *bnd) {
+                                             DevResult *results, int *bnd, int *prog, int (*corner_lds)[4]) {
     using DP = WaveWin16<M, R, ROOT>;
     int hop = 0, first_score = 0;                      // threads 0 and 1: their window chain
     bool active = threadIdx.x < 2 && more[threadIdx.x & 1];
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     for (;;) {
         DP dp{};                 // every member starts defined (c4_viterbi_kernel.h, viterbi_kernel)
         dp.kp = kp_lds;
-        dp.lane = threadIdx.x;
-        dp.run(job_lds[0], job_lds[1], seqs, bnd);
+        dp.lane = threadIdx.x & 63;
+        if constexpr (NW > 1) {
+            if (threadIdx.x < NW) prog[threadIdx.x] = 0;
+            if (threadIdx.x < 2) corner_lds[threadIdx.x][3] = 0;
+            __syncthreads();
+        }
+        dp.template run<NW>(job_lds[0], job_lds[1], seqs, bnd, wid, prog);
         // the lane that owned a window's corner cell hands it to the thread that keeps that window's chain
         int sc[2], rq[2], rt[2];
         bool set[2];
-        for (int h = 0; h < 2; h++) {
-            const unsigned long long owners = __ballot(dp.corner_set[h]);
-            const int owner = owners ? __ffsll((long long)owners) - 1 : 0;
-            sc[h] = __shfl(dp.corner_sc[h], owner); rq[h] = __shfl(dp.corner_rq[h], owner); rt[h] = __shfl(dp.corner_rt[h], owner);
-            set[h] = owners != 0;
+        if constexpr (NW == 1) {
+            for (int h = 0; h < 2; h++) {
+                const unsigned long long owners = __ballot(dp.corner_set[h]);
+                const int owner = owners ? __ffsll((long long)owners) - 1 : 0;
+                sc[h] = __shfl(dp.corner_sc[h], owner); rq[h] = __shfl(dp.corner_rq[h], owner); rt[h] = __shfl(dp.corner_rt[h], owner);
+                set[h] = owners != 0;
+            }
+            __syncthreads();
+        } else {                                           // ... through LDS: the corner's strip ran on one of the waves
+            for (int h = 0; h < 2; h++)
+                if (dp.corner_set[h]) {
+                    corner_lds[h][0] = dp.corner_sc[h]; corner_lds[h][1] = dp.corner_rq[h]; corner_lds[h][2] = dp.corner_rt[h];
+                    corner_lds[h][3] = 1;
+                }
+            __syncthreads();
+            for (int h = 0; h < 2; h++) {
+                sc[h] = corner_lds[h][0]; rq[h] = corner_lds[h][1]; rt[h] = corner_lds[h][2]; set[h] = corner_lds[h][3] != 0;
+            }
         }
-        __syncthreads();
         if (active) {
             const int h = threadIdx.x;
             DevJob &job = job_lds[h];
@@ -410,8 +462,8 @@ __device__ __forceinline__ void win16_chains(const KParams *kp_lds, const DevSeq
 
 // persistent waves; workgroup p of the queue runs the window chains of the p-th pair of the host's list (LaunchArgs::aux:
 // two job indices with the same root, the second -1 where a job runs alone)
-template <class M, int R, int WPE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
+template <class M, int R, int WPE, int NW = 1>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
 void win16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, const int *pairs, int n_pairs, DevResult *results,
                   DevScratch scratch, int *queue) {
     using RT = Roots<M>;
@@ -419,10 +471,12 @@ void win16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, cons
     __shared__ int next_job;
     __shared__ DevJob job_lds[2];
     __shared__ int more[2];
+    __shared__ int prog[NW];
+    __shared__ int corner_lds[2][4];
     {
         const int *src = reinterpret_cast<const int *>(kparams);
         int *dst = reinterpret_cast<int *>(&kp_lds);
-        for (int x = threadIdx.x; x < (int)(sizeof(KParams) / sizeof(int)); x += 64) dst[x] = src[x];
+        for (int x = threadIdx.x; x < (int)(sizeof(KParams) / sizeof(int)); x += 64 * NW) dst[x] = src[x];
     }
     __syncthreads();
     int *bnd = scratch.bnd + (long long)blockIdx.x * scratch.bnd_stride;
@@ -453,7 +507,7 @@ void win16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, cons
                     if (threadIdx.x == 0) WaveWin16<M, R, ROOT>::write_empty_column(bnd);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     __syncthreads();
-                    win16_chains<M, R, ROOT>(&kp_lds, seqs, job_lds, more, ia, ib, results, bnd);
+                    win16_chains<M, R, ROOT, NW>(&kp_lds, seqs, job_lds, more, ia, ib, results, bnd, prog, corner_lds);
                     ran = true;
                 }
             });
@@ -462,7 +516,7 @@ void win16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, cons
             if (threadIdx.x == 0) WaveWin16<M, R, -1>::write_empty_column(bnd);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
-            win16_chains<M, R, -1>(&kp_lds, seqs, job_lds, more, ia, ib, results, bnd);
+            win16_chains<M, R, -1, NW>(&kp_lds, seqs, job_lds, more, ia, ib, results, bnd, prog, corner_lds);
         } else if (!ran) {                                  // a root the model does not have: the host's mistake, say so
             if (threadIdx.x < 2 && more[threadIdx.x]) {
                 DevResult res;

@@ -11,6 +11,9 @@ const KernelInfo *kck16r_est2genome_r4w2_info();
 const KernelInfo *kck16r_est2genome_r6w2_info();
 const KernelInfo *kck16r_est2genome_r3w3_info();
 const KernelInfo *kck16r_est2genome_r2w4_info();
+const KernelInfo *kck16r_est2genome_r4w2n4_info();       // ... with the strips on 4 / 2 / 3 cooperating waves
+const KernelInfo *kck16r_est2genome_r4w2n2_info();
+const KernelInfo *kck16r_est2genome_r6w2n3_info();
 // variant: shapes kept for measurement (0 = the default of each form)
 const KernelInfo *get_kernel_ck16(int family, int variant, bool rooted) {
     if (family != FAM_EST2GENOME) return nullptr;
@@ -21,6 +24,9 @@ const KernelInfo *get_kernel_ck16(int family, int variant, bool rooted) {
             case 1: return kck16r_est2genome_r4w2_info();
             case 2: return kck16r_est2genome_r3w3_info();
             case 3: return kck16r_est2genome_r2w4_info();
+            case 4: return kck16r_est2genome_r4w2n4_info();
+            case 5: return kck16r_est2genome_r4w2n2_info();
+            case 6: return kck16r_est2genome_r6w2n3_info();
             default: return kck16r_est2genome_r6w2_info();
         }
     }

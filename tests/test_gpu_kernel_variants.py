@@ -489,7 +489,8 @@ def test_packed_16_bit_region_windows_agree_with_the_32_bit_windows(eng, monkeyp
     monkeypatch.setenv("C4GPU_TRACE", "1")
     monkeypatch.setenv("C4GPU_SEED_KSHIFT", "13")
     res = {}
-    for w in ("1", "2", "3", "4", "0"):
+    shapes = ("1", "2", "3", "4", "5", "6", "7", "8", "9")     # 1: chosen by the jobs; 5 ... 8: the strips of a window on 4 / 8 / 4 / 2 cooperating waves; 9: one wave
+    for w in shapes + ("0",):
         monkeypatch.setenv("C4GPU_WIN16", w)
         res[w] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=32, threshold=100)]
         err = capfd.readouterr().err
@@ -497,7 +498,7 @@ def test_packed_16_bit_region_windows_agree_with_the_32_bit_windows(eng, monkeyp
         # (the score pass behind them writes 16-bit dumps: kpk16f, its LDS-fed form, for these queries and residue codes)
         assert ("kwin16_est2genome" in err) == (w != "0") and ("kpk16f_est2genome" in err) == (w != "0"), err[-1500:]
         assert ("kmw2_est2genome_region_local_pack_seed2" in err) == (w == "0"), err[-1500:]
-    for w in ("1", "2", "3", "4"):
+    for w in shapes:
         assert res[w] == res["0"], w
     assert all(r is not None for r in res["0"][:-1])          # (the unrelated pair has a chance alignment above the threshold or not)
     # both strands were there: an intron-labelled run of a reverse-strand pair goes through the reverse intron state
@@ -515,12 +516,12 @@ def test_packed_16_bit_region_windows_agree_with_the_32_bit_windows(eng, monkeyp
         monkeypatch.setenv("C4GPU_SEED_KSHIFT", kshift)
         small = [pairs[0], pairs[1], pairs[3], pairs[5], pairs[11]]
         got = {}
-        for w in ("1", "3", "0"):
+        for w in ("1", "3", "5", "6", "9", "0"):
             monkeypatch.setenv("C4GPU_WIN16", w)
             got[w] = [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=100)]
             err = capfd.readouterr().err
             assert ("kwin16_est2genome" in err) == (w != "0"), err[-1500:]
-        assert got["1"] == got["0"] and got["3"] == got["0"], kshift
+        assert all(got[w] == got["0"] for w in ("1", "3", "5", "6", "9")), kshift
 
 
 @pytest.mark.parametrize("model_type,dpm", [("affine:local", 32), ("affine:local", 1), ("affine:local", 0),
@@ -593,9 +594,11 @@ def test_packed_16_bit_checkpoint_pass_agrees_with_the_32_bit_pass(eng, monkeypa
     monkeypatch.setenv("C4GPU_TRACE", "1")
     res, fin = {}, {}
     # C4GPU_CK16 = 1..4: the shapes of the rooted form (one strand's states: the jobs whose region pass said where END was
-    # entered from); C4GPU_CK16_ROOT=0: every job on the form that computes all inner states
+    # entered from), 5..7: the strips of a pair of jobs on 4 / 2 / 3 cooperating waves (1: chosen by the jobs' strips, 8: one wave); C4GPU_CK16_ROOT=0: every job on the
+    # form that computes all inner states
     rooted_seen = 0
-    for ck, tmax, root in (("1", None, "1"), ("2", None, "1"), ("3", None, "1"), ("4", None, "1"), ("1", None, "0"),
+    for ck, tmax, root in (("1", None, "1"), ("2", None, "1"), ("3", None, "1"), ("4", None, "1"), ("5", None, "1"),
+                           ("6", None, "1"), ("7", None, "1"), ("8", None, "1"), ("1", None, "0"),
                            ("1", "20000", "1"), ("0", None, "1")):
         monkeypatch.setenv("C4GPU_CK16", ck)
         monkeypatch.setenv("C4GPU_CK16_ROOT", root)
