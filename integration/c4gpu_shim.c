@@ -89,9 +89,16 @@ static gchar *shim_ctx_error = NULL;
  * load (c4gpu_ctx_warm_cancel), the thread is joined, and only then do the exit handlers run, with no thread left inside
  * the runtime.  Both ways out come through here: main()'s return (the wrapper below) and every exit() call of the
  * reference's own objects (general/argument.c's error handler among them), which the Makefile points at shim_exit with
- * objcopy --redefine-sym.  C4GPU_FAST_EXIT=1: after the join, skip the runtime's teardown (tens of milliseconds that a
- * process about to end has no use for) with _exit -- an option now, not the fix. */
+ * objcopy --redefine-sym.  After the join the process leaves with _exit (stdio flushed first) where the device thread was ever
+ * started: with no thread of ours left inside it, the runtime's OWN teardown in the exit handlers still ended one 0.2 s run in
+ * about two hundred with SIGSEGV after its complete, correct output (a warm-up cut short leaves code objects half way through
+ * the runtime's loader threads; profiles/r04_f_pytest_gpu.log), and a process about to end has no use for that teardown.
+ * C4GPU_FAST_EXIT=0 takes the ordinary exit (handlers and all). */
 static gboolean shim_joined = FALSE;
+static gboolean shim_fast_exit(void){
+    register const gchar *e = g_getenv("C4GPU_FAST_EXIT");
+    return shim_ctx_thread && !(e && e[0] == '0');
+    }
 static void shim_quiesce(void){
     register GThread *t;
     g_mutex_lock(&shim_ctx_lock);
@@ -106,7 +113,7 @@ static void shim_quiesce(void){
     }
 void shim_exit(int status){
     shim_quiesce();
-    if(shim_ctx_thread && g_getenv("C4GPU_FAST_EXIT")){
+    if(shim_fast_exit()){
         fflush(NULL);
         _exit(status);
         }
@@ -156,7 +163,7 @@ extern int exonerate_main_cpu(int argc, char **argv);
 int main(int argc, char **argv){
     register int rc = exonerate_main_cpu(argc, argv);
     shim_quiesce();
-    if(shim_ctx_thread && g_getenv("C4GPU_FAST_EXIT")){
+    if(shim_fast_exit()){
         fflush(NULL);
         _exit(rc);
         }
