@@ -1874,9 +1874,11 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
     // long targets under a local model, nothing blocked: the two-pass (windowed) form of the region pass
     std::vector<std::pair<int, DevResult>> region_done;
     {
-        // a dump every 8 192 columns (measured on the north-star batch: score pass 410 ms against 462 ms at 4 096, windows 204
-        // against 181 ms; 16 384: 408 and 272 ms), every 4 096 while some target of the call is too short for that
-        int kshift_env = 13;
+        // a dump every 8 192 columns (measured on the north-star batch with 32-bit dumps: score pass 410 ms against 462 ms at 4 096,
+        // windows 204 against 181 ms; 16 384: 408 and 272 ms), every 4 096 while some target of the call is too short for that
+        // -- and where the packed score pass serves, whose 16-bit dump rows cost it 1.4 ms per launch more at 4 096 while the
+        // windows save 9 (step on two lanes 442 -> 436 ms; 2 048: 438; gpurun_out/r4g_suite.log)
+        int kshift_env = (eng.family == FAM_EST2GENOME && eng.pk16_params_ok) ? 12 : 13;
         for (int i : region_pairs)
             if (plan[i].ar.target_length < (4 << 13) && plan[i].ar.target_length >= (4 << 12)) kshift_env = 12;
         if (getenv("C4GPU_SEED_KSHIFT")) kshift_env = atoi(getenv("C4GPU_SEED_KSHIFT"));
