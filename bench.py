@@ -232,7 +232,7 @@ def other_configs(ex, eng):
 def c5_heuristic_leg():
     """BASELINE config 5's heuristic leg through the drop-in binary (integration/_build/exonerate-gpu: the reference's own
     objects with libc4gpu.so behind its seams -- word scan, HSP extension and SDP on the device): 256 proteins of 300 aa against
-    one 10 Mb chromosome, -m protein2genome, default mode; wall time of the second of two runs, stdout compared by SHA-256 with
+    one 10 Mb chromosome, -m protein2genome, default mode; wall time of the better of the two runs after a first, cold one (all three in wall_s_runs), every stdout compared by SHA-256 with
     what the reference binary printed for the same input (tests/golden/bench_c5_heuristic.json, tools/make_c5_heuristic_golden.py:
     the reference needs 66 s on one core of the GPU box, too long for the bench).  Skipped where the binary is not built."""
     import hashlib, tempfile
@@ -245,19 +245,27 @@ def c5_heuristic_leg():
     with tempfile.TemporaryDirectory() as d:
         qf, tf = workloads.write_c5_heuristic_input(d)
         env = dict(os.environ, C4GPU_VERBOSE="1")
-        dt, r = 0.0, None
-        for _ in range(2):
+        dt, r, runs, slow = 0.0, None, [], []
+        for _ in range(3):              # the first run pays the cold start (binary, code objects: 5-9 s); wall_s = the better of the other two
             t0 = time.perf_counter()
             r = subprocess.run([exe] + want["args"] + [qf, tf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
-            dt = time.perf_counter() - t0
+            runs.append(round(time.perf_counter() - t0, 3))
             assert r.returncode == 0, r.stderr.decode()[-800:]
+            assert hashlib.sha256(r.stdout).hexdigest() == want["sha256"], "c5 heuristic leg: output differs from the reference's"
+        dt = min(runs[1:])
+        if dt > 4.0:
+            # where the time went when a run is slow (seen: hipMalloc of the 65 GB stream arena taking seconds instead of 0.3 ms)
+            rt = subprocess.run([exe] + want["args"] + [qf, tf], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                env=dict(env, C4GPU_TRACE="1"))
+            slow = [l.strip() for l in rt.stderr.decode().splitlines() if "arena of" in l or "sdp flush" in l][:12]
     assert hashlib.sha256(r.stdout).hexdigest() == want["sha256"], "c5 heuristic leg: output differs from the reference's"
     served = [l.split("c4gpu ", 1)[1].strip() for l in r.stderr.decode().splitlines() if "c4gpu sdp:" in l or "c4gpu seed:" in l]
     return {"c5_heuristic": {"workload": "config 5 (heuristic leg): exonerate-gpu -m protein2genome, 256 proteins of 300 aa x one 10 Mb "
                                          "chromosome, seeding + SDP on the device", "wall_s": dt, "alignments": want["alignments"],
                              "reference_wall_s_one_core": 66.3,
                              "checked": "stdout (%d vulgar lines) SHA-256 equal to the reference binary's, tests/golden/bench_c5_heuristic.json"
-                                        % want["alignments"], "device": served}}
+                                        % want["alignments"], "device": served, "wall_s_runs": runs,
+                             **({"slow_run_trace": slow} if slow else {})}}
 
 
 def revcomp(seq):
