@@ -1476,7 +1476,7 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
     if (kc16r && n16r && ck_env == 1) {
         // the shape by the strips of 256 rows the rooted jobs have: four (two) cooperating waves per pair of jobs where the
         // jobs fill them -- the launch then lasts as long as its work, not as its longest job's strips one after the other
-        // (north-star batch, two lanes: 481 -> 446 ms per step; gpurun_out/ck16) --, one wave per pair of short queries
+        // (north-star batch, two lanes: 481 -> 446 ms per step; profiles/r04_ck16_sweep.log) --, one wave per pair of short queries
         long long strips = 0;
         for (int x = 0; x < n; x++) if (group[x] == 2) strips += (plan[red[x]].ar.query_length + 1 + 255) / 256;
         kc16r = get_kernel_ck16(eng.family, strips >= 3LL * n16r ? 4 : strips >= 2LL * n16r ? 5 : 0, true);
@@ -1877,7 +1877,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
         // a dump every 8 192 columns (measured on the north-star batch with 32-bit dumps: score pass 410 ms against 462 ms at 4 096,
         // windows 204 against 181 ms; 16 384: 408 and 272 ms), every 4 096 while some target of the call is too short for that
         // -- and where the packed score pass serves, whose 16-bit dump rows cost it 1.4 ms per launch more at 4 096 while the
-        // windows save 9 (step on two lanes 442 -> 436 ms; 2 048: 438; gpurun_out/r4g_suite.log)
+        // windows save 9 (step on two lanes 442 -> 436 ms; 2 048: 438; profiles/r04_kshift_sweep.log)
         int kshift_env = (eng.family == FAM_EST2GENOME && eng.pk16_params_ok) ? 12 : 13;
         for (int i : region_pairs)
             if (plan[i].ar.target_length < (4 << 13) && plan[i].ar.target_length >= (4 << 12)) kshift_env = 12;
