@@ -1479,7 +1479,9 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
         // (north-star batch, two lanes: 481 -> 446 ms per step; profiles/r04_ck16_sweep.log) --, one wave per pair of short queries
         long long strips = 0;
         for (int x = 0; x < n; x++) if (group[x] == 2) strips += (plan[red[x]].ar.query_length + 1 + 255) / 256;
-        kc16r = get_kernel_ck16(eng.family, strips >= 3LL * n16r ? 4 : strips >= 2LL * n16r ? 5 : 0, true);
+        // (the four-wave shape at three waves per SIMD, 168 registers: 65 -> 52 ms per launch, step 436 -> 430 ms;
+        // profiles/r04_ck16_w3_sweep.log)
+        kc16r = get_kernel_ck16(eng.family, strips >= 3LL * n16r ? 8 : strips >= 2LL * n16r ? 5 : 0, true);
     }
     if (n16 && eng.ensure_ss16(seqs)) return -1;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) {

@@ -14,6 +14,7 @@ const KernelInfo *kck16r_est2genome_r2w4_info();
 const KernelInfo *kck16r_est2genome_r4w2n4_info();       // ... with the strips on 4 / 2 / 3 cooperating waves
 const KernelInfo *kck16r_est2genome_r4w2n2_info();
 const KernelInfo *kck16r_est2genome_r6w2n3_info();
+const KernelInfo *kck16r_est2genome_r4w3n4_info();       // three waves per SIMD (168 registers, some of the state in scratch)
 // variant: shapes kept for measurement (0 = the default of each form)
 const KernelInfo *get_kernel_ck16(int family, int variant, bool rooted) {
     if (family != FAM_EST2GENOME) return nullptr;
@@ -27,6 +28,7 @@ const KernelInfo *get_kernel_ck16(int family, int variant, bool rooted) {
             case 4: return kck16r_est2genome_r4w2n4_info();
             case 5: return kck16r_est2genome_r4w2n2_info();
             case 6: return kck16r_est2genome_r6w2n3_info();
+            case 8: return kck16r_est2genome_r4w3n4_info();
             default: return kck16r_est2genome_r6w2_info();
         }
     }

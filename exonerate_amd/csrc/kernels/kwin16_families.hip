@@ -20,6 +20,7 @@ WIN16_KERNEL(kwin16_est2genome_r4w2n4, Est2GenomeDesc, 4, 2, 4)
 WIN16_KERNEL(kwin16_est2genome_r2w4n8, Est2GenomeDesc, 2, 4, 8)
 WIN16_KERNEL(kwin16_est2genome_r2w4n4, Est2GenomeDesc, 2, 4, 4)
 WIN16_KERNEL(kwin16_est2genome_r4w2n2, Est2GenomeDesc, 4, 2, 2)
+WIN16_KERNEL(kwin16_est2genome_r4w3n2, Est2GenomeDesc, 4, 3, 2)
 const KernelInfo *get_kernel_win16(int family, int variant) {
     if (family != FAM_EST2GENOME) return nullptr;
     switch (variant) {
@@ -30,6 +31,7 @@ const KernelInfo *get_kernel_win16(int family, int variant) {
         case 5: return &kwin16_est2genome_r2w4n8;
         case 6: return &kwin16_est2genome_r2w4n4;
         case 7: return &kwin16_est2genome_r4w2n2;
+        case 9: return &kwin16_est2genome_r4w3n2;
         default: return &kwin16_est2genome_r4w2;
     }
 }

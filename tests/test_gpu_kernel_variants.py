@@ -489,7 +489,7 @@ def test_packed_16_bit_region_windows_agree_with_the_32_bit_windows(eng, monkeyp
     monkeypatch.setenv("C4GPU_TRACE", "1")
     monkeypatch.setenv("C4GPU_SEED_KSHIFT", "13")
     res = {}
-    shapes = ("1", "2", "3", "4", "5", "6", "7", "8", "9")     # 1: chosen by the jobs; 5 ... 8: the strips of a window on 4 / 8 / 4 / 2 cooperating waves; 9: one wave
+    shapes = ("1", "2", "3", "4", "5", "6", "7", "8", "9", "10")     # 10: two waves at three per SIMD; 1: chosen by the jobs; 5 ... 8: the strips of a window on 4 / 8 / 4 / 2 cooperating waves; 9: one wave
     for w in shapes + ("0",):
         monkeypatch.setenv("C4GPU_WIN16", w)
         res[w] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=32, threshold=100)]
@@ -594,11 +594,11 @@ def test_packed_16_bit_checkpoint_pass_agrees_with_the_32_bit_pass(eng, monkeypa
     monkeypatch.setenv("C4GPU_TRACE", "1")
     res, fin = {}, {}
     # C4GPU_CK16 = 1..4: the shapes of the rooted form (one strand's states: the jobs whose region pass said where END was
-    # entered from), 5..7: the strips of a pair of jobs on 4 / 2 / 3 cooperating waves (1: chosen by the jobs' strips, 8: one wave); C4GPU_CK16_ROOT=0: every job on the
+    # entered from), 5..7: the strips of a pair of jobs on 4 / 2 / 3 cooperating waves (1: chosen by the jobs' strips, 8: one wave, 9: four waves at three per SIMD); C4GPU_CK16_ROOT=0: every job on the
     # form that computes all inner states
     rooted_seen = 0
     for ck, tmax, root in (("1", None, "1"), ("2", None, "1"), ("3", None, "1"), ("4", None, "1"), ("5", None, "1"),
-                           ("6", None, "1"), ("7", None, "1"), ("8", None, "1"), ("1", None, "0"),
+                           ("6", None, "1"), ("7", None, "1"), ("8", None, "1"), ("9", None, "1"), ("1", None, "0"),
                            ("1", "20000", "1"), ("0", None, "1")):
         monkeypatch.setenv("C4GPU_CK16", ck)
         monkeypatch.setenv("C4GPU_CK16_ROOT", root)
