@@ -17,7 +17,7 @@ from . import _abi
 from ._abi import (ALPHABET_DNA, ALPHABET_PROTEIN, IMPOSSIBLY_LOW_SCORE, MODE_FIND_SCORE, MODE_FIND_PATH,
                    MODE_FIND_REGION, MODE_FIND_CHECKPOINTS)
 
-__all__ = ["Model", "Engine", "Alignment", "ResidentBatch", "default_params", "C4GpuError"]
+__all__ = ["Model", "Engine", "Alignment", "ResidentBatch", "Stage", "default_params", "C4GpuError"]
 
 
 class C4GpuError(RuntimeError):
@@ -225,12 +225,16 @@ class SubOpt:
 def _pairs(pairs):
     arr = (_abi.Pair * max(1, len(pairs)))()
     keep = []
-    seen = {}                      # equal sequences share one buffer: the library uploads each buffer once
+    seen = {}                      # one object handed over in many pairs (one contig against many queries) is one buffer:
+    #                                the library uploads each buffer once.  Keyed by identity: hashing 400 MB of residues to
+    #                                find equal copies would cost more than uploading them
+    def buf(x):
+        got = seen.get(id(x))
+        if got is None:
+            got = seen[id(x)] = x if isinstance(x, bytes) else x.encode()
+        return got
     for i, (q, t) in enumerate(pairs):
-        q = q if isinstance(q, bytes) else q.encode()
-        t = t if isinstance(t, bytes) else t.encode()
-        q = seen.setdefault(q, q)
-        t = seen.setdefault(t, t)
+        q, t = buf(q), buf(t)
         keep.append((q, t))
         arr[i].query, arr[i].query_len, arr[i].target, arr[i].target_len = q, len(q), t, len(t)
     return arr, keep
@@ -487,6 +491,14 @@ class ResidentBatch:
         if _lib().c4gpu_batch_run(self.h, what, dpmemory, threshold) != 0:
             raise _err("c4gpu_batch_run")
 
+    def swap(self, stage):
+        """Take the sequences `stage` has loaded (c4gpu_batch_swap_stage); the stage gets this batch's previous ones, whose
+        buffers its next load reuses.  Earlier results of the batch are dropped."""
+        if _lib().c4gpu_batch_swap_stage(self.h, stage.h) != 0:
+            raise _err("c4gpu_batch_swap_stage")
+        self._keep, stage._keep = stage._keep, self._keep
+        self.n, stage.n = stage.n, self.n
+
     def run_regions(self, regions, dpmemory=32, threshold=IMPOSSIBLY_LOW_SCORE, active=None):
         """Optimal_find_path of every pair over its own region (query_start, target_start, query_length,
         target_length) of the rectangle: what --refine region asks for (c4gpu_batch_run_regions)."""
@@ -552,4 +564,28 @@ class ResidentBatch:
     def close(self):
         if self.h:
             _lib().c4gpu_batch_destroy(self.h)
+            self.h = None
+
+
+class Stage:
+    """The next batch on its way to the device (c4gpu_stage): load() from one thread while ResidentBatch.run() is in
+    progress on another (ctypes releases the GIL inside both), then ResidentBatch.swap(stage)."""
+
+    def __init__(self, engine, model):
+        self.engine, self.model = engine, model
+        self._keep, self.n = [], 0
+        self.h = _lib().c4gpu_stage_create(engine.ctx, model.c, model.params)
+        if not self.h:
+            raise _err("c4gpu_stage_create")
+
+    def load(self, pairs):
+        arr, self._keep = _pairs(pairs)
+        self.n = len(pairs)
+        if _lib().c4gpu_stage_load(self.h, arr, len(pairs)) != 0:
+            raise _err("c4gpu_stage_load")
+        return _lib().c4gpu_stage_load_ms(self.h)
+
+    def close(self):
+        if self.h:
+            _lib().c4gpu_stage_destroy(self.h)
             self.h = None

@@ -88,6 +88,31 @@ template <typename F> void parallel_for(long long n, long long min_per_thread, F
 }
 
 // ---- small RAII device buffer ------------------------------------------------------------------------------
+// hipFree waits for the whole device: with two launch lanes and a staging stream in flight, a launch buffer that has to grow
+// in the middle of a step would stall its lane until the other lane's kernels (hundreds of ms) have finished.  A buffer that
+// is outgrown is therefore retired, not freed: it goes onto this list and is freed when its owner is (batch / stage / context
+// destruction: nothing is in flight then), or at once when the list holds more than 16 GB.
+struct RetiredBuffers {
+    std::mutex lock;
+    std::vector<std::pair<void *, size_t>> list;
+    size_t bytes = 0;
+    void retire(void *p, size_t n) {
+        std::vector<std::pair<void *, size_t>> drop;
+        {
+            std::lock_guard<std::mutex> hold(lock);
+            list.emplace_back(p, n); bytes += n;
+            if (bytes > ((size_t)16 << 30)) { drop.swap(list); bytes = 0; }
+        }
+        for (auto &d : drop) (void)hipFree(d.first);
+    }
+    void flush() {
+        std::vector<std::pair<void *, size_t>> drop;
+        { std::lock_guard<std::mutex> hold(lock); drop.swap(list); bytes = 0; }
+        for (auto &d : drop) (void)hipFree(d.first);
+    }
+};
+static RetiredBuffers g_retired;
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
@@ -98,7 +123,11 @@ struct DevBuf {
     DevBuf &operator=(const DevBuf &) = delete;
     int alloc(size_t count) {
         if (count <= n && p) return 0;
-        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        // every buffer is made an eighth larger than asked (small ones twice as large): in a stream of batches of about one
+        // size a launch buffer would otherwise be outgrown whenever a batch needs a little more
+        if (p) { g_retired.retire(p, n * sizeof(T)); p = nullptr; n = 0; }
+        count += count / 8;
+        if (count * sizeof(T) < ((size_t)1 << 20)) count *= 2;
         if (!count) count = 1;
         HIP_OK(hipMalloc((void **)&p, count * sizeof(T)));
         n = count;
@@ -114,6 +143,26 @@ struct DevBuf {
     }
     int download(T *dst, size_t count, hipStream_t s) const {
         if (count) HIP_OK(hipMemcpyAsync(dst, p, count * sizeof(T), hipMemcpyDeviceToHost, s));
+        return 0;
+    }
+    void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
+};
+
+// Page-locked host memory that is kept between uses (c4gpu_stage: the gathered residues of the next batch): the DMA engine
+// reads it at PCIe speed, hipMemcpyAsync returns at once, and nothing is page-faulted in after the first use.
+struct PinBuf {
+    uint8_t *p = nullptr;
+    size_t n = 0;
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    PinBuf() = default;
+    PinBuf(const PinBuf &) = delete;
+    PinBuf &operator=(const PinBuf &) = delete;
+    int reserve(size_t bytes) {
+        if (bytes <= n && p) return 0;
+        if (p) { (void)hipHostFree(p); p = nullptr; n = 0; }
+        bytes += bytes / 8;                      // the next batch of a stream of batches is about this size, rarely the same
+        HIP_OK(hipHostMalloc((void **)&p, bytes, hipHostMallocDefault));
+        n = bytes;
         return 0;
     }
 };
@@ -286,6 +335,112 @@ __global__ void splice_kernel(const uint8_t *__restrict__ seq, const long long *
         o[pos] = (int)r;
     }
   }
+}
+
+// The same arrays, tiled: a workgroup takes 1 024 consecutive positions of one sequence and computes all four site types for
+// them.  The four PSSMs, the residue -> column tables and the tile's residues (with the columns of every model looked up once)
+// sit in LDS; a thread owns four consecutive positions and slides a four-byte window of columns along the model, so one LDS
+// byte read serves four positions per model row; the four values of a position leave as 16-byte stores.  Every position's sum
+// is the same chain of float adds in the same order as above (no reassociation), so the arrays are bit-identical; positions
+// whose window is clipped by an end of the sequence take the one-by-one loop.  With `out16` (est2genome batches whose
+// parameters allow the packed passes) the kernel also writes the packed passes' splice array -- the four values clamped to 16
+// bits with the calc constant of a pre-splice transition folded in (fold[type]; ss16_kernel's formula) -- instead of a second
+// pass that reads the 16 bytes per position back.
+struct SpliceFold { int add[4]; };
+constexpr int SPLICE_TILE = 1024, SPLICE_HALO = C4GPU_SPLICE_MAX_LEN;
+__global__ __launch_bounds__(256) void splice_tile_kernel(const uint8_t *__restrict__ seq, const long long *off, const int *len, int n_seqs,
+                                                          const c4gpu_splice_model *__restrict__ models, int *__restrict__ out,
+                                                          long long stride, SpliceFold fold, uint2 *__restrict__ out16) {
+    __shared__ float sdata[4][C4GPU_SPLICE_MAX_LEN * 5];
+    __shared__ uint8_t sindex[4][256];
+    __shared__ __attribute__((aligned(16))) uint8_t scol[4][SPLICE_TILE + 2 * SPLICE_HALO + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t sraw[SPLICE_TILE + 16];
+    __shared__ int s_mlen[4], s_after[4], s_gtag[4], s_e1[4], s_e2[4];
+    const int tid = threadIdx.x;
+    for (int x = tid; x < 4 * C4GPU_SPLICE_MAX_LEN * 5; x += 256) sdata[x / (C4GPU_SPLICE_MAX_LEN * 5)][x % (C4GPU_SPLICE_MAX_LEN * 5)] =
+        models[x / (C4GPU_SPLICE_MAX_LEN * 5)].data[(x % (C4GPU_SPLICE_MAX_LEN * 5)) / 5][x % 5];
+    for (int x = tid; x < 4 * 256; x += 256) sindex[x >> 8][x & 255] = models[x >> 8].index[x & 255];
+    if (tid < 4) {
+        s_mlen[tid] = models[tid].model_length; s_after[tid] = models[tid].splice_after; s_gtag[tid] = models[tid].gtag_only;
+        s_e1[tid] = models[tid].expect_one; s_e2[tid] = models[tid].expect_two;
+    }
+    __syncthreads();
+    for (int pair = blockIdx.y; pair < n_seqs; pair += gridDim.y) {
+        const uint8_t *s = seq + off[pair];
+        const int n = len[pair];
+        for (int tile = blockIdx.x * SPLICE_TILE; tile < n; tile += gridDim.x * SPLICE_TILE) {
+            __syncthreads();                                   // the tile before has been read
+            // residues tile - HALO .. tile + TILE + HALO as model columns (outside the sequence: never read), tile .. tile + TILE + 1 raw
+            const int lo = tile - SPLICE_HALO;
+            for (int x = tid; x < SPLICE_TILE + 2 * SPLICE_HALO; x += 256) {
+                const int p = lo + x;
+                const uint8_t b = (p >= 0 && p < n) ? s[p] : 0;
+                for (int k = 0; k < 4; k++) scol[k][x] = sindex[k][b];
+            }
+            for (int x = tid; x < SPLICE_TILE + 2; x += 256) sraw[x] = (tile + x < n) ? s[tile + x] : 0;
+            __syncthreads();
+            const int p0 = tile + 4 * tid;                     // this thread's positions p0 .. p0 + 3
+            if (p0 >= n) continue;
+            int v[4][4];                                       // [type][position]
+            for (int k = 0; k < 4; k++) {
+                const int mlen = s_mlen[k], after = s_after[k];
+                const float *d = sdata[k];
+                const uint8_t *c = scol[k] + (p0 - after - lo);     // column of residue p0 - after + i at c[i]
+                float sc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (p0 - after >= 0 && p0 + 3 - after + mlen <= n) {
+                    unsigned w = (unsigned)c[0] | ((unsigned)c[1] << 8) | ((unsigned)c[2] << 16);
+                    for (int i = 0; i < mlen; i++) {
+                        w |= (unsigned)c[i + 3] << 24;
+                        const float *row = d + 5 * i;
+                        sc[0] = sc[0] + row[w & 0xff];
+                        sc[1] = sc[1] + row[(w >> 8) & 0xff];
+                        sc[2] = sc[2] + row[(w >> 16) & 0xff];
+                        sc[3] = sc[3] + row[w >> 24];
+                        w >>= 8;
+                    }
+                } else {
+                    for (int q = 0; q < 4; q++) {
+                        const int pos = p0 + q;
+                        if (pos >= n) break;
+                        int seq_start = pos - after, model_start = 0, calc_length = mlen;
+                        if (seq_start < 0) { model_start = -seq_start; seq_start = 0; calc_length -= model_start; }
+                        if (seq_start + calc_length > n) calc_length = n - seq_start;
+                        float score = 0.0f;
+                        for (int i = 0; i < calc_length; i++) score = score + d[5 * (model_start + i) + scol[k][seq_start + i - lo]];
+                        sc[q] = score;
+                    }
+                }
+                for (int q = 0; q < 4; q++) {
+                    float score = sc[q];
+                    if (s_gtag[k]) {                            // Splice_predict_is_on_GTAG, splice.c:312-318 (past the end: the NUL)
+                        const int pos = p0 + q;
+                        const int b1 = sraw[4 * tid + q], b2 = pos + 1 < n ? sraw[4 * tid + q + 1] : 0;
+                        const int u1 = (b1 >= 'a' && b1 <= 'z') ? b1 - 32 : b1, u2 = (b2 >= 'a' && b2 <= 'z') ? b2 - 32 : b2;
+                        if (u1 != s_e1[k] || u2 != s_e2[k]) score = -987654321.0f;
+                    }
+                    const double r = score < 0 ? (double)score - 0.5 : (double)score + 0.5;
+                    v[k][q] = (int)r;
+                }
+            }
+            const long long base = off[pair] + p0;               // sequences start at multiples of four: 16-byte aligned
+            if (p0 + 3 < n) {
+                for (int k = 0; k < 4; k++)
+                    *reinterpret_cast<int4 *>(out + (long long)k * stride + base) = make_int4(v[k][0], v[k][1], v[k][2], v[k][3]);
+            } else {
+                for (int k = 0; k < 4; k++)
+                    for (int q = 0; q < 4 && p0 + q < n; q++) out[(long long)k * stride + base + q] = v[k][q];
+            }
+            if (out16) {
+                auto c16 = [](int x) { return x < -32768 ? -32768 : (x > 32767 ? 32767 : x); };
+                for (int q = 0; q < 4 && p0 + q < n; q++) {
+                    uint2 o;
+                    o.x = ((unsigned)c16(fold.add[0] + v[0][q]) & 0xffffu) | ((unsigned)c16(fold.add[1] + v[1][q]) << 16);
+                    o.y = ((unsigned)c16(fold.add[2] + v[2][q]) & 0xffffu) | ((unsigned)c16(fold.add[3] + v[3][q]) << 16);
+                    out16[base + q] = o;
+                }
+            }
+        }
+    }
 }
 
 // ---- HSP seeding: the ungapped X-drop extension of HSPset_seed_hsp (src/comparison/hspset.c:933-997) ----------------
@@ -563,7 +718,11 @@ struct ResidentSeqs {
     DevBuf<long long> d_utoff;
     DevBuf<int> d_utlen;
 
-    int build(c4gpu_ctx *ctx, int family, const c4gpu_params *params, const c4gpu_pair *pairs, int n) {
+    // page-locked staging of the residues, kept between the batches of a c4gpu_stage (build with pin = true)
+    PinBuf pin_q, pin_t;
+
+    int build(c4gpu_ctx *ctx, int family, const c4gpu_params *params, const c4gpu_pair *pairs, int n, bool pin = false,
+              const SpliceFold *fold16 = nullptr) {
         const bool trace = getenv("C4GPU_TRACE") != nullptr;          // read on every call: tests switch it
         const auto t_begin = std::chrono::steady_clock::now();
         auto lap = [&](const char *what) {
@@ -600,36 +759,62 @@ struct ResidentSeqs {
         n_utargets = (int)ut.size();
         // one host buffer per side, every byte written exactly once (residues, 'A' in the gaps up to the next multiple
         // of four and in the 64-byte tail the kernels may read into) by several threads: a value-initialised vector of
-        // this size (410 MB of targets for the north-star batch) is page-faulted in and written twice on one core
-        struct HostBuf {
-            std::unique_ptr<uint8_t[]> p; size_t n;
-            explicit HostBuf(size_t n_) : p(new uint8_t[n_]), n(n_) {}
-            uint8_t *data() { return p.get(); }
-            size_t size() const { return n; }
-        } hq((size_t)total_q + 64), ht((size_t)total_t + 64);
-        auto gather = [&](HostBuf &dst, const std::vector<int> &uniq, bool query, long long total) {
-            parallel_for((long long)uniq.size(), 16, [&](long long first, long long last) {
-                for (long long x = first; x < last; x++) {
+        // this size (410 MB of targets for the north-star batch) is page-faulted in and written twice on one core.
+        // A stage (c4gpu_stage: `pin` set) gathers into page-locked buffers it keeps between batches, slice by slice, each
+        // slice on its way over the link while the next one is gathered.
+        const size_t hq_n = (size_t)total_q + 64, ht_n = (size_t)total_t + 64;
+        std::unique_ptr<uint8_t[]> own_q, own_t;
+        uint8_t *hq = nullptr, *ht = nullptr;
+        if (pin) {
+            if (pin_q.reserve(hq_n) || pin_t.reserve(ht_n)) return -1;
+            hq = pin_q.p; ht = pin_t.p;
+        } else {
+            own_q.reset(new uint8_t[hq_n]); own_t.reset(new uint8_t[ht_n]);
+            hq = own_q.get(); ht = own_t.get();
+        }
+        hipStream_t s = ctx->stream;
+        if (qraw.alloc(hq_n) || traw.alloc(ht_n)) return -1;
+        // gathers the unique sequences [ua, ub) of one side; returns the byte range they cover
+        auto gather = [&](uint8_t *dst, const std::vector<int> &uniq, bool query, size_t ua, size_t ub) {
+            parallel_for((long long)(ub - ua), 16, [&](long long first, long long last) {
+                for (long long x = (long long)ua + first; x < (long long)ua + last; x++) {
                     const int i = uniq[x];
                     const int len = query ? qlen[i] : tlen[i];
-                    uint8_t *d = dst.data() + (query ? qoff[i] : toff[i]);
+                    uint8_t *d = dst + (query ? qoff[i] : toff[i]);
                     if (len) memcpy(d, query ? pairs[i].query : pairs[i].target, len);
                     for (int k = len; k < ((len + 3) & ~3); k++) d[k] = 'A';
                 }
             });
-            memset(dst.data() + total, 'A', 64);
         };
-        gather(hq, uq, true, total_q);
-        gather(ht, ut, false, total_t);
+        auto side = [&](uint8_t *host, uint8_t *devp, const std::vector<int> &uniq, bool query, long long total, size_t host_n) -> int {
+            const size_t slice = pin ? (size_t)32 << 20 : ~(size_t)0;          // bytes per slice
+            size_t ua = 0;
+            long long sent = 0;
+            while (ua < uniq.size()) {
+                size_t ub = ua;
+                long long end = sent;
+                while (ub < uniq.size() && (size_t)(end - sent) < slice) {
+                    const int i = uniq[ub++];
+                    end = (query ? qoff[i] : toff[i]) + (((query ? qlen[i] : tlen[i]) + 3) & ~3LL);
+                }
+                gather(host, uniq, query, ua, ub);
+                if (pin && end > sent) HIP_OK(hipMemcpyAsync(devp + sent, host + sent, (size_t)(end - sent), hipMemcpyHostToDevice, s));
+                sent = end; ua = ub;
+            }
+            memset(host + total, 'A', 64);
+            if (pin) HIP_OK(hipMemcpyAsync(devp + total, host + total, 64, hipMemcpyHostToDevice, s));
+            else HIP_OK(hipMemcpyAsync(devp, host, host_n, hipMemcpyHostToDevice, s));
+            return 0;
+        };
+        if (side(hq, qraw.p, uq, true, total_q, hq_n) || side(ht, traw.p, ut, false, total_t, ht_n)) return -1;
         lap("sequences gathered");
         PrepTables pt;
         memcpy(pt.submat_index, params->submat_index, 256);
         memcpy(pt.nt2d, params->nt2d, 256);
         memcpy(pt.trans, params->trans, 4096);
         memcpy(pt.aa, params->aa, 40);
-        hipStream_t s = ctx->stream;
-        if (tables.upload(&pt, 1, s) || qraw.upload(hq.data(), hq.size(), s) || traw.upload(ht.data(), ht.size(), s) ||
-            qcode.alloc(hq.size()) || tcode.alloc(ht.size()) || d_qoff.upload(qoff.data(), n, s) ||
+        if (tables.upload(&pt, 1, s) ||
+            qcode.alloc(hq_n) || tcode.alloc(ht_n) || d_qoff.upload(qoff.data(), n, s) ||
             d_toff.upload(toff.data(), n, s) || d_qlen.upload(qlen.data(), n, s) || d_tlen.upload(tlen.data(), n, s) ||
             d_utoff.upload(utoff.data(), n_utargets, s) || d_utlen.upload(utlen.data(), n_utargets, s))
             return -1;
@@ -637,30 +822,42 @@ struct ResidentSeqs {
         int zero[2] = {0, 0};
         if (bad.upload(zero, 2, s)) return -1;
         const int blocks = 1024;
-        hipLaunchKernelGGL(encode_kernel, dim3(blocks), dim3(256), 0, s, qraw.p, qcode.p, (long long)hq.size(), tables.p, bad.p);
+        hipLaunchKernelGGL(encode_kernel, dim3(blocks), dim3(256), 0, s, qraw.p, qcode.p, (long long)hq_n, tables.p, bad.p);
         int max_t = 1;
         for (int i = 0; i < n; i++) max_t = std::max(max_t, tlen[i]);
         const int xb = std::min(256, (max_t + 255) / 256), yb = std::max(1, std::min(n_utargets, 32768));
         if (family_is_p2d(family)) {
             hipLaunchKernelGGL(codon_kernel, dim3(xb, yb), dim3(256), 0, s, traw.p, tcode.p, d_utoff.p, d_utlen.p, n_utargets, tables.p, bad.p);
         } else {
-            hipLaunchKernelGGL(encode_kernel, dim3(blocks), dim3(256), 0, s, traw.p, tcode.p, (long long)ht.size(), tables.p, bad.p, bad.p + 1);
+            hipLaunchKernelGGL(encode_kernel, dim3(blocks), dim3(256), 0, s, traw.p, tcode.p, (long long)ht_n, tables.p, bad.p, bad.p + 1);
         }
         dev.ss = nullptr;
         dev.ss16 = nullptr;
         dev.ss_stride = 0;
         ss16_built = false;
         if (family_has_splice(family)) {
-            if (splice_models.upload(params->splice, 4, s) || ss.alloc((size_t)4 * ht.size())) return -1;
+            if (splice_models.upload(params->splice, 4, s) || ss.alloc((size_t)4 * ht_n)) return -1;
+            bool tiled = !(getenv("C4GPU_SPLICE_TILE") && atoi(getenv("C4GPU_SPLICE_TILE")) == 0);     // 0: the one-position-per-thread kernel
+            for (int k = 0; k < 4; k++)
+                tiled = tiled && params->splice[k].splice_after >= 0 && params->splice[k].splice_after <= SPLICE_HALO &&
+                        params->splice[k].model_length >= 0 && params->splice[k].model_length <= C4GPU_SPLICE_MAX_LEN;
+            if (tiled) {
+                if (fold16 && ss16.alloc(ht_n)) return -1;
+                const int tiles = std::max(1, std::min(4096, (max_t + SPLICE_TILE - 1) / SPLICE_TILE));
+                hipLaunchKernelGGL(splice_tile_kernel, dim3(tiles, yb), dim3(256), 0, s, traw.p, d_utoff.p, d_utlen.p, n_utargets,
+                                   splice_models.p, ss.p, (long long)ht_n, fold16 ? *fold16 : SpliceFold{{0, 0, 0, 0}},
+                                   fold16 ? ss16.p : (uint2 *)nullptr);
+                if (fold16) { ss16_built = true; dev.ss16 = nullptr; }
+            } else
             hipLaunchKernelGGL(splice_kernel, dim3(xb, yb, 4), dim3(256), 0, s, traw.p, d_utoff.p, d_utlen.p, n_utargets,
-                               splice_models.p, ss.p, (long long)ht.size());
+                               splice_models.p, ss.p, (long long)ht_n);
             dev.ss = ss.p;
-            dev.ss_stride = (long long)ht.size();
-            ss_len = (long long)ht.size();
+            dev.ss_stride = (long long)ht_n;
+            ss_len = (long long)ht_n;
         }
         dev.tn4 = nullptr;
         if (family_has_phase(family)) {
-            if (tn4.alloc(ht.size())) return -1;
+            if (tn4.alloc(ht_n)) return -1;
             hipLaunchKernelGGL(tn4_kernel, dim3(xb, yb), dim3(256), 0, s, traw.p, tn4.p, d_utoff.p, d_utlen.p, n_utargets, tables.p);
             dev.tn4 = tn4.p;
         }
@@ -693,6 +890,22 @@ struct ResidentSeqs {
         }
         dev.qcode = qcode.p; dev.tcode = tcode.p; dev.qoff = d_qoff.p; dev.toff = d_toff.p; dev.tlen = d_tlen.p;
         return 0;
+    }
+
+    // everything but the lock changes hands (c4gpu_batch_swap_stage: the batch takes the sequences a stage has loaded, the
+    // stage takes the batch's old ones and loads the next batch into their buffers)
+    void swap_with(ResidentSeqs &o) {
+        std::swap(n_pairs, o.n_pairs);
+        qoff.swap(o.qoff); toff.swap(o.toff); qlen.swap(o.qlen); tlen.swap(o.tlen);
+        std::swap(total_q, o.total_q); std::swap(total_t, o.total_t);
+        qraw.swap(o.qraw); traw.swap(o.traw); qcode.swap(o.qcode); tcode.swap(o.tcode);
+        d_qoff.swap(o.d_qoff); d_toff.swap(o.d_toff); d_qlen.swap(o.d_qlen); d_tlen.swap(o.d_tlen); ss.swap(o.ss);
+        tn4.swap(o.tn4); ss16.swap(o.ss16); std::swap(ss16_built, o.ss16_built);
+        tdense.swap(o.tdense); std::swap(tdense_n, o.tdense_n); std::swap(ss_len, o.ss_len);
+        tables.swap(o.tables); splice_models.swap(o.splice_models); bad.swap(o.bad);
+        std::swap(dev, o.dev);
+        std::swap(n_utargets, o.n_utargets); d_utoff.swap(o.d_utoff); d_utlen.swap(o.d_utlen);
+        std::swap(pin_q.p, o.pin_q.p); std::swap(pin_q.n, o.pin_q.n); std::swap(pin_t.p, o.pin_t.p); std::swap(pin_t.n, o.pin_t.n);
     }
 };
 
@@ -2303,6 +2516,25 @@ struct c4gpu_batch {
     }
 };
 
+// The next batch on its way to the device while the current one is aligned (c4gpu_stage_load on one thread, c4gpu_batch_run
+// on another): its own stream (non-blocking: no implicit synchronisation with the streams the passes run on), its own
+// engine for the parameter block the packed splice array is built from, page-locked host buffers and device arrays that the
+// batch it is swapped into hands back for the batch after.
+struct c4gpu_stage {
+    c4gpu_ctx ctx;
+    c4gpu_model model;
+    c4gpu_params params;
+    Engine eng;
+    ResidentSeqs seqs;
+    bool loaded = false;
+    double load_ms = 0;
+    ~c4gpu_stage() {
+        if (ctx.stream) (void)hipStreamDestroy(ctx.stream);
+        if (ctx.ev0) (void)hipEventDestroy(ctx.ev0);
+        if (ctx.ev1) (void)hipEventDestroy(ctx.ev1);
+    }
+};
+
 extern "C" {
 
 int c4gpu_abi_version(void) { return C4GPU_ABI_VERSION; }
@@ -2378,6 +2610,7 @@ void c4gpu_ctx_destroy(c4gpu_ctx *ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->sdp_arena) (void)hipFree(ctx->sdp_arena);
     delete ctx;
+    g_retired.flush();
 }
 
 void c4gpu_ctx_set_stream(c4gpu_ctx *ctx, void *hip_stream) { ctx->stream = (hipStream_t)hip_stream; }
@@ -2695,6 +2928,90 @@ void c4gpu_batch_destroy(c4gpu_batch *b) {
     b->clear_loop();
     for (auto &a : b->alignments) c4gpu_alignment_clear(&a);
     delete b;
+    g_retired.flush();
+}
+
+c4gpu_stage *c4gpu_stage_create(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params) {
+    try {
+        if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+        std::unique_ptr<c4gpu_stage> st(new c4gpu_stage);
+        st->ctx.device = ctx->device; st->ctx.prop = ctx->prop;
+        st->model = *model; st->params = *params;
+        // lowest priority: the passes of the batch that is running get the compute units first, the staging kernels fill
+        // what their tails leave idle (a load has a whole step's time)
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        if (hipStreamCreateWithPriority(&st->ctx.stream, hipStreamNonBlocking, prio_least) != hipSuccess ||
+            hipEventCreate(&st->ctx.ev0) != hipSuccess || hipEventCreate(&st->ctx.ev1) != hipSuccess) {
+            c4h::set_error("c4gpu_stage_create: cannot create the staging stream");
+            return nullptr;
+        }
+        if (st->eng.init(&st->ctx, &st->model, &st->params)) return nullptr;
+        if (hipStreamSynchronize(st->ctx.stream) != hipSuccess) return nullptr;
+        return st.release();
+    } catch (const std::exception &e) {
+        c4h::set_error(std::string("c4gpu_stage_create: ") + e.what());
+        return nullptr;
+    }
+}
+
+int c4gpu_stage_load(c4gpu_stage *st, const c4gpu_pair *pairs, int32_t n_pairs) {
+    try {
+        if (hipSetDevice(st->ctx.device) != hipSuccess) return -1;
+        const auto t0 = std::chrono::steady_clock::now();
+        st->loaded = false;
+        // the packed passes' splice array: written by the splice kernel itself here (ss16_kernel's formula with the calc
+        // constants of the pre-splice transitions as `fold`), where the first packed launch would otherwise build it inside
+        // the step (C4GPU_PK16=0: no packed pass, no array)
+        const bool pk = !(getenv("C4GPU_PK16") && atoi(getenv("C4GPU_PK16")) == 0) && n_pairs >= 2 && st->eng.pk16_params_ok &&
+                        st->eng.family == FAM_EST2GENOME;
+        SpliceFold fold{{0, 0, 0, 0}};
+        for (int i = 0; i < st->model.n_calcs; i++)
+            if (st->model.calcs[i].kind == C4GPU_CALC_SPLICE_PRE) fold.add[st->model.calcs[i].param & 3] = st->model.calcs[i].value;
+            else if (st->model.calcs[i].kind == C4GPU_CALC_SPLICE_POST) fold.add[st->model.calcs[i].param & 3] = 0;
+        if (st->seqs.build(&st->ctx, st->eng.family, &st->params, pairs, n_pairs, true, pk ? &fold : nullptr)) return -1;
+        if (pk && st->eng.ensure_ss16(st->seqs)) return -1;            // (only where the tiled splice kernel did not run)
+        if (pk && getenv("C4GPU_SS16_CHECK")) {
+            // test hook: the array the splice kernel wrote against the one ss16_kernel builds from the int arrays
+            DevBuf<uint2> chk;
+            const size_t nn = (size_t)st->seqs.ss_len;
+            if (chk.alloc(nn)) return -1;
+            HIP_OK(pk16_build_splice(st->eng.family, st->eng.kparams.p, st->seqs.dev.ss, st->seqs.dev.ss_stride, st->seqs.ss_len, chk.p, st->ctx.stream));
+            std::vector<uint2> a(nn), b(nn);
+            if (chk.download(a.data(), nn, st->ctx.stream) || st->seqs.ss16.download(b.data(), nn, st->ctx.stream)) return -1;
+            HIP_OK(hipStreamSynchronize(st->ctx.stream));
+            for (int i = 0; i < st->seqs.n_pairs; i++)
+                for (long long x = st->seqs.toff[i]; x < st->seqs.toff[i] + st->seqs.tlen[i]; x++)
+                    if (a[x].x != b[x].x || a[x].y != b[x].y) {
+                        c4h::set_error("C4GPU_SS16_CHECK: the fused packed splice array differs from ss16_kernel's");
+                        return -1;
+                    }
+        }
+        st->loaded = true;
+        st->load_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return 0;
+    } catch (const std::exception &e) {
+        c4h::set_error(std::string("c4gpu_stage_load: ") + e.what());
+        return -1;
+    }
+}
+
+double c4gpu_stage_load_ms(const c4gpu_stage *st) { return st->load_ms; }
+
+void c4gpu_stage_destroy(c4gpu_stage *st) { delete st; g_retired.flush(); }
+
+int c4gpu_batch_swap_stage(c4gpu_batch *b, c4gpu_stage *st) {
+    if (!st->loaded) { c4h::set_error("c4gpu_batch_swap_stage: the stage holds no loaded batch"); return -1; }
+    if (memcmp(&b->model, &st->model, sizeof(c4gpu_model)) || memcmp(&b->params, &st->params, sizeof(c4gpu_params))) {
+        c4h::set_error("c4gpu_batch_swap_stage: batch and stage were made for different models / parameters");
+        return -1;
+    }
+    b->clear_loop();
+    for (auto &a : b->alignments) c4gpu_alignment_clear(&a);
+    b->alignments.clear(); b->scores.clear(); b->regions.clear(); b->pair_thresholds.clear();
+    b->seqs.swap_with(st->seqs);
+    st->loaded = false;
+    return 0;
 }
 
 int c4gpu_batch_run(c4gpu_batch *b, int what, int dpmemory_mb, c4gpu_score threshold) {

@@ -162,3 +162,31 @@ def write_c5_heuristic_input(directory, n=256, seed=20260935):
     with open(tf, "w") as f:
         f.write(">chr\n%s\n" % contig.decode())
     return qf, tf
+
+
+def _est2genome_chunk(a):
+    first, count, qlen, tlen = a
+    return est2genome_pairs(count, qlen, tlen, first=first)
+
+
+def est2genome_batches(firsts, n_pairs, qlen=1000, tlen=100000, workers=None):
+    """Several C4 batches at once -- batch b = pairs [firsts[b], firsts[b] + n_pairs) of the same seeded generator -- made by a
+    pool of worker processes (one batch of 4 096 pairs takes one core 6 s; bench.py aligns a fresh batch every step).  The
+    workers are forked: call this BEFORE the process opens a HIP device or a process group (bench.py does)."""
+    import multiprocessing as mp
+    import os
+    if workers is None:
+        try:
+            workers = len(os.sched_getaffinity(0))
+        except AttributeError:
+            workers = os.cpu_count() or 1
+        workers = max(1, min(32, workers))
+    chunk = 64
+    tasks = [(f + c, min(chunk, n_pairs - c), qlen, tlen) for f in firsts for c in range(0, n_pairs, chunk)]
+    if workers == 1 or len(tasks) <= 2:
+        parts = [_est2genome_chunk(t) for t in tasks]
+    else:
+        with mp.get_context("fork").Pool(min(workers, len(tasks))) as pool:
+            parts = pool.map(_est2genome_chunk, tasks, chunksize=1)
+    per = (n_pairs + chunk - 1) // chunk
+    return [[p for part in parts[b * per:(b + 1) * per] for p in part] for b in range(len(firsts))]

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define C4GPU_ABI_VERSION 4
+#define C4GPU_ABI_VERSION 5
 
 /* src/c4/c4.h:28-30 */
 typedef int32_t c4gpu_score;
@@ -361,6 +361,27 @@ int64_t      c4gpu_batch_export(c4gpu_batch *b, int32_t *out, int64_t cap);
  * switches the measurement on. */
 int          c4gpu_batch_kernel_stats(c4gpu_batch *b, int mode, int reset, double *ms, int64_t *launches,
                                       int64_t *cells);
+
+/* A stream of batches: the NEXT batch is staged while the current one is aligned.  What the reference pays per pair before
+ * its first DP cell -- Sequence_strncpy of both sequences (src/sequence/sequence.c:588) and the splice site prediction of
+ * the target (Intron_Data / SplicePredictor_predict_array_int, src/model/intron.c:259-269, src/sequence/splice.c) -- is,
+ * per batch, here: gathering the residues into page-locked host memory, the copy over PCIe, residue coding and the splice
+ * arrays built on the device.  A c4gpu_stage does that on a stream of its own from whatever thread calls
+ * c4gpu_stage_load, while another thread is inside c4gpu_batch_run on the same context; c4gpu_batch_swap_stage then hands
+ * the loaded sequences to the batch (which keeps its engine, launch lanes and launch buffers) and the batch's previous
+ * sequences to the stage, whose next load reuses their device arrays and page-locked buffers: no allocation, no page
+ * fault and no pageable copy per batch after the first two.
+ *   c4gpu_stage_load   blocks until the batch is resident (0 / -1, c4gpu_last_error); the pairs' buffers are read during
+ *                      the call only.  One load at a time per stage; never concurrently with c4gpu_batch_swap_stage.
+ *   c4gpu_batch_swap_stage  between two runs of `b` (not while one is in progress); the batch's earlier results are
+ *                      dropped.  Model and parameters of stage and batch must be bytewise equal.
+ *   c4gpu_stage_load_ms     wall time of the last load (host clock around the whole call). */
+typedef struct c4gpu_stage c4gpu_stage;
+c4gpu_stage *c4gpu_stage_create(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params);
+int          c4gpu_stage_load(c4gpu_stage *st, const c4gpu_pair *pairs, int32_t n_pairs);
+double       c4gpu_stage_load_ms(const c4gpu_stage *st);
+int          c4gpu_batch_swap_stage(c4gpu_batch *b, c4gpu_stage *st);
+void         c4gpu_stage_destroy(c4gpu_stage *st);
 
 /* ---- HSP seeding (src/comparison/hspset.c) ------------------------------------------------------------------------ */
 
