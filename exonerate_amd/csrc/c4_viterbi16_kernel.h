@@ -170,7 +170,7 @@ struct WaveDP16 {
     // LDS-active cycles of the first LDS-fed form were conflicts, profiles/r04_c_sq.csv)
     static constexpr int STAGE_COLS = 128, STAGE_INTS = 8;
     static constexpr int PROF_INTS = NCODE * 128;                 // query profile: ints per (wave, job): [code][lane] of 8 bytes
-    static_assert(!IO || (VAR >= 1 && F::has_splice() && R == 4), "the staged form is built for the packed splice entries and 4 rows per lane");
+    static_assert(!IO || (VAR >= 1 && F::has_splice() && (R == 4 || R == 2)), "the staged form is built for the packed splice entries and 4 or 2 rows per lane");
     static_assert(!F::has_phase(), "split-codon calcs are not packed");
     static_assert(M::NDES <= 1, "one shadow designation");
     typedef __attribute__((address_space(3))) int lds_int;
@@ -264,7 +264,8 @@ struct WaveDP16 {
     // IO 1: the profile entries of the next column's codes; issued in the middle of a step, when the stage entry has arrived
     __device__ __forceinline__ void prefetch_profile() {
         const lds_int *pa = lds_at(prof_a[0] + nx_off[0]), *pb = lds_at(prof_a[1] + nx_off[1]);
-        nx_prof[0] = pa[0]; nx_prof[1] = pa[1]; nx_prof[2] = pb[0]; nx_prof[3] = pb[1];
+        nx_prof[0] = pa[0]; nx_prof[2] = pb[0];
+        if constexpr (R == 4) { nx_prof[1] = pa[1]; nx_prof[3] = pb[1]; }       // (two rows per lane: half an entry)
     }
     // IO 1: columns c0 + lane of both jobs into the stage -- clamped as prefetch_column clamps them, the splice values of the two
     // jobs interleaved into packed halves (what step() did with four v_perm per step), the residue codes as profile offsets
@@ -308,7 +309,7 @@ struct WaveDP16 {
                 });
                 lds_int *p = lds_at(prof_a[H] + d * 512);
                 p[0] = pk_pack(v[0], v[1]);
-                p[1] = pk_pack(v[2], v[3]);
+                if constexpr (R == 4) p[1] = pk_pack(v[R - 2], v[R - 1]);
             }
         });
     }
@@ -387,8 +388,10 @@ struct WaveDP16 {
             const int a0 = nx_prof[0], a1 = nx_prof[1], b0 = nx_prof[2], b1 = nx_prof[3];
             ms[0] = (int)__builtin_amdgcn_perm((unsigned)b0, (unsigned)a0, 0x05040100u);
             ms[1] = (int)__builtin_amdgcn_perm((unsigned)b0, (unsigned)a0, 0x07060302u);
-            ms[2] = (int)__builtin_amdgcn_perm((unsigned)b1, (unsigned)a1, 0x05040100u);
-            ms[3] = (int)__builtin_amdgcn_perm((unsigned)b1, (unsigned)a1, 0x07060302u);
+            if constexpr (R == 4) {
+                ms[R - 2] = (int)__builtin_amdgcn_perm((unsigned)b1, (unsigned)a1, 0x05040100u);
+                ms[R - 1] = (int)__builtin_amdgcn_perm((unsigned)b1, (unsigned)a1, 0x07060302u);
+            }
         } else {
             static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
                 ms[RR] = pk_pack(kp->submat[qrow[0][RR] + nx_tcode[0]], kp->submat[qrow[1][RR] + nx_tcode[1]]);

@@ -41,6 +41,17 @@ static hipError_t kpk16f_est2genome_launch(const LaunchArgs &a) {
 static const KernelInfo kpk16f_est2genome = {kpk16f_est2genome_launch, (const void *)viterbi16_kernel_mw<Est2GenomeDesc, 4, 4, 3, 2, true, 1>,
                                              "kpk16f_est2genome", 4, 2, WaveDP16<Est2GenomeDesc, 4, 2, true, 1>::BND, Est2GenomeDesc::NS,
                                              Est2GenomeDesc::MAXAT, 4, WaveDP16<Est2GenomeDesc, 4, 2, true, 1>::SEEDW};
+// variant 6: variant 5 on EIGHT cooperating waves of two rows per lane -- the same 1 024 query rows per workgroup on twice the
+// waves, for launches with at most one pair of jobs per compute unit (the 512-pair shard of a strong-scaled run: 256 pairs of
+// jobs on 256 CUs would otherwise be one wave per SIMD, which issues an instruction every ~5 cycles whatever else is free)
+static hipError_t kpk16g_est2genome_launch(const LaunchArgs &a) {
+    hipLaunchKernelGGL((viterbi16_kernel_mw<Est2GenomeDesc, 2, 8, 2, 2, true, 1>), dim3(a.grid), dim3(64 * 8), 0, a.stream,
+                       a.kp, a.seqs, a.jobs, a.n_jobs, a.results, a.scratch, a.queue, reinterpret_cast<const uint8_t *>(a.aux));
+    return hipGetLastError();
+}
+static const KernelInfo kpk16g_est2genome = {kpk16g_est2genome_launch, (const void *)viterbi16_kernel_mw<Est2GenomeDesc, 2, 8, 2, 2, true, 1>,
+                                             "kpk16g_est2genome", 2, 2, WaveDP16<Est2GenomeDesc, 2, 2, true, 1>::BND, Est2GenomeDesc::NS,
+                                             Est2GenomeDesc::MAXAT, 8, WaveDP16<Est2GenomeDesc, 2, 2, true, 1>::SEEDW};
 int pk16_staged_codes() { return WaveDP16<Est2GenomeDesc, 4, 1, true, 1>::NCODE; }
 int pk16_staged_rows() { return 4 * 64 * 4; }
 // the packed splice array of variant 1 (ss16_kernel): n positions of the batch's concatenated targets
@@ -51,6 +62,6 @@ hipError_t pk16_build_splice(int family, const KParams *kp, const int *ss, long 
 }
 const KernelInfo *get_kernel_pk16(int family, int variant) {
     if (family != FAM_EST2GENOME) return nullptr;
-    return variant == 5 ? &kpk16f_est2genome : variant == 4 ? &kpk16e_est2genome : variant == 3 ? &kpk16d_est2genome : variant == 2 ? &kpk16c_est2genome : variant == 1 ? &kpk16b_est2genome : &kpk16_est2genome;
+    return variant == 6 ? &kpk16g_est2genome : variant == 5 ? &kpk16f_est2genome : variant == 4 ? &kpk16e_est2genome : variant == 3 ? &kpk16d_est2genome : variant == 2 ? &kpk16c_est2genome : variant == 1 ? &kpk16b_est2genome : &kpk16_est2genome;
 }
 }

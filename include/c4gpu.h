@@ -315,6 +315,13 @@ int         c4gpu_optimal_find_path_batch_subopt(c4gpu_ctx *ctx, const c4gpu_mod
                                                  c4gpu_alignment *alignments);
 void        c4gpu_alignment_clear(c4gpu_alignment *a);
 
+/* Does a pair of this size pass the guard of the packed 16-bit passes (every score a path can reach
+ * fits 16 000, the intron length test cannot fail on the upper side) under this model and these parameters?  1 / 0; -1: the
+ * model is not device-accelerated.  Host-only, no device needed: what a caller (or a test) can ask to know which kernels a
+ * launch will take; the results are the reference's either way. */
+int         c4gpu_packed_route_fits(const c4gpu_model *model, const c4gpu_params *params, int32_t query_length,
+                                    int32_t target_length);
+
 /* Device-resident batches (bench / shim hot loop): upload once, run many times. */
 typedef struct c4gpu_batch c4gpu_batch;
 c4gpu_batch *c4gpu_batch_create(c4gpu_ctx *ctx, const c4gpu_model *model, const c4gpu_params *params,

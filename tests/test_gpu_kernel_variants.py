@@ -357,6 +357,7 @@ def test_packed_16_bit_score_pass_agrees_with_the_32_bit_pass(eng, monkeypatch, 
     pairs.append((q, _rand(rng, 3000) + _mutate(rng, q[:400], 0.03) + "GT" + _rand(rng, 45000) + "AG" + _mutate(rng, q[400:], 0.03) + _rand(rng, 2000)))
     pairs.append((_rand(rng, 500), _rand(rng, 25000)))                         # unrelated; nine jobs: the last lane pair is half empty
     monkeypatch.setenv("C4GPU_TRACE", "1")
+    monkeypatch.setenv("C4GPU_PK16_NW8", "0")      # (small launches would take the eight-wave shape of the score pass)
     res = {}
     # 1, 3, 4: the forms of the packed pass (c4_viterbi16_kernel.h: VAR 1 = default, VAR 0 = every instruction its own asm
     # statement, VAR 2 = progress counters between the cooperating waves instead of a barrier per chunk)
@@ -410,6 +411,7 @@ def test_staged_packed_score_pass_agrees_with_the_plain_one(eng, monkeypatch, ca
     q = _rand(rng, 800)
     pairs.append((q, _rand(rng, 3000) + _mutate(rng, q[:400], 0.03) + "GT" + _rand(rng, 45000) + "AG" + _mutate(rng, q[400:], 0.03) + _rand(rng, 2000)))
     monkeypatch.setenv("C4GPU_TRACE", "1")
+    monkeypatch.setenv("C4GPU_PK16_NW8", "0")      # (a launch this small would take the eight-wave shape: its own test below)
     res = {}
     # C4GPU_PK16_IO: 2 (the default) = the LDS-fed form with progress counters between its cooperating waves (kpk16f), 1 = the same
     # with a barrier per chunk (kpk16e), 0 = the form that loads per step (kpk16d)
@@ -463,6 +465,55 @@ def test_staged_packed_score_pass_agrees_with_the_plain_one(eng, monkeypatch, ca
     assert d == [x.as_dict() if x else None for x in eng.find_path(model, tall, dpmemory=32, threshold=20)]
 
 
+
+def test_staged_packed_score_pass_on_eight_waves_of_two_rows(eng, monkeypatch, capfd):
+    """A launch with at most one pair of jobs per compute unit (the 512-pair shard of a strong-scaled run, and every smaller
+    call) runs the LDS-fed packed score pass on EIGHT cooperating waves of two rows per lane (kpk16g: the same 1 024 rows per
+    workgroup, twice the waves); C4GPU_PK16_NW8=0 keeps four waves of four rows, =1 forces eight.  Ragged batch, odd job count,
+    one to eight strips of 128 rows (idle waves), N in queries and targets, a 45 000-column intron, tiny dump intervals: the
+    same alignments as the four-wave form and the 32-bit pass, and EVERY pair the oracle finishes in seconds against the
+    oracle."""
+    rng = random.Random(777)
+    model = ex.Model("est2genome")
+    pairs = []
+    for k, (ql, tl) in enumerate([(1023, 30000), (400, 52000), (1000, 9000), (640, 30011), (1000, 100000), (130, 20000), (897, 41000),
+                                  (64, 5000), (257, 12345), (1, 3000), (128, 7000), (129, 7001), (1022, 4000)]):
+        q, t = _seeded_pairs(rng, "est2genome", ql, tl, 1)[0]
+        if k % 2:
+            i, j = rng.randrange(len(t) - 40), rng.randrange(max(1, len(q) - 3))
+            t = t[:i] + "N" * 7 + t[i + 7:]
+            q = q[:j] + "N" + q[j + 1:]
+        pairs.append((q, t))
+    q = _rand(rng, 800)
+    pairs.append((q, _rand(rng, 3000) + _mutate(rng, q[:400], 0.03) + "GT" + _rand(rng, 45000) + "AG" + _mutate(rng, q[400:], 0.03) + _rand(rng, 2000)))
+    monkeypatch.setenv("C4GPU_TRACE", "1")
+    res = {}
+    for nw8, pk in ((None, "1"), ("1", "1"), ("0", "1"), ("0", "0")):
+        if nw8 is None:
+            monkeypatch.delenv("C4GPU_PK16_NW8", raising=False)
+        else:
+            monkeypatch.setenv("C4GPU_PK16_NW8", nw8)
+        monkeypatch.setenv("C4GPU_PK16", pk)
+        res[nw8, pk] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=32, threshold=20)]
+        err = capfd.readouterr().err
+        assert ("kpk16g_est2genome" in err) == (nw8 in (None, "1") and pk == "1"), err[-1500:]
+        assert ("kpk16f_est2genome" in err) == (nw8 == "0" and pk == "1"), err[-1500:]
+    assert res[None, "1"] == res["1", "1"] == res["0", "1"] == res["0", "0"]
+    checked = 0
+    for k, (q, t) in enumerate(pairs):
+        if (len(q) + 1) * (len(t) + 1) <= 1.3e7:
+            assert res[None, "1"][k] == oracle_lib.find_path(model.c, model.params, q.encode(), t.encode(), dpmemory=32, threshold=20), k
+            checked += 1
+    assert checked >= 8
+    monkeypatch.setenv("C4GPU_SEED_KSHIFT", "6")
+    monkeypatch.delenv("C4GPU_PK16_NW8", raising=False)
+    monkeypatch.setenv("C4GPU_PK16", "1")
+    small = pairs[:4] + pairs[5:13]
+    a = [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=20)]
+    assert "kpk16g_est2genome" in capfd.readouterr().err
+    monkeypatch.setenv("C4GPU_PK16", "0")
+    assert a == [x.as_dict() if x else None for x in eng.find_path(model, small, dpmemory=32, threshold=20)]
+
 def test_packed_16_bit_region_windows_agree_with_the_32_bit_windows(eng, monkeypatch, capfd):
     """The region windows run two windows per lane in packed 16-bit halves (c4_win16_kernel.h) behind the packed score pass,
     from its 16-bit dumps, each chain over the component of the state its END was entered from (one strand of est2genome);
@@ -487,6 +538,7 @@ def test_packed_16_bit_region_windows_agree_with_the_32_bit_windows(eng, monkeyp
     pairs.append((q.translate(comp)[::-1], t.translate(comp)[::-1]))
     pairs.append((_rand(rng, 500), _rand(rng, 35000)))                         # unrelated: below the threshold
     monkeypatch.setenv("C4GPU_TRACE", "1")
+    monkeypatch.setenv("C4GPU_PK16_NW8", "0")      # (small launches would take the eight-wave shape of the score pass)
     monkeypatch.setenv("C4GPU_SEED_KSHIFT", "13")
     res = {}
     shapes = ("1", "2", "3", "4", "5", "6", "7", "8", "9", "10")     # 10: two waves at three per SIMD; 1: chosen by the jobs; 5 ... 8: the strips of a window on 4 / 8 / 4 / 2 cooperating waves; 9: one wave
