@@ -277,10 +277,50 @@ def c5_heuristic_leg():
     served = [l.split("c4gpu ", 1)[1].strip() for l in r.stderr.decode().splitlines() if "c4gpu sdp:" in l or "c4gpu seed:" in l]
     return {"c5_heuristic": {"workload": "config 5 (heuristic leg): exonerate-gpu -m protein2genome, 256 proteins of 300 aa x one 10 Mb "
                                          "chromosome, seeding + SDP on the device", "wall_s": dt, "alignments": want["alignments"],
-                             "reference_wall_s_one_core": 66.3,
+                             "wall_s_cold": runs[0], "wall_s_warm_median": sorted(runs[1:])[len(runs[1:]) // 2],
+                             "reference_wall_s_one_core": {"value": want.get("reference_wall_s_one_core_build_container"),
+                                                           "machine": "build container (not the GPU box; 66.3 s were measured once on a GPU box's host, profiles/r03_c5_heuristic.md)"},
                              "checked": "stdout (%d vulgar lines) SHA-256 equal to the reference binary's, tests/golden/bench_c5_heuristic.json"
                                         % want["alignments"], "device": served, "wall_s_runs": runs,
                              **({"slow_run_trace": slow} if slow else {})}}
+
+
+def c4_dropin_leg():
+    """BASELINE config 4 through the command line: integration/_build/exonerate-gpu (the reference's own objects with libc4gpu.so
+    behind the batching seam in front of GAM_Result_exhaustive_create) on 64 cDNAs x 64 genomic windows, all against all = 4 096
+    rectangles of 1 001 x 100 001 cells, -m est2genome -E yes -S no --revcomp no: wall time of the whole process (FASTA parsing,
+    flattening, device, replay through the reference's printers) of a cold run and of the better of two warm ones, stdout compared by
+    SHA-256 with what the reference binary printed for the same files (tests/golden/bench_c4_dropin.json,
+    tools/make_c4_dropin_golden.py: ~5 h of one core).  Skipped where the binary or the golden file is missing."""
+    import hashlib, tempfile
+    from exonerate_amd import workloads
+    exe = os.path.join(ROOT, "integration", "_build", "exonerate-gpu")
+    gold = os.path.join(ROOT, "tests", "golden", "bench_c4_dropin.json")
+    if not (os.path.exists(exe) and os.path.exists(gold)):
+        return {}
+    want = json.load(open(gold))
+    cells = want["queries"] * want["targets"] * 1001 * 100001
+    with tempfile.TemporaryDirectory() as d:
+        qf, tf = workloads.write_c4_dropin_input(d, want["queries"], want["targets"])
+        env = dict(os.environ, C4GPU_VERBOSE="1")
+        runs, r = [], None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            r = subprocess.run([exe] + want["args"] + [qf, tf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            runs.append(round(time.perf_counter() - t0, 3))
+            assert r.returncode == 0, r.stderr.decode()[-800:]
+            assert hashlib.sha256(r.stdout).hexdigest() == want["sha256"], "c4 drop-in leg: output differs from the reference's"
+    flush = [l.split("c4gpu: ", 1)[1].strip() for l in r.stderr.decode().splitlines() if "c4gpu: flush of" in l or "c4gpu: batch of" in l]
+    warm = min(runs[1:])
+    return {"c4_dropin": {"workload": "config 4 through the command line: exonerate-gpu -m est2genome -E yes -S no --revcomp no, 64 cDNAs x 64 "
+                                      "windows all against all (4 096 rectangles of 1 001 x 100 001 cells), one process",
+                          "wall_s_cold": runs[0], "wall_s_warm": warm, "wall_s_runs": runs, "value": cells / warm, "value_cold": cells / runs[0],
+                          "unit": "cells/s", "alignments": want["alignments"],
+                          "checked": "stdout (%d vulgar lines, %d bytes) SHA-256 equal to the reference binary's, tests/golden/bench_c4_dropin.json"
+                                     % (want["alignments"], want["bytes"]),
+                          "reference_wall_s": {"value": want["reference_wall_s_build_container"], "processes": want["reference_processes"],
+                                               "machine": "build container (not the GPU box)"},
+                          "device": flush}}
 
 
 def revcomp(seq):
@@ -733,6 +773,7 @@ def main():
     # config 5's heuristic leg and config 4 through the drop-in binary are processes of their own: run once this process has
     # given the device's memory back (beside a resident batch their arenas are allocated ten times more slowly)
     if rank == 0 and isinstance(locals().get("out"), dict) and "configs" in out:
+        out["configs"].update(c4_dropin_leg())
         out["configs"].update(c5_heuristic_leg())
     if use_dist:
         dist.destroy_process_group()

@@ -113,6 +113,78 @@ struct RetiredBuffers {
 };
 static RetiredBuffers g_retired;
 
+// Small transfers between the passes go through page-locked memory.  A copy to or from pageable memory is carried out by a
+// copy KERNEL of one workgroup (__amd_rocclr_copyBuffer), which needs a compute unit with room for it -- and while the other
+// launch lane's persistent kernel fills the device there is none until one of its workgroups retires: the job list of the next
+// pass waited 30-105 ms per pass for that (rocprofv3 kernel trace of the wide-region batch, profiles/r05_wide_trace.md).  From
+// page-locked memory the same copy is a DMA transfer that needs no compute unit.  Every thread that talks to the device owns
+// one arena of page-locked memory (taken from a pool, handed back when the thread ends): an upload copies its source into the
+// arena first (the source is consumed when upload() returns, as with a pageable copy), a download lands in the arena and is
+// copied out to its destination by c4_stream_sync(), which every wait for a stream in this library goes through.
+struct PinArena {
+    uint8_t *base = nullptr;
+    size_t cap = 0, head = 0;
+    struct Pending { void *dst; const void *src; size_t bytes; };
+    std::vector<Pending> pending;
+    hipStream_t stream = nullptr;
+    bool stream_set = false;
+};
+struct PinArenaPool {
+    std::mutex lock;
+    std::vector<PinArena *> idle;
+    PinArena *take() {
+        {
+            std::lock_guard<std::mutex> hold(lock);
+            if (!idle.empty()) { PinArena *a = idle.back(); idle.pop_back(); return a; }
+        }
+        PinArena *a = new PinArena;
+        const size_t cap = (size_t)64 << 20;
+        if (hipHostMalloc((void **)&a->base, cap, hipHostMallocDefault) == hipSuccess) a->cap = cap;
+        else { (void)hipGetLastError(); a->base = nullptr; a->cap = 0; }            // no arena: transfers go directly
+        return a;
+    }
+    void give(PinArena *a) { std::lock_guard<std::mutex> hold(lock); idle.push_back(a); }
+};
+static PinArenaPool g_pin_pool;
+struct PinArenaRef {
+    PinArena *a = nullptr;
+    ~PinArenaRef() { if (a) { a->pending.clear(); a->head = 0; a->stream_set = false; g_pin_pool.give(a); } }
+    PinArena *get() { if (!a) a = g_pin_pool.take(); return a; }
+};
+static thread_local PinArenaRef t_pin;
+static const bool g_pin_off = getenv("C4GPU_PIN_XFER") && atoi(getenv("C4GPU_PIN_XFER")) == 0;       // 0: pageable copies, as before
+
+// every wait for a stream: the downloads of this thread that landed in its arena reach their destinations
+static hipError_t c4_stream_sync(hipStream_t s) {
+    const hipError_t e = hipStreamSynchronize(s);
+    PinArena *a = t_pin.a;
+    if (a && (!a->pending.empty() || a->head)) {
+        if (a->stream_set && a->stream != s) (void)hipStreamSynchronize(a->stream);     // (a thread uses one stream; be safe)
+        for (const PinArena::Pending &pd : a->pending) memcpy(pd.dst, pd.src, pd.bytes);
+        a->pending.clear();
+        a->head = 0;
+        a->stream_set = false;
+    }
+    return e;
+}
+// bytes of the calling thread's arena for a transfer on stream s (nullptr: too large, or no arena -- copy directly)
+static uint8_t *pin_slot(size_t bytes, hipStream_t s) {
+    if (g_pin_off || !bytes) return nullptr;
+    PinArena *a = t_pin.get();
+    if (!a->cap || bytes > a->cap / 4) return nullptr;
+    if (a->stream_set && a->stream != s) { (void)c4_stream_sync(a->stream); }
+    const size_t at = (a->head + 63) & ~(size_t)63;
+    if (at + bytes > a->cap) {
+        // full: everything in flight must land before its bytes are reused (the pending copy-outs are carried out now;
+        // their destinations are not read before the caller's own wait, which then finds nothing left to do)
+        (void)c4_stream_sync(s);
+        return pin_slot(bytes, s);
+    }
+    a->head = at + bytes;
+    a->stream = s; a->stream_set = true;
+    return a->base + at;
+}
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
@@ -138,11 +210,36 @@ struct DevBuf {
     }
     int upload(const T *src, size_t count, hipStream_t s) {
         if (alloc(count)) return -1;
-        if (count) HIP_OK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+        if (!count) return 0;
+        if (uint8_t *slot = pin_slot(count * sizeof(T), s)) {
+            memcpy(slot, src, count * sizeof(T));
+            HIP_OK(hipMemcpyAsync(p, slot, count * sizeof(T), hipMemcpyHostToDevice, s));
+        } else {
+            HIP_OK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+        }
         return 0;
     }
+    // the data is at `dst` after the next c4_stream_sync(s) of the calling thread
     int download(T *dst, size_t count, hipStream_t s) const {
-        if (count) HIP_OK(hipMemcpyAsync(dst, p, count * sizeof(T), hipMemcpyDeviceToHost, s));
+        if (!count) return 0;
+        if (uint8_t *slot = pin_slot(count * sizeof(T), s)) {
+            HIP_OK(hipMemcpyAsync(slot, p, count * sizeof(T), hipMemcpyDeviceToHost, s));
+            t_pin.a->pending.push_back(PinArena::Pending{dst, slot, count * sizeof(T)});
+        } else {
+            HIP_OK(hipMemcpyAsync(dst, p, count * sizeof(T), hipMemcpyDeviceToHost, s));
+        }
+        return 0;
+    }
+    // zeroes the first `count` elements without a fill kernel (which, like a copy kernel, waits for a compute unit)
+    int zero(size_t count, hipStream_t s) {
+        if (alloc(count)) return -1;
+        if (!count) return 0;
+        if (uint8_t *slot = pin_slot(count * sizeof(T), s)) {
+            memset(slot, 0, count * sizeof(T));
+            HIP_OK(hipMemcpyAsync(p, slot, count * sizeof(T), hipMemcpyHostToDevice, s));
+        } else {
+            HIP_OK(hipMemsetAsync(p, 0, count * sizeof(T), s));
+        }
         return 0;
     }
     void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
@@ -636,8 +733,19 @@ struct FusePair { long long off; int count, status; };      // merged (transitio
 // open intron started at) that lies 32 767 columns or more behind the cell is known there only as "that far back", and two
 // such positions are interchangeable — the one thing ever computed from a shadow is the intron's length at its 3' site
 // (intron.c:150-160), which passes the minimum either way and cannot exceed the maximum (Engine::pk16_fits).
-__host__ __device__ inline bool final_cell_equiv(const int *computed, const int *predicted, int n_slots, int target_end, bool packed) {
-    if (computed[0] != predicted[0]) return false;
+//
+// The SCORE of the cell is not compared (strict_score = false, the default; C4GPU_CELL_STRICT=1 compares it: the form of rounds
+// 1-4).  A continuation sub-DP starts from ONE cell of ONE state (viterbi.c:705-714) and every score in it is that cell's
+// score plus calcs along a path from it: max-plus is translation invariant, so a first cell whose score differs by d gives the
+// same winners, the same ties, the same traceback and a final cell whose score differs by d and whose shadows are the same.
+// The reference threads the computed cell through (optimal.c:283,301) and never looks at the checkpoint pass's score again;
+// where intron length limits break optimal substructure the two differ by a few points (pair 3 775 of the all-against-all
+// batch: 74 computed, 71 predicted, same intron start) -- the paths of every later sub-alignment are the ones the batch
+// computed.  What does decide later cells are the shadow slots, and those are compared.  (Unset states hold -987654321
+// whatever d is; a real candidate beats them by ~10^9 either way.)
+__host__ __device__ inline bool final_cell_equiv(const int *computed, const int *predicted, int n_slots, int target_end, bool packed,
+                                                 bool strict_score = false) {
+    if (strict_score && computed[0] != predicted[0]) return false;
     for (int l = 1; l < n_slots; l++) {
         if (computed[l] == predicted[l]) continue;
         if (!(packed && (long long)target_end - predicted[l] - 2 >= 32767 && (long long)target_end - computed[l] - 2 >= 32767)) return false;
@@ -645,11 +753,13 @@ __host__ __device__ inline bool final_cell_equiv(const int *computed, const int 
     return true;
 }
 
+inline bool cell_strict() { return getenv("C4GPU_CELL_STRICT") && atoi(getenv("C4GPU_CELL_STRICT")) != 0; }      // read on every call: a test switches it
+
 // one thread per checkpoint job: verify the chain of final cells, then Alignment_add (alignment.c:75-102) over the runs
 // of its sub-alignments in path order (each job's walk wrote its runs END -> START)
 __global__ void fuse_stitch_kernel(const DevJob *parents, const DevVsa *vsa, const int *first, int n_parents,
                                    const DevResult *sub, const uint32_t *runs, int path_cs, const int *flags,
-                                   unsigned long long *out_used, int *out, FusePair *pairs, int n_packed) {
+                                   unsigned long long *out_used, int *out, FusePair *pairs, int n_packed, int strict_score) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= n_parents) return;
     FusePair fp; fp.off = 0; fp.count = 0; fp.status = 1;
@@ -665,7 +775,7 @@ __global__ void fuse_stitch_kernel(const DevJob *parents, const DevVsa *vsa, con
         // the next sub-alignment was seeded with the predicted cell: it must be the one this one produced
         if (k + 1 < cnt) {
             const DevVsa &dv = vsa[pj.vsa_off + (cnt - 1 - k)];
-            bad |= !final_cell_equiv(r.final_cell, dv.final_cell, path_cs, dv.ts + dv.tl, x < n_packed);
+            bad |= !final_cell_equiv(r.final_cell, dv.final_cell, path_cs, dv.ts + dv.tl, x < n_packed, strict_score != 0);
             if (bad) break;
         }
     }
@@ -818,7 +928,7 @@ struct ResidentSeqs {
             d_toff.upload(toff.data(), n, s) || d_qlen.upload(qlen.data(), n, s) || d_tlen.upload(tlen.data(), n, s) ||
             d_utoff.upload(utoff.data(), n_utargets, s) || d_utlen.upload(utlen.data(), n_utargets, s))
             return -1;
-        if (trace) { HIP_OK(hipStreamSynchronize(s)); lap("uploaded"); }
+        if (trace) { HIP_OK(c4_stream_sync(s)); lap("uploaded"); }
         int zero[2] = {0, 0};
         if (bad.upload(zero, 2, s)) return -1;
         const int blocks = 1024;
@@ -865,7 +975,7 @@ struct ResidentSeqs {
         lap("kernels queued");
         int hbad2[2] = {0, 0};
         if (bad.download(hbad2, 2, s)) return -1;
-        HIP_OK(hipStreamSynchronize(s));
+        HIP_OK(c4_stream_sync(s));
         const int hbad = hbad2[0];
         tdense_n = 0;
         if (!family_is_p2d(family) && hbad2[1]) {
@@ -877,7 +987,7 @@ struct ResidentSeqs {
                 if (hbad2[1] >> c & 1) { if (nd < 8) { tab[c] = (uint8_t)nd; tab[24 + nd] = (uint8_t)c; } nd++; }
             if (nd <= 8) {
                 if (tdense.upload(tab, 32, s)) return -1;
-                HIP_OK(hipStreamSynchronize(s));
+                HIP_OK(c4_stream_sync(s));
                 tdense_n = nd;
             }
         }
@@ -1142,7 +1252,7 @@ struct Engine {
         if (!seqs.ss16_built) {
             if (seqs.ss16.alloc((size_t)seqs.ss_len)) return -1;
             HIP_OK(pk16_build_splice(family, kparams.p, seqs.dev.ss, seqs.dev.ss_stride, seqs.ss_len, seqs.ss16.p, ctx->stream));
-            HIP_OK(hipStreamSynchronize(ctx->stream));
+            HIP_OK(c4_stream_sync(ctx->stream));
             seqs.ss16_built = true;
         }
         return 0;
@@ -1497,7 +1607,7 @@ struct Engine {
             if (d_results.download(res.data(), n, s) || d_runs_used.download(&used, 1, s) ||
                 d_vsa.download(vsa.data(), vsa_total, s) || d_ckpt_dump.download(dump.data(), dump_total, s))
                 return -1;
-            HIP_OK(hipStreamSynchronize(s));
+            HIP_OK(c4_stream_sync(s));
             lap("kernel + results");
             if (ctx->timing) {
                 float ms = 0;
@@ -1511,11 +1621,11 @@ struct Engine {
             }
             runs.resize(used);
             if (d_runs_out.download(runs.data(), used, s)) return -1;
-            HIP_OK(hipStreamSynchronize(s));
+            HIP_OK(c4_stream_sync(s));
             if (span == 2) {                                 // END cells back into the callers' matrices
                 std::vector<int> host(span_total);
                 if (d_span.download(host.data(), span_total, s)) return -1;
-                HIP_OK(hipStreamSynchronize(s));
+                HIP_OK(c4_stream_sync(s));
                 for (int x = 0; x < n; x++) {
                     const long long cnt = (long long)(jobs[x].Q + 1) * (jobs[x].T + 1) * span_cs;
                     memcpy(specs[order[x]].span_out, host.data() + jobs[x].span_off, sizeof(int) * cnt);
@@ -1820,7 +1930,7 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
     std::vector<DevResult> &res = eng.hf_res;
     res.resize(n);
     if (eng.d_fres.download(res.data(), n, s)) return -1;
-    HIP_OK(hipStreamSynchronize(s));
+    HIP_OK(c4_stream_sync(s));
     if (ctx->timing) {
         float ms = 0;
         HIP_OK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
@@ -1837,12 +1947,12 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
     if (eng.d_ffirst.upload(first.data(), n + 1, s) || eng.d_fsub_jobs.alloc(n_sub) || eng.d_fflags.alloc(n) ||
         eng.d_fstats.upload(stats.data(), FUSE_STATS, s))
         return -1;
-    HIP_OK(hipMemsetAsync(eng.d_fflags.p, 0, sizeof(int) * n, s));
+    if (eng.d_fflags.zero(n, s)) return -1;
     hipLaunchKernelGGL(fuse_expand_kernel, dim3(n), dim3(64), 0, s, eng.d_fjobs.p, eng.d_fvsa.p, eng.d_ffirst.p, n,
                        eng.d_fsub_jobs.p, rule, dpmemory_mb, kp->R, eng.d_fflags.p, eng.d_fstats.p);
     HIP_OK(hipGetLastError());
     if (eng.d_fstats.download(stats.data(), FUSE_STATS, s)) return -1;
-    HIP_OK(hipStreamSynchronize(s));
+    HIP_OK(c4_stream_sync(s));
     lap("jobs listed");
     const long long max_runs = (long long)stats[FUSE_MAX_OPS_CAP], max_tb = (long long)stats[FUSE_MAX_TB];
     const long long sub_T = (long long)stats[FUSE_MAX_T], ops_total = (long long)stats[FUSE_OPS_TOTAL];
@@ -1871,7 +1981,7 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
         HIP_OK(kp->launch(a));
         if (ctx->timing) HIP_OK(hipEventRecord(ctx->ev1, s));
         if (eng.d_runs_used.download(&used, 1, s)) return -1;
-        HIP_OK(hipStreamSynchronize(s));
+        HIP_OK(c4_stream_sync(s));
         if (ctx->timing) {
             float ms = 0;
             HIP_OK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
@@ -1888,18 +1998,18 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
         return -1;
     hipLaunchKernelGGL(fuse_stitch_kernel, dim3((n + 63) / 64), dim3(64), 0, s, eng.d_fjobs.p, eng.d_fvsa.p, eng.d_ffirst.p, n,
                        eng.d_fsub_res.p, eng.d_runs_out.p, 1 + m->total_shadow_designations, eng.d_fflags.p, eng.d_runs_used.p,
-                       eng.d_fout.p, eng.d_fpairs.p, n16);
+                       eng.d_fout.p, eng.d_fpairs.p, n16, cell_strict() ? 1 : 0);
     HIP_OK(hipGetLastError());
     std::vector<FusePair> &fps = eng.hf_pairs;
     fps.resize(n);
     unsigned long long out_used = 0;
     if (eng.d_fpairs.download(fps.data(), n, s) || eng.d_runs_used.download(&out_used, 1, s)) return -1;
-    HIP_OK(hipStreamSynchronize(s));
+    HIP_OK(c4_stream_sync(s));
     std::vector<int> &out = eng.hf_out;
     out.resize(2 * (size_t)out_used);
     if (out_used) {
         if (eng.d_fout.download(out.data(), 2 * (size_t)out_used, s)) return -1;
-        HIP_OK(hipStreamSynchronize(s));
+        HIP_OK(c4_stream_sync(s));
     }
     lap("stitched + downloaded");
     int n_done = 0;
@@ -1923,7 +2033,7 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
     if (n_done < n) {
         std::vector<DevVsa> vsa((size_t)vsa_total);
         if (eng.d_fvsa.download(vsa.data(), vsa_total, s)) return -1;
-        HIP_OK(hipStreamSynchronize(s));
+        HIP_OK(c4_stream_sync(s));
         for (int x = 0; x < n; x++) {
             if (fps[x].status == 0) continue;
             JobOut o;
@@ -2103,6 +2213,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
         if (trace) fprintf(stderr, "c4gpu trace: find_path_batch: %-28s at %.3f ms\n", what,
                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     };
+    const bool strict_cells = cell_strict();
     std::vector<PairPlan> plan(n);
     std::vector<JobSpec> &specs = eng.fp_specs;
     std::vector<JobOut> &outs = eng.fp_outs;
@@ -2332,11 +2443,19 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
             // scheduled in the same round used the old value: it must not have changed
             if (!first_round && !children.empty() &&
                 !final_cell_equiv(children.back().final_cell, sg[k].final_cell, 1 + m->total_shadow_designations,
-                                  sg[k].region.target_start + sg[k].region.target_length, packed_pair[refs[x].pair] != 0)) {
+                                  sg[k].region.target_start + sg[k].region.target_length, packed_pair[refs[x].pair] != 0, strict_cells)) {
+                // Who has used the old value?  Only a sibling whose own nested pass ran in this round seeded with it: the
+                // segment right behind this one, if it is a checkpoint job of this round too.  Every other use lies ahead --
+                // the sub-alignment pass of step 4 seeds segment k + 1 with the cell the nested pass has just written (what
+                // optimal.c:283,301 does) and verifies every final cell against its prediction there -- so only that case
+                // sends the pair down the call-by-call route (one launch per section: 50 launches of 2 ms for a chance
+                // alignment across a 100 kb window, profiles/r05_wide_trace.md).
+                const bool next_in_round = x + 1 < group[g + 1] && refs[x + 1].seg == k + 1;
                 if (getenv("C4GPU_TRACE"))
-                    fprintf(stderr, "c4gpu trace: pair %d nested segment %d: final cell %d/%d after the nested pass, %d/%d predicted\n",
-                            refs[x].pair, k, children.back().final_cell[0], children.back().final_cell[1], sg[k].final_cell[0], sg[k].final_cell[1]);
-                redo[refs[x].pair] = 1;
+                    fprintf(stderr, "c4gpu trace: pair %d nested segment %d: final cell %d/%d after the nested pass, %d/%d predicted%s\n",
+                            refs[x].pair, k, children.back().final_cell[0], children.back().final_cell[1], sg[k].final_cell[0], sg[k].final_cell[1],
+                            next_in_round ? ": the next segment's nested pass used the old cell, sequential route" : "");
+                if (next_in_round || (getenv("C4GPU_NESTED_REDO") && atoi(getenv("C4GPU_NESTED_REDO")) != 0)) redo[refs[x].pair] = 1;
             }
             sg.erase(sg.begin() + k);
             sg.insert(sg.begin() + k, children.begin(), children.end());
@@ -2398,7 +2517,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
             if (redo[i] || repairing[i] >= 0) continue;     // redone below from the first stale sub-alignment
             for (uint32_t r : outs[x].runs) c4h::alignment_add(&a, &cap[i], (int)(r >> 24), (int)(r & 0xffffff));
             if (!final_cell_equiv(outs[x].res.final_cell, sg[k].final_cell, path_cs,
-                                  sg[k].region.target_start + sg[k].region.target_length, packed_pair[i] != 0)) {
+                                  sg[k].region.target_start + sg[k].region.target_length, packed_pair[i] != 0, strict_cells)) {
                 if (getenv("C4GPU_TRACE"))
                     fprintf(stderr, "c4gpu trace: pair %d sub-alignment %d: final cell %d/%d computed, %d/%d predicted\n", i,
                             k, outs[x].res.final_cell[0], outs[x].res.final_cell[1], sg[k].final_cell[0], sg[k].final_cell[1]);
@@ -2414,9 +2533,19 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
         });
         // the repair launches below take the pairs in list order
         std::sort(repairs.begin(), repairs.end(), [](const Repair &x, const Repair &y) { return x.pair < y.pair; });
-        // Optimal_compute_subalignments (optimal.c:266-313) for the stale tails, all affected pairs in
-        // lock-step: one small launch per remaining sub-alignment, each seeded with the cell its predecessor
-        // actually produced.
+        // Optimal_compute_subalignments (optimal.c:266-313) for the stale tails, all affected pairs in lock-step: one small
+        // launch per sub-alignment that has to be recomputed, seeded with the cell its predecessor actually produced.  A
+        // recomputed sub-alignment that ends in the cell the batch had PREDICTED for it re-joins the batch: the sub-alignments
+        // behind it were seeded with exactly that cell, so what the batch computed for them is what the reference computes
+        // (same inputs), up to the next one whose final cell differs -- where the next repair starts.  (Without this a miss
+        // early in a wide region cost one launch per remaining section: 50 launches of 2 ms for a chance alignment across a
+        // 100 kb window, profiles/r05_wide_trace.md; differences in a cell are mostly an intron start that the next match
+        // state forgets.)  C4GPU_REPAIR_REJOIN=0: recompute every sub-alignment behind a miss (test hook).
+        const bool rejoin = !(getenv("C4GPU_REPAIR_REJOIN") && atoi(getenv("C4GPU_REPAIR_REJOIN")) == 0);
+        std::vector<size_t> first_of(n, 0);
+        for (size_t r = 0; r < red.size(); r++) first_of[red[r]] = seg_first[r];
+        std::vector<JobOut> routs;
+        long long repair_launches = 0, repaired = 0, rejoined = 0;
         while (!repairs.empty()) {
             specs.clear();
             for (const Repair &rp : repairs) {
@@ -2427,17 +2556,40 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
                 s.final_state = (rp.next_seg + 1 < (int)sg.size()) ? sg[rp.next_seg + 1].first_state : m->end_state;
                 specs.push_back(s);
             }
-            if (eng.run(seqs, MODE_PATH, true, specs, outs)) return -1;
+            if (eng.run(seqs, MODE_PATH, true, specs, routs)) return -1;
+            repair_launches++; repaired += (long long)repairs.size();
             std::vector<Repair> next;
             for (size_t x = 0; x < repairs.size(); x++) {
                 Repair rp = repairs[x];
                 c4gpu_alignment &a = alignments[rp.pair];
-                for (uint32_t r : outs[x].runs) c4h::alignment_add(&a, &cap[rp.pair], (int)(r >> 24), (int)(r & 0xffffff));
-                memcpy(rp.seed, outs[x].res.final_cell, sizeof rp.seed);
-                if (++rp.next_seg < (int)plan[rp.pair].segs.size()) next.push_back(rp);
+                const std::vector<Segment> &sg = plan[rp.pair].segs;
+                const int nseg = (int)sg.size();
+                for (uint32_t r : routs[x].runs) c4h::alignment_add(&a, &cap[rp.pair], (int)(r >> 24), (int)(r & 0xffffff));
+                memcpy(rp.seed, routs[x].res.final_cell, sizeof rp.seed);
+                const int j = rp.next_seg;
+                if (j + 1 >= nseg) continue;
+                const bool joined = rejoin && final_cell_equiv(rp.seed, sg[j].final_cell, path_cs,
+                                                               sg[j].region.target_start + sg[j].region.target_length, packed_pair[rp.pair] != 0, strict_cells);
+                if (!joined) { rp.next_seg = j + 1; next.push_back(rp); continue; }
+                rejoined++;
+                // the batch's own results from j + 1 on, up to (and including) the next sub-alignment that misses its prediction
+                for (int k = j + 1; k < nseg; k++) {
+                    const JobOut &bo = outs[first_of[rp.pair] + k];
+                    for (uint32_t r : bo.runs) c4h::alignment_add(&a, &cap[rp.pair], (int)(r >> 24), (int)(r & 0xffffff));
+                    if (k + 1 < nseg && !final_cell_equiv(bo.res.final_cell, sg[k].final_cell, path_cs,
+                                                          sg[k].region.target_start + sg[k].region.target_length, packed_pair[rp.pair] != 0, strict_cells)) {
+                        rp.next_seg = k + 1;
+                        memcpy(rp.seed, bo.res.final_cell, sizeof rp.seed);
+                        next.push_back(rp);
+                        break;
+                    }
+                }
             }
             repairs.swap(next);
         }
+        if (repair_launches && getenv("C4GPU_TRACE"))
+            fprintf(stderr, "c4gpu trace: stale tails: %lld sub-alignments recomputed in %lld launches, %lld re-joined the batch\n",
+                    repaired, repair_launches, rejoined);
     }
     lap("alignments assembled");
     for (int i : red)
@@ -2472,7 +2624,7 @@ struct SideLane {
         HIP_OK(hipEventCreate(&ctx.ev0));
         HIP_OK(hipEventCreate(&ctx.ev1));
         if (eng.init(&ctx, m, p)) return -1;
-        HIP_OK(hipStreamSynchronize(ctx.stream));
+        HIP_OK(c4_stream_sync(ctx.stream));
         return 0;
     }
 };
@@ -2626,7 +2778,7 @@ int c4gpu_memrule_device(c4gpu_ctx *ctx, const c4gpu_model *model, int dpmemory_
     hipLaunchKernelGGL(memrule_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rule, dpmemory_mb, dq.p, dt.p, n, dr.p, dw.p);
     HIP_OK(hipGetLastError());
     if (dr.download(reduced, n, s) || dw.download(rows, n, s)) return -1;
-    HIP_OK(hipStreamSynchronize(s));
+    HIP_OK(c4_stream_sync(s));
     return 0;
 }
 
@@ -2681,7 +2833,7 @@ int c4gpu_splice_predict(c4gpu_ctx *ctx, const c4gpu_params *params, const uint8
         HIP_OK(hipMemcpyAsync(out[k], seqs.ss.p + (long long)k * seqs.dev.ss_stride, sizeof(int) * (size_t)target_len,
                               hipMemcpyDeviceToHost, ctx->stream));
     }
-    HIP_OK(hipStreamSynchronize(ctx->stream));
+    HIP_OK(c4_stream_sync(ctx->stream));
     return 0;
 }
 
@@ -2732,7 +2884,7 @@ extern "C" int c4gpu_hsp_extend_chains(c4gpu_ctx *ctx, const c4gpu_params *param
                            d_first.p, n_chains, d_h0.p, d_submat.p, aq, at, seedlen, dropoff, d_out.p);
         HIP_OK(hipGetLastError());
         if (d_out.download(out, n_seeds, s)) return -1;
-        HIP_OK(hipStreamSynchronize(s));
+        HIP_OK(c4_stream_sync(s));
         return 0;
     } catch (const std::exception &e) {
         c4h::set_error(std::string("c4gpu_hsp_extend_chains: ") + e.what());
@@ -2775,7 +2927,7 @@ extern "C" int c4gpu_hsp_extend_batch(c4gpu_ctx *ctx, const c4gpu_params *params
                            n_seeds, d_submat.p, aq, at, seedlen, dropoff, d_out.p);
         HIP_OK(hipGetLastError());
         if (d_out.download(out, n_seeds, s)) return -1;
-        HIP_OK(hipStreamSynchronize(s));
+        HIP_OK(c4_stream_sync(s));
         return 0;
     } catch (const std::exception &e) {
         c4h::set_error(std::string("c4gpu_hsp_extend_batch: ") + e.what());
@@ -2996,7 +3148,7 @@ c4gpu_stage *c4gpu_stage_create(c4gpu_ctx *ctx, const c4gpu_model *model, const 
             return nullptr;
         }
         if (st->eng.init(&st->ctx, &st->model, &st->params)) return nullptr;
-        if (hipStreamSynchronize(st->ctx.stream) != hipSuccess) return nullptr;
+        if (c4_stream_sync(st->ctx.stream) != hipSuccess) return nullptr;
         return st.release();
     } catch (const std::exception &e) {
         c4h::set_error(std::string("c4gpu_stage_create: ") + e.what());
@@ -3028,7 +3180,7 @@ int c4gpu_stage_load(c4gpu_stage *st, const c4gpu_pair *pairs, int32_t n_pairs) 
             HIP_OK(pk16_build_splice(st->eng.family, st->eng.kparams.p, st->seqs.dev.ss, st->seqs.dev.ss_stride, st->seqs.ss_len, chk.p, st->ctx.stream));
             std::vector<uint2> a(nn), b(nn);
             if (chk.download(a.data(), nn, st->ctx.stream) || st->seqs.ss16.download(b.data(), nn, st->ctx.stream)) return -1;
-            HIP_OK(hipStreamSynchronize(st->ctx.stream));
+            HIP_OK(c4_stream_sync(st->ctx.stream));
             for (int i = 0; i < st->seqs.n_pairs; i++)
                 for (long long x = st->seqs.toff[i]; x < st->seqs.toff[i] + st->seqs.tlen[i]; x++)
                     if (a[x].x != b[x].x || a[x].y != b[x].y) {

@@ -190,3 +190,19 @@ def est2genome_batches(firsts, n_pairs, qlen=1000, tlen=100000, workers=None):
             parts = pool.map(_est2genome_chunk, tasks, chunksize=1)
     per = (n_pairs + chunk - 1) // chunk
     return [[p for part in parts[b * per:(b + 1) * per] for p in part] for b in range(len(firsts))]
+
+
+def write_c4_dropin_input(directory, nq=64, nt=64, seed=20260932):
+    """BASELINE config 4 through the command line: nq cDNAs of 1 kb and nt genomic windows of 100 kb as FASTA files (window i
+    holds cDNA i's gene), aligned all against all by `exonerate -m est2genome -E yes -S no --revcomp no`: nq x nt rectangles
+    of 1 001 x 100 001 cells (64 x 64 = 4 096).  tools/make_c4_dropin_golden.py, bench.py's `configs.c4_dropin`."""
+    import os
+    pairs = est2genome_pairs(max(nq, nt), 1000, 100000, seed=seed)
+    qf, tf = os.path.join(directory, "q.fa"), os.path.join(directory, "t.fa")
+    with open(qf, "w") as f:
+        for i in range(nq):
+            f.write(">cdna%d\n%s\n" % (i, pairs[i][0].decode()))
+    with open(tf, "w") as f:
+        for i in range(nt):
+            f.write(">win%d\n%s\n" % (i, pairs[i][1].decode()))
+    return qf, tf

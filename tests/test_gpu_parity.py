@@ -381,15 +381,55 @@ def test_stale_sub_alignment_tails_are_recomputed(eng, monkeypatch, capfd):
     model = ex.Model("est2genome")
     q, t = workloads.est2genome_pairs(1, 1000, 100000, first=214)[0]
     monkeypatch.setenv("C4GPU_TRACE", "1")
+    # C4GPU_CELL_STRICT=1: a final cell whose SCORE differs from the prediction counts as a miss (the form of rounds 1-4) and the
+    # tail is recomputed; the default compares the shadow slots only (a score offset moves no decision of a continuation sub-DP:
+    # c4_engine.hip, final_cell_equiv) and keeps the batch's results -- both must give the oracle's alignments
+    monkeypatch.setenv("C4GPU_CELL_STRICT", "1")
     found = eng.find_all_paths(model, [(q, t)], dpmemory=32, threshold=300, max_paths=2)[0]
     err = capfd.readouterr().err
     assert "predicted" in err, "this input no longer exercises the repair route"
+    monkeypatch.delenv("C4GPU_CELL_STRICT")
+    relaxed = eng.find_all_paths(model, [(q, t)], dpmemory=32, threshold=300, max_paths=2)[0]
+    assert [a.as_dict() for a in relaxed] == [a.as_dict() for a in found]
     # the oracle's loop over this pair (45 s of CPU), written down by tools/make_stale_tails_golden.py
     import json, os
     exp = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stale_tails_pair214.json")))
     assert (exp["dpmemory"], exp["threshold"], exp["max_paths"]) == (32, 300, 2)
     assert [a.as_dict() for a in found] == exp["alignments"]
     assert len(found) == 2
+
+
+def test_score_offsets_and_repaired_tails_on_wide_chance_alignments(eng, monkeypatch, capfd):
+    """Chance alignments across whole 100 kb windows (8 cDNAs against 8 windows, all against all: 56 of the 64 pairs) have
+    ~54 sections each, and a few per hundred end a section a few points above the cell the checkpoint pass predicted (intron
+    length limits: no optimal substructure) -- same shadow slots, another score.  Three ways through, one result:
+      * default: the shadow slots decide (a score offset moves no decision of a continuation sub-DP, final_cell_equiv): the
+        batch's results stand, no repair launch;
+      * C4GPU_CELL_STRICT=1: the score counts as a miss, the tail is recomputed, and a recomputed sub-alignment that ends in
+        the predicted cell re-joins the batch's own results;
+      * C4GPU_CELL_STRICT=1 C4GPU_REPAIR_REJOIN=0 C4GPU_NESTED_REDO=1: every sub-alignment behind a miss recomputed one launch
+        at a time / the pair follows the reference call by call (the form of rounds 1-4, pinned on the oracle at full size by
+        test_stale_sub_alignment_tails_are_recomputed)."""
+    from exonerate_amd import workloads
+    model = ex.Model("est2genome")
+    base = workloads.est2genome_pairs(8, 1000, 100000, first=56)        # (cDNA 58 against window 63 misses a cell in section 4)
+    pairs = [(base[i][0], base[j][1]) for i in range(8) for j in range(8)]
+    monkeypatch.setenv("C4GPU_TRACE", "1")
+    got, misses = {}, {}
+    for name, env in (("relaxed", {}), ("strict", {"C4GPU_CELL_STRICT": "1"}),
+                      ("old", {"C4GPU_CELL_STRICT": "1", "C4GPU_REPAIR_REJOIN": "0", "C4GPU_NESTED_REDO": "1"})):
+        for k in ("C4GPU_CELL_STRICT", "C4GPU_REPAIR_REJOIN", "C4GPU_NESTED_REDO"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        capfd.readouterr()
+        got[name] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=32, threshold=100)]
+        err = capfd.readouterr().err
+        misses[name] = err.count(" predicted")
+    assert got["relaxed"] == got["strict"] == got["old"]
+    assert sum(1 for a in got["relaxed"] if a) == 64
+    assert misses["old"] >= 1, "this input no longer has a section that misses its predicted cell"
+    assert misses["relaxed"] < misses["old"]
 
 
 @pytest.mark.parametrize("name,mtype,qa,match_state,span_state", SPAN_SETS)
