@@ -38,7 +38,7 @@ static gboolean shim_tried = FALSE, shim_verbose = FALSE;
 /* exonerate.c:85 calls Codegen_ArgumentSet_create(arg) once while it assembles its option sets; the archive's
  * definition is renamed Codegen_ArgumentSet_create_cpu by the Makefile and this one adds ours after it. */
 extern Codegen_ArgumentSet *Codegen_ArgumentSet_create_cpu(Argument *arg);
-static struct { gboolean use_gpu; gint device; gint batch; } shim_args = {TRUE, 0, 4096};
+static struct { gboolean use_gpu; gint device; gint batch; } shim_args = {TRUE, 0, 2048};
 
 static void shim_start_ctx(void);
 
@@ -53,7 +53,7 @@ Codegen_ArgumentSet *Codegen_ArgumentSet_create(Argument *arg){
         ArgumentSet_add_option(as, '\0', "gpudevice", "ordinal",
                 "HIP device to use", "0", Argument_parse_int, &shim_args.device);
         ArgumentSet_add_option(as, '\0', "gpubatch", "pairs",
-                "Pairs of an exhaustive run collected per GPU batch (0 = one Viterbi call at a time)", "4096",
+                "Pairs of an exhaustive run collected per GPU batch (0 = one Viterbi call at a time)", "2048",
                 Argument_parse_int, &shim_args.batch);
         Argument_absorb_ArgumentSet(arg, as);
     } else {
@@ -633,9 +633,20 @@ static gboolean shim_can_batch(GAM *gam, Sequence *query, Sequence *target){
     if((gam->optimal->type & (Optimal_Type_SCORE|Optimal_Type_PATH|Optimal_Type_REDUCED_SPACE))
        != (Optimal_Type_SCORE|Optimal_Type_PATH|Optimal_Type_REDUCED_SPACE))
         return FALSE;
-    ud = Model_Type_create_data(gam->gas->type, query, target);
-    ok = shim_flatten(gam->optimal->find_path->model, ud, &fm);
-    Model_Type_destroy_data(gam->gas->type, ud);
+    {   /* whether the model is one of the accelerated families does not depend on the pair: asked once per model (the
+         * per-pair user data the flattening reads -- Match tables, splice predictors -- are the process's static argument
+         * sets); at 4 096 pairs of a run the repeated check was 0.1 ms per pair */
+        static C4_Model *seen_model = NULL;
+        static gboolean seen_ok = FALSE;
+        static Alphabet_Type seen_q, seen_t;
+        if((seen_model == gam->optimal->find_path->model) && (seen_q == query->alphabet->type) && (seen_t == target->alphabet->type))
+            return seen_ok;
+        ud = Model_Type_create_data(gam->gas->type, query, target);
+        ok = shim_flatten(gam->optimal->find_path->model, ud, &fm);
+        Model_Type_destroy_data(gam->gas->type, ud);
+        seen_model = gam->optimal->find_path->model; seen_q = query->alphabet->type; seen_t = target->alphabet->type;
+        seen_ok = ok;
+        }
     return ok;
     }
 
@@ -663,32 +674,65 @@ static C4_Score shim_query_threshold(GAM *gam, Sequence *query){
     return threshold;
     }
 
-static void shim_flush(void){
-    register guint i, n;
-    register gint k, rounds_max = g_getenv("C4GPU_BATCH_ROUNDS") ? atoi(g_getenv("C4GPU_BATCH_ROUNDS")) : 4;
-    register GAM *gam;
-    register ShimPending *sp;
-    register c4gpu_batch *batch = NULL;
-    register gpointer ud;
-    register C4_Score threshold;
-    register gint dpmemory;
+/* A flush has three parts: PREPARE on the main thread (the reference's Sequence / Model_Type objects are read here: flattened
+ * residues, flattened model and parameters, per-query thresholds), DEVICE (library calls only: stage the batch, run the rounds,
+ * keep every pair's alignments) and REPLAY on the main thread (each pair through the reference's own
+ * GAM_Result_exhaustive_create, in submission order).  The device part of a batch runs on a thread of its own while the main
+ * thread goes on reading sequences and collecting the next batch, and while it replays the batch before: at most one batch on
+ * the device and one behind it, replayed strictly in submission order (C4GPU_ASYNC=0: one after the other on the main thread,
+ * the form of rounds 1-4). */
+typedef struct {
+    GPtrArray *todo;
+    guint n;
+    GAM *gam;
+    C4_Score threshold;
+    gint dpmemory, rounds_max;
+    gboolean flattened;
     c4gpu_model fm;
     c4gpu_params params;
     c4gpu_pair *pair;
     gchar **str;
+    c4gpu_score *per_pair;            /* --percent thresholds, or NULL */
+    GThread *thread;
+    gint rounds_done;
+    gchar *error;
+    gint64 t_start, t_prepared, t_dev0, t_dev1;
+} ShimFlushJob;
+
+static GMutex shim_device_lock;           /* one batch on the device at a time */
+static ShimFlushJob *shim_in_flight = NULL;
+
+static gboolean shim_async(void){
+    static gint on = -1;
+    if(on < 0)
+        on = (g_getenv("C4GPU_ASYNC") && (atoi(g_getenv("C4GPU_ASYNC")) == 0)) ? 0 : 1;
+    return on;
+    }
+
+static ShimFlushJob *shim_flush_prepare(void){
+    register guint i, n;
+    register ShimPending *sp;
+    register gpointer ud;
+    register ShimFlushJob *job;
     GPtrArray *todo = shim_pending;
-    gint64 t_start = g_get_monotonic_time(), t_gpu0 = 0, t_gpu1 = 0;
     if((!todo) || (!todo->len))
-        return;
-    shim_pending = NULL;          /* pairs submitted while replaying start a new collection */
+        return NULL;
+    shim_mark("flush: start");
+    shim_pending = NULL;          /* pairs submitted from here on start a new collection */
     shim_pending_bytes = 0.0;
-    n = todo->len;
+    job = g_new0(ShimFlushJob, 1);
+    job->t_start = g_get_monotonic_time();
+    job->todo = todo;
+    n = job->n = todo->len;
     sp = todo->pdata[0];
-    gam = sp->gam;
-    threshold = gam->gas->threshold;
-    dpmemory = gam->optimal->find_path->vas->traceback_memory_limit;
-    pair = g_new0(c4gpu_pair, n);
-    str = g_new0(gchar*, 2*n);
+    job->gam = sp->gam;
+    job->threshold = job->gam->gas->threshold;
+    job->dpmemory = job->gam->optimal->find_path->vas->traceback_memory_limit;
+    job->rounds_max = g_getenv("C4GPU_BATCH_ROUNDS") ? atoi(g_getenv("C4GPU_BATCH_ROUNDS")) : 4;
+    if(!job->gam->gas->use_subopt)
+        job->rounds_max = 1;
+    job->pair = g_new0(c4gpu_pair, n);
+    job->str = g_new0(gchar*, 2*n);
     {   /* one flattened copy per Sequence: pairs that share a Sequence share the buffer, and the library
          * keeps one device copy (and one set of splice arrays) per buffer */
         register GHashTable *flat = g_hash_table_new(g_direct_hash, g_direct_equal);
@@ -696,52 +740,91 @@ static void shim_flush(void){
             register gchar *qs, *ts;
             sp = todo->pdata[i];
             if(!(qs = g_hash_table_lookup(flat, sp->query))){
-                qs = str[2*i] = Sequence_get_str(sp->query);
+                qs = job->str[2*i] = Sequence_get_str(sp->query);
                 g_hash_table_insert(flat, sp->query, qs);
                 }
             if(!(ts = g_hash_table_lookup(flat, sp->target))){
-                ts = str[2*i+1] = Sequence_get_str(sp->target);
+                ts = job->str[2*i+1] = Sequence_get_str(sp->target);
                 g_hash_table_insert(flat, sp->target, ts);
                 }
-            pair[i].query = (const uint8_t*)qs;  pair[i].query_len = sp->query->len;
-            pair[i].target = (const uint8_t*)ts; pair[i].target_len = sp->target->len;
+            job->pair[i].query = (const uint8_t*)qs;  job->pair[i].query_len = sp->query->len;
+            job->pair[i].target = (const uint8_t*)ts; job->pair[i].target_len = sp->target->len;
             }
         g_hash_table_destroy(flat);
         }
     sp = todo->pdata[0];
-    t_gpu0 = g_get_monotonic_time();
-    ud = Model_Type_create_data(gam->gas->type, sp->query, sp->target);
-    if(shim_flatten(gam->optimal->find_path->model, ud, &fm)){
-        shim_params(ud, &params);
-        batch = c4gpu_batch_create(shim_ctx, &fm, &params, pair, n);
-        }
-    Model_Type_destroy_data(gam->gas->type, ud);
-    if(batch && gam->gas->percent_threshold){
+    ud = Model_Type_create_data(job->gam->gas->type, sp->query, sp->target);
+    memset(&job->fm, 0, sizeof(job->fm));
+    if((job->flattened = shim_flatten(job->gam->optimal->find_path->model, ud, &job->fm)))
+        shim_params(ud, &job->params);
+    Model_Type_destroy_data(job->gam->gas->type, ud);
+    if(job->flattened && job->gam->gas->percent_threshold){
         /* one threshold per query (cached by Sequence): pairs below it stop after the score pass */
         register GHashTable *seen = g_hash_table_new(g_direct_hash, g_direct_equal);
-        c4gpu_score *per_pair = g_new(c4gpu_score, n);
+        job->per_pair = g_new(c4gpu_score, n);
         for(i = 0; i < n; i++){
             gpointer v;
             sp = todo->pdata[i];
             if(!g_hash_table_lookup_extended(seen, sp->query, NULL, &v)){
-                v = GINT_TO_POINTER(shim_query_threshold(gam, sp->query));
+                v = GINT_TO_POINTER(shim_query_threshold(job->gam, sp->query));
                 g_hash_table_insert(seen, sp->query, v);
                 }
-            per_pair[i] = GPOINTER_TO_INT(v);
+            job->per_pair[i] = GPOINTER_TO_INT(v);
             }
-        c4gpu_batch_set_thresholds(batch, per_pair);
-        g_free(per_pair);
         g_hash_table_destroy(seen);
         }
-    if(batch && (c4gpu_batch_run(batch, 2, dpmemory, threshold) == 0)){
-        if(!gam->gas->use_subopt)
-            rounds_max = 1;
-        for(k = 0; k < rounds_max; k++){
+    job->t_prepared = g_get_monotonic_time();
+    return job;
+    }
+
+/* library calls and plain memory only: runs on the flush thread */
+static gpointer shim_flush_device(gpointer data){
+    register ShimFlushJob *job = data;
+    register guint i, n = job->n;
+    register gint k = 0;
+    register ShimPending *sp;
+    register c4gpu_batch *batch = NULL;
+    /* ONE batch object and one stage for the whole run (per model and parameters): a flush stages its pairs through the stage's
+     * page-locked buffers and swaps them into the batch, which keeps its engine, launch lanes and launch buffers -- a batch
+     * created and destroyed per flush allocated and freed ~15 GB of device memory each time (the second 2 048-pair flush of a
+     * run took 1 630 ms on the device where the passes themselves take 520) */
+    static c4gpu_batch *res_batch = NULL;
+    static c4gpu_stage *res_stage = NULL;
+    static c4gpu_model res_fm;
+    static c4gpu_params res_params;
+    g_mutex_lock(&shim_device_lock);
+    job->t_dev0 = g_get_monotonic_time();
+    if(job->flattened){
+        if(res_stage && (memcmp(&res_fm, &job->fm, sizeof(res_fm)) || memcmp(&res_params, &job->params, sizeof(res_params)))){
+            if(res_batch)
+                c4gpu_batch_destroy(res_batch);
+            c4gpu_stage_destroy(res_stage);
+            res_batch = NULL;
+            res_stage = NULL;
+            }
+        if(!res_stage){
+            res_fm = job->fm;
+            res_params = job->params;
+            res_stage = c4gpu_stage_create(shim_ctx, &res_fm, &res_params);
+            }
+        if(res_stage && (c4gpu_stage_load(res_stage, job->pair, n) == 0)){
+            if(!res_batch)
+                res_batch = c4gpu_batch_create(shim_ctx, &res_fm, &res_params, job->pair, 1);      /* (swapped out at once) */
+            if(res_batch && (c4gpu_batch_swap_stage(res_batch, res_stage) == 0)){
+                batch = res_batch;
+                c4gpu_batch_set_thresholds(batch, NULL);
+                }
+            }
+        }
+    if(batch && job->per_pair)
+        c4gpu_batch_set_thresholds(batch, job->per_pair);
+    if(batch && (c4gpu_batch_run(batch, 2, job->dpmemory, job->threshold) == 0)){
+        for(k = 0; k < job->rounds_max; k++){
             register gint found = 1;
-            if(k && ((found = c4gpu_batch_next_paths(batch, dpmemory, threshold)) < 0))
+            if(k && ((found = c4gpu_batch_next_paths(batch, job->dpmemory, job->threshold)) < 0))
                 break;
             for(i = 0; i < n; i++){
-                sp = todo->pdata[i];
+                sp = job->todo->pdata[i];
                 if(sp->done)
                     continue;                          /* this pair left the loop in an earlier round */
                 sp->round = g_renew(c4gpu_alignment, sp->round, k+1);
@@ -755,29 +838,57 @@ static void shim_flush(void){
                 break;
                 }
             }
-        if(shim_verbose)
-            g_message("c4gpu: batch of %d pairs, %d round(s) on the device", n, k);
+        job->rounds_done = k;
     } else {
-        g_warning("c4gpu: %s -- batch falls back to per-call", c4gpu_last_error());
+        job->error = g_strdup(c4gpu_last_error());
         }
-    if(batch)
-        c4gpu_batch_destroy(batch);
-    t_gpu1 = g_get_monotonic_time();
+    job->t_dev1 = g_get_monotonic_time();
+    g_mutex_unlock(&shim_device_lock);
+    return NULL;
+    }
+
+static void shim_flush_replay(ShimFlushJob *job){
+    register guint i, n = job->n;
+    register gint k;
+    register ShimPending *sp;
+    gint64 t_rep0, t_rep_create = 0, t_rep_submit = 0, t_rep_destroy = 0, t_wait0 = g_get_monotonic_time();
+    if(job->thread){
+        g_thread_join(job->thread);
+        job->thread = NULL;
+        }
+    t_rep0 = g_get_monotonic_time();
+    if(job->error)
+        g_warning("c4gpu: %s -- batch falls back to per-call", job->error);
+    else if(shim_verbose)
+        g_message("c4gpu: batch of %d pairs, %d round(s) on the device", n, job->rounds_done);
     for(i = 0; i < 2*n; i++)
-        g_free(str[i]);
-    g_free(str);
-    g_free(pair);
+        g_free(job->str[i]);
+    g_free(job->str);
+    g_free(job->pair);
+    g_free(job->per_pair);
     /* replay in submission order through the reference's own code */
     for(i = 0; i < n; i++){
         register GAM_Result *gam_result;
-        sp = todo->pdata[i];
+        gint64 r0 = shim_verbose ? g_get_monotonic_time() : 0, r1 = 0, r2 = 0;
+        sp = job->todo->pdata[i];
         shim_replay_pair = sp;
         shim_replay_call = 0;
         gam_result = GAM_Result_exhaustive_create_cpu(sp->gam, sp->query, sp->target);
         shim_replay_pair = NULL;
+        if(shim_verbose)
+            r1 = g_get_monotonic_time();
         if(gam_result){
             GAM_Result_submit(gam_result);
+            if(shim_verbose)
+                r2 = g_get_monotonic_time();
             GAM_Result_destroy(gam_result);
+            }
+        if(shim_verbose){
+            t_rep_create += r1 - r0;
+            if(gam_result){
+                t_rep_submit += r2 - r1;
+                t_rep_destroy += g_get_monotonic_time() - r2;
+                }
             }
         for(k = 0; k < sp->round_total; k++)
             c4gpu_alignment_clear(&sp->round[k]);
@@ -787,11 +898,63 @@ static void shim_flush(void){
         Sequence_destroy(sp->target);
         g_free(sp);
         }
-    g_ptr_array_free(todo, TRUE);
+    g_ptr_array_free(job->todo, TRUE);
     if(shim_verbose)
-        g_message("c4gpu: flush of %d pairs: %.0f ms flattening, %.0f ms on the device (upload, passes, read-back), "
-                  "%.0f ms replaying through the reference", n, (t_gpu0 - t_start) / 1e3, (t_gpu1 - t_gpu0) / 1e3,
-                  (g_get_monotonic_time() - t_gpu1) / 1e3);
+        g_message("c4gpu: flush of %d pairs: %.0f ms flattening, %.0f ms on the device (upload, passes, read-back; started %.0f ms after "
+                  "the flush, the main thread waited %.0f ms for it), %.0f ms replaying through the reference "
+                  "(GAM_Result_exhaustive_create %.0f, GAM_Result_submit %.0f, GAM_Result_destroy %.0f ms)", n,
+                  (job->t_prepared - job->t_start) / 1e3, (job->t_dev1 - job->t_dev0) / 1e3, (job->t_dev0 - job->t_prepared) / 1e3,
+                  (t_rep0 - t_wait0) / 1e3, (g_get_monotonic_time() - t_rep0) / 1e3, t_rep_create / 1e3, t_rep_submit / 1e3,
+                  t_rep_destroy / 1e3);
+    g_free(job->error);
+    g_free(job);
+    return;
+    }
+
+/* everything collected so far is printed when this returns (what every caller that must keep the output order needs) */
+static void shim_flush(void){
+    register ShimFlushJob *job = shim_flush_prepare();
+    if(job){
+        if(shim_in_flight && shim_async())       /* the last batch goes to the device while the one before it is replayed */
+            job->thread = g_thread_new("c4gpu-flush", shim_flush_device, job);
+        else
+            shim_flush_device(job);
+        }
+    if(shim_in_flight){
+        shim_flush_replay(shim_in_flight);
+        shim_in_flight = NULL;
+        }
+    if(job)
+        shim_flush_replay(job);
+    return;
+    }
+
+/* a full batch while more pairs are coming: its device part starts on a thread of its own; the batch before it (whose device
+ * part has had the whole collection time of this one) is replayed now, beside it */
+static void shim_flush_async(void){
+    register ShimFlushJob *job, *before = shim_in_flight;
+    if(!shim_async()){
+        shim_flush();
+        return;
+        }
+    if(!(job = shim_flush_prepare()))
+        return;
+    job->thread = g_thread_new("c4gpu-flush", shim_flush_device, job);
+    shim_in_flight = job;
+    if(before)
+        shim_flush_replay(before);
+    return;
+    }
+
+/* GAM_Result_add_alignment (gam.c:673) writes every match cell of an alignment into the pair's SubOpt range tree, whatever
+ * --subopt says; with -S no nothing ever reads it (the tree only serves the next Optimal_find_path of the same pair).  While a
+ * pair of a batch is replayed with use_subopt off, the call is dropped: ~1 000 tree insertions per chance alignment, 0.06 ms per
+ * pair of the all-against-all run.  Every other caller (hpair.c:805, any run with -S yes) reaches the reference's function. */
+extern void SubOpt_add_alignment_cpu(SubOpt *subopt, Alignment *alignment);
+void SubOpt_add_alignment(SubOpt *subopt, Alignment *alignment){
+    if(shim_replay_pair && (!shim_replay_pair->gam->gas->use_subopt) && !g_getenv("C4GPU_KEEP_SUBOPT"))
+        return;
+    SubOpt_add_alignment_cpu(subopt, alignment);
     return;
     }
 
@@ -804,8 +967,10 @@ GAM_Result *GAM_Result_exhaustive_create(GAM *gam, Sequence *query, Sequence *ta
     if(shim_pending && shim_pending->len
     && (((ShimPending*)shim_pending->pdata[0])->gam != gam))
         shim_flush();
-    if(!shim_pending)
+    if(!shim_pending){
         shim_pending = g_ptr_array_new();
+        shim_mark("first pair of a batch collected");
+        }
     sp = g_new0(ShimPending, 1);
     sp->gam = GAM_share(gam);
     sp->query = Sequence_share(query);
@@ -815,7 +980,7 @@ GAM_Result *GAM_Result_exhaustive_create(GAM *gam, Sequence *query, Sequence *ta
     shim_pending_bytes += 22.0 * target->len + 2.0 * query->len;
     if(((gint)shim_pending->len >= shim_batch_size())
     || (shim_pending_bytes > (g_getenv("C4GPU_BATCH_GB") ? atof(g_getenv("C4GPU_BATCH_GB")) : 96.0) * 1e9))
-        shim_flush();
+        shim_flush_async();
     return NULL;                  /* the result is submitted by the flush, in submission order */
     }
 
