@@ -378,6 +378,11 @@ def main():
     g0 = time.perf_counter()
     host_batches = workloads.est2genome_batches([b * n_step + rank * n_local for b in range(nb)], n_local, args.qlen, args.tlen,
                                                 workers=max(1, min(32, cores // max(1, world))))
+    # robustness legs (single GPU, full run only): one batch of 1 100-nt cDNAs (five strips of 256 rows: off the staged packed
+    # score pass, whose queries must fit the four strips of a workgroup)
+    want_robust = (not stub) and world == 1 and (not args.no_configs) and n_local >= 1024 and args.qlen == 1000
+    long_q = workloads.est2genome_batches([nb * n_step], n_local, 1100, args.tlen,
+                                          workers=max(1, min(32, cores)))[0] if want_robust else None
     gen_s = time.perf_counter() - g0
     pairs = host_batches[0]
     first_pass_cells = sum((len(q) + 1) * (len(t) + 1) for q, t in pairs)       # the same for every batch: fixed lengths
@@ -599,6 +604,47 @@ def main():
                  "kernel_ms_per_step": {"score": sh_stats[0]["ms"] / 4, "region": sh_stats[2]["ms"] / 4, "checkpoint": sh_stats[3]["ms"] / 4,
                                         "path": sh_stats[1]["ms"] / 4}}
 
+    # Robustness: what the headline's synthetic alphabet and query length hide.  (a) the same batch with N, R, Y, K sprinkled
+    # over the targets (8 residue codes: the staged packed score pass holds a query profile for six); (b) cDNAs of 1 100 nt
+    # (five strips).  Resident, one warm-up and two timed passes each; pair 0 of each against the reference binary.
+    robust = None
+    if want_robust and not use_dist:
+        import numpy as np
+        robust = {}
+
+        def leg(name, label, batch_pairs):
+            stage.load(batch_pairs); batch.swap(stage)
+            batch.run(2)
+            for m in range(4):
+                batch.kernel_stats(m, reset=True)
+            sync()
+            c0 = time.perf_counter()
+            for _ in range(2):
+                batch.run(2); batch.export()
+            dt = (time.perf_counter() - c0) / 2
+            ks = {m: batch.kernel_stats(m) for m in range(4)}
+            cells = sum((len(q) + 1) * (len(t) + 1) for q, t in batch_pairs)
+            rec = {"workload": label, "ms_per_step_resident": dt * 1e3, "value": cells / dt, "unit": "cells/s",
+                   "kernel_ms_per_step": {"score": ks[0]["ms"] / 2, "region": ks[2]["ms"] / 2, "checkpoint": ks[3]["ms"] / 2, "path": ks[1]["ms"] / 2}}
+            if not args.no_cpu_baseline:
+                ref = reference_one_core(batch_pairs[0])
+                if ref is not None:
+                    got = batch.alignment(0)
+                    assert got is not None and got.vulgar("qy", "tg") == ref[1], "%s: GPU vulgar differs from the reference" % name
+                    rec["checked"] = "pair 0 against the reference binary: vulgar identical"
+            robust[name] = rec
+
+        rng = np.random.default_rng(20260940)
+        noisy = []
+        for q, t in host_batches[0]:
+            a = np.frombuffer(t, dtype=np.uint8).copy()
+            pos = rng.integers(0, len(a), size=len(a) // 300)
+            a[pos] = np.frombuffer(b"NRYK", dtype=np.uint8)[rng.integers(0, 4, size=len(pos))]
+            noisy.append((q, a.tobytes()))
+        leg("c4_eight_codes", "the north-star batch with N, R, Y, K at 0.3 % of the target positions (8 residue codes)", noisy)
+        del noisy
+        leg("c4_query_1100", "cDNAs of 1 100 nt (five strips of 256 rows) against 100 kb windows", long_q)
+
     # both strands ("once with revcomp on, doubling cells"): what the reference does for DNA queries by
     # default (fastapipe.c:42-44): each cDNA and its reverse complement against the same window; the windows are
     # shared buffers, so the device holds each once.  Streaming like the headline; one warm-up + two timed steps.
@@ -754,6 +800,10 @@ def main():
             if shard:
                 shard["frac_of_4096_pair_rate"] = shard["value"] / value
                 out["configs"]["c4_shard512"] = shard
+            if robust:
+                for rec in robust.values():
+                    rec["frac_of_resident_headline"] = rec["value"] / (first_pass_cells / (resident_ms * 1e-3)) if resident_ms else None
+                out["configs"].update(robust)
         # the all-cores leg runs at N=1 only; at N>1 the one-core leg ran before the process group was formed (early_cpu)
         if early_cpu is not None:
             rec, ref_line = early_cpu

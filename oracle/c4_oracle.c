@@ -1208,3 +1208,6 @@ int32_t oracle_hsp_set(const c4gpu_params *params, int match_type, const uint8_t
 
 /* ---- SDP (src/sdp/): restated in its own file, same translation unit ------------------------------------------- */
 #include "c4_oracle_sdp.c"
+
+/* ---- the seeder's automaton walk (src/comparison/seeder.c:649-720,852-915): its own file, same translation unit ---- */
+#include "c4_oracle_seed.c"

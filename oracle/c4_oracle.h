@@ -120,4 +120,10 @@ int64_t oracle_cells_visited(int reset);
 #ifdef __cplusplus
 }
 #endif
+/* The seeder's automaton walk (seeder.c:649-720,852-915; c4_oracle_seed.c): the (query, query position, target position)
+ * triples of the HSPset_seed_hsp calls the reference's walk makes over `symbols`, in its order. */
+int64_t oracle_seed_walk(int32_t width, int32_t wordlen, int32_t n_words, const uint64_t *codes, const int32_t *seed_first,
+                         const int32_t *seeds, const int32_t *nbr_first, const int32_t *nbrs, const uint8_t *symbols,
+                         int32_t n_symbols, int32_t tpos_modifier, int32_t *out, int64_t cap);
+
 #endif

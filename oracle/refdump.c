@@ -801,6 +801,183 @@ static void run_sdp(gchar *model_name, gchar *input_path, gint subopt_max, gint 
     return;
     }
 
+/* ---- the seeder's automaton walk (src/comparison/seeder.c:852-915 -> fsm.c:186-198 / seeder.c:698-720 -> :649-695):
+ * per record a fresh Seeder over the record's queries; dumps (1) the words the queries put into the automaton, read off the
+ * trie before it is compiled (or off the VFSM's leaf table) with each word's OWN seeds in list order and its neighbour words
+ * in list order -- the structure Seeder_FSM_traverse_func walks --, (2) the target as the columns of the automaton after the
+ * reference's own masking, (3) every (query, query position, target position) the reference's walk hands to HSPset_seed_hsp,
+ * in order (the call is intercepted at link time: -Wl,--wrap=HSPset_seed_hsp in oracle/Makefile).  Untranslated matches. */
+#include "seeder.h"
+#include "fsm.h"
+#include "vfsm.h"
+typedef struct { Sequence *query; gint query_pos, target_pos; } SeedCall;
+static GArray *seed_calls = NULL;
+extern void __real_HSPset_seed_hsp(HSPset *hsp_set, guint query_start, guint target_start);
+void __wrap_HSPset_seed_hsp(HSPset *hsp_set, guint query_start, guint target_start){
+    if(seed_calls){
+        SeedCall c;
+        c.query = hsp_set->query; c.query_pos = query_start; c.target_pos = target_start;
+        g_array_append_val(seed_calls, c);
+        }
+    __real_HSPset_seed_hsp(hsp_set, query_start, target_start);
+    return;
+    }
+static void seeds_report(Comparison *comparison, gpointer user_data){ return; }
+
+typedef struct { guint64 code; Seeder_WordInfo *info; } SeedWord;
+typedef struct { FSM_Node *node; guint64 code; } SeedTrieItem;
+
+static void run_seeds(gchar *match_name, gchar *input_path){
+    register FILE *fp = fopen(input_path, "r");
+    register gboolean is_protein = !strcmp(match_name, "protein2protein");
+    register Alphabet *alpha = Alphabet_create(is_protein ? Alphabet_Type_PROTEIN : Alphabet_Type_DNA, FALSE);
+    register Match *match = Match_find(is_protein ? Match_Type_PROTEIN2PROTEIN : Match_Type_DNA2DNA);
+    register HSP_Param *hsp_param = HSP_Param_create(match, TRUE);
+    register Comparison_Param *cparam = Comparison_Param_create(alpha->type, alpha->type, is_protein ? NULL : hsp_param,
+                                                                is_protein ? hsp_param : NULL, NULL);
+    gchar *line = g_malloc(1<<24);
+    if(!fp)
+        g_error("cannot open [%s]", input_path);
+    while(fgets(line, 1<<24, fp)){
+        gchar **f, **qs;
+        register Seeder *seeder;
+        register GPtrArray *queries = g_ptr_array_new();
+        register GArray *words = g_array_new(FALSE, FALSE, sizeof(SeedWord));
+        register GHashTable *word_of = g_hash_table_new(g_direct_hash, g_direct_equal);
+        register Sequence *target, *masked;
+        register gchar *seq;
+        register gint i, k, width, wordlen;
+        register guint w;
+        guchar column[256];
+        g_strchomp(line);
+        if((!line[0]) || (line[0] == '#'))
+            continue;
+        f = g_strsplit(line, "\t", 3);                  /* id, "q0,q1,...", target */
+        qs = g_strsplit(f[1], ",", -1);
+        seeder = Seeder_create(0, cparam, 0, seeds_report, NULL);
+        for(k = 0; qs[k]; k++){
+            gchar *name = g_strdup_printf("q%d", k);
+            register Sequence *q = Sequence_create(name, NULL, qs[k], 0, Sequence_Strand_FORWARD, alpha);
+            g_ptr_array_add(queries, q);
+            Seeder_add_query(seeder, q);
+            g_free(name);
+            }
+        wordlen = seeder->any_hsp_param->wordlen;
+        memset(column, 0, sizeof(column));
+        if(seeder->seeder_fsm){                          /* the trie before FSM_compile: `next` is NULL where there is no child */
+            register FSM *fsm = seeder->seeder_fsm->fsm;
+            register GArray *level = g_array_new(FALSE, FALSE, sizeof(SeedTrieItem)), *next_level;
+            register gint depth, c;
+            SeedTrieItem it;
+            width = fsm->width;
+            for(i = 1; i < 256; i++)
+                column[i] = fsm->traversal_filter[i];
+            it.node = fsm->root; it.code = 0;
+            g_array_append_val(level, it);
+            for(depth = 0; depth + 1 < wordlen; depth++){
+                next_level = g_array_new(FALSE, FALSE, sizeof(SeedTrieItem));
+                for(w = 0; w < level->len; w++){
+                    register SeedTrieItem *p = &g_array_index(level, SeedTrieItem, w);
+                    for(c = 1; c < fsm->width; c++)
+                        if(p->node[c].next){
+                            it.node = p->node[c].next; it.code = p->code * fsm->width + c;
+                            g_array_append_val(next_level, it);
+                            }
+                    }
+                g_array_free(level, TRUE);
+                level = next_level;
+                }
+            for(w = 0; w < level->len; w++){
+                register SeedTrieItem *p = &g_array_index(level, SeedTrieItem, w);
+                for(c = 1; c < fsm->width; c++)
+                    if(p->node[c].data){
+                        SeedWord sw;
+                        sw.code = p->code * fsm->width + c; sw.info = p->node[c].data;
+                        g_hash_table_insert(word_of, sw.info, GINT_TO_POINTER(words->len + 1));
+                        g_array_append_val(words, sw);
+                        }
+                }
+            g_array_free(level, TRUE);
+        } else {
+            register VFSM *vfsm = seeder->seeder_vfsm->vfsm;
+            register VFSM_Int leaf;
+            register gchar *word = g_new0(gchar, vfsm->depth + 1);
+            width = vfsm->alphabet_size + 1;
+            for(i = 1; i < 256; i++)
+                column[i] = (guchar)vfsm->index[toupper(i)];
+            for(leaf = 0; leaf < vfsm->lrw; leaf++){
+                register Seeder_WordInfo *info = seeder->seeder_vfsm->leaf[leaf];
+                SeedWord sw;
+                if(!info)
+                    continue;
+                VFSM_state2word(vfsm, VFSM_leaf2state(vfsm, leaf), word);
+                sw.code = 0;
+                for(i = 0; i < wordlen; i++)
+                    sw.code = sw.code * width + (guchar)vfsm->index[(guchar)word[i]];
+                sw.info = info;
+                g_hash_table_insert(word_of, sw.info, GINT_TO_POINTER(words->len + 1));
+                g_array_append_val(words, sw);
+                }
+            g_free(word);
+            }
+        printf("{\"id\":\"%s\",\"match\":\"%s\",\"automaton\":\"%s\",\"width\":%d,\"wordlen\":%d,\"tpos_modifier\":%d,\"n_queries\":%d,\"words\":[",
+               f[0], match_name, seeder->seeder_fsm ? "fsm" : "vfsm", width, wordlen, wordlen - 1, queries->len);
+        for(w = 0; w < words->len; w++){
+            register SeedWord *sw = &g_array_index(words, SeedWord, w);
+            register Seeder_Seed *seed;
+            register Seeder_Neighbour *nb;
+            register gboolean first = TRUE;
+            printf("%s[%lu,[", w ? "," : "", (gulong)sw->code);
+            for(seed = sw->info->seed_list; seed; seed = seed->next){
+                register gint qi = -1;
+                for(k = 0; k < (gint)queries->len; k++)
+                    if(queries->pdata[k] == seed->context->query_info->query)
+                        qi = k;
+                printf("%s[%d,%d]", first ? "" : ",", qi, seed->query_pos);
+                first = FALSE;
+                }
+            printf("],[");
+            first = TRUE;
+            for(nb = sw->info->neighbour_list; nb; nb = nb->next){
+                printf("%s%d", first ? "" : ",", GPOINTER_TO_INT(g_hash_table_lookup(word_of, nb->word_info)) - 1);
+                first = FALSE;
+                }
+            printf("]]");
+            }
+        /* the string the reference walks (Seeder_add_target: Sequence_mask, Sequence_get_str), as automaton columns */
+        target = Sequence_create("tg", NULL, f[2], 0, Sequence_Strand_FORWARD, alpha);
+        masked = Sequence_mask(target);
+        seq = Sequence_get_str(masked);
+        Sequence_destroy(masked);
+        printf("],\"symbols\":[");
+        for(i = 0; seq[i]; i++)
+            printf("%s%d", i ? "," : "", column[(guchar)seq[i]]);
+        g_free(seq);
+        seed_calls = g_array_new(FALSE, FALSE, sizeof(SeedCall));
+        Seeder_add_target(seeder, target);
+        printf("],\"expected\":[");
+        for(w = 0; w < seed_calls->len; w++){
+            register SeedCall *c = &g_array_index(seed_calls, SeedCall, w);
+            register gint qi = -1;
+            for(k = 0; k < (gint)queries->len; k++)
+                if(queries->pdata[k] == c->query)
+                    qi = k;
+            printf("%s[%d,%d,%d]", w ? "," : "", qi, c->query_pos, c->target_pos);
+            }
+        printf("]}\n");
+        g_array_free(seed_calls, TRUE);
+        seed_calls = NULL;
+        g_array_free(words, TRUE);
+        g_hash_table_destroy(word_of);
+        Sequence_destroy(target);
+        /* (the seeder and its queries are left to the end of the process: Seeder_destroy frees the query infos it shares) */
+        g_strfreev(f); g_strfreev(qs);
+        }
+    fclose(fp);
+    g_free(line);
+    return;
+    }
+
 int Argument_main(Argument *arg){
     register ArgumentSet *as = ArgumentSet_create("refdump options");
     gchar *cmd, *model_name, *input_path;
@@ -837,6 +1014,7 @@ int Argument_main(Argument *arg){
     Splice_ArgumentSet_create(arg);
     HSPset_ArgumentSet_create(arg);
     SDP_ArgumentSet_create(arg);
+    Seeder_ArgumentSet_create(arg);
     Argument_process(arg, "refdump", "reference table/golden dumper", "");
     if(!strcmp(cmd, "tables"))
         dump_tables();
@@ -850,6 +1028,8 @@ int Argument_main(Argument *arg){
         }
     else if(!strcmp(cmd, "hsp"))
         run_hsp(g_strdup(model_name), input_path);
+    else if(!strcmp(cmd, "seeds"))
+        run_seeds(g_strdup(model_name), input_path);
     else if(!strcmp(cmd, "sdp"))
         run_sdp(g_strdup(model_name), input_path, subopt_max > 0 ? subopt_max : 1, subopt_threshold);
     else if(!strcmp(cmd, "golden"))

@@ -24,7 +24,7 @@ _lib = None
 def load():
     global _lib
     if _lib is None:
-        srcs = [os.path.join(ROOT, "oracle", f) for f in ("c4_oracle.c", "c4_oracle_sdp.c")]
+        srcs = [os.path.join(ROOT, "oracle", f) for f in ("c4_oracle.c", "c4_oracle_sdp.c", "c4_oracle_seed.c")]
         if (not os.path.exists(SO)) or os.path.getmtime(SO) < max(os.path.getmtime(x) for x in srcs):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "port"],
                                   stdout=subprocess.DEVNULL)
@@ -222,3 +222,34 @@ def sdp(model, params, q, t, hsps, query_advance=1, target_advance=1, dropoff=50
         res.append(alignment_to_dict(model, out[i], lib.oracle_alignment_format, qid, len(q), len(t)))
         lib.oracle_alignment_clear(out[i])
     return ub.value, res
+
+
+def seed_walk(rec):
+    """The seeder's walk over one reference-generated record (tests/golden/seeds_*.jsonl): the (query, query position,
+    target position) triples in the reference's call order (oracle_seed_walk, oracle/c4_oracle_seed.c)."""
+    import numpy as np
+    lib = load()
+    words = sorted(range(len(rec["words"])), key=lambda w: rec["words"][w][0])           # ascending codes
+    place = {w: k for k, w in enumerate(words)}
+    codes = np.array([rec["words"][w][0] for w in words], dtype=np.uint64)
+    seed_first, seeds, nbr_first, nbrs = [0], [], [0], []
+    for w in words:
+        _, own, nb = rec["words"][w]
+        for q, p in own:
+            seeds += [q, p]
+        seed_first.append(len(seeds) // 2)
+        nbrs += [place[v] for v in nb]
+        nbr_first.append(len(nbrs))
+    sf, sd = np.array(seed_first, dtype=np.int32), np.array(seeds + [0], dtype=np.int32)
+    nf, nb_ = np.array(nbr_first, dtype=np.int32), np.array(nbrs + [0], dtype=np.int32)
+    sym = np.array(rec["symbols"] + [0], dtype=np.uint8)
+    lib.oracle_seed_walk.restype = C.c_int64
+    ptr = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    args = [C.c_int32(rec["width"]), C.c_int32(rec["wordlen"]), C.c_int32(len(words)), ptr(codes, C.c_uint64), ptr(sf, C.c_int32),
+            ptr(sd, C.c_int32), ptr(nf, C.c_int32), ptr(nb_, C.c_int32), ptr(sym, C.c_uint8), C.c_int32(len(rec["symbols"])),
+            C.c_int32(rec["tpos_modifier"])]
+    n = lib.oracle_seed_walk(*args, None, C.c_int64(0))
+    out = np.zeros(3 * max(1, n), dtype=np.int32)
+    got = lib.oracle_seed_walk(*args, ptr(out, C.c_int32), C.c_int64(n))
+    assert got == n
+    return out[:3 * n].reshape(n, 3).tolist()

@@ -4,7 +4,7 @@ cannot fail on the upper side.  Each case puts a WINDOWED launch (dumps every 25
 columns take the two-pass route) just inside and just outside one term of the guard, asserts from C4GPU_TRACE which score
 kernel ran, and compares EVERY pair with the oracle (Optimal_find_path, optimal.c:368-413):
   * --intronpenalty -1 / -5: an intron's two sites can outweigh its opening, so a path gains per intron the target has room for;
-  * the longest query the guard lets through against 5 000 columns (about 3 130 nt), and one row more;
+  * the longest query the guard lets through against 2 600 columns (about 3 160 nt), and one row more;
   * --maxintron against T + 4: the packed length counter saturates and cannot see "too long";
   * a substitution score of 16: (Q + 1) x 16 (+ the introns' term) <= 16 000 flips just under 1 000 rows;
 and a forced disagreement between a window and the score pass (C4GPU_FORCE_CORNER_MISMATCH) hands exactly those pairs to the
@@ -110,12 +110,12 @@ def test_small_intron_penalties_at_the_edge_of_the_gain_bound(eng, monkeypatch, 
 
 
 def test_longest_query_the_guard_lets_through(eng, monkeypatch, capfd):
-    """(Q + 1) x 5 + what introns can gain <= 16 000: about 3 130 rows against 5 000 columns under the default parameters (3 197
+    """(Q + 1) x 5 + what introns can gain <= 16 000: about 3 160 rows against 2 600 columns under the default parameters (3 197
     against a target without room for an intron).  The longest query that fits runs thirteen strips of 256 rows on the packed
     kernels (HBM carry rows between super-strips), one row more the 32-bit kernels."""
     model = ex.Model("est2genome")
     lib = _abi.load()
-    T = 5000
+    T = 2600
     fits = lambda q: lib.c4gpu_packed_route_fits(model.c, model.params, q, T)
     lo, hi = 1000, 4000
     assert fits(lo) == 1 and fits(hi) == 0
@@ -124,10 +124,10 @@ def test_longest_query_the_guard_lets_through(eng, monkeypatch, capfd):
         lo, hi = (mid, hi) if fits(mid) == 1 else (lo, mid)
     assert 3000 < lo < 3200, lo
     rng = random.Random(3199)
-    packed = _batch(rng, [(lo, T), (lo, T - 400), (2900, T)])
+    packed = _batch(rng, [(lo, T), (2900, T - 300)])
     assert all(len(t) <= T for _, t in packed)
     _run(eng, model, packed, monkeypatch, capfd, want_packed=True)
-    _run(eng, model, _batch(rng, [(lo + 1, T), (lo, T - 400), (2900, T)]), monkeypatch, capfd, want_packed=False)
+    _run(eng, model, _batch(rng, [(lo + 1, T), (2900, T - 300)]), monkeypatch, capfd, want_packed=False)
 
 
 def test_max_intron_against_the_target_length(eng, monkeypatch, capfd):

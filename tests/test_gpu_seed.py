@@ -1,11 +1,14 @@
 """The seeder's word scan on the device (c4gpu_seed_scan <-> Seeder_add_target's automaton walk, seeder.c:649-720,852-915)
-against a plain dictionary scan: every position whose last W symbols spell a word of the table, in position order, each
+against what the reference's own walk did (tests/golden/seeds_*.jsonl: oracle/refdump.c --cmd seeds; the oracle's restatement is
+pinned on the same records in tests/test_oracle_seed.py) and, at sizes no reference vector has, against a plain dictionary scan: every position whose last W symbols spell a word of the table, in position order, each
 with the word's emissions in list order; symbols outside the alphabet (column 0) reset the automaton.  The drop-in's use
 of it against the reference's own traversal, hit for hit: tests/test_integration_gpu.py (C4GPU_SEED_CHECK)."""
 import random
 import pytest
 
 import exonerate_amd as ex
+import oracle_lib
+from test_oracle_seed import SEED_SETS, load_seed_set
 
 pytestmark = pytest.mark.gpu
 
@@ -34,6 +37,26 @@ def _expected(width, wordlen, words, symbols):
             f, n = table[code]
             out += [(i, f + k) for k in range(n)]
     return out
+
+
+@pytest.mark.parametrize("name", SEED_SETS)
+def test_scan_reproduces_the_reference_walk(eng, name):
+    """Every reference-generated seeder record: the word table as the drop-in builds it (a word's emission list = its own seeds,
+    then the seeds of each neighbour word: Seeder_FSM_traverse_func, seeder.c:675-692) goes to the device, the hits come back in
+    walk order, and (query, query position, position - tpos_modifier) of every hit is the reference's HSPset_seed_hsp call,
+    call for call; the oracle's walk gives the same list."""
+    for rec in load_seed_set(name):
+        words, emits = [], []
+        for code, own, nbrs in rec["words"]:
+            mine = list(own)
+            for v in nbrs:
+                mine += rec["words"][v][1]
+            words.append((code, len(mine)))
+            emits += mine
+        hits, _ = eng.seed_scan(rec["width"], rec["wordlen"], words, bytes(rec["symbols"]))
+        got = [[emits[e][0], emits[e][1], pos - rec["tpos_modifier"]] for pos, e in hits]
+        assert got == rec["expected"], rec["id"]
+        assert got == oracle_lib.seed_walk(rec), rec["id"]
 
 
 @pytest.mark.parametrize("width,wordlen,n,n_words,seed", [

@@ -274,6 +274,49 @@ def hsp_cases(kind, n, seed):
     return cases
 
 
+def seed_cases(kind, n, seed):
+    """Records for the seeder's walk (refdump --cmd seeds): several queries per seeder -- some share words, so that a word's seed
+    list holds seeds of several queries -- and one target that holds mutated copies of them, residues outside the alphabet
+    (N / X: the walk's reset), lower case (soft-masked: Sequence_mask) and, for DNA, a low-complexity stretch whose words repeat."""
+    rng = random.Random(seed)
+    cases = []
+    for k in range(n):
+        if kind == "dna2dna":
+            q0 = rand_dna(rng, rng.choice([40, 90, 200]))
+            qs = [q0, rand_dna(rng, rng.randint(20, 60)) + q0[len(q0) // 3:len(q0) // 3 + 30] + rand_dna(rng, rng.randint(0, 40))]
+            if k % 3 == 0:
+                qs.append(rand_dna(rng, 25) + "ACACACACACACACACACAC" + rand_dna(rng, 10))
+            t = rand_dna(rng, rng.randint(0, 60)) + mutate(rng, q0, rng.choice([0.0, 0.03, 0.08]), "ACGT") + "NNN" + rand_dna(rng, rng.randint(5, 80))
+            t += qs[1][5:] + rand_dna(rng, 17).lower() + mutate(rng, q0[10:], 0.02, "ACGT")
+            if k % 3 == 0:
+                t += "ACACACACACACACACACACACACAC" + rand_dna(rng, 9)
+            if k % 4 == 1:
+                t = t[:30] + t[30:70].lower() + t[70:]
+        else:
+            q0 = rand_dna(rng, rng.choice([24, 35]), AA)
+            qs = [q0, rand_dna(rng, 8, AA) + q0[6:20] + rand_dna(rng, 6, AA)]
+            t = rand_dna(rng, rng.randint(0, 20), AA) + mutate(rng, q0, rng.choice([0.0, 0.08]), AA) + "X" + rand_dna(rng, rng.randint(3, 25), AA)
+            t += qs[1][2:] + rand_dna(rng, 6, AA).lower()
+        cases.append(("seeds_%s%03d" % (kind[:3], k), qs, t))
+    return cases
+
+
+def run_seeds(kind, cases, extra=()):
+    with tempfile.NamedTemporaryFile("w", suffix=".tsv", delete=False) as f:
+        for cid, qs, t in cases:
+            f.write("%s\t%s\t%s\n" % (cid, ",".join(qs), t))
+        path = f.name
+    out = subprocess.run([REFDUMP, "--cmd", "seeds", "--model", kind, "--input", path] + list(extra),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout.decode()
+    os.unlink(path)
+    recs = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+    assert len(recs) == len(cases)
+    for r, (cid, qs, t) in zip(recs, cases):
+        assert r["id"] == cid
+        r["queries"], r["target"] = qs, t
+    return recs
+
+
 def run_hsp(kind, cases, extra=()):
     with tempfile.NamedTemporaryFile("w", suffix=".tsv", delete=False) as f:
         for cid, q, t, seeds in cases:
@@ -528,6 +571,20 @@ def main():
             for r in recs:
                 f.write(json.dumps(r, separators=(",", ":")) + "\n")
         print(name, len(recs) - 1, "pairs,", sum(len(r["seeds"]) for r in recs[1:]), "seeds,", sum(len(r["set"]) for r in recs[1:]), "HSPs")
+    # the seeder's automaton walk (seeder.c:649-720,852-915): word tables off the reference's automaton + the calls its walk made
+    for name, kind, n, extra in (("seeds_dna2dna", "dna2dna", 8, ()), ("seeds_dna2dna_w9", "dna2dna", 5, ("--dnawordlen", "9")),
+                                 ("seeds_dna2dna_compact", "dna2dna", 4, ("--forcefsm", "compact")),
+                                 ("seeds_dna2dna_hood", "dna2dna", 3, ("--dnawordlen", "8", "--dnawordlimit", "5")),
+                                 ("seeds_protein2protein", "protein2protein", 3, ("--proteinwordlimit", "2")),
+                                 ("seeds_protein2protein_compact", "protein2protein", 2, ("--proteinwordlimit", "1", "--forcefsm", "compact"))):
+        if only and name not in only:
+            continue
+        recs = run_seeds(kind, seed_cases(kind, n, 77 + len(name)), extra)
+        with open(os.path.join(OUT, name + ".jsonl"), "w") as f:
+            for r in recs:
+                f.write(json.dumps(r, separators=(",", ":")) + "\n")
+        print(name, len(recs), "seeders,", sum(len(r["words"]) for r in recs), "words,", sum(sum(len(w[2]) for w in r["words"]) for r in recs),
+              "neighbour links,", sum(len(r["expected"]) for r in recs), "seeds", [r["automaton"] for r in recs][:1])
     if not only or "scoring_data_alt" in only:
         out = subprocess.run([REFDUMP, "--cmd", "data"] + ALT_FLAGS, stdout=subprocess.PIPE, check=True).stdout.decode()
         dd = json.loads(out)
