@@ -29,7 +29,10 @@ names = ["FETCH_SIZE", "WRITE_SIZE", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCL
          "SQ_INSTS_VALU", "SQ_WAIT_ANY", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS"]
 with open(f"{dst}/{tag}_pmc.csv", "w") as o:
     o.write("# rocprofv3 --pmc, three separate passes (FETCH_SIZE | WRITE_SIZE | SQ_*), python bench.py --steps 1 --warmup 1;\n"
-            "# values are SUMS over the dispatches of that kernel in the run (column 'dispatches'); FETCH/WRITE in KiB, SQ_* in quad-cycles\n")
+            "# values are SUMS over the dispatches of that kernel in the run (column 'dispatches'); FETCH/WRITE in KiB, SQ_* in quad-cycles\n"
+            "# vgpr: rocprofv3's VGPR_Count column, which for these wave64 kernels is HALF the per-lane register count of the code object\n"
+            "# (.vgpr_count in the kernel's metadata, llvm-readelf --notes: 84 here <-> 168 for the packed score pass): waves per SIMD =\n"
+            "# floor(512 / (2 x vgpr)); lds_bytes and scratch_bytes are per workgroup / per lane as rocprofv3 reports them\n")
     o.write("kernel,dispatches,vgpr,agpr,sgpr,lds_bytes,scratch_bytes,workgroup,grid," + ",".join(names) + "\n")
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
         o.write('"%s",%d,%s,' % (k, int(v.get("dispatches:SQ_WAVES", v.get("dispatches:FETCH_SIZE", 0))), ",".join(meta[k]))
