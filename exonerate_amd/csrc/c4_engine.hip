@@ -1385,6 +1385,14 @@ struct Engine {
                         bool strips_ok = true;
                         for (int i = 0; i < n && strips_ok; i++) strips_ok = specs[i].region.query_length + 1 <= pk16_staged_rows();
                         if (strips_ok) { ki = ke; staged_codes = seqs.tdense.p; }
+                        else if (io_env == 2 && !(getenv("C4GPU_PK16_R6") && atoi(getenv("C4GPU_PK16_R6")) == 0)) {
+                            // queries of 1 024 .. 1 535 rows: six rows per lane put them into the four strips of one workgroup
+                            // (C4GPU_PK16_R6=0: the form that loads per step, in two passes over the target)
+                            const KernelInfo *kh = get_kernel_pk16(family, 7);
+                            bool six_ok = kh != nullptr;
+                            for (int i = 0; i < n && six_ok; i++) six_ok = specs[i].region.query_length + 1 <= pk16_staged_rows6();
+                            if (six_ok) { ki = kh; staged_codes = seqs.tdense.p; }
+                        }
                         // ... on eight waves of two rows per lane where the launch has at most one pair of jobs per compute unit (the
                         // shard of a strong-scaled run): twice the waves on the same rows (C4GPU_PK16_NW8=0: never; 1: always)
                         const int nw8_env = getenv("C4GPU_PK16_NW8") ? atoi(getenv("C4GPU_PK16_NW8")) : -1;

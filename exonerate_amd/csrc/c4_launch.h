@@ -80,6 +80,7 @@ const KernelInfo *get_kernel_win16(int family, int variant = 0);
 // (Q + 1) a workgroup covers
 int pk16_staged_codes();
 int pk16_staged_rows();
+int pk16_staged_rows6();            // ... of the six-rows-per-lane form (get_kernel_pk16 variant 7)
 hipError_t pk16_build_splice(int family, const KParams *kp, const int *ss, long long ss_stride, long long n, void *out, hipStream_t s);
 
 #define C4K_DEFINE_KERNEL_SPAN(SYMBOL, M, RVAL, MODE, CONT, LOCAL, PACK, WPE, SUBV, SPANV)                                          \

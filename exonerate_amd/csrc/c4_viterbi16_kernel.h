@@ -169,8 +169,12 @@ struct WaveDP16 {
     // plane read is 64 consecutive words: no bank conflict (column-major entries of 32 bytes put 64 lanes on 8 banks: 72 % of the
     // LDS-active cycles of the first LDS-fed form were conflicts, profiles/r04_c_sq.csv)
     static constexpr int STAGE_COLS = 128, STAGE_INTS = 8;
-    static constexpr int PROF_INTS = NCODE * 128;                 // query profile: ints per (wave, job): [code][lane] of 8 bytes
-    static_assert(!IO || (VAR >= 1 && F::has_splice() && (R == 4 || R == 2)), "the staged form is built for the packed splice entries and 4 or 2 rows per lane");
+    // query profile: per (wave, job) [code][lane] entries of NP ints (two rows' scores per int); 8 bytes per entry for 2 and 4 rows
+    // per lane (a b64 read; half of it unused with 2 rows), 12 for 6 rows (three ints: 64 lanes x 12 contiguous bytes per code, no
+    // bank conflict either)
+    static constexpr int NP = (R + 1) / 2, PROF_EB = (R == 6) ? 12 : 8, PROF_CODE = 64 * PROF_EB;
+    static constexpr int PROF_INTS = NCODE * PROF_CODE / 4;
+    static_assert(!IO || (VAR >= 1 && F::has_splice() && (R == 6 || R == 4 || R == 2)), "the staged form is built for the packed splice entries and 2, 4 or 6 rows per lane");
     static_assert(!F::has_phase(), "split-codon calcs are not packed");
     static_assert(M::NDES <= 1, "one shadow designation");
     typedef __attribute__((address_space(3))) int lds_int;
@@ -201,7 +205,7 @@ struct WaveDP16 {
     // IO 1
     int ring_in_mask, ring_out_mask;                    // 255, or 0 for the constant column of the first / last wave
     int nx_sp4[4], nx_off[2];                           // next column: packed splice values; profile byte offsets of its two codes
-    int nx_prof[4];                                     // ... and the profile entries of those codes: job A rows 0-1, 2-3, job B rows 0-1, 2-3
+    int nx_prof[6];                                     // ... and the profile entries of those codes: job A rows 0-1, 2-3, 4-5 in [0..2], job B in [3..5]
     int prof_a[2];                                      // LDS byte address of this lane's profile entry of code 0, per job
     int stage_a, stage_base;                            // LDS byte address of the next column's stage entry; of the wave's stage (4 KB-aligned)
     const uint8_t *tdense;                              // [24] code -> dense index (0xff: not in the launch), [24 + d] code of index d
@@ -264,8 +268,7 @@ struct WaveDP16 {
     // IO 1: the profile entries of the next column's codes; issued in the middle of a step, when the stage entry has arrived
     __device__ __forceinline__ void prefetch_profile() {
         const lds_int *pa = lds_at(prof_a[0] + nx_off[0]), *pb = lds_at(prof_a[1] + nx_off[1]);
-        nx_prof[0] = pa[0]; nx_prof[2] = pb[0];
-        if constexpr (R == 4) { nx_prof[1] = pa[1]; nx_prof[3] = pb[1]; }       // (two rows per lane: half an entry)
+        static_for<NP>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; nx_prof[K] = pa[K]; nx_prof[3 + K] = pb[K]; });
     }
     // IO 1: columns c0 + lane of both jobs into the stage -- clamped as prefetch_column clamps them, the splice values of the two
     // jobs interleaved into packed halves (what step() did with four v_perm per step), the residue codes as profile offsets
@@ -279,7 +282,7 @@ struct WaveDP16 {
             int tp = t0[H] + c - 2;
             tp = tp < 0 ? 0 : (tp > tlast[H] ? tlast[H] : tp);
             sv[H] = ss16[H][(unsigned)tp];
-            off[H] = (int)tdense[tc[H][(unsigned)ti]] * 512;
+            off[H] = (int)tdense[tc[H][(unsigned)ti]] * PROF_CODE;
         });
         lds_int *p = stage + (c & (STAGE_COLS - 1));
         p[0 * STAGE_COLS] = (int)__builtin_amdgcn_perm(sv[1].x, sv[0].x, 0x05040100u);
@@ -307,9 +310,8 @@ struct WaveDP16 {
                 static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
                     v[RR] = (i0 + RR > Q[H]) ? DEAD_ROW : clamp16(kp->submat[qr[RR] + code]);
                 });
-                lds_int *p = lds_at(prof_a[H] + d * 512);
-                p[0] = pk_pack(v[0], v[1]);
-                if constexpr (R == 4) p[1] = pk_pack(v[R - 2], v[R - 1]);
+                lds_int *p = lds_at(prof_a[H] + d * PROF_CODE);
+                static_for<NP>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; p[K] = pk_pack(v[2 * K], v[2 * K + 1 < R ? 2 * K + 1 : 2 * K]); });
             }
         });
     }
@@ -385,13 +387,10 @@ struct WaveDP16 {
         const int j = s - lane;
         int ms[R];
         if constexpr (IO == 1) {
-            const int a0 = nx_prof[0], a1 = nx_prof[1], b0 = nx_prof[2], b1 = nx_prof[3];
-            ms[0] = (int)__builtin_amdgcn_perm((unsigned)b0, (unsigned)a0, 0x05040100u);
-            ms[1] = (int)__builtin_amdgcn_perm((unsigned)b0, (unsigned)a0, 0x07060302u);
-            if constexpr (R == 4) {
-                ms[R - 2] = (int)__builtin_amdgcn_perm((unsigned)b1, (unsigned)a1, 0x05040100u);
-                ms[R - 1] = (int)__builtin_amdgcn_perm((unsigned)b1, (unsigned)a1, 0x07060302u);
-            }
+            static_for<NP>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
+                ms[2 * K] = (int)__builtin_amdgcn_perm((unsigned)nx_prof[3 + K], (unsigned)nx_prof[K], 0x05040100u);
+                if constexpr (2 * K + 1 < R) ms[2 * K + 1] = (int)__builtin_amdgcn_perm((unsigned)nx_prof[3 + K], (unsigned)nx_prof[K], 0x07060302u);
+            });
         } else {
             static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
                 ms[RR] = pk_pack(kp->submat[qrow[0][RR] + nx_tcode[0]], kp->submat[qrow[1][RR] + nx_tcode[1]]);
@@ -775,7 +774,7 @@ void viterbi16_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *job
             dp.kp = kparams;
             dp.tdense = tdense;
             static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
-                dp.prof_a[H] = DP::lds_addr((typename DP::lds_int *)prof_mem + (wid * 2 + H) * DP::PROF_INTS) + dp.lane * 8;
+                dp.prof_a[H] = DP::lds_addr((typename DP::lds_int *)prof_mem + (wid * 2 + H) * DP::PROF_INTS) + dp.lane * DP::PROF_EB;
             });
             dp.template run_mw<NW>(jobs[ia], jobs[ib], seqs, bnd, (typename DP::lds_int *)rings, wid, (typename DP::lds_int *)progress,
                                    (typename DP::lds_int *)stage_mem + wid * DP::STAGE_COLS * DP::STAGE_INTS, (typename DP::lds_int *)edge_cols);

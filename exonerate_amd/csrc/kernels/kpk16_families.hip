@@ -52,6 +52,18 @@ static hipError_t kpk16g_est2genome_launch(const LaunchArgs &a) {
 static const KernelInfo kpk16g_est2genome = {kpk16g_est2genome_launch, (const void *)viterbi16_kernel_mw<Est2GenomeDesc, 2, 8, 2, 2, true, 1>,
                                              "kpk16g_est2genome", 2, 2, WaveDP16<Est2GenomeDesc, 2, 2, true, 1>::BND, Est2GenomeDesc::NS,
                                              Est2GenomeDesc::MAXAT, 8, WaveDP16<Est2GenomeDesc, 2, 2, true, 1>::SEEDW};
+// variant 7: the staged form with SIX rows per lane (strips of 384 rows: queries of up to 1 535 nt in the four strips of one
+// workgroup, where four rows per lane need a second pass over the target for rows 1 024 ..: cDNAs of 1.1 kb ran at half the rate
+// of 1 kb ones, bench.py configs.c4_query_1100), two waves per SIMD
+static hipError_t kpk16h_est2genome_launch(const LaunchArgs &a) {
+    hipLaunchKernelGGL((viterbi16_kernel_mw<Est2GenomeDesc, 6, 4, 2, 2, true, 1>), dim3(a.grid), dim3(64 * 4), 0, a.stream,
+                       a.kp, a.seqs, a.jobs, a.n_jobs, a.results, a.scratch, a.queue, reinterpret_cast<const uint8_t *>(a.aux));
+    return hipGetLastError();
+}
+static const KernelInfo kpk16h_est2genome = {kpk16h_est2genome_launch, (const void *)viterbi16_kernel_mw<Est2GenomeDesc, 6, 4, 2, 2, true, 1>,
+                                             "kpk16h_est2genome", 6, 2, WaveDP16<Est2GenomeDesc, 6, 2, true, 1>::BND, Est2GenomeDesc::NS,
+                                             Est2GenomeDesc::MAXAT, 4, WaveDP16<Est2GenomeDesc, 6, 2, true, 1>::SEEDW};
+int pk16_staged_rows6() { return 6 * 64 * 4; }
 int pk16_staged_codes() { return WaveDP16<Est2GenomeDesc, 4, 1, true, 1>::NCODE; }
 int pk16_staged_rows() { return 4 * 64 * 4; }
 // the packed splice array of variant 1 (ss16_kernel): n positions of the batch's concatenated targets
@@ -62,6 +74,6 @@ hipError_t pk16_build_splice(int family, const KParams *kp, const int *ss, long 
 }
 const KernelInfo *get_kernel_pk16(int family, int variant) {
     if (family != FAM_EST2GENOME) return nullptr;
-    return variant == 6 ? &kpk16g_est2genome : variant == 5 ? &kpk16f_est2genome : variant == 4 ? &kpk16e_est2genome : variant == 3 ? &kpk16d_est2genome : variant == 2 ? &kpk16c_est2genome : variant == 1 ? &kpk16b_est2genome : &kpk16_est2genome;
+    return variant == 7 ? &kpk16h_est2genome : variant == 6 ? &kpk16g_est2genome : variant == 5 ? &kpk16f_est2genome : variant == 4 ? &kpk16e_est2genome : variant == 3 ? &kpk16d_est2genome : variant == 2 ? &kpk16c_est2genome : variant == 1 ? &kpk16b_est2genome : &kpk16_est2genome;
 }
 }

@@ -459,7 +459,13 @@ def test_staged_packed_score_pass_agrees_with_the_plain_one(eng, monkeypatch, ca
     tall = pairs + [(q, t)]
     d = [x.as_dict() if x else None for x in eng.find_path(model, tall, dpmemory=32, threshold=20)]
     err = capfd.readouterr().err
-    assert "kpk16d_est2genome" in err and "kpk16e_est2genome" not in err and "kpk16f_est2genome" not in err, err[-1500:]
+    # (five strips of 256 rows = four of 384: the six-rows-per-lane form of the staged pass, tests/test_gpu_pk16_edges.py)
+    assert "kpk16h_est2genome" in err and "kpk16e_est2genome" not in err and "kpk16f_est2genome" not in err, err[-1500:]
+    monkeypatch.setenv("C4GPU_PK16_R6", "0")
+    assert d == [x.as_dict() if x else None for x in eng.find_path(model, tall, dpmemory=32, threshold=20)]
+    err = capfd.readouterr().err
+    assert "kpk16d_est2genome" in err and "kpk16h_est2genome" not in err, err[-1500:]
+    monkeypatch.delenv("C4GPU_PK16_R6")
     monkeypatch.setenv("C4GPU_PK16", "0")
     assert c == [x.as_dict() if x else None for x in eng.find_path(model, many, dpmemory=32, threshold=20)]
     assert d == [x.as_dict() if x else None for x in eng.find_path(model, tall, dpmemory=32, threshold=20)]

@@ -181,3 +181,35 @@ def test_a_disagreeing_window_demotes_its_pair_not_the_batch(eng, monkeypatch, c
     monkeypatch.setenv("C4GPU_STRICT", "1")
     with pytest.raises(ex.C4GpuError):
         eng.find_path(model, pairs, dpmemory=32, threshold=20)
+
+
+def test_six_rows_per_lane_for_queries_of_1024_to_1535_rows(eng, monkeypatch, capfd):
+    """cDNAs longer than 1 023 nt do not fit the four strips of 256 rows the staged packed score pass holds per workgroup; up to
+    1 535 nt they fit four strips of 384 rows (kpk16h: six rows per lane, two waves per SIMD) instead of taking a second pass over
+    the target on the form that loads per step.  Ragged batch around both edges (1 024 and 1 535 rows), N in a target, every pair
+    against the oracle; a query of 1 536 nt sends the launch back to the per-step form; C4GPU_PK16_R6=0 gives the same
+    alignments."""
+    model = ex.Model("est2genome")
+    rng = random.Random(1535)
+    pairs = _batch(rng, [(1024, 3000), (1100, 2600), (1535, 2800), (700, 2500), (1300, 6000)])
+    q, t = pairs[4]
+    pairs[4] = (q, t[:900] + "NNNNN" + t[905:])
+    err = _run(eng, model, pairs, monkeypatch, capfd, want_packed=True)
+    assert "kpk16h_est2genome" in err and "kpk16h_est2genome: 2 workgroups per CU" in err, err[:1500]
+    got = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=32, threshold=20)]
+    monkeypatch.setenv("C4GPU_PK16_R6", "0")
+    capfd.readouterr()
+    assert got == [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=32, threshold=20)]
+    assert "kpk16h" not in capfd.readouterr().err
+    monkeypatch.delenv("C4GPU_PK16_R6")
+    longer = _batch(rng, [(1536, 2600), (1100, 2600)])
+    err = _run(eng, model, longer, monkeypatch, capfd, want_packed=True)
+    assert "kpk16h" not in err and "kpk16d_est2genome" in err
+    # at the default dump interval: 1.2 kb against 40 kb, both forms
+    monkeypatch.delenv("C4GPU_SEED_KSHIFT")
+    big = _batch(rng, [(1200, 40000), (1400, 36000), (1024, 33000)], introns=4)
+    capfd.readouterr()
+    a = [x.as_dict() if x else None for x in eng.find_path(model, big, dpmemory=32, threshold=20)]
+    assert "kpk16h_est2genome" in capfd.readouterr().err
+    monkeypatch.setenv("C4GPU_PK16", "0")
+    assert a == [x.as_dict() if x else None for x in eng.find_path(model, big, dpmemory=32, threshold=20)]
