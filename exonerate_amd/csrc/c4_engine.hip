@@ -1821,10 +1821,19 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
         // jobs fill them -- the launch then lasts as long as its work, not as its longest job's strips one after the other
         // (north-star batch, two lanes: 481 -> 446 ms per step; profiles/r04_ck16_sweep.log) --, one wave per pair of short queries
         long long strips = 0;
-        for (int x = 0; x < n; x++) if (group[x] == 2) strips += (plan[red[x]].ar.query_length + 1 + 255) / 256;
+        int rows_max = 0;
+        for (int x = 0; x < n; x++)
+            if (group[x] == 2) {
+                strips += (plan[red[x]].ar.query_length + 1 + 255) / 256;
+                rows_max = std::max(rows_max, plan[red[x]].ar.query_length + 1);
+            }
         // (the four-wave shape at three waves per SIMD, 168 registers: 65 -> 52 ms per launch, step 436 -> 430 ms;
         // profiles/r04_ck16_w3_sweep.log)
         kc16r = get_kernel_ck16(eng.family, strips >= 3LL * n16r ? 8 : strips >= 2LL * n16r ? 5 : 0, true);
+        // regions of 1 025 .. 1 152 rows are five strips of 256 -- a second round for one wave of four -- and three strips of
+        // 384: the six-rows-per-lane shape on three waves takes them in one round (cDNAs of 1.1 kb)
+        if (rows_max > 1024 && rows_max <= 3 * 384 && strips >= 4LL * n16r && get_kernel_ck16(eng.family, 6, true))
+            kc16r = get_kernel_ck16(eng.family, 6, true);
     }
     if (n16 && eng.ensure_ss16(seqs)) return -1;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
