@@ -50,6 +50,22 @@ __device__ __forceinline__ int bfi32(int mask, int a, int b) {
 // from ROOT (a corner-to-corner path of another component is also a local path ending in that cell, so it scores no more
 // than that component's state did in the region pass, which lost against — or, behind it in transition order, did not beat —
 // ROOT's), and every cell, payload and checkpoint the traceback follows lies in ROOT's component.
+// The substitution scores of a lane's R query rows against each residue code of the launch's targets as a QUERY PROFILE in LDS
+// (round 5; the packed score pass has had one since round 4, c4_viterbi16_kernel.h IO 1): one entry of NP ints per (job, code,
+// lane) -- two rows' scores per int, exactly the halves pk_pack(submat[row code x 24 + target code], ...) made per step --, rebuilt
+// per strip.  A step reads one entry per job (the bank depends on the lane only: conflict-free) where it read 2 R words of the
+// 24 x 24 table at computed addresses (56-64 % of the LDS-active cycles of these two passes were bank conflicts,
+// profiles/r04_i_sq.csv).  The targets arrive as DENSE codes (0 .. 7: ResidentSeqs::tcode_dense, built at staging where the
+// batch's targets hold at most eight residue codes; the host takes the packed checkpoint pass and windows only then), handed over
+// in DevSeqs::sub_rows, which no packed kernel reads otherwise; dense index d stands for row code tdense[24 + d] of the matrix.
+template <int R>
+struct Prof16 {
+    static constexpr int NCODE = 8;
+    static constexpr int NP = (R + 1) / 2, EB = NP == 3 ? 12 : 8;        // ints / bytes per entry (8 bytes also where one int is used)
+    static constexpr int CODE = 64 * EB;                  // bytes per code: the 64 lanes' entries, contiguous
+    static constexpr int INTS = NCODE * CODE / 4;         // ints per (wave, job)
+};
+
 template <class M, int R, int ROOT = -1>
 struct WaveCK16 {
     using F = Facts<M>;
@@ -88,7 +104,8 @@ struct WaveCK16 {
     // 3' site's length test is the counter's sign; what leaves the kernel (and what the dumps bring) is the length itself
     int open_il_pk, lim_pk, fifteen, at_pk[4], cv_pk[16];
     C16 col[NCOL][R], nbr[NCOL], expo, nx_carry;
-    int qrow[2][R];
+    int prof_a[2];                                        // LDS byte address of this lane's profile entry of dense code 0, per job
+    const uint8_t *tdense;                                // the launch's code table: [24 + d] = matrix row code of dense index d
     int nx_tcode[2];
     uint2 nx_sp16[2];
     bool carry_cols;
@@ -117,6 +134,27 @@ struct WaveCK16 {
             nx_carry.srp[S] = p[1];
             if constexpr (live(S)) nx_carry.il[S] = p[2];
         });
+    }
+    // this lane's rows i0 .. i0 + R - 1 of job H against every dense code: the halves step() used to build from the matrix per
+    // step (rows outside the job score as row code 0 did: they feed nothing a result reads)
+    template <int H>
+    __device__ __forceinline__ void build_profile(int i0) {
+        using P16 = Prof16<R>;
+        typedef __attribute__((address_space(3))) int lds_int;
+        int qr[R];
+        static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+            const int i = i0 + RR;
+            qr[RR] = 24 * ((i >= 1 && i <= Q[H]) ? (int)qc[H][q0[H] + i - 1] : 0);
+        });
+        for (int d = 0; d < P16::NCODE; d++) {
+            const int code = tdense[24 + d];
+            int v[R];
+            static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_; v[RR] = kp->submat[qr[RR] + code]; });
+            lds_int *p = (lds_int *)(size_t)(unsigned)(prof_a[H] + d * P16::CODE);
+            static_for<P16::NP>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
+                p[K] = pk_pack(v[2 * K], v[2 * K + 1 < R ? 2 * K + 1 : 2 * K]);
+            });
+        }
     }
     __device__ __forceinline__ void prefetch_column(int j) {
         constexpr int mat = F::match_at();
@@ -187,9 +225,17 @@ struct WaveCK16 {
     __device__ __forceinline__ void step(int s, int i0, bool first_strip, bool last_strip, const int *bnd_in, int *bnd_out) {
         const int j = s - lane;
         int ms[R];
-        static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
-            ms[RR] = pk_pack(kp->submat[qrow[0][RR] + nx_tcode[0]], kp->submat[qrow[1][RR] + nx_tcode[1]]);
-        });
+        {
+            using P16 = Prof16<R>;
+            typedef __attribute__((address_space(3))) int lds_int;
+            const lds_int *pa = (const lds_int *)(size_t)(unsigned)(prof_a[0] + nx_tcode[0] * P16::CODE);
+            const lds_int *pb = (const lds_int *)(size_t)(unsigned)(prof_a[1] + nx_tcode[1] * P16::CODE);
+            static_for<P16::NP>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
+                const int ea = pa[K], eb = pb[K];
+                ms[2 * K] = (int)__builtin_amdgcn_perm((unsigned)eb, (unsigned)ea, 0x05040100u);
+                if constexpr (2 * K + 1 < R) ms[2 * K + 1] = (int)__builtin_amdgcn_perm((unsigned)eb, (unsigned)ea, 0x07060302u);
+            });
+        }
         int sp[4] = {0, 0, 0, 0};
         if constexpr (F::has_splice()) {
             sp[0] = (int)__builtin_amdgcn_perm(nx_sp16[1].x, nx_sp16[0].x, 0x05040100u);
@@ -338,7 +384,7 @@ struct WaveCK16 {
             Q[H] = jx.Q; T[H] = jx.T; q0[H] = jx.q0; t0[H] = jx.t0;
             tlast[H] = seqs.tlen[jx.pair] > 0 ? seqs.tlen[jx.pair] - 1 : 0;
             qc[H] = seqs.qcode + seqs.qoff[jx.pair];
-            tc[H] = seqs.tcode + seqs.toff[jx.pair];
+            tc[H] = reinterpret_cast<const uint8_t *>(seqs.sub_rows) + seqs.toff[jx.pair];        // dense codes (Prof16)
             ss16[H] = F::has_splice() ? seqs.ss16 + seqs.toff[jx.pair] : nullptr;
             cp_count[H] = jx.cp_count;
             section[H] = jx.T / (jx.cp_count + 1);
@@ -366,10 +412,7 @@ struct WaveCK16 {
         for (int b = wid; b < nstrips; b += NW) {
             const int i0 = b * W + lane * R;
             static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
-                static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
-                    const int i = i0 + RR;
-                    qrow[H][RR] = 24 * ((i >= 1 && i <= Q[H]) ? (int)qc[H][q0[H] + i - 1] : 0);
-                });
+                build_profile<H>(i0);
                 cp_next_j[H] = section[H] > 0 ? section[H] : 0x7fffffff; cp_next_i[H] = 0;
                 cp_phase[H] = section[H] > 0 ? (MAXAT - 1) % section[H] : 0;
             });
@@ -500,7 +543,7 @@ struct WaveCK16 {
 template <class M, int R, int ROOT, int NW>
 __device__ __forceinline__ void ckpt16_pair(const KParams *kp_lds, const DevSeqs &seqs, const DevJob *jobs, int ia, int ib,
                                             DevResult *results, DevVsa *vsas, int *bnd, int *ck_a, int *ck_b, int *prog,
-                                            int (*corner_lds)[4]) {
+                                            int (*corner_lds)[4], int *prof_mem, const uint8_t *tdense) {
     using DP = WaveCK16<M, R, ROOT>;
     if (threadIdx.x == 0) DP::write_empty_column(bnd);
     if constexpr (NW > 1) {
@@ -512,6 +555,13 @@ __device__ __forceinline__ void ckpt16_pair(const KParams *kp_lds, const DevSeqs
     DP dp{};                 // every member starts defined (c4_viterbi_kernel.h, viterbi_kernel)
     dp.kp = kp_lds;
     dp.lane = threadIdx.x & 63;
+    dp.tdense = tdense;
+    {
+        typedef __attribute__((address_space(3))) int lds_int;
+        const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        for (int h = 0; h < 2; h++)
+            dp.prof_a[h] = (int)(unsigned)(size_t)((lds_int *)prof_mem + (w * 2 + h) * Prof16<R>::INTS) + dp.lane * Prof16<R>::EB;
+    }
     dp.template run<NW>(jobs[ia], jobs[ib], seqs, bnd, ck_a, ck_b, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), prog);
     // the lane that owned a job's corner cell hands it to the lane that walks the job's checkpoints
     int sc[2], srp[2];
@@ -560,6 +610,9 @@ void ckpt16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, con
     __shared__ int next_job;
     __shared__ int prog[NW];
     __shared__ int corner_lds[2][4];
+    __shared__ __attribute__((aligned(16))) int prof_mem[NW * 2 * Prof16<R>::INTS];
+    __shared__ uint8_t tdense_lds[32];
+    if (threadIdx.x < 32) tdense_lds[threadIdx.x] = reinterpret_cast<const uint8_t *>(seqs.sub_colptr)[threadIdx.x];
     {
         const int *src = reinterpret_cast<const int *>(kparams);
         int *dst = reinterpret_cast<int *>(&kp_lds);
@@ -581,7 +634,7 @@ void ckpt16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, con
             static_for<RT::count()>([&](auto X_) __attribute__((always_inline)) { constexpr int X = X_;
                 constexpr int ROOT = RT::root(X);
                 if (!ran && root == ROOT) {
-                    ckpt16_pair<M, R, ROOT, NW>(&kp_lds, seqs, jobs, ia, ib, results, vsas, bnd, ck_a, ck_b, prog, corner_lds);
+                    ckpt16_pair<M, R, ROOT, NW>(&kp_lds, seqs, jobs, ia, ib, results, vsas, bnd, ck_a, ck_b, prog, corner_lds, prof_mem, tdense_lds);
                     ran = true;
                 }
             });
@@ -593,7 +646,7 @@ void ckpt16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, con
                 results[threadIdx.x ? ib : ia] = res;
             }
         } else {
-            ckpt16_pair<M, R, -1, NW>(&kp_lds, seqs, jobs, ia, ib, results, vsas, bnd, ck_a, ck_b, prog, corner_lds);
+            ckpt16_pair<M, R, -1, NW>(&kp_lds, seqs, jobs, ia, ib, results, vsas, bnd, ck_a, ck_b, prog, corner_lds, prof_mem, tdense_lds);
         }
     }
 }

@@ -368,6 +368,15 @@ __global__ void encode_kernel(const uint8_t *__restrict__ in, uint8_t *__restric
     }
 }
 
+// the targets' row codes as DENSE indices (0 .. 7) into the batch's code table (tab[code] -> index): what the packed checkpoint
+// pass and region windows index their query profiles by (Prof16, c4_ckpt16_kernel.h)
+__global__ void dense_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, long long n, const uint8_t *__restrict__ tab) {
+    for (long long x = blockIdx.x * (long long)blockDim.x + threadIdx.x; x < n; x += (long long)gridDim.x * blockDim.x) {
+        const uint8_t d = tab[in[x]];
+        out[x] = d < 8 ? d : 0;
+    }
+}
+
 // protein2dna target: row of the residue encoded by the codon starting at each position
 // (Translate_base, translate.h:73-76, then the submat index)
 __global__ void codon_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const long long *off,
@@ -816,6 +825,7 @@ struct ResidentSeqs {
     // index (0xff: absent), [24, 32) dense index -> code; tdense_n = 0: not known (codon-coded targets)
     DevBuf<uint8_t> tdense;
     int tdense_n = 0;
+    DevBuf<uint8_t> tcode_dense;          // the targets as dense indices into that table (dense_kernel); with tdense_n in 1 .. 8
     long long ss_len = 0;                 // positions per splice array
     DevBuf<PrepTables> tables;
     DevBuf<c4gpu_splice_model> splice_models;
@@ -986,7 +996,9 @@ struct ResidentSeqs {
             for (int c = 0; c < 24; c++)
                 if (hbad2[1] >> c & 1) { if (nd < 8) { tab[c] = (uint8_t)nd; tab[24 + nd] = (uint8_t)c; } nd++; }
             if (nd <= 8) {
-                if (tdense.upload(tab, 32, s)) return -1;
+                if (tdense.upload(tab, 32, s) || tcode_dense.alloc(ht_n)) return -1;
+                hipLaunchKernelGGL(dense_kernel, dim3(blocks), dim3(256), 0, s, tcode.p, tcode_dense.p, (long long)ht_n, tdense.p);
+                HIP_OK(hipGetLastError());
                 HIP_OK(c4_stream_sync(s));
                 tdense_n = nd;
             }
@@ -1011,7 +1023,7 @@ struct ResidentSeqs {
         qraw.swap(o.qraw); traw.swap(o.traw); qcode.swap(o.qcode); tcode.swap(o.tcode);
         d_qoff.swap(o.d_qoff); d_toff.swap(o.d_toff); d_qlen.swap(o.d_qlen); d_tlen.swap(o.d_tlen); ss.swap(o.ss);
         tn4.swap(o.tn4); ss16.swap(o.ss16); std::swap(ss16_built, o.ss16_built);
-        tdense.swap(o.tdense); std::swap(tdense_n, o.tdense_n); std::swap(ss_len, o.ss_len);
+        tdense.swap(o.tdense); std::swap(tdense_n, o.tdense_n); std::swap(ss_len, o.ss_len); tcode_dense.swap(o.tcode_dense);
         tables.swap(o.tables); splice_models.swap(o.splice_models); bad.swap(o.bad);
         std::swap(dev, o.dev);
         std::swap(n_utargets, o.n_utargets); d_utoff.swap(o.d_utoff); d_utlen.swap(o.d_utlen);
@@ -1373,7 +1385,8 @@ struct Engine {
                 // writes its dumps as 16-bit rows: window rows and columns must fit 15 / 16 bits
                 const int w16_env = getenv("C4GPU_WIN16") ? atoi(getenv("C4GPU_WIN16")) : 1;     // read on every call: a test switches it
                 const KernelInfo *kd = (fits && pk_env == 1 && w16_env) ? get_kernel_pk16(family, 3) : nullptr;
-                if (kd && get_kernel_win16(family, 0) && seed->kshift <= 15) {
+                // (the packed windows index a query profile by the targets' dense codes: at most eight residue codes in the batch)
+                if (kd && get_kernel_win16(family, 0) && seed->kshift <= 15 && seqs.tdense_n > 0) {
                     bool rows_ok = true;
                     for (int i = 0; i < n && rows_ok; i++) rows_ok = specs[i].region.query_length < 32000;
                     if (rows_ok) { ki = kd; seed->fmt16 = true; }
@@ -1589,6 +1602,12 @@ struct Engine {
                 a.seqs.sub_colptr = d_sub_colptr.p; a.seqs.sub_rows = d_sub_q.p;
             }
             a.seqs.ss16 = seqs.ss16_built ? seqs.ss16.p : nullptr;
+            if (seed && seed->mode == 2 && seed->fmt16) {
+                // the packed windows' dense target codes and code table ride in the two pointers no packed kernel reads otherwise
+                if (seqs.tdense_n <= 0) { c4h::set_error("packed region windows without a residue-code table"); return -1; }
+                a.seqs.sub_rows = reinterpret_cast<const int *>(seqs.tcode_dense.p);
+                a.seqs.sub_colptr = reinterpret_cast<const int *>(seqs.tdense.p);
+            }
             a.seqs.seed = nullptr;
             if (seed) {
                 if (seed->mode == 1 && d_seed.alloc((size_t)std::max<long long>(seed_total, 1))) return -1;
@@ -1784,7 +1803,7 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
     // call: a test switches them)
     const int ck_env = getenv("C4GPU_CK16") ? atoi(getenv("C4GPU_CK16")) : 1;
     const bool ck_root_env = !(getenv("C4GPU_CK16_ROOT") && atoi(getenv("C4GPU_CK16_ROOT")) == 0);
-    const bool ck16_on = ck_env > 0 && cont_free && eng.pk16_params_ok;
+    const bool ck16_on = ck_env > 0 && cont_free && eng.pk16_params_ok && seqs.tdense_n > 0;      // (dense target codes: Prof16)
     const KernelInfo *kc16 = ck16_on ? get_kernel_ck16(eng.family, 0, false) : nullptr;
     const KernelInfo *kc16r = (ck16_on && ck_root_env) ? get_kernel_ck16(eng.family, ck_env == 8 ? 0 : ck_env - 1, true) : nullptr;   // 1: chosen below, 8: variant 0
     const int ck16_tmax = getenv("C4GPU_CK16_TMAX") ? atoi(getenv("C4GPU_CK16_TMAX")) : 0x7fffffff;      // test hook
@@ -1927,6 +1946,10 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
         a.jobs = eng.d_fjobs.p; a.n_jobs = n16; a.results = eng.d_fres.p;
         a.scratch.bnd_stride = bnd16_per_wave; a.scratch.carry = carry16 ? 1 : 0;
         a.scratch.ckpt = eng.d_ckpt.p; a.scratch.ckpt_stride = max_ckpt16;
+        if (pairs_r || pairs_a) {
+            a.seqs.sub_rows = reinterpret_cast<const int *>(seqs.tcode_dense.p);       // the packed pass's dense target codes and code
+            a.seqs.sub_colptr = reinterpret_cast<const int *>(seqs.tdense.p);          // table (Prof16, c4_ckpt16_kernel.h)
+        }
         if (pairs_r) {
             a.queue = eng.d_queue.p; a.grid = (int)grid16r; a.aux = eng.d_pairs.p; a.n_aux = pairs_r;
             HIP_OK(kc16r->launch(a));
@@ -1935,6 +1958,7 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
             a.queue = eng.d_queue.p + 1; a.grid = (int)grid16a; a.aux = eng.d_pairs.p + 2 * pairs_r; a.n_aux = pairs_a;
             HIP_OK(kc16->launch(a));
         }
+        a.seqs.sub_rows = nullptr; a.seqs.sub_colptr = nullptr;
         if (n32) {
             a.jobs = eng.d_fjobs.p + n16; a.n_jobs = n32; a.results = eng.d_fres.p + n16; a.queue = eng.d_queue.p + 2; a.grid = (int)grid;
             a.aux = nullptr; a.n_aux = 0;
@@ -2751,6 +2775,8 @@ extern "C" {
 int c4gpu_abi_version(void) { return C4GPU_ABI_VERSION; }
 const char *c4gpu_last_error(void) { return c4h::g_error.c_str(); }
 
+static std::atomic<int> g_warm_cancel{0};        // c4gpu_ctx_warm_cancel; reset by every c4gpu_ctx_create
+
 c4gpu_ctx *c4gpu_ctx_create(int device_ordinal) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -2760,6 +2786,7 @@ c4gpu_ctx *c4gpu_ctx_create(int device_ordinal) {
         return nullptr;
     }
     if (device_ordinal < 0 || device_ordinal >= count) { c4h::set_error("bad device ordinal"); return nullptr; }
+    g_warm_cancel.store(0, std::memory_order_relaxed);       // a cancelled warm-up belongs to the context that was being left
     c4gpu_ctx *ctx = new c4gpu_ctx;
     ctx->device = device_ordinal;
     if (hipSetDevice(device_ordinal) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device_ordinal) != hipSuccess ||
@@ -2805,7 +2832,6 @@ int c4gpu_memrule_device(c4gpu_ctx *ctx, const c4gpu_model *model, int dpmemory_
 // c4gpu_ctx_warm_cancel(): a warm-up that is running (on whatever thread) returns before its next load, one that has not
 // started loads nothing -- so that a caller that is about to leave can join its warm-up thread within one load (the drop-in's
 // way out, integration/c4gpu_shim.c: no thread is inside the HIP runtime when the exit handlers run).
-static std::atomic<int> g_warm_cancel{0};
 void c4gpu_ctx_warm_cancel(void) { g_warm_cancel.store(1, std::memory_order_relaxed); }
 void c4gpu_ctx_warm(c4gpu_ctx *ctx) {
     if (!ctx || g_warm_cancel.load(std::memory_order_relaxed) || hipSetDevice(ctx->device) != hipSuccess) return;

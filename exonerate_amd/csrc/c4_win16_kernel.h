@@ -69,7 +69,8 @@ struct WaveWin16 {
     // 3' site's length test is the counter's sign; what leaves the kernel (and what the dumps bring) is the length itself
     int open_il_pk, lim_pk, fifteen, at_pk[4], cv_pk[16];
     C16 col[NCOL][R], nbr[NCOL], expo, nx_carry;
-    int qrow[2][R];
+    int prof_a[2];                                        // this lane's query profile entry of dense code 0, per window (Prof16, c4_ckpt16_kernel.h)
+    const uint8_t *tdense;
     int nx_tcode[2];
     uint2 nx_sp16[2];
     bool carry_cols;
@@ -99,6 +100,26 @@ struct WaveWin16 {
             nx_carry.rt[S] = p[2];
             if constexpr (live(S)) nx_carry.il[S] = p[3];
         });
+    }
+    // this lane's rows of window H against every dense code (Prof16, c4_ckpt16_kernel.h)
+    template <int H>
+    __device__ __forceinline__ void build_profile(int i0) {
+        using P16 = Prof16<R>;
+        typedef __attribute__((address_space(3))) int lds_int;
+        int qr[R];
+        static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
+            const int i = i0 + RR;
+            qr[RR] = 24 * ((i >= 1 && i <= Q[H]) ? (int)qc[H][q0[H] + i - 1] : 0);
+        });
+        for (int d = 0; d < P16::NCODE; d++) {
+            const int code = tdense[24 + d];
+            int v[R];
+            static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_; v[RR] = kp->submat[qr[RR] + code]; });
+            lds_int *p = (lds_int *)(size_t)(unsigned)(prof_a[H] + d * P16::CODE);
+            static_for<P16::NP>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
+                p[K] = pk_pack(v[2 * K], v[2 * K + 1 < R ? 2 * K + 1 : 2 * K]);
+            });
+        }
     }
     __device__ __forceinline__ void prefetch_column(int j) {
         constexpr int mat = F::match_at();
@@ -169,9 +190,17 @@ struct WaveWin16 {
     __device__ __forceinline__ void step(int s, int i0, bool last_strip, const int *bnd_in, int *bnd_out) {
         const int j = s - lane;
         int ms[R];
-        static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
-            ms[RR] = pk_pack(kp->submat[qrow[0][RR] + nx_tcode[0]], kp->submat[qrow[1][RR] + nx_tcode[1]]);
-        });
+        {
+            using P16 = Prof16<R>;
+            typedef __attribute__((address_space(3))) int lds_int;
+            const lds_int *pa = (const lds_int *)(size_t)(unsigned)(prof_a[0] + nx_tcode[0] * P16::CODE);
+            const lds_int *pb = (const lds_int *)(size_t)(unsigned)(prof_a[1] + nx_tcode[1] * P16::CODE);
+            static_for<P16::NP>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
+                const int ea = pa[K], eb = pb[K];
+                ms[2 * K] = (int)__builtin_amdgcn_perm((unsigned)eb, (unsigned)ea, 0x05040100u);
+                if constexpr (2 * K + 1 < R) ms[2 * K + 1] = (int)__builtin_amdgcn_perm((unsigned)eb, (unsigned)ea, 0x07060302u);
+            });
+        }
         int sp[4] = {0, 0, 0, 0};
         if constexpr (F::has_splice()) {
             sp[0] = (int)__builtin_amdgcn_perm(nx_sp16[1].x, nx_sp16[0].x, 0x05040100u);
@@ -285,7 +314,7 @@ struct WaveWin16 {
             Q[H] = jx.Q; T[H] = jx.T; q0[H] = jx.q0; t0[H] = jx.t0;
             tlast[H] = seqs.tlen[jx.pair] > 0 ? seqs.tlen[jx.pair] - 1 : 0;
             qc[H] = seqs.qcode + seqs.qoff[jx.pair];
-            tc[H] = seqs.tcode + seqs.toff[jx.pair];
+            tc[H] = reinterpret_cast<const uint8_t *>(seqs.sub_rows) + seqs.toff[jx.pair];        // dense codes (Prof16)
             ss16[H] = F::has_splice() ? seqs.ss16 + seqs.toff[jx.pair] : nullptr;
             seeded[H] = jx.seed_off >= 0;
             seed_rd[H] = seqs.seed + (seeded[H] ? jx.seed_off : 0);
@@ -314,12 +343,7 @@ struct WaveWin16 {
         const int PS = nsteps_r + 1;
         for (int b = wid; b < nstrips; b += NW) {
             const int i0 = b * W + lane * R;
-            static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
-                static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
-                    const int i = i0 + RR;
-                    qrow[H][RR] = 24 * ((i >= 1 && i <= Q[H]) ? (int)qc[H][q0[H] + i - 1] : 0);
-                });
-            });
+            static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_; build_profile<H>(i0); });
             static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
                 expo.sc[S] = NEG16; expo.il[S] = 0; expo.rq[S] = 0; expo.rt[S] = 0;
                 static_for<NCOL>([&](auto D_) __attribute__((always_inline)) { constexpr int D = D_;
@@ -383,7 +407,8 @@ struct WaveWin16 {
 // where the hop budget ran out.  job_lds[1] is an idle window when the pair holds one job.
 template <class M, int R, int ROOT, int NW>
 __device__ __forceinline__ void win16_chains(const KParams *kp_lds, const DevSeqs &seqs, DevJob *job_lds, int *more, int ia, int ib,
-                                             DevResult *results, int *bnd, int *prog, int (*corner_lds)[4]) {
+                                             DevResult *results, int *bnd, int *prog, int (*corner_lds)[4], int *prof_mem,
+                                             const uint8_t *tdense) {
     using DP = WaveWin16<M, R, ROOT>;
     int hop = 0, first_score = 0;                      // threads 0 and 1: their window chain
     bool active = threadIdx.x < 2 && more[threadIdx.x & 1];
@@ -392,6 +417,12 @@ __device__ __forceinline__ void win16_chains(const KParams *kp_lds, const DevSeq
         DP dp{};                 // every member starts defined (c4_viterbi_kernel.h, viterbi_kernel)
         dp.kp = kp_lds;
         dp.lane = threadIdx.x & 63;
+        dp.tdense = tdense;
+        {
+            typedef __attribute__((address_space(3))) int lds_int;
+            for (int h = 0; h < 2; h++)
+                dp.prof_a[h] = (int)(unsigned)(size_t)((lds_int *)prof_mem + (wid * 2 + h) * Prof16<R>::INTS) + dp.lane * Prof16<R>::EB;
+        }
         if constexpr (NW > 1) {
             if (threadIdx.x < NW) prog[threadIdx.x] = 0;
             if (threadIdx.x < 2) corner_lds[threadIdx.x][3] = 0;
@@ -473,6 +504,9 @@ void win16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, cons
     __shared__ int more[2];
     __shared__ int prog[NW];
     __shared__ int corner_lds[2][4];
+    __shared__ __attribute__((aligned(16))) int prof_mem[NW * 2 * Prof16<R>::INTS];
+    __shared__ uint8_t tdense_lds[32];
+    if (threadIdx.x < 32) tdense_lds[threadIdx.x] = reinterpret_cast<const uint8_t *>(seqs.sub_colptr)[threadIdx.x];
     {
         const int *src = reinterpret_cast<const int *>(kparams);
         int *dst = reinterpret_cast<int *>(&kp_lds);
@@ -507,7 +541,7 @@ void win16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, cons
                     if (threadIdx.x == 0) WaveWin16<M, R, ROOT>::write_empty_column(bnd);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     __syncthreads();
-                    win16_chains<M, R, ROOT, NW>(&kp_lds, seqs, job_lds, more, ia, ib, results, bnd, prog, corner_lds);
+                    win16_chains<M, R, ROOT, NW>(&kp_lds, seqs, job_lds, more, ia, ib, results, bnd, prog, corner_lds, prof_mem, tdense_lds);
                     ran = true;
                 }
             });
@@ -516,7 +550,7 @@ void win16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, cons
             if (threadIdx.x == 0) WaveWin16<M, R, -1>::write_empty_column(bnd);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
-            win16_chains<M, R, -1, NW>(&kp_lds, seqs, job_lds, more, ia, ib, results, bnd, prog, corner_lds);
+            win16_chains<M, R, -1, NW>(&kp_lds, seqs, job_lds, more, ia, ib, results, bnd, prog, corner_lds, prof_mem, tdense_lds);
         } else if (!ran) {                                  // a root the model does not have: the host's mistake, say so
             if (threadIdx.x < 2 && more[threadIdx.x]) {
                 DevResult res;

@@ -124,10 +124,15 @@ def test_longest_query_the_guard_lets_through(eng, monkeypatch, capfd):
         lo, hi = (mid, hi) if fits(mid) == 1 else (lo, mid)
     assert 3000 < lo < 3200, lo
     rng = random.Random(3199)
-    packed = _batch(rng, [(lo, T), (2900, T - 300)])
-    assert all(len(t) <= T for _, t in packed)
+
+    def pair(qlen, tlen):          # a target shorter than its query: it holds two exons of the query's first 1 800 nt
+        q = _rand(rng, qlen)
+        t = _rand(rng, 150) + _mutate(rng, q[:900], 0.03) + "GT" + _rand(rng, 300) + "AG" + _mutate(rng, q[900:1800], 0.03)
+        return q, (t + _rand(rng, tlen))[:tlen]
+
+    packed = [pair(lo, T), pair(2900, T - 300)]
     _run(eng, model, packed, monkeypatch, capfd, want_packed=True)
-    _run(eng, model, _batch(rng, [(lo + 1, T), (2900, T - 300)]), monkeypatch, capfd, want_packed=False)
+    _run(eng, model, [pair(lo + 1, T), pair(2900, T - 300)], monkeypatch, capfd, want_packed=False)
 
 
 def test_max_intron_against_the_target_length(eng, monkeypatch, capfd):

@@ -66,8 +66,10 @@ out = {
         "insts_per_launch": v["SQ_INSTS_VALU"] / n,
         # cells per launch: the PMC run makes LAUNCHES_IN_PMC_RUN steps (warm-up + one); a large batch runs as two halves on
         # two launch lanes, i.e. two dispatches per step of half the pairs each
-        "lane_ops_per_cell": v["SQ_INSTS_VALU"] / n * 64 / (cfg["pairs_per_gpu"] * (cfg["query_len"] + 1) * (cfg["target_len"] + 1)
-                                                            * LAUNCHES_IN_PMC_RUN / n),
+        # (every dispatch of the run covers pairs_per_gpu / launches_per_step pairs: round 5's bench stages and aligns more batches
+        # per run than the two timed-plus-warm-up steps -- resident passes, the staging measurement -- all of the full size)
+        "lane_ops_per_cell": v["SQ_INSTS_VALU"] / n * 64 / (cfg["pairs_per_gpu"] / max(1, bench["roofline"].get("launches_per_step", 2))
+                                                            * (cfg["query_len"] + 1) * (cfg["target_len"] + 1)),
         "active_frac_of_wave_cycles": v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"],
         "wait_frac_of_wave_cycles": v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"],
         "waves_per_launch": waves,
