@@ -1394,6 +1394,14 @@ struct Engine {
                     // and the targets hold few enough residue codes for the query profile (C4GPU_PK16_IO=0: never; 1: with a barrier per chunk instead of progress counters)
                     const int io_env = getenv("C4GPU_PK16_IO") ? atoi(getenv("C4GPU_PK16_IO")) : 2;
                     const KernelInfo *ke = (rows_ok && io_env) ? get_kernel_pk16(family, io_env == 2 ? 5 : 4) : nullptr;     // 2 (default): progress counters between the cooperating waves; 1: a barrier per chunk
+                    // seven or eight codes (IUPAC ambiguity codes in the targets): the staged form with the larger profile, where every
+                    // query fits its four strips of 256 rows (C4GPU_PK16_C8=0: the form that loads per step)
+                    if (ke && seqs.tdense_n > pk16_staged_codes() && seqs.tdense_n <= 8 && io_env == 2 &&
+                        !(getenv("C4GPU_PK16_C8") && atoi(getenv("C4GPU_PK16_C8")) == 0) && get_kernel_pk16(family, 8)) {
+                        bool strips_ok = true;
+                        for (int i = 0; i < n && strips_ok; i++) strips_ok = specs[i].region.query_length + 1 <= pk16_staged_rows();
+                        if (strips_ok) { ki = get_kernel_pk16(family, 8); staged_codes = seqs.tdense.p; }
+                    }
                     if (ke && seqs.tdense_n > 0 && seqs.tdense_n <= pk16_staged_codes()) {
                         bool strips_ok = true;
                         for (int i = 0; i < n && strips_ok; i++) strips_ok = specs[i].region.query_length + 1 <= pk16_staged_rows();

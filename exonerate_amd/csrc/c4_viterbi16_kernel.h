@@ -149,7 +149,7 @@ struct Dump16 {
 //     (job, code, lane) -- a query profile, rebuilt per strip: a step reads two entries (conflict-free: the bank depends on
 //     the lane only) instead of 2 R table words at computed addresses.
 // 301 -> ~225 instructions per step of 8 cells (profiles/r04_score_budget.md).
-template <class M, int R, int VAR = 0, bool DUMP16 = false, int IO = 0>
+template <class M, int R, int VAR = 0, bool DUMP16 = false, int IO = 0, int NCODE_ = 6>
 struct WaveDP16 {
     using F = Facts<M>;
     using W32 = WaveDP<M, R, MODE_SCORE, false, true, false, false, 0, 1>;     // the 32-bit score pass: dump layout
@@ -164,7 +164,7 @@ struct WaveDP16 {
     // steps between two meetings of the cooperating waves; IO 1: also between two refills of the column stage, whose 128
     // columns hold the 63 + 64 columns the lanes of a wave read during a chunk
     static constexpr int CH = IO ? 63 / NCOL * NCOL : (64 + NCOL - 1) / NCOL * NCOL;
-    static constexpr int NCODE = 6;                      // IO 1: residue codes a launch's targets may hold
+    static constexpr int NCODE = NCODE_;                 // IO 1: residue codes a launch's targets may hold (6; 8 in the form for IUPAC-coded targets)
     // column stage: 128 columns x 8 planes of one int (six used), plane-major -- the lanes of a wave read consecutive columns, so a
     // plane read is 64 consecutive words: no bank conflict (column-major entries of 32 bytes put 64 lanes on 8 banks: 72 % of the
     // LDS-active cycles of the first LDS-fed form were conflicts, profiles/r04_c_sq.csv)
@@ -728,11 +728,11 @@ __global__ void ss16_kernel(const KParams *kp, const int *ss, long long ss_strid
 // launch holds an odd number: its high half repeats it)
 // (IO 1: `tdense` is the launch's residue-code table -- [0, 24) code -> dense index, [24, 24 + NCODE) dense index -> code; the
 // host takes this kernel only when every query fits NW strips and the targets hold at most NCODE codes)
-template <class M, int R, int NW, int WPE, int VAR = 0, bool DUMP16 = false, int IO = 0>
+template <class M, int R, int NW, int WPE, int VAR = 0, bool DUMP16 = false, int IO = 0, int NCODE_ = 6>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
 void viterbi16_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, int n_jobs, DevResult *results,
                          DevScratch scratch, int *queue, const uint8_t *tdense = nullptr) {
-    using DP = WaveDP16<M, R, VAR, DUMP16, IO>;
+    using DP = WaveDP16<M, R, VAR, DUMP16, IO, NCODE_>;
     // IO 1 leaves the launch constants in memory (a strip reads them once) and spends the LDS on the column stages (4 KB per
     // wave, 4 KB-aligned: the running stage address wraps with one v_and_or), the query profiles and the rings: 52.2 KB per
     // workgroup, three workgroups per CU

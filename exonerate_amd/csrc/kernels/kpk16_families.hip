@@ -64,6 +64,17 @@ static const KernelInfo kpk16h_est2genome = {kpk16h_est2genome_launch, (const vo
                                              "kpk16h_est2genome", 6, 2, WaveDP16<Est2GenomeDesc, 6, 2, true, 1>::BND, Est2GenomeDesc::NS,
                                              Est2GenomeDesc::MAXAT, 4, WaveDP16<Est2GenomeDesc, 6, 2, true, 1>::SEEDW};
 int pk16_staged_rows6() { return 6 * 64 * 4; }
+// variant 8: variant 5 with a query profile for EIGHT residue codes (targets with IUPAC ambiguity codes beside A C G T N: the six-code
+// form sent such batches to the form that loads per step, 0.77 of the rate, bench.py configs.c4_eight_codes): 61.6 KB of LDS, two
+// workgroups per CU, compiled for two waves per SIMD (256 registers: nothing in scratch)
+static hipError_t kpk16i_est2genome_launch(const LaunchArgs &a) {
+    hipLaunchKernelGGL((viterbi16_kernel_mw<Est2GenomeDesc, 4, 4, 2, 2, true, 1, 8>), dim3(a.grid), dim3(64 * 4), 0, a.stream,
+                       a.kp, a.seqs, a.jobs, a.n_jobs, a.results, a.scratch, a.queue, reinterpret_cast<const uint8_t *>(a.aux));
+    return hipGetLastError();
+}
+static const KernelInfo kpk16i_est2genome = {kpk16i_est2genome_launch, (const void *)viterbi16_kernel_mw<Est2GenomeDesc, 4, 4, 2, 2, true, 1, 8>,
+                                             "kpk16i_est2genome", 4, 2, WaveDP16<Est2GenomeDesc, 4, 2, true, 1, 8>::BND, Est2GenomeDesc::NS,
+                                             Est2GenomeDesc::MAXAT, 4, WaveDP16<Est2GenomeDesc, 4, 2, true, 1, 8>::SEEDW};
 int pk16_staged_codes() { return WaveDP16<Est2GenomeDesc, 4, 1, true, 1>::NCODE; }
 int pk16_staged_rows() { return 4 * 64 * 4; }
 // the packed splice array of variant 1 (ss16_kernel): n positions of the batch's concatenated targets
@@ -74,6 +85,6 @@ hipError_t pk16_build_splice(int family, const KParams *kp, const int *ss, long 
 }
 const KernelInfo *get_kernel_pk16(int family, int variant) {
     if (family != FAM_EST2GENOME) return nullptr;
-    return variant == 7 ? &kpk16h_est2genome : variant == 6 ? &kpk16g_est2genome : variant == 5 ? &kpk16f_est2genome : variant == 4 ? &kpk16e_est2genome : variant == 3 ? &kpk16d_est2genome : variant == 2 ? &kpk16c_est2genome : variant == 1 ? &kpk16b_est2genome : &kpk16_est2genome;
+    return variant == 8 ? &kpk16i_est2genome : variant == 7 ? &kpk16h_est2genome : variant == 6 ? &kpk16g_est2genome : variant == 5 ? &kpk16f_est2genome : variant == 4 ? &kpk16e_est2genome : variant == 3 ? &kpk16d_est2genome : variant == 2 ? &kpk16c_est2genome : variant == 1 ? &kpk16b_est2genome : &kpk16_est2genome;
 }
 }

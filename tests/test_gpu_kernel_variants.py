@@ -454,7 +454,23 @@ def test_staged_packed_score_pass_agrees_with_the_plain_one(eng, monkeypatch, ca
     many = pairs[:3] + [(q, t[:100] + "RY" + t[102:])] + pairs[4:]
     c = [x.as_dict() if x else None for x in eng.find_path(model, many, dpmemory=32, threshold=20)]
     err = capfd.readouterr().err
-    assert "kpk16d_est2genome" in err and "kpk16e_est2genome" not in err and "kpk16f_est2genome" not in err, err[-1500:]
+    # (round 5: seven and eight codes take the staged form with the eight-code profile, kpk16i; C4GPU_PK16_C8=0: the per-step form)
+    assert "kpk16i_est2genome" in err and "kpk16e_est2genome" not in err and "kpk16f_est2genome" not in err, err[-1500:]
+    monkeypatch.setenv("C4GPU_PK16_C8", "0")
+    assert c == [x.as_dict() if x else None for x in eng.find_path(model, many, dpmemory=32, threshold=20)]
+    err = capfd.readouterr().err
+    assert "kpk16d_est2genome" in err and "kpk16i_est2genome" not in err, err[-1500:]
+    monkeypatch.delenv("C4GPU_PK16_C8")
+    # nine codes (K, M beside them): no code table at all -- the 32-bit dumps and windows behind the packed score pass
+    q9, t9 = pairs[3]
+    nine = pairs[:3] + [(q9, t9[:100] + "RYKM" + t9[104:])] + pairs[4:]
+    c9 = [x.as_dict() if x else None for x in eng.find_path(model, nine, dpmemory=32, threshold=20)]
+    err = capfd.readouterr().err
+    assert "kpk16i_est2genome" not in err and "kwin16" not in err, err[-1500:]
+    monkeypatch.setenv("C4GPU_PK16", "0")
+    assert c9 == [x.as_dict() if x else None for x in eng.find_path(model, nine, dpmemory=32, threshold=20)]
+    monkeypatch.setenv("C4GPU_PK16", "1")
+    capfd.readouterr()
     q, t = _seeded_pairs(rng, "est2genome", 1024, 100000, 1)[0]           # a target long enough for the windowed route
     tall = pairs + [(q, t)]
     d = [x.as_dict() if x else None for x in eng.find_path(model, tall, dpmemory=32, threshold=20)]
