@@ -1413,6 +1413,10 @@ struct Engine {
                             bool six_ok = kh != nullptr;
                             for (int i = 0; i < n && six_ok; i++) six_ok = specs[i].region.query_length + 1 <= pk16_staged_rows6();
                             if (six_ok) { ki = kh; staged_codes = seqs.tdense.p; }
+                            // ... longer ones in several super-strips of that form (C4GPU_PK16_LONG=0: the per-step form)
+                            else if (get_kernel_pk16(family, 9) && !(getenv("C4GPU_PK16_LONG") && atoi(getenv("C4GPU_PK16_LONG")) == 0)) {
+                                ki = get_kernel_pk16(family, 9); staged_codes = seqs.tdense.p;
+                            }
                         }
                         // ... on eight waves of two rows per lane where the launch has at most one pair of jobs per compute unit (the
                         // shard of a strong-scaled run): twice the waves on the same rows (C4GPU_PK16_NW8=0: never; 1: always)

@@ -149,7 +149,7 @@ struct Dump16 {
 //     (job, code, lane) -- a query profile, rebuilt per strip: a step reads two entries (conflict-free: the bank depends on
 //     the lane only) instead of 2 R table words at computed addresses.
 // 301 -> ~225 instructions per step of 8 cells (profiles/r04_score_budget.md).
-template <class M, int R, int VAR = 0, bool DUMP16 = false, int IO = 0, int NCODE_ = 6>
+template <class M, int R, int VAR = 0, bool DUMP16 = false, int IO = 0, int NCODE_ = 6, bool MEMC = false>
 struct WaveDP16 {
     using F = Facts<M>;
     using W32 = WaveDP<M, R, MODE_SCORE, false, true, false, false, 0, 1>;     // the 32-bit score pass: dump layout
@@ -202,6 +202,10 @@ struct WaveDP16 {
     uint2 nx_sp16[2];
     lds_int *ring_in, *ring_out;
     bool use_ring_in, use_ring_out, carry_ok, carry_cols;
+    // IO 1 with MEMC (queries of more rows than one workgroup's strips hold): between two super-strips the bottom row of the last
+    // wave goes through the workgroup's slab in memory as in the IO 0 form -- written by the last wave (mem_out), read by the first
+    // wave of the next super-strip (mem_in); every other boundary stays a ring in LDS.  Wave-uniform.
+    bool mem_in, mem_out;
     // IO 1
     int ring_in_mask, ring_out_mask;                    // 255, or 0 for the constant column of the first / last wave
     int nx_sp4[4], nx_off[2];                           // next column: packed splice values; profile byte offsets of its two codes
@@ -236,6 +240,16 @@ struct WaveDP16 {
     __device__ __forceinline__ void prefetch_carry(int s_next, const int *bnd_in) {
         const int jx = s_next < 0 ? 0 : (s_next > Tm ? Tm : s_next);
         if constexpr (IO == 1) {
+            if constexpr (MEMC) {
+                if (mem_in) {
+                    const int *p = bnd_in + (long long)jx * BND;
+                    for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
+                        nx_carry.sc[S] = p[slot];
+                        if constexpr (live(S)) nx_carry.il[S] = p[slot + 1];
+                    });
+                    return;
+                }
+            }
             const lds_int *p = ring_in + (jx & ring_in_mask) * BND;
             for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
                 nx_carry.sc[S] = p[slot];
@@ -465,11 +479,21 @@ struct WaveDP16 {
         if constexpr (IO == 1) {
             // the last wave's ring is one column nobody reads; inside the rectangle's columns (JINT) lane 63 is always on a column
             if (lane == 63 && (JINT || (j >= 0 && j <= Tm))) {
-                lds_int *p = ring_out + (j & ring_out_mask) * BND;
-                for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
-                    p[slot] = expo.sc[S];
-                    if constexpr (live(S)) p[slot + 1] = expo.il[S];
-                });
+                bool to_memory = false;
+                if constexpr (MEMC) to_memory = mem_out;
+                if (to_memory) {
+                    int *p = bnd_out + (long long)j * BND;
+                    for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
+                        p[slot] = expo.sc[S];
+                        if constexpr (live(S)) p[slot + 1] = expo.il[S];
+                    });
+                } else {
+                    lds_int *p = ring_out + (j & ring_out_mask) * BND;
+                    for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
+                        p[slot] = expo.sc[S];
+                        if constexpr (live(S)) p[slot + 1] = expo.il[S];
+                    });
+                }
             }
         } else if (!last_strip && lane == 63 && j >= 0 && j <= Tm) {
             if (use_ring_out) {
@@ -631,6 +655,8 @@ struct WaveDP16 {
                 if (wid == NW - 1) ring_out = edge + BND;
                 ring_in_mask = wid > 0 ? RING - 1 : 0;
                 ring_out_mask = wid < NW - 1 ? RING - 1 : 0;
+                mem_in = MEMC && wid == 0 && sb > 0;
+                mem_out = MEMC && wid == NW - 1 && sb < nsuper - 1;
                 stage_base = lds_addr(stage);
                 stage_a = lds_addr(stage) + ((0 - lane) & (STAGE_COLS - 1)) * 4;
             }
@@ -728,11 +754,11 @@ __global__ void ss16_kernel(const KParams *kp, const int *ss, long long ss_strid
 // launch holds an odd number: its high half repeats it)
 // (IO 1: `tdense` is the launch's residue-code table -- [0, 24) code -> dense index, [24, 24 + NCODE) dense index -> code; the
 // host takes this kernel only when every query fits NW strips and the targets hold at most NCODE codes)
-template <class M, int R, int NW, int WPE, int VAR = 0, bool DUMP16 = false, int IO = 0, int NCODE_ = 6>
+template <class M, int R, int NW, int WPE, int VAR = 0, bool DUMP16 = false, int IO = 0, int NCODE_ = 6, bool MEMC = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
 void viterbi16_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, int n_jobs, DevResult *results,
                          DevScratch scratch, int *queue, const uint8_t *tdense = nullptr) {
-    using DP = WaveDP16<M, R, VAR, DUMP16, IO, NCODE_>;
+    using DP = WaveDP16<M, R, VAR, DUMP16, IO, NCODE_, MEMC>;
     // IO 1 leaves the launch constants in memory (a strip reads them once) and spends the LDS on the column stages (4 KB per
     // wave, 4 KB-aligned: the running stage address wraps with one v_and_or), the query profiles and the rings: 52.2 KB per
     // workgroup, three workgroups per CU

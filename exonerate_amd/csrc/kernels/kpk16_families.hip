@@ -64,6 +64,17 @@ static const KernelInfo kpk16h_est2genome = {kpk16h_est2genome_launch, (const vo
                                              "kpk16h_est2genome", 6, 2, WaveDP16<Est2GenomeDesc, 6, 2, true, 1>::BND, Est2GenomeDesc::NS,
                                              Est2GenomeDesc::MAXAT, 4, WaveDP16<Est2GenomeDesc, 6, 2, true, 1>::SEEDW};
 int pk16_staged_rows6() { return 6 * 64 * 4; }
+// variant 9: variant 7 for queries of ANY length the packed guard lets through (up to ~3 190 rows): super-strips of 1 536 rows one
+// after the other, the row between two of them through the workgroup's slab in memory (MEMC) -- cDNAs of 1.6 - 3 kb stay on the
+// staged form (two or three passes over the target) instead of the form that loads per step
+static hipError_t kpk16j_est2genome_launch(const LaunchArgs &a) {
+    hipLaunchKernelGGL((viterbi16_kernel_mw<Est2GenomeDesc, 6, 4, 2, 2, true, 1, 6, true>), dim3(a.grid), dim3(64 * 4), 0, a.stream,
+                       a.kp, a.seqs, a.jobs, a.n_jobs, a.results, a.scratch, a.queue, reinterpret_cast<const uint8_t *>(a.aux));
+    return hipGetLastError();
+}
+static const KernelInfo kpk16j_est2genome = {kpk16j_est2genome_launch, (const void *)viterbi16_kernel_mw<Est2GenomeDesc, 6, 4, 2, 2, true, 1, 6, true>,
+                                             "kpk16j_est2genome", 6, 2, WaveDP16<Est2GenomeDesc, 6, 2, true, 1, 6, true>::BND, Est2GenomeDesc::NS,
+                                             Est2GenomeDesc::MAXAT, 4, WaveDP16<Est2GenomeDesc, 6, 2, true, 1, 6, true>::SEEDW};
 // variant 8: variant 5 with a query profile for EIGHT residue codes (targets with IUPAC ambiguity codes beside A C G T N: the six-code
 // form sent such batches to the form that loads per step, 0.77 of the rate, bench.py configs.c4_eight_codes): 61.6 KB of LDS, two
 // workgroups per CU, compiled for two waves per SIMD (256 registers: nothing in scratch)
@@ -85,6 +96,6 @@ hipError_t pk16_build_splice(int family, const KParams *kp, const int *ss, long 
 }
 const KernelInfo *get_kernel_pk16(int family, int variant) {
     if (family != FAM_EST2GENOME) return nullptr;
-    return variant == 8 ? &kpk16i_est2genome : variant == 7 ? &kpk16h_est2genome : variant == 6 ? &kpk16g_est2genome : variant == 5 ? &kpk16f_est2genome : variant == 4 ? &kpk16e_est2genome : variant == 3 ? &kpk16d_est2genome : variant == 2 ? &kpk16c_est2genome : variant == 1 ? &kpk16b_est2genome : &kpk16_est2genome;
+    return variant == 9 ? &kpk16j_est2genome : variant == 8 ? &kpk16i_est2genome : variant == 7 ? &kpk16h_est2genome : variant == 6 ? &kpk16g_est2genome : variant == 5 ? &kpk16f_est2genome : variant == 4 ? &kpk16e_est2genome : variant == 3 ? &kpk16d_est2genome : variant == 2 ? &kpk16c_est2genome : variant == 1 ? &kpk16b_est2genome : &kpk16_est2genome;
 }
 }

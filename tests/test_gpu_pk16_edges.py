@@ -192,8 +192,8 @@ def test_six_rows_per_lane_for_queries_of_1024_to_1535_rows(eng, monkeypatch, ca
     """cDNAs longer than 1 023 nt do not fit the four strips of 256 rows the staged packed score pass holds per workgroup; up to
     1 535 nt they fit four strips of 384 rows (kpk16h: six rows per lane, two waves per SIMD) instead of taking a second pass over
     the target on the form that loads per step.  Ragged batch around both edges (1 024 and 1 535 rows), N in a target, every pair
-    against the oracle; a query of 1 536 nt sends the launch back to the per-step form; C4GPU_PK16_R6=0 gives the same
-    alignments."""
+    against the oracle; a query of 1 536 nt and more runs super-strips of that form one after the other (kpk16j); C4GPU_PK16_R6=0 /
+    C4GPU_PK16_LONG=0 give the same alignments on the per-step form."""
     model = ex.Model("est2genome")
     rng = random.Random(1535)
     pairs = _batch(rng, [(1024, 3000), (1100, 2600), (1535, 2800), (700, 2500), (1300, 6000)])
@@ -207,9 +207,18 @@ def test_six_rows_per_lane_for_queries_of_1024_to_1535_rows(eng, monkeypatch, ca
     assert got == [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=32, threshold=20)]
     assert "kpk16h" not in capfd.readouterr().err
     monkeypatch.delenv("C4GPU_PK16_R6")
-    longer = _batch(rng, [(1536, 2600), (1100, 2600)])
+    # one row more: two super-strips of 1 536 rows, the row between them through memory (kpk16j); 2 000 rows likewise;
+    # C4GPU_PK16_LONG=0: the form that loads per step
+    longer = _batch(rng, [(1536, 2600), (1100, 2600), (2000, 2400)])
     err = _run(eng, model, longer, monkeypatch, capfd, want_packed=True)
-    assert "kpk16h" not in err and "kpk16d_est2genome" in err
+    assert "kpk16h" not in err and "kpk16j_est2genome" in err
+    got_long = [a.as_dict() if a else None for a in eng.find_path(model, longer, dpmemory=32, threshold=20)]
+    monkeypatch.setenv("C4GPU_PK16_LONG", "0")
+    capfd.readouterr()
+    assert got_long == [a.as_dict() if a else None for a in eng.find_path(model, longer, dpmemory=32, threshold=20)]
+    err = capfd.readouterr().err
+    assert "kpk16j" not in err and "kpk16d_est2genome" in err
+    monkeypatch.delenv("C4GPU_PK16_LONG")
     # at the default dump interval: 1.2 kb against 40 kb, both forms
     monkeypatch.delenv("C4GPU_SEED_KSHIFT")
     big = _batch(rng, [(1200, 40000), (1400, 36000), (1024, 33000)], introns=4)
