@@ -383,6 +383,9 @@ def main():
     want_robust = (not stub) and world == 1 and (not args.no_configs) and n_local >= 1024 and args.qlen == 1000
     long_q = workloads.est2genome_batches([nb * n_step], n_local, 1100, args.tlen,
                                           workers=max(1, min(32, cores)))[0] if want_robust else None
+    # ... and one of 2 048 cDNAs of 2 500 nt (seven strips of 384 rows: two super-strips of the staged form, kpk16j)
+    longer_q = workloads.est2genome_batches([(nb + 1) * n_step], n_local // 2, 2500, args.tlen,
+                                            workers=max(1, min(32, cores)))[0] if want_robust else None
     gen_s = time.perf_counter() - g0
     pairs = host_batches[0]
     first_pass_cells = sum((len(q) + 1) * (len(t) + 1) for q, t in pairs)       # the same for every batch: fixed lengths
@@ -644,6 +647,7 @@ def main():
         leg("c4_eight_codes", "the north-star batch with N, R, Y, K at 0.3 % of the target positions (8 residue codes)", noisy)
         del noisy
         leg("c4_query_1100", "cDNAs of 1 100 nt (five strips of 256 rows) against 100 kb windows", long_q)
+        leg("c4_query_2500", "%d cDNAs of 2 500 nt against 100 kb windows" % len(longer_q), longer_q)
 
     # both strands ("once with revcomp on, doubling cells"): what the reference does for DNA queries by
     # default (fastapipe.c:42-44): each cDNA and its reverse complement against the same window; the windows are

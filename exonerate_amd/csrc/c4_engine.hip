@@ -1219,13 +1219,24 @@ struct Engine {
                     }
                     best[k] = (int)std::floor(sum + 0.5) + 1;
                 }
-                int pre = -0x40000000, post = -0x40000000;
-                for (int i = 0; i < m->n_calcs; i++) {
-                    const int prm = m->calcs[i].param & 3;
-                    if (m->calcs[i].kind == C4GPU_CALC_SPLICE_PRE) pre = std::max(pre, m->calcs[i].value + best[prm]);
-                    if (m->calcs[i].kind == C4GPU_CALC_SPLICE_POST) post = std::max(post, m->calcs[i].value + best[prm]);
+                // an intron enters its state through a pre-splice transition and leaves it through a post-splice transition OF THE
+                // SAME STATE (est2genome: the forward strand's intron state and the reverse strand's are two states that share
+                // nothing): the most one intron can add is the best such pairing per state, not the best pre-site of one strand
+                // with the best post-site of the other (rounds 3-4: that bound put 2 x T / 30 on top of every query; per state
+                // it is 1, and 1 kb x 100 kb queries of up to ~2 500 nt fit where ~1 865 did)
+                long long gain = -0x40000000LL;
+                for (int st = 0; st < m->n_states; st++) {
+                    long long pre = -0x40000000LL, post = -0x40000000LL;
+                    for (int k = 0; k < m->n_transitions; k++) {
+                        const c4gpu_transition &t = m->transitions[k];
+                        if (t.calc < 0) continue;
+                        const c4gpu_calc &cc = m->calcs[t.calc];
+                        const int prm = cc.param & 3;
+                        if (cc.kind == C4GPU_CALC_SPLICE_PRE && t.output == st) pre = std::max<long long>(pre, (long long)cc.value + best[prm]);
+                        if (cc.kind == C4GPU_CALC_SPLICE_POST && t.input == st) post = std::max<long long>(post, (long long)cc.value + best[prm]);
+                    }
+                    if (pre > -0x40000000LL && post > -0x40000000LL) gain = std::max(gain, pre + post);
                 }
-                const long long gain = (long long)pre + post;
                 pk16_intron_gain = (int)std::max<long long>(0, std::min<long long>(gain, 1 << 20));
                 pk16_intron_cols = std::max(4, params->min_intron);
             }

@@ -4,7 +4,7 @@ cannot fail on the upper side.  Each case puts a WINDOWED launch (dumps every 25
 columns take the two-pass route) just inside and just outside one term of the guard, asserts from C4GPU_TRACE which score
 kernel ran, and compares EVERY pair with the oracle (Optimal_find_path, optimal.c:368-413):
   * --intronpenalty -1 / -5: an intron's two sites can outweigh its opening, so a path gains per intron the target has room for;
-  * the longest query the guard lets through against 2 600 columns (about 3 160 nt), and one row more;
+  * the longest query the guard lets through (3 199 nt under the default parameters), and one row more;
   * --maxintron against T + 4: the packed length counter saturates and cannot see "too long";
   * a substitution score of 16: (Q + 1) x 16 (+ the introns' term) <= 16 000 flips just under 1 000 rows;
 and a forced disagreement between a window and the score pass (C4GPU_FORCE_CORNER_MISMATCH) hands exactly those pairs to the
@@ -110,8 +110,7 @@ def test_small_intron_penalties_at_the_edge_of_the_gain_bound(eng, monkeypatch, 
 
 
 def test_longest_query_the_guard_lets_through(eng, monkeypatch, capfd):
-    """(Q + 1) x 5 + what introns can gain <= 16 000: about 3 160 rows against 2 600 columns under the default parameters (3 197
-    against a target without room for an intron).  The longest query that fits runs thirteen strips of 256 rows on the packed
+    """(Q + 1) x 5 + what introns can gain <= 16 000: 3 199 rows under the default parameters (an intron's two sites never outweigh its opening there: 13 + 16 - 30).  The longest query that fits runs thirteen strips of 256 rows on the packed
     kernels (HBM carry rows between super-strips), one row more the 32-bit kernels."""
     model = ex.Model("est2genome")
     lib = _abi.load()
