@@ -695,6 +695,7 @@ __global__ __launch_bounds__(64) void fuse_expand_kernel(const DevJob *parents, 
         DevJob j;
         memset(&j, 0, sizeof j);
         j.pair = pj.pair; j.q0 = dv.qs; j.t0 = dv.ts; j.Q = dv.ql; j.T = dv.tl;
+        j.root = pj.root;                    // the state the alignment's END is entered from (0: not known): BYROOT path kernels
         j.first_state = dv.first_state;
         // optimal.c:204-213,283-301: first cell = final cell of the sub-alignment before it (the parent's first cell for
         // the first one), final state = first state of the next one (the parent's final state for the last one)

@@ -63,56 +63,7 @@ __device__ __forceinline__ int clamp16(int x) { return x < -32768 ? -32768 : (x 
 
 constexpr int NEG16 = (int)0x80008000u;          // -32 768 in both halves
 
-// The components of a model as seen from END.  A path ends with a transition into END from one state (its "root"); every
-// state of the path can reach that root, so a pass that only has to reproduce ONE path whose root is known (the region
-// windows, the checkpoint pass: the whole-rectangle score pass has already decided which transition into END won, and a
-// pass restricted to the path's region can only confirm it: c4_win16_kernel.h, c4_ckpt16_kernel.h) needs the states from
-// which the root can be reached and no others.  est2genome: the forward-strand states {2, 3, 4, 8} and the reverse-strand
-// states {5, 6, 7, 9} never feed each other (they only share START and END), so such a pass computes half the model.
-// ROOT = -1 stands for "every inner state" (a model with one component, or a root that is not known).
-template <class M>
-struct Roots {
-    static constexpr bool inner(int s) { return s != M::START && s != M::END; }
-    static constexpr int count() {
-        int n = 0;
-        for (int k = 0; k < M::NT; k++) {
-            if (M::tr[k].out != M::END || !inner(M::tr[k].in)) continue;
-            bool seen = false;
-            for (int x = 0; x < k; x++) if (M::tr[x].out == M::END && M::tr[x].in == M::tr[k].in) seen = true;
-            n += seen ? 0 : 1;
-        }
-        return n;
-    }
-    static constexpr int root(int idx) {           // the idx-th distinct source state of END, in transition order
-        int n = 0;
-        for (int k = 0; k < M::NT; k++) {
-            if (M::tr[k].out != M::END || !inner(M::tr[k].in)) continue;
-            bool seen = false;
-            for (int x = 0; x < k; x++) if (M::tr[x].out == M::END && M::tr[x].in == M::tr[k].in) seen = true;
-            if (seen) continue;
-            if (n == idx) return M::tr[k].in;
-            n++;
-        }
-        return -1;
-    }
-    static constexpr bool member(int rt, int s) {  // can inner state s reach rt (rt itself included)?  rt < 0: every inner state
-        if (!inner(s)) return false;
-        if (rt < 0) return true;
-        bool in[M::NS] = {};
-        in[rt] = true;
-        for (int it = 0; it < M::NS; it++)
-            for (int k = 0; k < M::NT; k++)
-                if (in[M::tr[k].out] && inner(M::tr[k].in)) in[M::tr[k].in] = true;
-        return in[s];
-    }
-    // the first root whose component holds s (-1: none)
-    static constexpr int root_of(int s) { for (int r = 0; r < count(); r++) if (member(root(r), s)) return root(r); return -1; }
-    // do the components of the roots overlap?  (then restricting a pass to one of them saves nothing worth a kernel)
-    static constexpr bool disjoint() {
-        for (int s = 0; s < M::NS; s++) { int n = 0; for (int r = 0; r < count(); r++) n += member(root(r), s); if (n > 1) return false; }
-        return count() >= 2;
-    }
-};
+// (Roots<M>, the components of a model as seen from END: c4_viterbi_kernel.h)
 
 // The column dumps in 16-bit form (DUMP16: what the packed region windows of c4_win16_kernel.h start from): per dumped row
 // the scores of the inner states (START is never set and nothing reads END), then the intron lengths something can still

@@ -205,7 +205,58 @@ __device__ __forceinline__ bool scope_ok(int scope, bool at_q, bool at_t) {
 // the corner cell, whose region-start payload is reported.  A payload that entered through the dump carries the
 // identity of its entry cell (row, state, column) instead of a start: the host then walks one dump further left
 // (find_path_batch), so the payload work is done over the alignment's own extent only.
-template <class M, int R, int MODE, bool CONT, bool LOCAL, bool PACK = false, bool SUB = false, int SPAN = 0, int SEED = 0>
+// The components of a model as seen from END.  A path ends with a transition into END from one state (its "root"); every
+// state of the path can reach that root, so a pass that only has to reproduce ONE path whose root is known (the region
+// windows, the checkpoint pass: the whole-rectangle score pass has already decided which transition into END won, and a
+// pass restricted to the path's region can only confirm it: c4_win16_kernel.h, c4_ckpt16_kernel.h) needs the states from
+// which the root can be reached and no others.  est2genome: the forward-strand states {2, 3, 4, 8} and the reverse-strand
+// states {5, 6, 7, 9} never feed each other (they only share START and END), so such a pass computes half the model.
+// ROOT = -1 stands for "every inner state" (a model with one component, or a root that is not known).
+template <class M>
+struct Roots {
+    static constexpr bool inner(int s) { return s != M::START && s != M::END; }
+    static constexpr int count() {
+        int n = 0;
+        for (int k = 0; k < M::NT; k++) {
+            if (M::tr[k].out != M::END || !inner(M::tr[k].in)) continue;
+            bool seen = false;
+            for (int x = 0; x < k; x++) if (M::tr[x].out == M::END && M::tr[x].in == M::tr[k].in) seen = true;
+            n += seen ? 0 : 1;
+        }
+        return n;
+    }
+    static constexpr int root(int idx) {           // the idx-th distinct source state of END, in transition order
+        int n = 0;
+        for (int k = 0; k < M::NT; k++) {
+            if (M::tr[k].out != M::END || !inner(M::tr[k].in)) continue;
+            bool seen = false;
+            for (int x = 0; x < k; x++) if (M::tr[x].out == M::END && M::tr[x].in == M::tr[k].in) seen = true;
+            if (seen) continue;
+            if (n == idx) return M::tr[k].in;
+            n++;
+        }
+        return -1;
+    }
+    static constexpr bool member(int rt, int s) {  // can inner state s reach rt (rt itself included)?  rt < 0: every inner state
+        if (!inner(s)) return false;
+        if (rt < 0) return true;
+        bool in[M::NS] = {};
+        in[rt] = true;
+        for (int it = 0; it < M::NS; it++)
+            for (int k = 0; k < M::NT; k++)
+                if (in[M::tr[k].out] && inner(M::tr[k].in)) in[M::tr[k].in] = true;
+        return in[s];
+    }
+    // the first root whose component holds s (-1: none)
+    static constexpr int root_of(int s) { for (int r = 0; r < count(); r++) if (member(root(r), s)) return root(r); return -1; }
+    // do the components of the roots overlap?  (then restricting a pass to one of them saves nothing worth a kernel)
+    static constexpr bool disjoint() {
+        for (int s = 0; s < M::NS; s++) { int n = 0; for (int r = 0; r < count(); r++) n += member(root(r), s); if (n > 1) return false; }
+        return count() >= 2;
+    }
+};
+
+template <class M, int R, int MODE, bool CONT, bool LOCAL, bool PACK = false, bool SUB = false, int SPAN = 0, int SEED = 0, int COMP = 0>
 struct WaveDP {
     using F = Facts<M>;
     static constexpr int NDES = M::NDES;
@@ -232,6 +283,24 @@ struct WaveDP {
                   "dumps are written by the score pass and read by the packed region pass");
     static_assert(SEED == 0 || (!CONT && !SUB && SPAN == 0), "seeded passes: plain whole-rectangle kernels only");
     using C = Cell<M, X>;
+
+    // COMP > 0: only the states of ONE component of the model are computed -- the inner states that can reach Roots<M>::root(COMP - 1),
+    // the state the path's END is entered from (est2genome: one strand's four states and the transitions between them: half the
+    // model).  Exact for every call whose path is known to lie in that component: a sub-alignment between two checkpoint cells of an
+    // alignment with that root starts in a state of the component (or in START) and nothing outside the component can be reached
+    // from there -- the two strands only share START and END -- so the states left out hold -987654321 in the full kernel too.
+    // Same traceback word layout, same carry row layout (slots of the states left out are neither written nor read).
+    using RTc = Roots<M>;
+    static constexpr bool alive(int s) {
+        if (COMP == 0 || s == M::START || s == M::END) return true;
+        return RTc::member(RTc::root(COMP - 1), s);
+    }
+    static constexpr unsigned alive_mask() { unsigned m = 0; for (int s = 0; s < M::NS; s++) m |= alive(s) ? (1u << s) : 0u; return m; }
+    static constexpr bool tr_alive(int k) {
+        if (COMP == 0) return true;
+        if (M::tr[k].out == M::END) return M::tr[k].in == M::START || alive(M::tr[k].in);
+        return alive(M::tr[k].out) && alive(M::tr[k].in);
+    }
 
     // Is slot e of state s ever read?  A designation slot only matters while a path to a consuming
     // transition exists that does not pass through a state that re-starts the shadow (e.g. est2genome:
@@ -348,6 +417,12 @@ struct WaveDP {
         static_for<M::NT>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
             constexpr int k = K;
             constexpr TrDesc t = M::tr[k];
+            // a transition of the other component (COMP) is skipped -- except that a transition out of START still does the
+            // continuation's seeding below at ITS place in the order: the reference seeds the first cell inside its transition
+            // loop, at the first valid transition out of START (viterbi.c:705-714), i.e. after the silent transitions with smaller
+            // ids have been evaluated in the origin cell and before the others (est2genome: 6 -> 5 and 7 -> 5 before, 3 -> 2 and
+            // 4 -> 2 after), whichever component that transition belongs to
+            if constexpr (!tr_alive(k) && !(CONT && t.in == M::START)) return;
             // Layout_transition_is_valid (layout.c:122-154)
             bool valid = true;
             if constexpr (t.aq > 0) valid = valid & i_ok;
@@ -376,6 +451,7 @@ struct WaveDP {
             if constexpr (CONT && t.in == M::START) {
                 if (__builtin_amdgcn_ballot_w64(valid)) {
                     static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
+                        if constexpr (!alive(S)) return;             // (COMP: the first state is one of the component's)
                         const bool seed = valid & (first_state == S);
                         const int old_sc = c.sc[S], fc0 = first_cell[0];
                         c.sc[S] = seed ? fc0 : old_sc;
@@ -393,6 +469,7 @@ struct WaveDP {
                     });
                 }
             }
+            if constexpr (!tr_alive(k)) return;                  // (COMP: seeded above where it is a transition out of START)
             // source cell: same cell (silent), row above (lane-local or the neighbour's), earlier columns
             constexpr int PD = (PH - t.at + NCOL) % NCOL;
             const C &cell_src = (t.aq == 0) ? col[PD][RR] : (RR > 0 ? col[PD][RR > 0 ? RR - 1 : 0] : nbr[PD]);
@@ -526,7 +603,7 @@ struct WaveDP {
         int slot = 0;
         static_for<M::NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
             if constexpr (F::exported(S)) {
-                fn(S_, slot);
+                if constexpr (alive(S)) fn(S_, slot);            // (COMP: the slots of the other component's states stay where they are)
                 slot += 1 + XS;
             }
         });
@@ -1199,7 +1276,13 @@ struct WaveDP {
 // Kernel: persistent waves, one job at a time per wave.
 // -------------------------------------------------------------------------------------------------------------
 // WPE: waves per SIMD the register allocator must leave room for (1 = no cap: 512 unified registers)
-template <class M, int R, int MODE, bool CONT, bool LOCAL, bool PACK, int WPE, bool SUB = false, int SPAN = 0>
+template <class T> struct TypeTag { using type = T; };
+
+// BYROOT (continuation passes of a model whose inner states fall into two components that only share START and END: est2genome's
+// strands): a job that names the state its alignment's END is entered from (DevJob::root, handed down from the region pass through
+// the checkpoint pass to every sub-alignment) runs the instantiation that computes that state's component only (WaveDP, COMP);
+// a job that does not (root 0), or whose first state is not of that component, runs the whole model.
+template <class M, int R, int MODE, bool CONT, bool LOCAL, bool PACK, int WPE, bool SUB = false, int SPAN = 0, bool BYROOT = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void viterbi_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs,
                                                      int n_jobs, DevResult *results, DevVsa *vsas, uint8_t *ops,
                                                      DevScratch scratch, int *queue) {
@@ -1233,6 +1316,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
         // undefined wherever a member is read before it is written, and what the registers held decided
         // (tests/test_gpu_parity.py after tests/test_gpu_kernel_variants.py; -ftrivial-auto-var-init=zero and =pattern
         // both gave the reference's answer, as does this)
+      auto do_job = [&](auto tag_) __attribute__((always_inline)) {
+        using DP = typename decltype(tag_)::type;
         DP dp{};
         dp.kp = &kp_lds;
         dp.lane = threadIdx.x;
@@ -1286,6 +1371,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
             const uint32_t *runs = scratch.runs + (long long)wave * scratch.runs_stride;
             for (int x = threadIdx.x; x < run_n; x += 64) scratch.runs_out[run_off + x] = runs[x];
             __syncthreads();
+        }
+      };
+        using RTk = Roots<M>;
+        if constexpr (BYROOT && CONT && RTk::count() == 2 && RTk::disjoint()) {
+            using DP1 = WaveDP<M, R, MODE, CONT, LOCAL, PACK, SUB, SPAN, 0, 1>;
+            using DP2 = WaveDP<M, R, MODE, CONT, LOCAL, PACK, SUB, SPAN, 0, 2>;
+            const int root = job.root, fs = job.first_state;            // wave-uniform
+            constexpr unsigned m1 = DP1::alive_mask(), m2 = DP2::alive_mask();     // (START and END are in both)
+            const int ls = job.final_state;
+            const bool in1 = root == RTk::root(0) && ((m1 >> fs) & 1u) && ((m1 >> ls) & 1u);
+            const bool in2 = root == RTk::root(1) && ((m2 >> fs) & 1u) && ((m2 >> ls) & 1u);
+            if (in1) do_job(TypeTag<DP1>{});
+            else if (in2) do_job(TypeTag<DP2>{});
+            else do_job(TypeTag<DP>{});
+        } else {
+            do_job(TypeTag<DP>{});
         }
     }
 }
