@@ -683,7 +683,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 // one workgroup (one wave) per checkpoint job x; its children are out[first[x]] .. out[first[x + 1] - 1] in path order
 __global__ __launch_bounds__(64) void fuse_expand_kernel(const DevJob *parents, const DevVsa *vsa, const int *first, int n_parents,
                                                          DevJob *out, c4h::MemRule rule, int dpmemory_mb, int path_R,
-                                                         int *flags, unsigned long long *stats) {
+                                                         int *flags, unsigned long long *stats, int keep_root) {
     const int x = blockIdx.x;
     if (x >= n_parents) return;
     const DevJob &pj = parents[x];
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(64) void fuse_expand_kernel(const DevJob *parents, 
         DevJob j;
         memset(&j, 0, sizeof j);
         j.pair = pj.pair; j.q0 = dv.qs; j.t0 = dv.ts; j.Q = dv.ql; j.T = dv.tl;
-        j.root = pj.root;                    // the state the alignment's END is entered from (0: not known): BYROOT path kernels
+        j.root = keep_root ? pj.root : 0;    // the state the alignment's END is entered from (0: not known): BYROOT path kernels
         j.first_state = dv.first_state;
         // optimal.c:204-213,283-301: first cell = final cell of the sub-alignment before it (the parent's first cell for
         // the first one), final state = first state of the next one (the parent's final state for the last one)
@@ -2014,7 +2014,8 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
         return -1;
     if (eng.d_fflags.zero(n, s)) return -1;
     hipLaunchKernelGGL(fuse_expand_kernel, dim3(n), dim3(64), 0, s, eng.d_fjobs.p, eng.d_fvsa.p, eng.d_ffirst.p, n,
-                       eng.d_fsub_jobs.p, rule, dpmemory_mb, kp->R, eng.d_fflags.p, eng.d_fstats.p);
+                       eng.d_fsub_jobs.p, rule, dpmemory_mb, kp->R, eng.d_fflags.p, eng.d_fstats.p,
+                       (getenv("C4GPU_BYROOT") && atoi(getenv("C4GPU_BYROOT")) == 0) ? 0 : 1);
     HIP_OK(hipGetLastError());
     if (eng.d_fstats.download(stats.data(), FUSE_STATS, s)) return -1;
     HIP_OK(c4_stream_sync(s));

@@ -769,3 +769,39 @@ def test_memory_rule_on_the_device_is_the_host_rule(eng):
                 assert red[k] == lib.c4gpu_use_reduced_space(model.c, r, dpm), (mt, dpm, q, t)
                 if red[k] and rows[k] >= 0 and dpm > 0:
                     assert rows[k] == lib.c4gpu_checkpoint_rows(model.c, r, dpm), (mt, dpm, q, t)
+
+
+
+def test_sub_alignments_on_the_kernel_of_their_root(eng, monkeypatch):
+    """The sub-alignment pass of the device route runs a job that names its alignment's root (the state END is entered from:
+    known where the packed score pass found the end cell) on the path kernel of that root's COMPONENT -- one strand of est2genome,
+    half the transitions (c4_viterbi_kernel.h: COMP, BYROOT); C4GPU_BYROOT=0 hands the jobs over without a root (whole model).  The
+    continuation's seeding keeps its place in the transition order (viterbi.c:705-714: at the first transition out of START by
+    id, i.e. behind 6 -> 5 / 7 -> 5 and in front of 3 -> 2 / 4 -> 2 whichever strand the job is on), which matters where a
+    checkpoint cell sits in a gap state.  Forward and reverse strands, indels at 8 % (checkpoint cells in gap states), tiny dump
+    intervals so that short targets take the route, -D 1 (many sections): both forms give the same alignments, and every pair the
+    oracle's."""
+    rng = random.Random(2718)
+    model = ex.Model("est2genome")
+    pairs = []
+    for k, (ql, tl) in enumerate([(700, 5000), (900, 7000), (560, 4000), (1000, 6000), (640, 9000), (800, 5200), (1023, 4800), (530, 3000)]):
+        q = _rand(rng, ql)
+        c1, c2 = ql // 3, 2 * ql // 3
+        d5, d3 = ("CT", "AC") if k % 2 else ("GT", "AG")        # odd pairs: introns of the other strand (the reverse-strand states)
+        gene = (_mutate(rng, q[:c1], 0.08) + d5 + _rand(rng, rng.randint(80, 900)) + d3 + _mutate(rng, q[c1:c2], 0.08) +
+                d5 + _rand(rng, rng.randint(80, 600)) + d3 + _mutate(rng, q[c2:], 0.08))
+        t = _rand(rng, rng.randint(50, 400)) + gene
+        pairs.append((q, t + _rand(rng, max(10, tl - len(t)))))
+    monkeypatch.setenv("C4GPU_SEED_KSHIFT", "8")
+    got = {}
+    for dp in (32, 1):
+        for byroot in ("1", "0"):
+            monkeypatch.setenv("C4GPU_BYROOT", byroot)
+            got[dp, byroot] = [a.as_dict() if a else None for a in eng.find_path(model, pairs, dpmemory=dp, threshold=20)]
+        assert got[dp, "1"] == got[dp, "0"], dp
+        for k, (q, t) in enumerate(pairs):
+            assert got[dp, "1"][k] == oracle_lib.find_path(model.c, model.params, q.encode(), t.encode(), dpmemory=dp, threshold=20), (dp, k)
+    assert sum(1 for a in got[32, "1"] if a) == len(pairs)
+    # both strands occur: the vulgar line labels the splice sites of a forward intron 5 .. 3 and of a reverse one 3 .. 5
+    fwd = sum(1 for a in got[32, "1"] if " 5 0 2 I " in a["vulgar"]), sum(1 for a in got[32, "1"] if " 3 0 2 I " in a["vulgar"])
+    assert fwd[0] >= 2 and fwd[1] >= 2, fwd
