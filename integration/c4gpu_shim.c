@@ -701,6 +701,7 @@ typedef struct {
 
 static GMutex shim_device_lock;           /* one batch on the device at a time */
 static ShimFlushJob *shim_in_flight = NULL;
+static volatile gint shim_device_busy = 0;        /* a flush thread is between taking and releasing the device */
 
 static gboolean shim_async(void){
     static gint on = -1;
@@ -793,6 +794,7 @@ static gpointer shim_flush_device(gpointer data){
     static c4gpu_model res_fm;
     static c4gpu_params res_params;
     g_mutex_lock(&shim_device_lock);
+    g_atomic_int_set(&shim_device_busy, 1);
     job->t_dev0 = g_get_monotonic_time();
     if(job->flattened){
         if(res_stage && (memcmp(&res_fm, &job->fm, sizeof(res_fm)) || memcmp(&res_params, &job->params, sizeof(res_params)))){
@@ -843,6 +845,7 @@ static gpointer shim_flush_device(gpointer data){
         job->error = g_strdup(c4gpu_last_error());
         }
     job->t_dev1 = g_get_monotonic_time();
+    g_atomic_int_set(&shim_device_busy, 0);
     g_mutex_unlock(&shim_device_lock);
     return NULL;
     }
@@ -980,6 +983,13 @@ GAM_Result *GAM_Result_exhaustive_create(GAM *gam, Sequence *query, Sequence *ta
     shim_pending_bytes += 22.0 * target->len + 2.0 * query->len;
     if(((gint)shim_pending->len >= shim_batch_size())
     || (shim_pending_bytes > (g_getenv("C4GPU_BATCH_GB") ? atof(g_getenv("C4GPU_BATCH_GB")) : 96.0) * 1e9))
+        shim_flush_async();
+    /* ... and whenever the device has nothing to do and a batch worth a launch has collected (an eighth of --gpubatch, at
+     * least 256 pairs): the first pairs of a run go to the device while the reference's front end is still reading the rest,
+     * and every later flush takes what has collected while the one before it ran (C4GPU_EAGER=0: only full batches) */
+    else if(shim_async() && (!g_atomic_int_get(&shim_device_busy))
+         && ((gint)shim_pending->len >= MAX(256, shim_batch_size() / 8))
+         && !(g_getenv("C4GPU_EAGER") && (atoi(g_getenv("C4GPU_EAGER")) == 0)))
         shim_flush_async();
     return NULL;                  /* the result is submitted by the flush, in submission order */
     }
