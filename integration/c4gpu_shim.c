@@ -984,12 +984,13 @@ GAM_Result *GAM_Result_exhaustive_create(GAM *gam, Sequence *query, Sequence *ta
     if(((gint)shim_pending->len >= shim_batch_size())
     || (shim_pending_bytes > (g_getenv("C4GPU_BATCH_GB") ? atof(g_getenv("C4GPU_BATCH_GB")) : 96.0) * 1e9))
         shim_flush_async();
-    /* ... and whenever the device has nothing to do and a batch worth a launch has collected (an eighth of --gpubatch, at
-     * least 256 pairs): the first pairs of a run go to the device while the reference's front end is still reading the rest,
-     * and every later flush takes what has collected while the one before it ran (C4GPU_EAGER=0: only full batches) */
+    /* C4GPU_EAGER=1 (off by default): also whenever the device has nothing to do and an eighth of --gpubatch (at least 256 pairs)
+     * has collected, so that the first pairs of a run go to the device while the front end is still reading the rest.  Measured
+     * on the 64 x 64 run (profiles/r05_dropin_c4.log): 1.71 s at best against 1.73-1.87 s without, but 2.4-2.6 s in two runs of
+     * three -- the small first batch sizes the launch buffers, and the full batches behind it grow them in the middle of a run */
     else if(shim_async() && (!g_atomic_int_get(&shim_device_busy))
          && ((gint)shim_pending->len >= MAX(256, shim_batch_size() / 8))
-         && !(g_getenv("C4GPU_EAGER") && (atoi(g_getenv("C4GPU_EAGER")) == 0)))
+         && g_getenv("C4GPU_EAGER") && (atoi(g_getenv("C4GPU_EAGER")) != 0))
         shim_flush_async();
     return NULL;                  /* the result is submitted by the flush, in submission order */
     }
