@@ -238,7 +238,7 @@ def other_configs(ex, eng):
                      "value": cells / dt, "unit": "cells/s", "alignments_per_s": len(pairs) / dt,
                      "kernel_ms": {names[m]: ks[m]["ms"] for m in range(4)},
                      "dominant_kernel": {"pass": names[dom], "ms": ks[dom]["ms"], "launches": ks[dom]["launches"]},
-                     "checked": "%d alignments (every %dth pair: score, region, operations) equal to tests/golden/bench_configs.json"
+                     "checked": "%d alignments (every %dth pair: score, region, operations) equal to tests/golden/bench_configs.json (records made by the reference: refdump)"
                                 % (checked, want[name]["every"])}
         b.close()
     return out
