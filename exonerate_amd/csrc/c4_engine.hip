@@ -46,6 +46,7 @@ void set_error(const std::string &msg) { g_error = msg; }
 struct c4gpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = false;                      // c4gpu_ctx_own_stream: destroyed with the context
     hipDeviceProp_t prop;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // accumulated statistics of the Viterbi kernel launches (HIP events on the launch stream)
@@ -152,6 +153,7 @@ struct PinArenaRef {
     PinArena *get() { if (!a) a = g_pin_pool.take(); return a; }
 };
 static thread_local PinArenaRef t_pin;
+static const bool g_dl_eager = getenv("C4GPU_DL_EAGER") && atoi(getenv("C4GPU_DL_EAGER")) != 0;
 static const bool g_pin_off = getenv("C4GPU_PIN_XFER") && atoi(getenv("C4GPU_PIN_XFER")) == 0;       // 0: pageable copies, as before
 
 // every wait for a stream: the downloads of this thread that landed in its arena reach their destinations
@@ -189,7 +191,10 @@ template <class T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    // (retired, not freed: hipFree waits for every kernel on the device, those of other threads' batches included -- the HSP
+    // extension of the drop-in's main thread waited 0.35 s for the SDP passes of the flight beside it at the end of each of
+    // its calls; what is retired is freed at the next flush: context / batch / stage destroy, or once 16 GB are waiting)
+    ~DevBuf() { if (p) g_retired.retire(p, n * sizeof(T)); }
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
@@ -222,6 +227,11 @@ struct DevBuf {
     // the data is at `dst` after the next c4_stream_sync(s) of the calling thread
     int download(T *dst, size_t count, hipStream_t s) const {
         if (!count) return 0;
+        // a read-back is queued only once everything in front of it in its stream is over: a DMA copy that waits for a kernel
+        // waits in its engine's queue, and that queue is shared by all streams of the process -- the read-backs of the other
+        // launch lane, or of another thread's batch, then sit behind it until THIS stream's kernel ends (seen: a word scan's
+        // 8-byte read-back held up for the 0.36 s of another thread's SDP passes).  C4GPU_DL_EAGER=1: queue at once, as before
+        if (!g_dl_eager) (void)hipStreamSynchronize(s);
         if (uint8_t *slot = pin_slot(count * sizeof(T), s)) {
             HIP_OK(hipMemcpyAsync(slot, p, count * sizeof(T), hipMemcpyDeviceToHost, s));
             t_pin.a->pending.push_back(PinArena::Pending{dst, slot, count * sizeof(T)});
@@ -2878,11 +2888,29 @@ void c4gpu_ctx_destroy(c4gpu_ctx *ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->sdp_arena) (void)hipFree(ctx->sdp_arena);
+    if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     g_retired.flush();
 }
 
-void c4gpu_ctx_set_stream(c4gpu_ctx *ctx, void *hip_stream) { ctx->stream = (hipStream_t)hip_stream; }
+void c4gpu_ctx_set_stream(c4gpu_ctx *ctx, void *hip_stream) {
+    if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->owns_stream = false;
+    ctx->stream = (hipStream_t)hip_stream;
+}
+
+int c4gpu_ctx_own_stream(c4gpu_ctx *ctx) {
+    if (ctx->owns_stream) return 0;
+    if (hipSetDevice(ctx->device) != hipSuccess) { c4h::set_error("c4gpu_ctx_own_stream: cannot select the device"); return -1; }
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+        c4h::set_error("c4gpu_ctx_own_stream: cannot create a stream");
+        return -1;
+    }
+    ctx->stream = s;
+    ctx->owns_stream = true;
+    return 0;
+}
 
 int c4gpu_ctx_device_info(c4gpu_ctx *ctx, char *name, size_t name_len, int *n_cu, int64_t *mem_bytes) {
     if (name && name_len) snprintf(name, name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define C4GPU_ABI_VERSION 5
+#define C4GPU_ABI_VERSION 6
 
 /* src/c4/c4.h:28-30 */
 typedef int32_t c4gpu_score;
@@ -221,6 +221,11 @@ void        c4gpu_ctx_warm(c4gpu_ctx *ctx);
 void        c4gpu_ctx_warm_cancel(void);
 /* Use an externally owned HIP stream (e.g. torch's current stream) for all launches; NULL = default. */
 void        c4gpu_ctx_set_stream(c4gpu_ctx *ctx, void *hip_stream);
+/* Gives the context a non-blocking HIP stream of its own (destroyed with the context): the calls of a SECOND context of one
+ * process, made from a second host thread, then run beside the first one's instead of in the default stream's order
+ * (integration/c4gpu_sdp.c: a batch of SDP passes beside the word scans and HSP extensions of the comparisons behind it).
+ * 0, or -1 with last_error set. */
+int         c4gpu_ctx_own_stream(c4gpu_ctx *ctx);
 int         c4gpu_ctx_device_info(c4gpu_ctx *ctx, char *name, size_t name_len, int *n_cu, int64_t *mem_bytes);
 
 /* Defaults of the reference's ArgumentSets: nucleic / blosum62 matrices, standard genetic code,

@@ -62,7 +62,7 @@ static gdouble sdp_budget_bytes(void){
     return budget;
     }
 static ShimSdpPending *sdp_cur = NULL;
-static struct { long pairs, served_pairs, alignments, flushes; double device_ms, replay_ms; } sst;
+static struct { long pairs, served_pairs, alignments, flushes, async_flushes; double device_ms, replay_ms, waited_ms; } sst;
 
 static gboolean sdp_eligible(GAM *gam, Comparison *comparison){
     if((shim_batch_size() <= 0) || g_getenv("C4GPU_SDP_OFF") || sdp_cur)
@@ -140,96 +140,133 @@ static void sdp_host_pair(ShimSdpPending *p){
     return;
     }
 
-static void sdp_device_batch(GPtrArray *todo){
+/* A flush in three parts, like the exhaustive seam's (c4gpu_shim.c): PREPARE on the main thread (everything that reads the
+ * reference's objects: sequences flattened, HSPs gathered, model and scoring data), the DEVICE part -- one library call on
+ * plain arrays -- on a thread of its own with a context and a stream of its own, LAND on the main thread (join, results into
+ * the pending pairs, replay in submission order).  A flush that is cut in the middle of a run (the memory estimate) goes to
+ * the device while the main thread carries on with the comparisons behind it -- reading tries, word scans, HSP extensions,
+ * collecting the next batch -- and lands in front of the next flush or at the end: config 5's heuristic leg has ~0.6 s of such
+ * work behind its first flush of ~0.44 s (profiles/r05_c5_cold.md).  One flight at a time (two arenas of 65 GB do not fit
+ * beside the staged sequences everywhere); replays keep the submission order, and nothing else reports in between: whatever
+ * takes the reference's own path flushes -- and with that lands -- first (c4gpu_bsdp.c).  C4GPU_SDP_ASYNC=0: every flush
+ * synchronous on the main context, as before. */
+typedef struct {
+    GPtrArray *todo, *strings;
+    GArray *hsps;
+    c4gpu_pair *pair;
+    int32_t *first, *n_out;
+    c4gpu_alignment *out;
+    gboolean *usable, ready, async;
+    gint qa, ta, dropoff, rc;
+    C4_Score threshold;
+    c4gpu_model fm;
+    c4gpu_params params;
+    gchar *err;
+    GThread *thread;
+    gint64 t0, t_host;
+} SdpFlight;
+
+static SdpFlight *sdp_in_flight = NULL;
+static c4gpu_ctx *sdp_ctx2 = NULL;            /* the flight thread's context (own stream), opened by the first flight */
+
+static gboolean sdp_async(void){
+    static gint on = -1;
+    if(on < 0)
+        on = (g_getenv("C4GPU_SDP_ASYNC") && (atoi(g_getenv("C4GPU_SDP_ASYNC")) == 0)) ? 0 : 1;
+    return on;
+    }
+
+static SdpFlight *sdp_flight_prepare(GPtrArray *todo){
     register guint i, n = todo->len;
     register ShimSdpPending *p = todo->pdata[0];
     register GAM *gam = p->gam;
     register GHashTable *flat = g_hash_table_new(g_direct_hash, g_direct_equal);
-    register GPtrArray *strings = g_ptr_array_new();
-    register GArray *hsps = g_array_new(FALSE, FALSE, sizeof(c4gpu_hsp));
-    c4gpu_pair *pair = g_new0(c4gpu_pair, n);
-    int32_t *first = g_new0(int32_t, n + 1), *n_out = g_new0(int32_t, n);
-    c4gpu_alignment *out = g_new0(c4gpu_alignment, (gsize)n * SHIM_SDP_MAX);
-    gboolean *usable = g_new0(gboolean, n);
-    gint qa = 0, ta = 0;
+    register SdpFlight *f = g_new0(SdpFlight, 1);
     gpointer ud;
-    c4gpu_model fm;
-    c4gpu_params params;
+    f->t0 = g_get_monotonic_time();
+    f->todo = todo;
+    f->strings = g_ptr_array_new();
+    f->hsps = g_array_new(FALSE, FALSE, sizeof(c4gpu_hsp));
+    f->pair = g_new0(c4gpu_pair, n);
+    f->first = g_new0(int32_t, n + 1);
+    f->n_out = g_new0(int32_t, n);
+    f->out = g_new0(c4gpu_alignment, (gsize)n * SHIM_SDP_MAX);
+    f->usable = g_new0(gboolean, n);
+    f->rc = -1;
     for(i = 0; i < n; i++){
         register gchar *qs, *ts;
         gint pqa, pta;
-        register guint before = hsps->len;
+        register guint before = f->hsps->len;
         p = todo->pdata[i];
         if(!(qs = g_hash_table_lookup(flat, p->comparison->query))){
             qs = Sequence_get_str(p->comparison->query);
             g_hash_table_insert(flat, p->comparison->query, qs);
-            g_ptr_array_add(strings, qs);
+            g_ptr_array_add(f->strings, qs);
             }
         if(!(ts = g_hash_table_lookup(flat, p->comparison->target))){
             ts = Sequence_get_str(p->comparison->target);
             g_hash_table_insert(flat, p->comparison->target, ts);
-            g_ptr_array_add(strings, ts);
+            g_ptr_array_add(f->strings, ts);
             }
-        pair[i].query = (const uint8_t*)qs;  pair[i].query_len = p->comparison->query->len;
-        pair[i].target = (const uint8_t*)ts; pair[i].target_len = p->comparison->target->len;
-        first[i] = before;
-        usable[i] = sdp_gather_hsps(p->comparison, hsps, &pqa, &pta);
-        if(usable[i] && qa && ((pqa != qa) || (pta != ta)))
-            usable[i] = FALSE;
-        if(usable[i]){
-            qa = pqa; ta = pta;
+        f->pair[i].query = (const uint8_t*)qs;  f->pair[i].query_len = p->comparison->query->len;
+        f->pair[i].target = (const uint8_t*)ts; f->pair[i].target_len = p->comparison->target->len;
+        f->first[i] = before;
+        f->usable[i] = sdp_gather_hsps(p->comparison, f->hsps, &pqa, &pta);
+        if(f->usable[i] && f->qa && ((pqa != f->qa) || (pta != f->ta)))
+            f->usable[i] = FALSE;
+        if(f->usable[i]){
+            f->qa = pqa; f->ta = pta;
         } else {
-            g_array_set_size(hsps, before);             /* this pair brings no HSPs to the batch: nothing comes back */
+            g_array_set_size(f->hsps, before);          /* this pair brings no HSPs to the batch: nothing comes back */
             }
         }
-    first[n] = hsps->len;
+    f->first[n] = f->hsps->len;
     p = todo->pdata[0];
     ud = Model_Type_create_data(gam->gas->type, p->comparison->query, p->comparison->target);
-    if(qa && shim_flatten_any(gam->sdp->model, ud, &fm, FALSE)){
-        shim_params(ud, &params);
-        if(c4gpu_sdp_batch(shim_get_ctx(), &fm, &params, pair, n, (const c4gpu_hsp*)hsps->data, first, qa, ta,
-                           gam->sdp->sas->dropoff, gam->gas->threshold, SHIM_SDP_MAX, out, n_out) == 0){
-            for(i = 0; i < n; i++){
-                register gint k;
-                p = todo->pdata[i];
-                p->n = (n_out[i] < 0) ? 0 : n_out[i];     /* -1: the device could not serve this pair (memory): CPU */
-                for(k = 0; k < p->n; k++)
-                    p->alns[k] = out[(gsize)i * SHIM_SDP_MAX + k];
-                p->have = usable[i] && (n_out[i] >= 0) && (n_out[i] < SHIM_SDP_MAX);
-                }
-        } else {
-            g_warning("c4gpu: %s -- SDP stays on the CPU for this batch", c4gpu_last_error());
-            }
+    if(f->qa && shim_flatten_any(gam->sdp->model, ud, &f->fm, FALSE)){
+        shim_params(ud, &f->params);
+        f->ready = TRUE;
         }
     Model_Type_destroy_data(gam->gas->type, ud);
-    for(i = 0; i < strings->len; i++)
-        g_free(strings->pdata[i]);
-    g_ptr_array_free(strings, TRUE);
+    f->dropoff = gam->sdp->sas->dropoff;
+    f->threshold = gam->gas->threshold;
     g_hash_table_destroy(flat);
-    g_array_free(hsps, TRUE);
-    g_free(pair); g_free(first); g_free(n_out); g_free(out); g_free(usable);
-    return;
+    f->t_host = g_get_monotonic_time() - f->t0;
+    return f;
     }
 
-void shim_sdp_flush(void){
+/* nothing of the reference's is touched here: plain arrays in, plain arrays out */
+static gpointer sdp_flight_device(gpointer data){
+    register SdpFlight *f = data;
+    register c4gpu_ctx *ctx = NULL;
+    if(!f->ready)
+        return NULL;
+    if(f->async){
+        if(!sdp_ctx2){
+            sdp_ctx2 = c4gpu_ctx_create(shim_device_ordinal());
+            if(sdp_ctx2 && (c4gpu_ctx_own_stream(sdp_ctx2) != 0)){
+                c4gpu_ctx_destroy(sdp_ctx2);
+                sdp_ctx2 = NULL;
+                }
+            }
+        ctx = sdp_ctx2;
+    } else {
+        ctx = shim_get_ctx();
+        }
+    if(!ctx){
+        f->err = g_strdup(c4gpu_last_error());
+        return NULL;
+        }
+    f->rc = c4gpu_sdp_batch(ctx, &f->fm, &f->params, f->pair, f->todo->len, (const c4gpu_hsp*)f->hsps->data, f->first,
+                            f->qa, f->ta, f->dropoff, f->threshold, SHIM_SDP_MAX, f->out, f->n_out);
+    if(f->rc != 0)
+        f->err = g_strdup(c4gpu_last_error());      /* the error string is the calling thread's */
+    return NULL;
+    }
+
+static void sdp_replay(GPtrArray *todo){
     register guint i;
     register gint k;
-    register GPtrArray *todo = sdp_pending;
-    gint64 t0 = g_get_monotonic_time(), t1;
-    if((!todo) || (!todo->len))
-        return;
-    sdp_pending = NULL;
-    sdp_pending_bytes = 0.0;
-    sst.flushes++;
-    shim_mark("sdp flush: batch");
-    if(g_getenv("C4GPU_SDP_HOST")){
-        for(i = 0; i < todo->len; i++)
-            sdp_host_pair(todo->pdata[i]);
-    } else {
-        sdp_device_batch(todo);
-        }
-    t1 = g_get_monotonic_time();
-    shim_mark("sdp flush: replay");
     for(i = 0; i < todo->len; i++){                       /* replay in submission order */
         register ShimSdpPending *p = todo->pdata[i];
         register GAM_Result *gam_result;
@@ -252,8 +289,101 @@ void shim_sdp_flush(void){
         g_free(p);
         }
     g_ptr_array_free(todo, TRUE);
-    sst.device_ms += (t1 - t0) / 1e3;
+    return;
+    }
+
+static void sdp_flight_land(SdpFlight *f){
+    register guint i, n = f->todo->len;
+    gint64 t0 = g_get_monotonic_time(), t1;
+    if(f->thread){
+        g_thread_join(f->thread);
+        sst.waited_ms += (g_get_monotonic_time() - t0) / 1e3;
+        }
+    if(f->ready && (f->rc == 0)){
+        for(i = 0; i < n; i++){
+            register gint k;
+            register ShimSdpPending *p = f->todo->pdata[i];
+            p->n = (f->n_out[i] < 0) ? 0 : f->n_out[i];     /* -1: the device could not serve this pair (memory): CPU */
+            for(k = 0; k < p->n; k++)
+                p->alns[k] = f->out[(gsize)i * SHIM_SDP_MAX + k];
+            p->have = f->usable[i] && (f->n_out[i] >= 0) && (f->n_out[i] < SHIM_SDP_MAX);
+            }
+    } else if(f->ready){
+        g_warning("c4gpu: %s -- SDP stays on the CPU for this batch", f->err ? f->err : "SDP batch failed");
+        }
+    for(i = 0; i < f->strings->len; i++)
+        g_free(f->strings->pdata[i]);
+    g_ptr_array_free(f->strings, TRUE);
+    g_array_free(f->hsps, TRUE);
+    g_free(f->pair); g_free(f->first); g_free(f->n_out); g_free(f->out); g_free(f->usable); g_free(f->err);
+    t1 = g_get_monotonic_time();
+    shim_mark("sdp flush: replay");
+    sdp_replay(f->todo);
+    sst.device_ms += (f->async ? f->t_host + (t1 - t0) : (t1 - f->t0)) / 1e3;
     sst.replay_ms += (g_get_monotonic_time() - t1) / 1e3;
+    g_free(f);
+    return;
+    }
+
+/* lands what is in flight, then takes the pending pairs to the device: beside the main thread (`async`, left in flight) or
+ * on it (landed before the return) */
+static void sdp_flush_pending(gboolean async){
+    register GPtrArray *todo = sdp_pending;
+    register SdpFlight *f = NULL;
+    if(todo && todo->len){
+        sdp_pending = NULL;
+        sdp_pending_bytes = 0.0;
+        sst.flushes++;
+        shim_mark("sdp flush: batch");
+        if(g_getenv("C4GPU_SDP_HOST")){
+            register guint i;
+            gint64 t0 = g_get_monotonic_time(), t1;
+            if(sdp_in_flight){
+                sdp_flight_land(sdp_in_flight);
+                sdp_in_flight = NULL;
+                }
+            for(i = 0; i < todo->len; i++)
+                sdp_host_pair(todo->pdata[i]);
+            t1 = g_get_monotonic_time();
+            shim_mark("sdp flush: replay");
+            sdp_replay(todo);
+            sst.device_ms += (t1 - t0) / 1e3;
+            sst.replay_ms += (g_get_monotonic_time() - t1) / 1e3;
+            return;
+            }
+        f = sdp_flight_prepare(todo);
+        }
+    if(f && sdp_async() && (async || sdp_in_flight)){
+        /* its device part starts now; the flight before it (if any) is landed -- joined, replayed -- beside it.  The two
+         * never share the device thread's context: the one before ran on sdp_ctx2 as well, and has to be JOINED first */
+        if(sdp_in_flight && sdp_in_flight->thread){
+            gint64 w0 = g_get_monotonic_time();
+            g_thread_join(sdp_in_flight->thread);
+            sdp_in_flight->thread = NULL;
+            sst.waited_ms += (g_get_monotonic_time() - w0) / 1e3;
+            }
+        f->async = TRUE;
+        f->thread = g_thread_new("c4gpu-sdp", sdp_flight_device, f);
+        sst.async_flushes++;
+        }
+    if(sdp_in_flight){
+        sdp_flight_land(sdp_in_flight);
+        sdp_in_flight = NULL;
+        }
+    if(f){
+        if(f->thread && async){
+            sdp_in_flight = f;
+        } else {
+            if(!f->thread)
+                sdp_flight_device(f);
+            sdp_flight_land(f);
+            }
+        }
+    return;
+    }
+
+void shim_sdp_flush(void){
+    sdp_flush_pending(FALSE);
     return;
     }
 
@@ -297,7 +427,7 @@ gboolean shim_sdp_collect(GAM *gam, Comparison *comparison){
     sdp_pending_bytes += 20.0 * (comparison->query->len + comparison->target->len);
     if(((gint)sdp_pending->len >= shim_batch_size())
     || (sdp_pending_bytes > sdp_budget_bytes()))
-        shim_sdp_flush();
+        sdp_flush_pending(TRUE);          /* more comparisons are coming: this batch runs beside them */
     return TRUE;
     }
 
@@ -331,6 +461,7 @@ Alignment *SDP_Pair_next_path(SDP_Pair *sdp_pair, C4_Score threshold){
 void shim_sdp_report(void){
     if(g_getenv("C4GPU_VERBOSE") && sst.pairs)
         g_message("c4gpu sdp: %ld pairs in %ld flush(es): %ld served from device batches (%ld alignments); batches %.0f ms, "
-                  "replay %.0f ms", sst.pairs, sst.flushes, sst.served_pairs, sst.alignments, sst.device_ms, sst.replay_ms);
+                  "replay %.0f ms; %ld flush(es) beside the main thread, which waited %.0f ms for them", sst.pairs, sst.flushes,
+                  sst.served_pairs, sst.alignments, sst.device_ms, sst.replay_ms, sst.async_flushes, sst.waited_ms);
     return;
     }

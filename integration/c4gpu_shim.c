@@ -128,7 +128,13 @@ static gpointer shim_ctx_open(gpointer data){
     if(c4gpu_abi_version() != C4GPU_ABI_VERSION)
         why = g_strdup_printf("libc4gpu.so has ABI version %d, this binary was built for %d", c4gpu_abi_version(), C4GPU_ABI_VERSION);
     else
-        ctx = c4gpu_ctx_create(g_getenv("C4GPU_DEVICE") ? atoi(g_getenv("C4GPU_DEVICE")) : shim_args.device);
+        ctx = c4gpu_ctx_create(shim_device_ordinal());
+    /* a stream of its own instead of the default one: whatever is launched in the default stream waits for every kernel
+     * that is running in ANY stream of the process -- the word scan of the next target then sat behind the SDP passes of the
+     * flight beside it for their whole 0.4 s (rocprofv3 kernel trace, profiles/r05_c5_cold.md).  C4GPU_DEFAULT_STREAM=1:
+     * the default stream, as before */
+    if(ctx && (!g_getenv("C4GPU_DEFAULT_STREAM")) && (c4gpu_ctx_own_stream(ctx) != 0))
+        g_warning("c4gpu: %s -- launching in the default stream", c4gpu_last_error());
     shim_t_ready = g_get_monotonic_time();
     g_mutex_lock(&shim_ctx_lock);
     shim_ctx = ctx;
@@ -168,6 +174,10 @@ int main(int argc, char **argv){
         _exit(rc);
         }
     return rc;
+    }
+
+gint shim_device_ordinal(void){
+    return g_getenv("C4GPU_DEVICE") ? atoi(g_getenv("C4GPU_DEVICE")) : shim_args.device;
     }
 
 c4gpu_ctx *shim_get_ctx(void){

@@ -26,6 +26,19 @@ def _run(exe, args, env=None):
     return r.stdout.decode(), r.stderr.decode()
 
 
+class _Ref:
+    """The reference binary on `args`, started at once on a host core and collected when its output is first needed: the
+    drop-in's run of the same command goes beside it instead of after it (the reference is the slower of the two)."""
+
+    def __init__(self, args):
+        self.p = subprocess.Popen([CPU_EXE] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+
+    def out(self):
+        o, e = self.p.communicate(timeout=900)
+        assert self.p.returncode == 0, e.decode()[-2000:]
+        return o.decode()
+
+
 @pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
                     reason="reference binaries are built in the build container (make -C integration)")
 @pytest.mark.parametrize("model,extra,batch", [
@@ -71,8 +84,9 @@ def test_exonerate_gpu_output_is_byte_identical(tmp_path, model, extra, batch):
     _fasta(tf, ts)
     args = ["-m", model, "-E", "yes", "--showalignment", "yes", "--showvulgar", "yes",
             "--showcigar", "yes", "-V", "0"] + ([] if "-S" in extra else ["-S", "no"]) + extra + [qf, tf]
-    ref_out, _ = _run(CPU_EXE, args)
+    ref = _Ref(args)
     gpu_out, gpu_err = _run(GPU_EXE, args, {"C4GPU_VERBOSE": "1", "C4GPU_BATCH": batch})
+    ref_out = ref.out()
     assert "c4gpu:" in gpu_err, "the GPU engine was not used:\n" + gpu_err[-1500:]
     assert ("c4gpu: batch of" in gpu_err) == (batch != "0"), gpu_err[-1500:]
     assert gpu_out == ref_out
@@ -106,8 +120,9 @@ def test_exonerate_gpu_suboptimal_alignments(tmp_path, model, batch):
     _fasta(tf, ts)
     args = ["-m", model, "-E", "yes", "-S", "yes", "--showalignment", "no", "--showvulgar", "yes", "-V", "0",
             "--score", "300", qf, tf]
-    ref_out, _ = _run(CPU_EXE, args)
+    ref = _Ref(args)
     gpu_out, gpu_err = _run(GPU_EXE, args, {"C4GPU_VERBOSE": "1", "C4GPU_BATCH": batch})
+    ref_out = ref.out()
     if batch == "0":
         assert "with blocked cells" in gpu_err        # per-call: the SubOpt_Index itself crossed the boundary
     else:
@@ -134,8 +149,9 @@ def test_exonerate_gpu_heuristic_with_refinement(tmp_path, refine):
     _fasta(qf, qs)
     _fasta(tf, ts)
     args = ["-m", "est2genome", "--refine", refine, "--showalignment", "yes", "--showvulgar", "yes", "-V", "0", qf, tf]
-    ref_out, _ = _run(CPU_EXE, args)
+    ref = _Ref(args)
     gpu_out, gpu_err = _run(GPU_EXE, args, {"C4GPU_VERBOSE": "1"})
+    ref_out = ref.out()
     assert "c4gpu: est2genome mode" in gpu_err, gpu_err[-1500:]
     assert gpu_out == ref_out
     assert ref_out.count("vulgar:") >= 3
@@ -153,8 +169,9 @@ def test_exonerate_gpu_command_line_switch(tmp_path):
     _fasta(qf, [("qy", q)])
     _fasta(tf, [("tg", dna(200) + q[:150] + "GT" + dna(400) + "AG" + q[150:] + dna(100))])
     args = ["-m", "est2genome", "-E", "yes", "-S", "no", "--showalignment", "no", "--showvulgar", "yes", "-V", "0", qf, tf]
-    ref_out, _ = _run(CPU_EXE, args)
+    ref = _Ref(args)
     off_out, off_err = _run(GPU_EXE, ["--gpu", "no"] + args, {"C4GPU_VERBOSE": "1"})
+    ref_out = ref.out()
     assert "c4gpu" not in off_err and off_out.replace("--gpu no ", "") == ref_out
     one_out, one_err = _run(GPU_EXE, ["--gpubatch", "0"] + args, {"C4GPU_VERBOSE": "1"})
     assert "c4gpu: est2genome mode" in one_err and "batch of" not in one_err
@@ -177,9 +194,10 @@ def test_multi_process_query_shards_restore_submission_order(tmp_path):
     _fasta(qf, qs)
     _fasta(tf, ts)
     args = ["-m", "est2genome", "-E", "yes", "-S", "no", "--showalignment", "no", "--showvulgar", "yes", "-V", "0", qf, tf]
-    ref_out, _ = _run(CPU_EXE, args)
+    ref = _Ref(args)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "integration", "exonerate_multigpu.py"), "--gpus", "3",
                         "--devices", "0,0,0", "--"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    ref_out = ref.out()
     assert r.returncode == 0, r.stderr.decode()[-1500:]
     assert r.stdout.decode() == ref_out
     assert ref_out.count("vulgar:") >= 7
@@ -204,8 +222,9 @@ def test_low_complexity_inputs_tie_everywhere(tmp_path, model):
     _fasta(tf, ts)
     args = ["-m", model, "-E", "yes", "-S", "no", "--showalignment", "no", "--showvulgar", "yes", "--showcigar", "yes",
             "-V", "0", qf, tf]
-    ref_out, _ = _run(CPU_EXE, args)
+    ref = _Ref(args)
     gpu_out, gpu_err = _run(GPU_EXE, args, {"C4GPU_VERBOSE": "1"})
+    ref_out = ref.out()
     assert "c4gpu: batch of" in gpu_err
     assert gpu_out == ref_out
     assert ref_out.count("vulgar:") >= 4
@@ -227,8 +246,9 @@ def test_selenocysteine_stays_in_the_device_batch(tmp_path):
     _fasta(qf, qs)
     _fasta(tf, ts)
     args = ["-m", "affine:local", "-E", "yes", "-S", "no", "--showalignment", "yes", "--showvulgar", "yes", "-V", "0", qf, tf]
-    ref_out, _ = _run(CPU_EXE, args)
+    ref = _Ref(args)
     gpu_out, gpu_err = _run(GPU_EXE, args, {"C4GPU_VERBOSE": "1"})
+    ref_out = ref.out()
     assert gpu_out == ref_out and ref_out.count("vulgar:") == 4
     assert "batch of 4 pairs" in gpu_err and "using the CPU Viterbi" not in gpu_err, gpu_err[-1500:]
 
@@ -255,8 +275,9 @@ def test_c1_protein_heuristic_run_takes_the_sdp_batches(tmp_path):
     _fasta(tf, [("tg", "".join(target)[:10000])])
     args = ["-m", "affine:local", "--querytype", "protein", "--targettype", "protein", "--showalignment", "yes",
             "--showvulgar", "yes", "-V", "0", qf, tf]
-    ref_out, _ = _run(CPU_EXE, args)
+    ref = _Ref(args)
     gpu_out, gpu_err = _run(GPU_EXE, args, {"C4GPU_VERBOSE": "1"})
+    ref_out = ref.out()
     assert gpu_out == ref_out
     assert ref_out.count("vulgar:") >= 20
     m = re.search(r"c4gpu sdp: (\d+) pairs in (\d+) flush\(es\): (\d+) served from device batches \((\d+) alignments\)", gpu_err)
@@ -319,6 +340,14 @@ def test_heuristic_sdp_mode_takes_its_alignments_from_device_batches(tmp_path, m
     pairs, flushes, served_pairs, alignments = hb.sdp_served(err)
     assert served_pairs == pairs >= 6 and alignments >= 6
     assert "c4gpu hsp:" in err
+    if batch == "3":
+        # flushes cut in the middle of the run go to the device on a thread and a context of their own while the main thread
+        # carries on with the comparisons behind them (c4gpu_sdp.c); C4GPU_SDP_ASYNC=0: every flush on the main thread
+        m = re.search(r"(\d+) flush\(es\) beside the main thread", err)
+        assert m and int(m.group(1)) >= 1 and flushes >= 2, err[-800:]
+        ref, gpu, err = hb.run_pair(tmp_path, model, ["--gappedextension", "yes"] + extra,
+                                    {"C4GPU_BATCH": batch, "C4GPU_SDP_ASYNC": "0"}, n=8, seed=21)
+        assert gpu == ref and " 0 flush(es) beside the main thread" in err, err[-800:]
     if model == "est2genome" and not extra:
         # an arena too small for some pairs (C4GPU_SDP_ARENA_MB: a test hook; the second round's arena is eight times the
         # size): those pairs are run again or handed back to the reference's scheduler one by one, the output stays identical
@@ -342,8 +371,9 @@ def test_heuristic_bsdp_on_north_star_shaped_input(tmp_path):
     _fasta(tf, [("t%d" % k, t.decode()) for k, (q, t) in enumerate(pairs)])
     args = ["-m", "est2genome", "--gappedextension", "no", "--refine", "region", "-S", "no", "--showalignment", "yes",
             "--showvulgar", "yes", "-V", "0", qf, tf]
-    ref_out, _ = _run(CPU_EXE, args)
+    ref = _Ref(args)
     gpu_out, gpu_err = _run(GPU_EXE, args, {"C4GPU_VERBOSE": "1"})
+    ref_out = ref.out()
     assert gpu_out == ref_out and ref_out.count("vulgar:") >= 6
     s_ok, s_all, p_ok, p_all = hb.served(gpu_err)
     assert s_ok + p_ok >= 0.95 * (s_all + p_all), gpu_err[-800:]
