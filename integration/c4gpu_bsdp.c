@@ -418,7 +418,7 @@ static void bsdp_host_scores(ShimHPending *hp){
             g_hash_table_insert(seen, opts[o], opts[o]);
             if((!shim_flatten_any(m, ud, &fm, TRUE)) || (c4gpu_model_device_family(&fm) < 0))
                 g_warning("c4gpu bsdp: model [%s] has no device family", m->name);
-            else if(g_getenv("C4GPU_VERBOSE"))
+            else if(shim_env("C4GPU_VERBOSE"))
                 g_message("c4gpu bsdp: model [%s] -> device family %d", m->name, c4gpu_model_device_family(&fm));
             }
         }
@@ -779,7 +779,7 @@ void shim_bsdp_flush(void){
     bsdp_mode = BSDP_OFF;
     t1 = g_get_monotonic_time();
     /* 3. all candidate DPs of all pairs */
-    if(g_getenv("C4GPU_BSDP_HOST")){
+    if(shim_env("C4GPU_BSDP_HOST")){
         for(i = 0; i < todo->len; i++)
             bsdp_host_scores(todo->pdata[i]);
         have_scores = TRUE;
@@ -801,7 +801,7 @@ void shim_bsdp_flush(void){
         }
     /* 3b. --refine: the first refinement of every pair as one more batch on the same resident pairs */
     if(have_scores && (((ShimHPending*)todo->pdata[0])->gam->gas->refinement != GAM_Refinement_NONE)
-    && ((ShimHPending*)todo->pdata[0])->gam->optimal && (!g_getenv("C4GPU_REFINE_BATCH_OFF")))
+    && ((ShimHPending*)todo->pdata[0])->gam->optimal && (!shim_env("C4GPU_REFINE_BATCH_OFF")))
         bsdp_refine(todo, batch);
     if(batch)
         c4gpu_batch_destroy(batch);
@@ -842,8 +842,8 @@ GAM_Result *GAM_Result_heuristic_create(GAM *gam, Comparison *comparison){
     register gboolean batchable = (shim_batch_size() > 0) && (!gam->gas->use_gapped_extension) && gam->heuristic
         && (bsdp_mode == BSDP_OFF)
         && (!Comparison_Param_get_HSPSet_Argument_Set(comparison->param)->geneseed_threshold)
-        && (g_getenv("C4GPU_BSDP_HOST") || (shim_ctx_nowait() != NULL))
-        && (!g_getenv("C4GPU_BSDP_OFF"));
+        && (shim_env("C4GPU_BSDP_HOST") || (shim_ctx_nowait() != NULL))
+        && (!shim_env("C4GPU_BSDP_OFF"));
     /* --gappedextension yes: the SDP seam (c4gpu_sdp.c) takes the pairs of the models it covers */
     if(gam->gas->use_gapped_extension && (bsdp_mode == BSDP_OFF) && (!shim_sdp_replaying())
     && shim_sdp_collect(gam, comparison))
@@ -872,7 +872,7 @@ GAM_Result *GAM_Result_heuristic_create(GAM *gam, Comparison *comparison){
     }
 
 void shim_bsdp_report(void){
-    if(g_getenv("C4GPU_VERBOSE") && st.pairs)
+    if(shim_env("C4GPU_VERBOSE") && st.pairs)
         g_message("c4gpu bsdp: %ld pairs in %ld flush(es): %ld candidate sub-DPs (%ld spans) in device batches; "
                   "%ld of %ld score calls and %ld of %ld path calls served from them; %ld of %ld refinements from "
                   "refinement batches; dry runs %.0f ms, device %.0f ms, refinement %.0f ms, replay %.0f ms", st.pairs,

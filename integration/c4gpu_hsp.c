@@ -44,7 +44,7 @@ static gint hsp_match_kind(HSPset *hsp_set){
 static gboolean hsp_eligible(HSPset *hsp_set){
     static gint off = -1;
     if(off < 0)
-        off = g_getenv("C4GPU_HSP_OFF") ? 1 : 0;
+        off = shim_env("C4GPU_HSP_OFF") ? 1 : 0;
     if(off || (!hsp_set->horizon) || (hsp_set->param->seed_repeat > 1) || (hsp_match_kind(hsp_set) < 0))
         return FALSE;
     /* the mask functions are always set (match.c:670,679) and ask the sequence's alphabet: without --softmaskquery /
@@ -58,7 +58,7 @@ static gboolean hsp_eligible(HSPset *hsp_set){
      * being opened, shim_ctx_nowait) stays with that function: the replay starts from an empty set */
     if(!hsp_set->is_empty)
         return FALSE;
-    return g_getenv("C4GPU_HSP_HOST") || (shim_ctx_nowait() != NULL);
+    return shim_env("C4GPU_HSP_HOST") || (shim_ctx_nowait() != NULL);
     }
 
 void HSPset_seed_hsp(HSPset *hsp_set, guint query_start, guint target_start){
@@ -167,7 +167,7 @@ static void hsp_flush(void){
      * device a chain's seeds are taken in order and the ones below the running horizon are not extended at all
      * (c4gpu_hsp_extend_chains): a long identical diagonal costs one extension instead of one per word hit.
      * C4GPU_HSP_CHAIN=0: every seed is extended and the replay alone applies the horizon */
-    if(!g_getenv("C4GPU_HSP_HOST") && !(g_getenv("C4GPU_HSP_CHAIN") && !atoi(g_getenv("C4GPU_HSP_CHAIN")))){
+    if(!shim_env("C4GPU_HSP_HOST") && !(shim_env("C4GPU_HSP_CHAIN") && !atoi(shim_env("C4GPU_HSP_CHAIN")))){
         register GArray *h0 = g_array_new(FALSE, FALSE, sizeof(gint32));
         chain_of = g_new(gint32, total + 1);
         for(i = 0; i < n_sets; i++){
@@ -203,7 +203,7 @@ static void hsp_flush(void){
         n_chains = h0->len;
         horizon0 = (gint32*)g_array_free(h0, FALSE);
         }
-    if(g_getenv("C4GPU_HSP_HOST")){
+    if(shim_env("C4GPU_HSP_HOST")){
         /* the reference's own extension, one scratch HSPset per seed (nothing in its way) */
         for(i = 0; i < n_sets; i++){
             register ShimSeedSet *ss = hsp_order->pdata[i];
@@ -301,7 +301,7 @@ HSPset *HSPset_finalise(HSPset *hsp_set){
     }
 
 void shim_hsp_report(void){
-    if(g_getenv("C4GPU_VERBOSE") && hst.sets)
+    if(shim_env("C4GPU_VERBOSE") && hst.sets)
         g_message("c4gpu hsp: %ld word hits of %ld HSP sets extended in %ld device batch(es) (%.0f ms incl. flattening and "
                   "replay), %ld HSPs passed their horizon", hst.seeds, hst.sets, hst.flushes, hst.device_ms, hst.stored);
     return;

@@ -52,8 +52,8 @@ static gdouble sdp_budget_bytes(void){
     if(budget <= 0.0){
         int64_t mem = 0;
         register c4gpu_ctx *ctx = shim_get_ctx();
-        if(g_getenv("C4GPU_SDP_GB"))
-            budget = atof(g_getenv("C4GPU_SDP_GB")) * 1e9;
+        if(shim_env("C4GPU_SDP_GB"))
+            budget = atof(shim_env("C4GPU_SDP_GB")) * 1e9;
         else if(ctx && (c4gpu_ctx_device_info(ctx, NULL, 0, NULL, &mem) == 0) && (mem > 0))
             budget = MIN(0.8 * (gdouble)mem, 120e9);
         else
@@ -65,7 +65,7 @@ static ShimSdpPending *sdp_cur = NULL;
 static struct { long pairs, served_pairs, alignments, flushes, async_flushes; double device_ms, replay_ms, waited_ms; } sst;
 
 static gboolean sdp_eligible(GAM *gam, Comparison *comparison){
-    if((shim_batch_size() <= 0) || g_getenv("C4GPU_SDP_OFF") || sdp_cur)
+    if((shim_batch_size() <= 0) || shim_env("C4GPU_SDP_OFF") || sdp_cur)
         return FALSE;
     if((!gam->gas->use_gapped_extension) || (!gam->sdp))
         return FALSE;
@@ -75,7 +75,7 @@ static gboolean sdp_eligible(GAM *gam, Comparison *comparison){
         return FALSE;
     if(Comparison_Param_get_HSPSet_Argument_Set(comparison->param)->geneseed_threshold)
         return FALSE;
-    if((!g_getenv("C4GPU_SDP_HOST")) && (!shim_ctx_nowait()))
+    if((!shim_env("C4GPU_SDP_HOST")) && (!shim_ctx_nowait()))
         return FALSE;
     return TRUE;
     }
@@ -172,7 +172,7 @@ static c4gpu_ctx *sdp_ctx2 = NULL;            /* the flight thread's context (ow
 static gboolean sdp_async(void){
     static gint on = -1;
     if(on < 0)
-        on = (g_getenv("C4GPU_SDP_ASYNC") && (atoi(g_getenv("C4GPU_SDP_ASYNC")) == 0)) ? 0 : 1;
+        on = (shim_env("C4GPU_SDP_ASYNC") && (atoi(shim_env("C4GPU_SDP_ASYNC")) == 0)) ? 0 : 1;
     return on;
     }
 
@@ -335,7 +335,7 @@ static void sdp_flush_pending(gboolean async){
         sdp_pending_bytes = 0.0;
         sst.flushes++;
         shim_mark("sdp flush: batch");
-        if(g_getenv("C4GPU_SDP_HOST")){
+        if(shim_env("C4GPU_SDP_HOST")){
             register guint i;
             gint64 t0 = g_get_monotonic_time(), t1;
             if(sdp_in_flight){
@@ -459,7 +459,7 @@ Alignment *SDP_Pair_next_path(SDP_Pair *sdp_pair, C4_Score threshold){
     }
 
 void shim_sdp_report(void){
-    if(g_getenv("C4GPU_VERBOSE") && sst.pairs)
+    if(shim_env("C4GPU_VERBOSE") && sst.pairs)
         g_message("c4gpu sdp: %ld pairs in %ld flush(es): %ld served from device batches (%ld alignments); batches %.0f ms, "
                   "replay %.0f ms; %ld flush(es) beside the main thread, which waited %.0f ms for them", sst.pairs, sst.flushes,
                   sst.served_pairs, sst.alignments, sst.device_ms, sst.replay_ms, sst.async_flushes, sst.waited_ms);

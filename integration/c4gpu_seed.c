@@ -151,7 +151,7 @@ static gboolean seed_worth_it(ShimSeedTab *st, Sequence *target){
     register Seeder *seeder = st->seeder;
     register gdouble nodes = seeder->seeder_fsm ? (gdouble)seeder->seeder_fsm->fsm->chunk_count
                                                 : (gdouble)seeder->seeder_vfsm->vfsm->lrw / 64.0;
-    register gdouble factor = g_getenv("C4GPU_SEED_FACTOR") ? atof(g_getenv("C4GPU_SEED_FACTOR")) : 4.0;
+    register gdouble factor = shim_env("C4GPU_SEED_FACTOR") ? atof(shim_env("C4GPU_SEED_FACTOR")) : 4.0;
     return (gdouble)(st->walked + target->len) >= factor * nodes;
     }
 
@@ -215,7 +215,7 @@ static gboolean seed_build(ShimSeedTab *st){
         g_free(word);
         }
     seeder->is_prepared = TRUE;
-    if(g_getenv("C4GPU_SEED_HOST")){
+    if(shim_env("C4GPU_SEED_HOST")){
         st->host_index = g_hash_table_new(g_int64_hash, g_int64_equal);
         for(i = 0; i < (gint)st->codes->len; i++)
             g_hash_table_insert(st->host_index, &g_array_index(st->codes, guint64, i), GINT_TO_POINTER(i + 1));
@@ -344,9 +344,9 @@ void Seeder_add_target(Seeder *seeder, Sequence *target){
     gboolean ok = TRUE;
     static gint off = -1;
     if(off < 0)
-        off = (g_getenv("C4GPU_SEED_OFF") || (shim_batch_size() <= 0)) ? 1 : 0;
+        off = (shim_env("C4GPU_SEED_OFF") || (shim_batch_size() <= 0)) ? 1 : 0;
     shim_mark("Seeder_add_target");
-    if((!off) && (g_getenv("C4GPU_SEED_HOST") || shim_ctx_nowait())){
+    if((!off) && (shim_env("C4GPU_SEED_HOST") || shim_ctx_nowait())){
         st = seed_state(seeder);
         if(st->hopeless)
             st = NULL;
@@ -366,7 +366,7 @@ void Seeder_add_target(Seeder *seeder, Sequence *target){
         Seeder_add_target_cpu(seeder, target);
         return;
         }
-    if(g_getenv("C4GPU_SEED_CHECK")){
+    if(shim_env("C4GPU_SEED_CHECK")){
         /* the reference's own walk first, its seeds written down instead of extended (no set becomes non-empty, so its
          * report loop finds nothing to report) */
         theirs = seed_record = g_array_new(FALSE, FALSE, sizeof(ShimSeedRec));
@@ -463,10 +463,10 @@ void Seeder_destroy(Seeder *seeder){
     }
 
 void shim_seed_report(void){
-    if(g_getenv("C4GPU_VERBOSE") && sdst.cpu_targets)
+    if(shim_env("C4GPU_VERBOSE") && sdst.cpu_targets)
         g_message("c4gpu seed: %ld targets left to the reference's walk (their seeder's word table was not worth reading yet)",
                   sdst.cpu_targets);
-    if(g_getenv("C4GPU_VERBOSE") && sdst.targets)
+    if(shim_env("C4GPU_VERBOSE") && sdst.targets)
         g_message("c4gpu seed: %ld targets walked in %ld device scans (%ld symbols): %ld word hits; scans %.0f ms, "
                   "delivery %.0f ms, word tables (%ld words, %ld emissions) %.0f ms%s", sdst.targets, sdst.scans, sdst.symbols,
                   sdst.hits, sdst.scan_ms, sdst.host_ms, sdst.words, sdst.emits, sdst.table_ms,

@@ -67,11 +67,65 @@ Codegen_ArgumentSet *Codegen_ArgumentSet_create(Argument *arg){
  * then run beside the host's own start-up work (reading the queries, building the word automaton) instead of in front of
  * the first batch.  shim_get_ctx waits for the context only; the code-object loads go on in the background. */
 static gint64 shim_t0 = 0, shim_t_open = 0, shim_t_ready = 0, shim_t_warm = 0, shim_waited = 0;
-static void __attribute__((constructor)) shim_clock_start(void){ shim_t0 = g_get_monotonic_time(); }
+/* C4GPU_SEGV_TRACE=1: a SIGSEGV / SIGABRT writes the faulting thread's stack to stderr before the default action (the way out of
+ * short runs has ended in the runtime's own threads before: see shim_exit) */
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+static void shim_fault(int sig){
+    void *frames[48];
+    static const char head[] = "c4gpu: fatal signal, stack of the faulting thread:\n";
+    register int n = backtrace(frames, 48);
+    if(write(2, head, sizeof(head) - 1) < 0)
+        n = n + 0;
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+    }
+/* The process's C4GPU_* variables, copied once before main (one thread, nothing else running) and read from the copy ever after.
+ * getenv walks `environ` without a lock, and the HIP / HSA start-up on the device thread ADDS variables (setenv moves the array):
+ * the main thread's look-ups in the seams' hot paths (one per seeded HSP) then ran into freed memory -- SIGSEGV inside getenv in
+ * 3 % of the 0.3 s heuristic runs that overlap the device's start-up (tools/gpu_small_work_stress.sh: 9 of 300 before, 0 after). */
+extern char **environ;
+static struct { gchar *name, *value; } *shim_env_copy = NULL;
+static gint shim_env_n = 0;
+const gchar *shim_env(const gchar *name){
+    register gint i;
+    for(i = 0; i < shim_env_n; i++)
+        if(!strcmp(shim_env_copy[i].name, name))
+            return shim_env_copy[i].value;
+    return NULL;
+    }
+static void shim_env_snapshot(void){
+    register char **e;
+    register gint n = 0;
+    for(e = environ; e && *e; e++)
+        if(!strncmp(*e, "C4GPU_", 6))
+            n++;
+    shim_env_copy = calloc(n + 1, sizeof(*shim_env_copy));
+    for(e = environ; e && *e; e++){
+        register const char *eq = strchr(*e, '=');
+        if(strncmp(*e, "C4GPU_", 6) || !eq)
+            continue;
+        shim_env_copy[shim_env_n].name = strndup(*e, eq - *e);
+        shim_env_copy[shim_env_n].value = strdup(eq + 1);
+        shim_env_n++;
+        }
+    return;
+    }
+static void __attribute__((constructor)) shim_clock_start(void){
+    shim_t0 = g_get_monotonic_time();
+    shim_env_snapshot();
+    if(shim_env("C4GPU_SEGV_TRACE")){
+        signal(SIGSEGV, shim_fault);
+        signal(SIGABRT, shim_fault);
+        signal(SIGBUS, shim_fault);
+        }
+    }
 void shim_mark(const gchar *what){          /* C4GPU_TRACE: where the wall time of a run goes */
     static gint on = -1;
     if(on < 0)
-        on = g_getenv("C4GPU_TRACE") ? 1 : 0;
+        on = shim_env("C4GPU_TRACE") ? 1 : 0;
     if(on)
         g_printerr("c4gpu mark: %8.1f ms  %s\n", (g_get_monotonic_time() - shim_t0) / 1e3, what);
     return;
@@ -96,7 +150,7 @@ static gchar *shim_ctx_error = NULL;
  * C4GPU_FAST_EXIT=0 takes the ordinary exit (handlers and all). */
 static gboolean shim_joined = FALSE;
 static gboolean shim_fast_exit(void){
-    register const gchar *e = g_getenv("C4GPU_FAST_EXIT");
+    register const gchar *e = shim_env("C4GPU_FAST_EXIT");
     return shim_ctx_thread && !(e && e[0] == '0');
     }
 static void shim_quiesce(void){
@@ -129,11 +183,9 @@ static gpointer shim_ctx_open(gpointer data){
         why = g_strdup_printf("libc4gpu.so has ABI version %d, this binary was built for %d", c4gpu_abi_version(), C4GPU_ABI_VERSION);
     else
         ctx = c4gpu_ctx_create(shim_device_ordinal());
-    /* a stream of its own instead of the default one: whatever is launched in the default stream waits for every kernel
-     * that is running in ANY stream of the process -- the word scan of the next target then sat behind the SDP passes of the
-     * flight beside it for their whole 0.4 s (rocprofv3 kernel trace, profiles/r05_c5_cold.md).  C4GPU_DEFAULT_STREAM=1:
-     * the default stream, as before */
-    if(ctx && (!g_getenv("C4GPU_DEFAULT_STREAM")) && (c4gpu_ctx_own_stream(ctx) != 0))
+    /* C4GPU_OWN_STREAM=1: a stream of its own instead of the default one (tried while looking for what held the word scans up
+     * beside an SDP flight, profiles/r05_c5_cold.md: it was not the default stream, and the default stays) */
+    if(ctx && shim_env("C4GPU_OWN_STREAM") && (c4gpu_ctx_own_stream(ctx) != 0))
         g_warning("c4gpu: %s -- launching in the default stream", c4gpu_last_error());
     shim_t_ready = g_get_monotonic_time();
     g_mutex_lock(&shim_ctx_lock);
@@ -145,7 +197,7 @@ static gpointer shim_ctx_open(gpointer data){
     shim_ctx_ready = TRUE;
     g_cond_broadcast(&shim_ctx_cond);
     g_mutex_unlock(&shim_ctx_lock);
-    if(ctx && !g_getenv("C4GPU_NO_WARM"))
+    if(ctx && !shim_env("C4GPU_NO_WARM"))
         c4gpu_ctx_warm(ctx);
     shim_t_warm = g_get_monotonic_time();
     return NULL;
@@ -155,8 +207,8 @@ static void shim_start_ctx(void){
     if(shim_tried)
         return;
     shim_tried = TRUE;
-    shim_verbose = (g_getenv("C4GPU_VERBOSE") != NULL);
-    if((!shim_args.use_gpu) || g_getenv("C4GPU_DISABLE"))
+    shim_verbose = (shim_env("C4GPU_VERBOSE") != NULL);
+    if((!shim_args.use_gpu) || shim_env("C4GPU_DISABLE"))
         return;
     g_mutex_lock(&shim_ctx_lock);
     shim_ctx_thread = g_thread_new("c4gpu-ctx", shim_ctx_open, NULL);
@@ -177,7 +229,7 @@ int main(int argc, char **argv){
     }
 
 gint shim_device_ordinal(void){
-    return g_getenv("C4GPU_DEVICE") ? atoi(g_getenv("C4GPU_DEVICE")) : shim_args.device;
+    return shim_env("C4GPU_DEVICE") ? atoi(shim_env("C4GPU_DEVICE")) : shim_args.device;
     }
 
 c4gpu_ctx *shim_get_ctx(void){
@@ -212,7 +264,7 @@ c4gpu_ctx *shim_get_ctx(void){
 c4gpu_ctx *shim_ctx_nowait(void){
     register gboolean ready;
     shim_start_ctx();
-    if((!shim_ctx_thread) || g_getenv("C4GPU_WAIT"))
+    if((!shim_ctx_thread) || shim_env("C4GPU_WAIT"))
         return shim_get_ctx();
     g_mutex_lock(&shim_ctx_lock);
     ready = shim_ctx_ready;
@@ -396,7 +448,7 @@ static C4_Score shim_dp(C4_Model *model, Region *region, Viterbi_Data *vd, SubOp
     c4gpu_subopt *blocked = NULL;
     static gdouble min_cells = -1.0;
     if(min_cells < 0.0)
-        min_cells = g_getenv("C4GPU_MIN_CELLS") ? atof(g_getenv("C4GPU_MIN_CELLS")) : 1e5;
+        min_cells = shim_env("C4GPU_MIN_CELLS") ? atof(shim_env("C4GPU_MIN_CELLS")) : 1e5;
     /* a single small rectangle is faster on the host than one launch + copies (a batch is another matter) */
     if(cpu_func && (((gdouble)region->query_length + 1.0) * ((gdouble)region->target_length + 1.0) < min_cells))
         return cpu_func(model, region, vd, soi, user_data);
@@ -575,7 +627,7 @@ gpointer Bootstrapper_lookup(gchar *name){
     register int mode = shim_mode_of(name);
     register Viterbi_DP_Func cpu = (Viterbi_DP_Func)Bootstrapper_lookup_cpu(name);
     /* only the Optimal (full Viterbi) functions are ours: "optimal_58_<model>_32_find_32_<mode>" */
-    if((mode < 0) || strncmp(name, "optimal_58_", 11) || g_getenv("C4GPU_DISABLE") || (!shim_args.use_gpu))
+    if((mode < 0) || strncmp(name, "optimal_58_", 11) || shim_env("C4GPU_DISABLE") || (!shim_args.use_gpu))
         return (gpointer)cpu;
     /* no compiled CPU function of this name (the archive was built without the model) and no device either: leave
      * the slot empty, Viterbi_calculate then runs the reference's interpreted loop (viterbi.c:855-859) */
@@ -628,7 +680,7 @@ static gint shim_replay_call = 0;
 gint shim_batch_size(void){
     static gint size = -1;
     if(size < 0)
-        size = g_getenv("C4GPU_BATCH") ? atoi(g_getenv("C4GPU_BATCH")) : shim_args.batch;
+        size = shim_env("C4GPU_BATCH") ? atoi(shim_env("C4GPU_BATCH")) : shim_args.batch;
     return size;
     }
 
@@ -705,18 +757,26 @@ typedef struct {
     c4gpu_score *per_pair;            /* --percent thresholds, or NULL */
     GThread *thread;
     gint rounds_done;
+    gint slot;                        /* which of the two resident batches carries it */
     gchar *error;
     gint64 t_start, t_prepared, t_dev0, t_dev1;
 } ShimFlushJob;
 
-static GMutex shim_device_lock;           /* one batch on the device at a time */
+/* One batch on the device at a time.  C4GPU_SLOTS=2 (an experiment that stays opt-in): TWO resident batches (slots), taken in turn
+ * by the flushes, so that the device part of a flush starts beside the batch before it; slot 1 has a context and a stream of its
+ * own.  Measured on config 4 through the command line (64 x 64, two flushes of 2 048): the two device parts take 841 + 941 ms side
+ * by side against 709 + 627 ms one after the other -- end of the run at 1 675 / 1 957 / 3 067 ms against 1 751 / 1 833 / 1 907 ms:
+ * 0.08-0.15 s gained at best, and one run in three lost a second in a stalled allocation beside the other batch's kernels. */
+static GMutex shim_device_lock[2];
+static c4gpu_ctx *shim_ctx2 = NULL;
+static guint shim_flush_seq = 0;
 static ShimFlushJob *shim_in_flight = NULL;
 static volatile gint shim_device_busy = 0;        /* a flush thread is between taking and releasing the device */
 
 static gboolean shim_async(void){
     static gint on = -1;
     if(on < 0)
-        on = (g_getenv("C4GPU_ASYNC") && (atoi(g_getenv("C4GPU_ASYNC")) == 0)) ? 0 : 1;
+        on = (shim_env("C4GPU_ASYNC") && (atoi(shim_env("C4GPU_ASYNC")) == 0)) ? 0 : 1;
     return on;
     }
 
@@ -732,6 +792,7 @@ static ShimFlushJob *shim_flush_prepare(void){
     shim_pending = NULL;          /* pairs submitted from here on start a new collection */
     shim_pending_bytes = 0.0;
     job = g_new0(ShimFlushJob, 1);
+    job->slot = (shim_env("C4GPU_SLOTS") && (atoi(shim_env("C4GPU_SLOTS")) == 2)) ? (gint)(shim_flush_seq++ & 1) : 0;
     job->t_start = g_get_monotonic_time();
     job->todo = todo;
     n = job->n = todo->len;
@@ -739,7 +800,7 @@ static ShimFlushJob *shim_flush_prepare(void){
     job->gam = sp->gam;
     job->threshold = job->gam->gas->threshold;
     job->dpmemory = job->gam->optimal->find_path->vas->traceback_memory_limit;
-    job->rounds_max = g_getenv("C4GPU_BATCH_ROUNDS") ? atoi(g_getenv("C4GPU_BATCH_ROUNDS")) : 4;
+    job->rounds_max = shim_env("C4GPU_BATCH_ROUNDS") ? atoi(shim_env("C4GPU_BATCH_ROUNDS")) : 4;
     if(!job->gam->gas->use_subopt)
         job->rounds_max = 1;
     job->pair = g_new0(c4gpu_pair, n);
@@ -799,14 +860,31 @@ static gpointer shim_flush_device(gpointer data){
      * page-locked buffers and swaps them into the batch, which keeps its engine, launch lanes and launch buffers -- a batch
      * created and destroyed per flush allocated and freed ~15 GB of device memory each time (the second 2 048-pair flush of a
      * run took 1 630 ms on the device where the passes themselves take 520) */
-    static c4gpu_batch *res_batch = NULL;
-    static c4gpu_stage *res_stage = NULL;
-    static c4gpu_model res_fm;
-    static c4gpu_params res_params;
-    g_mutex_lock(&shim_device_lock);
-    g_atomic_int_set(&shim_device_busy, 1);
+    static c4gpu_batch *res_batches[2] = {NULL, NULL};
+    static c4gpu_stage *res_stages[2] = {NULL, NULL};
+    static c4gpu_model res_fms[2];
+    static c4gpu_params res_paramss[2];
+    register gint slot = job->slot;
+    register c4gpu_ctx *ctx;
+#define res_batch  res_batches[slot]
+#define res_stage  res_stages[slot]
+#define res_fm     res_fms[slot]
+#define res_params res_paramss[slot]
+    g_mutex_lock(&shim_device_lock[slot]);
+    g_atomic_int_inc(&shim_device_busy);
     job->t_dev0 = g_get_monotonic_time();
-    if(job->flattened){
+    ctx = shim_ctx;
+    if(slot == 1){
+        if(!shim_ctx2){
+            shim_ctx2 = c4gpu_ctx_create(shim_device_ordinal());
+            if(shim_ctx2 && (c4gpu_ctx_own_stream(shim_ctx2) != 0)){
+                c4gpu_ctx_destroy(shim_ctx2);
+                shim_ctx2 = NULL;
+                }
+            }
+        ctx = shim_ctx2;
+        }
+    if(job->flattened && ctx){
         if(res_stage && (memcmp(&res_fm, &job->fm, sizeof(res_fm)) || memcmp(&res_params, &job->params, sizeof(res_params)))){
             if(res_batch)
                 c4gpu_batch_destroy(res_batch);
@@ -817,17 +895,21 @@ static gpointer shim_flush_device(gpointer data){
         if(!res_stage){
             res_fm = job->fm;
             res_params = job->params;
-            res_stage = c4gpu_stage_create(shim_ctx, &res_fm, &res_params);
+            res_stage = c4gpu_stage_create(ctx, &res_fm, &res_params);
             }
         if(res_stage && (c4gpu_stage_load(res_stage, job->pair, n) == 0)){
             if(!res_batch)
-                res_batch = c4gpu_batch_create(shim_ctx, &res_fm, &res_params, job->pair, 1);      /* (swapped out at once) */
+                res_batch = c4gpu_batch_create(ctx, &res_fm, &res_params, job->pair, 1);      /* (swapped out at once) */
             if(res_batch && (c4gpu_batch_swap_stage(res_batch, res_stage) == 0)){
                 batch = res_batch;
                 c4gpu_batch_set_thresholds(batch, NULL);
                 }
             }
         }
+#undef res_batch
+#undef res_stage
+#undef res_fm
+#undef res_params
     if(batch && job->per_pair)
         c4gpu_batch_set_thresholds(batch, job->per_pair);
     if(batch && (c4gpu_batch_run(batch, 2, job->dpmemory, job->threshold) == 0)){
@@ -855,8 +937,8 @@ static gpointer shim_flush_device(gpointer data){
         job->error = g_strdup(c4gpu_last_error());
         }
     job->t_dev1 = g_get_monotonic_time();
-    g_atomic_int_set(&shim_device_busy, 0);
-    g_mutex_unlock(&shim_device_lock);
+    (void)g_atomic_int_dec_and_test(&shim_device_busy);
+    g_mutex_unlock(&shim_device_lock[slot]);
     return NULL;
     }
 
@@ -913,10 +995,10 @@ static void shim_flush_replay(ShimFlushJob *job){
         }
     g_ptr_array_free(job->todo, TRUE);
     if(shim_verbose)
-        g_message("c4gpu: flush of %d pairs: %.0f ms flattening, %.0f ms on the device (upload, passes, read-back; started %.0f ms after "
+        g_message("c4gpu: flush of %d pairs: %.0f ms flattening, %.0f ms on the device (upload, passes, read-back; slot %d, started %.0f ms after "
                   "the flush, the main thread waited %.0f ms for it), %.0f ms replaying through the reference "
                   "(GAM_Result_exhaustive_create %.0f, GAM_Result_submit %.0f, GAM_Result_destroy %.0f ms)", n,
-                  (job->t_prepared - job->t_start) / 1e3, (job->t_dev1 - job->t_dev0) / 1e3, (job->t_dev0 - job->t_prepared) / 1e3,
+                  (job->t_prepared - job->t_start) / 1e3, (job->t_dev1 - job->t_dev0) / 1e3, job->slot, (job->t_dev0 - job->t_prepared) / 1e3,
                   (t_rep0 - t_wait0) / 1e3, (g_get_monotonic_time() - t_rep0) / 1e3, t_rep_create / 1e3, t_rep_submit / 1e3,
                   t_rep_destroy / 1e3);
     g_free(job->error);
@@ -965,7 +1047,7 @@ static void shim_flush_async(void){
  * pair of the all-against-all run.  Every other caller (hpair.c:805, any run with -S yes) reaches the reference's function. */
 extern void SubOpt_add_alignment_cpu(SubOpt *subopt, Alignment *alignment);
 void SubOpt_add_alignment(SubOpt *subopt, Alignment *alignment){
-    if(shim_replay_pair && (!shim_replay_pair->gam->gas->use_subopt) && !g_getenv("C4GPU_KEEP_SUBOPT"))
+    if(shim_replay_pair && (!shim_replay_pair->gam->gas->use_subopt) && !shim_env("C4GPU_KEEP_SUBOPT"))
         return;
     SubOpt_add_alignment_cpu(subopt, alignment);
     return;
@@ -992,7 +1074,7 @@ GAM_Result *GAM_Result_exhaustive_create(GAM *gam, Sequence *query, Sequence *ta
     /* residues + codes + 4 int32 splice arrays + tn4 per target position; flush well inside the HBM */
     shim_pending_bytes += 22.0 * target->len + 2.0 * query->len;
     if(((gint)shim_pending->len >= shim_batch_size())
-    || (shim_pending_bytes > (g_getenv("C4GPU_BATCH_GB") ? atof(g_getenv("C4GPU_BATCH_GB")) : 96.0) * 1e9))
+    || (shim_pending_bytes > (shim_env("C4GPU_BATCH_GB") ? atof(shim_env("C4GPU_BATCH_GB")) : 96.0) * 1e9))
         shim_flush_async();
     /* C4GPU_EAGER=1 (off by default): also whenever the device has nothing to do and an eighth of --gpubatch (at least 256 pairs)
      * has collected, so that the first pairs of a run go to the device while the front end is still reading the rest.  Measured
@@ -1000,7 +1082,7 @@ GAM_Result *GAM_Result_exhaustive_create(GAM *gam, Sequence *query, Sequence *ta
      * three -- the small first batch sizes the launch buffers, and the full batches behind it grow them in the middle of a run */
     else if(shim_async() && (!g_atomic_int_get(&shim_device_busy))
          && ((gint)shim_pending->len >= MAX(256, shim_batch_size() / 8))
-         && g_getenv("C4GPU_EAGER") && (atoi(g_getenv("C4GPU_EAGER")) != 0))
+         && shim_env("C4GPU_EAGER") && (atoi(shim_env("C4GPU_EAGER")) != 0))
         shim_flush_async();
     return NULL;                  /* the result is submitted by the flush, in submission order */
     }

@@ -12,6 +12,7 @@
 #include "c4gpu.h"
 
 c4gpu_ctx *shim_get_ctx(void);
+const gchar *shim_env(const gchar *name);   /* a C4GPU_* variable as it was when the process started: never getenv (c4gpu_shim.c) */
 gint shim_device_ordinal(void);        /* --gpudevice / C4GPU_DEVICE: for a second context of the same device */
 c4gpu_ctx *shim_ctx_nowait(void);       /* NULL while the device is still being opened (small work does not wait) */
 void shim_mark(const gchar *what);
