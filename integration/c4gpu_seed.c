@@ -187,8 +187,15 @@ static gboolean seed_build(ShimSeedTab *st){
         st->column[0] = 0;
         seed_walk_trie(st, f);
         shim_mark("  trie read");
-        if(!f->is_compiled)
-            FSM_compile(f);                                    /* Seeder_prepare, seeder.c:779-784 */
+        /* FSM_compile (Seeder_prepare, seeder.c:783-788) is left to the reference's own walk, which prepares the seeder when it is
+         * first asked (seeder.c:865) -- that is only where a scan could not be served.  The failure links are of no use to the
+         * word table, and compiling a 256-protein seeder's automaton took as long as reading its words (C4GPU_SEED_COMPILE=1:
+         * compile here, as rounds 3-4 did) */
+        if((!f->is_compiled) && shim_env("C4GPU_SEED_COMPILE")){
+            FSM_compile(f);
+            seeder->is_prepared = TRUE;
+            shim_mark("  automaton compiled");
+            }
     } else {
         register VFSM *vfsm = seeder->seeder_vfsm->vfsm;
         register VFSM_Int leaf;
@@ -214,7 +221,8 @@ static gboolean seed_build(ShimSeedTab *st){
             }
         g_free(word);
         }
-    seeder->is_prepared = TRUE;
+    if(!seeder->seeder_fsm)
+        seeder->is_prepared = TRUE;                            /* (nothing to compile: Seeder_prepare only sets the flag) */
     if(shim_env("C4GPU_SEED_HOST")){
         st->host_index = g_hash_table_new(g_int64_hash, g_int64_equal);
         for(i = 0; i < (gint)st->codes->len; i++)
