@@ -261,7 +261,7 @@ def c5_heuristic_leg():
         qf, tf = workloads.write_c5_heuristic_input(d)
         env = dict(os.environ, C4GPU_VERBOSE="1")
         dt, r, runs, slow = 0.0, None, [], []
-        for _ in range(3):              # the first run pays the cold start (binary, code objects: 5-9 s); wall_s = the better of the other two
+        for _ in range(4):              # the first run pays the cold start; wall_s = the best of the other three, their median beside it
             t0 = time.perf_counter()
             r = subprocess.run([exe] + want["args"] + [qf, tf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
             runs.append(round(time.perf_counter() - t0, 3))

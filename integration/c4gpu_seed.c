@@ -91,11 +91,73 @@ static void seed_add_word(ShimSeedTab *st, guint64 code, Seeder_WordInfo *word_i
     return;
     }
 
+/* The last level of the walk: every word's code and the seeds it emits (its own, then those of its neighbours: seed_emit_word).
+ * Three dependent loads into cold memory per word -- 0.23 us each, 130 ms for the 570 000 words of a 128-protein seeder on one
+ * thread.  The nodes are read-only here and the words of different nodes are independent: slices of the node list go to a few
+ * threads, each with a table of its own, and the tables are joined in slice order (so the numbering is that of the one-thread
+ * walk).  C4GPU_SEED_THREADS=1: one thread. */
+typedef struct { FSM_Node *node; guint64 code; } ShimTrieItem;
+typedef struct { ShimSeedTab part; FSM *f; ShimTrieItem *item; guint n; } ShimWordSlice;
+static void seed_read_slice(ShimSeedTab *st, FSM *f, ShimTrieItem *item, guint n){
+    register guint k;
+    register gint c;
+    for(k = 0; k < n; k++)
+        for(c = 1; c < f->width; c++)
+            if(item[k].node[c].data)
+                seed_add_word(st, item[k].code * f->width + c, item[k].node[c].data);
+    return;
+    }
+static gpointer seed_read_slice_thread(gpointer data){
+    register ShimWordSlice *sl = data;
+    seed_read_slice(&sl->part, sl->f, sl->item, sl->n);
+    return NULL;
+    }
+static void seed_read_words(ShimSeedTab *st, FSM *f, GArray *words){
+    register gint n_threads = shim_env("C4GPU_SEED_THREADS") ? atoi(shim_env("C4GPU_SEED_THREADS")) : (gint)MIN(8, g_get_num_processors());
+    register gint t;
+    register guint k;
+    ShimWordSlice *sl;
+    GThread **th;
+    if((n_threads < 2) || (words->len < (shim_env("C4GPU_SEED_THREADS") ? (guint)n_threads : 4096u))){     /* (asked for: any size) */
+        seed_read_slice(st, f, (ShimTrieItem*)words->data, words->len);
+        return;
+        }
+    sl = g_new0(ShimWordSlice, n_threads);
+    th = g_new0(GThread*, n_threads);
+    for(t = 0; t < n_threads; t++){
+        register guint lo = (guint)(((guint64)words->len * t) / n_threads), hi = (guint)(((guint64)words->len * (t + 1)) / n_threads);
+        gint32 zero = 0;
+        sl[t].f = f;
+        sl[t].item = ((ShimTrieItem*)words->data) + lo;
+        sl[t].n = hi - lo;
+        sl[t].part.codes = g_array_new(FALSE, FALSE, sizeof(guint64));
+        sl[t].part.first = g_array_new(FALSE, FALSE, sizeof(gint32));
+        sl[t].part.emits = g_array_new(FALSE, FALSE, sizeof(ShimEmit));
+        g_array_append_val(sl[t].part.first, zero);
+        th[t] = g_thread_new("c4gpu-words", seed_read_slice_thread, &sl[t]);
+        }
+    for(t = 0; t < n_threads; t++){
+        register gint32 base = st->emits->len;
+        g_thread_join(th[t]);
+        g_array_append_vals(st->codes, sl[t].part.codes->data, sl[t].part.codes->len);
+        g_array_append_vals(st->emits, sl[t].part.emits->data, sl[t].part.emits->len);
+        for(k = 1; k < sl[t].part.first->len; k++){          /* (entry 0 is the slice's own leading zero) */
+            gint32 v = base + g_array_index(sl[t].part.first, gint32, k);
+            g_array_append_val(st->first, v);
+            }
+        g_array_free(sl[t].part.codes, TRUE);
+        g_array_free(sl[t].part.first, TRUE);
+        g_array_free(sl[t].part.emits, TRUE);
+        }
+    g_free(sl);
+    g_free(th);
+    return;
+    }
+
 /* The words of the automaton, level by level.  Before FSM_compile (fsm.c:136-184) `next` is NULL where the trie has no
  * child; after it every `next` is set, but a failure link leads to a node no deeper than its origin, so in a level-order
  * walk the edges into nodes not seen before are exactly the trie's own: the walk reads both forms.  Column c of a node at
  * the last level holds the word's data. */
-typedef struct { FSM_Node *node; guint64 code; } ShimTrieItem;
 static void seed_walk_trie(ShimSeedTab *st, FSM *f){
     register GArray *level = g_array_new(FALSE, FALSE, sizeof(ShimTrieItem)), *next_level, *words;
     /* (before FSM_compile every non-NULL `next` is a trie edge: no need to remember the nodes seen -- a hash insertion per node
@@ -129,12 +191,7 @@ static void seed_walk_trie(ShimSeedTab *st, FSM *f){
         g_hash_table_destroy(seen);
     /* the reference's traversal meets the words in no particular order; ours does not depend on it either (hash table) */
     words = level;
-    for(k = 0; k < words->len; k++){
-        register ShimTrieItem *p = &g_array_index(words, ShimTrieItem, k);
-        for(c = 1; c < f->width; c++)
-            if(p->node[c].data)
-                seed_add_word(st, p->code * f->width + c, p->node[c].data);
-        }
+    seed_read_words(st, f, words);
     g_array_free(words, TRUE);
     return;
     }

@@ -198,6 +198,10 @@ def test_word_scan_seam_equals_the_reference_walk(tmp_path, model, extra):
     assert "every seed equal to the reference's own walk" in err
     if model.startswith("protein2"):
         assert int(m.group(2)) == 3 * int(m.group(1))                  # three translated frames per target
+    if not extra or model == "protein2genome":
+        # the words of the last trie level read by several threads (slices joined in order; by default only from 4 096 nodes on)
+        ref, gpu, err = run_pair(tmp_path, model, extra, dict(env, C4GPU_SEED_THREADS="3"), n=6, seed=31)
+        assert gpu == ref and "every seed equal to the reference's own walk" in err
 
 
 @pytest.mark.parametrize("model,extra", [("est2genome", []), ("protein2dna", []), ("affine:local", ["--gappedextension", "yes"])])

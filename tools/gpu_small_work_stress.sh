@@ -13,6 +13,7 @@ PY
 ARGS="-m est2genome --gappedextension no -S no --showalignment yes --showvulgar yes -V 0 /tmp/sw/q.fa /tmp/sw/t.fa"
 oracle/_ref/exonerate-compiled $ARGS > /tmp/sw/ref.out 2>/dev/null
 export C4GPU_SEGV_TRACE=1
+[ -n "$STRESS_ENV" ] && export $STRESS_ENV       # e.g. STRESS_ENV=C4GPU_FAST_EXIT=0: the ordinary exit
 run_loop() {
   local bad=0
   for i in $(seq 1 $N); do
