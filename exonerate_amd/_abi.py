@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libc4gpu.so")
 
-ABI_VERSION = 6            # C4GPU_ABI_VERSION of include/c4gpu.h these structures mirror
+ABI_VERSION = 7            # C4GPU_ABI_VERSION of include/c4gpu.h these structures mirror
 MAX_STATES, MAX_TRANSITIONS, MAX_CALCS, MAX_SHADOWS, NAME_LEN = 16, 48, 16, 4, 48
 SPLICE_MAX_LEN = 32
 CELL_MAX = 1 + MAX_SHADOWS + 3
@@ -157,6 +157,7 @@ PROTOTYPES = [
     ("c4gpu_ctx_warm_cancel", None, []),
     ("c4gpu_ctx_set_stream", None, [C.c_void_p, C.c_void_p]),
     ("c4gpu_ctx_own_stream", C.c_int, [C.c_void_p]),
+    ("c4gpu_ctx_sdp_reserve", C.c_int, [C.c_void_p, C.c_int64]),
     ("c4gpu_ctx_device_info", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int),
                                         C.POINTER(C.c_int64)]),
     ("c4gpu_params_default", None, [C.POINTER(Params)]),

@@ -63,6 +63,7 @@ struct c4gpu_ctx {
     // SDP (c4_sdp_dev.inc): the arena the passes' step records grow in, kept between calls
     void *sdp_arena = nullptr;
     size_t sdp_arena_bytes = 0;
+    bool sdp_arena_keep = false;                   // c4gpu_ctx_sdp_reserve: the arena stays with the context between batches
 };
 
 namespace {
@@ -2897,6 +2898,32 @@ void c4gpu_ctx_set_stream(c4gpu_ctx *ctx, void *hip_stream) {
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     ctx->owns_stream = false;
     ctx->stream = (hipStream_t)hip_stream;
+}
+
+int c4gpu_ctx_sdp_reserve(c4gpu_ctx *ctx, int64_t bytes) {
+    if (hipSetDevice(ctx->device) != hipSuccess) { c4h::set_error("c4gpu_ctx_sdp_reserve: cannot select the device"); return -1; }
+    if (bytes <= 0) {
+        ctx->sdp_arena_keep = false;
+        if (ctx->sdp_arena) (void)hipFree(ctx->sdp_arena);
+        ctx->sdp_arena = nullptr; ctx->sdp_arena_bytes = 0;
+        return 0;
+    }
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { c4h::set_error("c4gpu_ctx_sdp_reserve: hipMemGetInfo failed"); return -1; }
+    size_t want = std::min<size_t>((size_t)bytes, (size_t)((double)(free_b + ctx->sdp_arena_bytes) * 0.6));
+    want &= ~(((size_t)1 << 16) - 1);                     // whole 64 KB chunks
+    ctx->sdp_arena_keep = true;
+    if (ctx->sdp_arena_bytes >= want) return 0;
+    if (ctx->sdp_arena) (void)hipFree(ctx->sdp_arena);
+    ctx->sdp_arena = nullptr; ctx->sdp_arena_bytes = 0;
+    if (hipMalloc(&ctx->sdp_arena, want) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->sdp_arena = nullptr;
+        c4h::set_error("c4gpu_ctx_sdp_reserve: allocation failed");
+        return -1;
+    }
+    ctx->sdp_arena_bytes = want;
+    return 0;
 }
 
 int c4gpu_ctx_own_stream(c4gpu_ctx *ctx) {

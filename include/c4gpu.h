@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define C4GPU_ABI_VERSION 6
+#define C4GPU_ABI_VERSION 7
 
 /* src/c4/c4.h:28-30 */
 typedef int32_t c4gpu_score;
@@ -226,6 +226,13 @@ void        c4gpu_ctx_set_stream(c4gpu_ctx *ctx, void *hip_stream);
  * (integration/c4gpu_sdp.c: a batch of SDP passes beside the word scans and HSP extensions of the comparisons behind it).
  * 0, or -1 with last_error set. */
 int         c4gpu_ctx_own_stream(c4gpu_ctx *ctx);
+/* Takes the arena the SDP passes write their step records to (c4gpu_sdp_batch) NOW, `bytes` large (at most 0.6 of the free device
+ * memory), and keeps it with the context between batches instead of giving a large one back after each: a context that serves
+ * nothing but SDP batches (the flight context of integration/c4gpu_sdp.c) allocates once, ahead of its first batch and beside the
+ * caller's other work -- the first hipMalloc of tens of GB in a process takes 0.3 ms or, after another process has just given
+ * memory back, 1.7-3 s (profiles/r05_c5_cold.md).  A batch that needs more still grows it.  bytes <= 0: give it back, batches
+ * allocate for themselves again.  Not beside a running batch of the same context.  0, or -1 with last_error set. */
+int         c4gpu_ctx_sdp_reserve(c4gpu_ctx *ctx, int64_t bytes);
 int         c4gpu_ctx_device_info(c4gpu_ctx *ctx, char *name, size_t name_len, int *n_cu, int64_t *mem_bytes);
 
 /* Defaults of the reference's ArgumentSets: nucleic / blosum62 matrices, standard genetic code,

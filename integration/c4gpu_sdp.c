@@ -167,7 +167,41 @@ typedef struct {
 } SdpFlight;
 
 static SdpFlight *sdp_in_flight = NULL;
-static c4gpu_ctx *sdp_ctx2 = NULL;            /* the flight thread's context (own stream), opened by the first flight */
+/* The flight thread's context (own stream).  It is opened, and its record arena taken (c4gpu_ctx_sdp_reserve), by a thread that
+ * starts as soon as the pending pairs add up to a batch worth a flight (8 GB of estimated records): the first allocation of
+ * tens of GB in a process takes 0.3 ms or -- after another process has just given memory back -- 1.7-3 s, and the arena is then
+ * there, allocated once and kept, when the first flush is cut a second later.  Whoever uses sdp_ctx2 takes sdp_ctx2_lock. */
+static c4gpu_ctx *sdp_ctx2 = NULL;
+static GMutex sdp_ctx2_lock;
+static GThread *sdp_reserve_thread = NULL;
+static gdouble sdp_reserve_ms = 0.0;
+
+static void sdp_ctx2_open(void){               /* (under sdp_ctx2_lock) */
+    int64_t mem = 0;
+    if(sdp_ctx2)
+        return;
+    sdp_ctx2 = c4gpu_ctx_create(shim_device_ordinal());
+    if(sdp_ctx2 && (c4gpu_ctx_own_stream(sdp_ctx2) != 0)){
+        c4gpu_ctx_destroy(sdp_ctx2);
+        sdp_ctx2 = NULL;
+        }
+    if(sdp_ctx2 && (!(shim_env("C4GPU_SDP_RESERVE") && (atof(shim_env("C4GPU_SDP_RESERVE")) <= 0.0)))
+    && (c4gpu_ctx_device_info(sdp_ctx2, NULL, 0, NULL, &mem) == 0)){
+        /* what a flush cut at the memory estimate asks for (config 5: 67.7 GB of a 288 GB device); C4GPU_SDP_RESERVE=<GB>, 0: none */
+        register gdouble want = shim_env("C4GPU_SDP_RESERVE") ? atof(shim_env("C4GPU_SDP_RESERVE")) * 1e9 : MIN(0.25 * (gdouble)mem, 70e9);
+        (void)c4gpu_ctx_sdp_reserve(sdp_ctx2, (int64_t)want);
+        }
+    return;
+    }
+
+static gpointer sdp_reserve_run(gpointer data){
+    gint64 t0 = g_get_monotonic_time();
+    g_mutex_lock(&sdp_ctx2_lock);
+    sdp_ctx2_open();
+    g_mutex_unlock(&sdp_ctx2_lock);
+    sdp_reserve_ms = (g_get_monotonic_time() - t0) / 1e3;
+    return NULL;
+    }
 
 static gboolean sdp_async(void){
     static gint on = -1;
@@ -242,25 +276,22 @@ static gpointer sdp_flight_device(gpointer data){
     if(!f->ready)
         return NULL;
     if(f->async){
-        if(!sdp_ctx2){
-            sdp_ctx2 = c4gpu_ctx_create(shim_device_ordinal());
-            if(sdp_ctx2 && (c4gpu_ctx_own_stream(sdp_ctx2) != 0)){
-                c4gpu_ctx_destroy(sdp_ctx2);
-                sdp_ctx2 = NULL;
-                }
-            }
+        g_mutex_lock(&sdp_ctx2_lock);               /* (waits for the thread that opens it, if that is still at it) */
+        sdp_ctx2_open();
         ctx = sdp_ctx2;
     } else {
         ctx = shim_get_ctx();
         }
     if(!ctx){
         f->err = g_strdup(c4gpu_last_error());
-        return NULL;
+    } else {
+        f->rc = c4gpu_sdp_batch(ctx, &f->fm, &f->params, f->pair, f->todo->len, (const c4gpu_hsp*)f->hsps->data, f->first,
+                                f->qa, f->ta, f->dropoff, f->threshold, SHIM_SDP_MAX, f->out, f->n_out);
+        if(f->rc != 0)
+            f->err = g_strdup(c4gpu_last_error());      /* the error string is the calling thread's */
         }
-    f->rc = c4gpu_sdp_batch(ctx, &f->fm, &f->params, f->pair, f->todo->len, (const c4gpu_hsp*)f->hsps->data, f->first,
-                            f->qa, f->ta, f->dropoff, f->threshold, SHIM_SDP_MAX, f->out, f->n_out);
-    if(f->rc != 0)
-        f->err = g_strdup(c4gpu_last_error());      /* the error string is the calling thread's */
+    if(f->async)
+        g_mutex_unlock(&sdp_ctx2_lock);
     return NULL;
     }
 
@@ -353,7 +384,8 @@ static void sdp_flush_pending(gboolean async){
             }
         f = sdp_flight_prepare(todo);
         }
-    if(f && sdp_async() && (async || sdp_in_flight)){
+    /* (the last flush of a run that already has the side context goes there too: its arena is waiting) */
+    if(f && sdp_async() && (async || sdp_in_flight || sdp_reserve_thread || sst.async_flushes)){
         /* its device part starts now; the flight before it (if any) is landed -- joined, replayed -- beside it.  The two
          * never share the device thread's context: the one before ran on sdp_ctx2 as well, and has to be JOINED first */
         if(sdp_in_flight && sdp_in_flight->thread){
@@ -384,6 +416,10 @@ static void sdp_flush_pending(gboolean async){
 
 void shim_sdp_flush(void){
     sdp_flush_pending(FALSE);
+    if(sdp_reserve_thread){                    /* nothing of ours is left inside the runtime when the caller moves on */
+        g_thread_join(sdp_reserve_thread);
+        sdp_reserve_thread = NULL;
+        }
     return;
     }
 
@@ -425,6 +461,8 @@ gboolean shim_sdp_collect(GAM *gam, Comparison *comparison){
         g_array_free(hsps, TRUE);
     }
     sdp_pending_bytes += 20.0 * (comparison->query->len + comparison->target->len);
+    if(sdp_async() && (!sdp_reserve_thread) && (!sdp_ctx2) && (sdp_pending_bytes > 8e9) && (!shim_env("C4GPU_SDP_HOST")))
+        sdp_reserve_thread = g_thread_new("c4gpu-sdp-arena", sdp_reserve_run, NULL);
     if(((gint)sdp_pending->len >= shim_batch_size())
     || (sdp_pending_bytes > sdp_budget_bytes()))
         sdp_flush_pending(TRUE);          /* more comparisons are coming: this batch runs beside them */
@@ -461,7 +499,8 @@ Alignment *SDP_Pair_next_path(SDP_Pair *sdp_pair, C4_Score threshold){
 void shim_sdp_report(void){
     if(shim_env("C4GPU_VERBOSE") && sst.pairs)
         g_message("c4gpu sdp: %ld pairs in %ld flush(es): %ld served from device batches (%ld alignments); batches %.0f ms, "
-                  "replay %.0f ms; %ld flush(es) beside the main thread, which waited %.0f ms for them", sst.pairs, sst.flushes,
-                  sst.served_pairs, sst.alignments, sst.device_ms, sst.replay_ms, sst.async_flushes, sst.waited_ms);
+                  "replay %.0f ms; %ld flush(es) beside the main thread, which waited %.0f ms for them (their context and arena were "
+                  "ready after %.0f ms on a thread of their own)", sst.pairs, sst.flushes,
+                  sst.served_pairs, sst.alignments, sst.device_ms, sst.replay_ms, sst.async_flushes, sst.waited_ms, sdp_reserve_ms);
     return;
     }
