@@ -469,6 +469,10 @@ gboolean shim_sdp_collect(GAM *gam, Comparison *comparison){
     return TRUE;
     }
 
+gboolean shim_sdp_busy(void){                 /* a thread of this seam may be inside the runtime */
+    return (sdp_in_flight != NULL) || (sdp_reserve_thread != NULL);
+    }
+
 gboolean shim_sdp_replaying(void){
     return sdp_cur != NULL;
     }

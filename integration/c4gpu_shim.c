@@ -143,16 +143,18 @@ static gchar *shim_ctx_error = NULL;
  * load (c4gpu_ctx_warm_cancel), the thread is joined, and only then do the exit handlers run, with no thread left inside
  * the runtime.  Both ways out come through here: main()'s return (the wrapper below) and every exit() call of the
  * reference's own objects (general/argument.c's error handler among them), which the Makefile points at shim_exit with
- * objcopy --redefine-sym.  After the join the process leaves with _exit (stdio flushed first) where the device thread was ever
- * started: with no thread of ours left inside it, the runtime's OWN teardown in the exit handlers still ended one 0.2 s run in
- * about two hundred with SIGSEGV after its complete, correct output (a warm-up cut short leaves code objects half way through
- * the runtime's loader threads; profiles/r04_f_pytest_gpu.log), and a process about to end has no use for that teardown.
- * C4GPU_FAST_EXIT=0 takes the ordinary exit (handlers and all). */
+ * objcopy --redefine-sym.  Then the ordinary exit(), handlers and all.  Rounds 3-4 left with _exit here (stdio flushed first)
+ * because one short run in about two hundred ended with SIGSEGV after its complete output; round 5 found the cause elsewhere --
+ * getenv on the main thread racing with the setenv calls of the HIP start-up on the device thread (shim_env above) -- and with
+ * that gone the ordinary exit ended 1 500 of 1 500 short runs cleanly (profiles/r05_small_work_stress_exit.log), so _exit is now
+ * the exception: C4GPU_FAST_EXIT=1 asks for it, and a way out that is taken while a flush thread is still on the device (an
+ * error exit in the middle of a run) takes it too. */
 static gboolean shim_joined = FALSE;
 static gboolean shim_fast_exit(void){
     register const gchar *e = shim_env("C4GPU_FAST_EXIT");
-    return shim_ctx_thread && !(e && e[0] == '0');
+    return shim_ctx_thread && e && (e[0] == '1');
     }
+static gboolean shim_flush_threads_alive(void);
 static void shim_quiesce(void){
     register GThread *t;
     g_mutex_lock(&shim_ctx_lock);
@@ -167,7 +169,7 @@ static void shim_quiesce(void){
     }
 void shim_exit(int status){
     shim_quiesce();
-    if(shim_fast_exit()){
+    if(shim_fast_exit() || shim_flush_threads_alive()){
         fflush(NULL);
         _exit(status);
         }
@@ -1026,6 +1028,10 @@ static void shim_flush(void){
 
 /* a full batch while more pairs are coming: its device part starts on a thread of its own; the batch before it (whose device
  * part has had the whole collection time of this one) is replayed now, beside it */
+static gboolean shim_flush_threads_alive(void){
+    return (shim_in_flight != NULL) || shim_sdp_busy();
+    }
+
 static void shim_flush_async(void){
     register ShimFlushJob *job, *before = shim_in_flight;
     if(!shim_async()){

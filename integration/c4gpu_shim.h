@@ -34,6 +34,7 @@ void shim_seed_report(void);
 /* c4gpu_sdp.c */
 gboolean shim_sdp_collect(GAM *gam, Comparison *comparison);
 gboolean shim_sdp_replaying(void);
+gboolean shim_sdp_busy(void);
 void shim_sdp_flush(void);
 void shim_sdp_report(void);
 

@@ -10,7 +10,7 @@ want = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_c5_heuristic.
 out = os.path.join(ROOT, "gpurun_out", "c5_ktrace")
 with tempfile.TemporaryDirectory() as d:
     qf, tf = workloads.write_c5_heuristic_input(d)
-    env = dict(os.environ, C4GPU_VERBOSE="1", C4GPU_TRACE="1", C4GPU_FAST_EXIT="0")     # _exit would skip the profiler's own exit handler
+    env = dict(os.environ, C4GPU_VERBOSE="1", C4GPU_TRACE="1")
     subprocess.run([exe] + want["args"] + [qf, tf], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)      # warm the page cache
     r = subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", out, "--", exe] + want["args"] + [qf, tf],
                        stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
