@@ -247,7 +247,7 @@ def other_configs(ex, eng):
 def c5_heuristic_leg():
     """BASELINE config 5's heuristic leg through the drop-in binary (integration/_build/exonerate-gpu: the reference's own
     objects with libc4gpu.so behind its seams -- word scan, HSP extension and SDP on the device): 256 proteins of 300 aa against
-    one 10 Mb chromosome, -m protein2genome, default mode; wall time of the better of the two runs after a first, cold one (all three in wall_s_runs), every stdout compared by SHA-256 with
+    one 10 Mb chromosome, -m protein2genome, default mode; wall time of the best of three runs after a first, cold one (all four in wall_s_runs; runs started back to back alternate between fast and slow: the first large allocation waits while the driver clears what the run before released, profiles/r05_c5_cold.md), every stdout compared by SHA-256 with
     what the reference binary printed for the same input (tests/golden/bench_c5_heuristic.json, tools/make_c5_heuristic_golden.py:
     the reference needs 66 s on one core of the GPU box, too long for the bench).  Skipped where the binary is not built."""
     import hashlib, tempfile
