@@ -289,6 +289,17 @@ class Engine:
             _lib().c4gpu_ctx_destroy(self.ctx)
             self.ctx = None
 
+    def own_stream(self):
+        """A non-blocking HIP stream of this context's own (c4gpu_ctx_own_stream): calls made on it from a second host thread
+        run beside another context's instead of in the default stream's order."""
+        if _lib().c4gpu_ctx_own_stream(self.ctx) != 0:
+            raise _err("c4gpu_ctx_own_stream")
+
+    def sdp_reserve(self, nbytes):
+        """Takes the SDP record arena now and keeps it between batches (c4gpu_ctx_sdp_reserve); nbytes <= 0 gives it back."""
+        if _lib().c4gpu_ctx_sdp_reserve(self.ctx, int(nbytes)) != 0:
+            raise _err("c4gpu_ctx_sdp_reserve")
+
     def device_info(self):
         name = C.create_string_buffer(256)
         ncu, mem = C.c_int(), C.c_int64()

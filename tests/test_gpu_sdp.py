@@ -160,3 +160,44 @@ def test_device_sdp_boundary_fuzz_against_oracle(eng, seed):
             assert [a.as_dict() for a in alns] == exp, (seed, cs["kind"], cs["variant"], cs["dropoff"], cs["threshold"], len(q), len(t), len(h))
             n += len(exp)
         assert n >= 3
+
+
+def test_sdp_batches_on_a_side_context_beside_alignments_on_the_main_one(eng):
+    """What the drop-in's SDP seam does with a flush cut in the middle of a run (integration/c4gpu_sdp.c): the batch on a second
+    context with a stream of its own and a record arena taken ahead and kept (c4gpu_ctx_own_stream, c4gpu_ctx_sdp_reserve), on a
+    second host thread, while the first goes on aligning on the main context.  Both give what they give alone."""
+    import threading
+    from exonerate_amd import workloads
+    name = BOUNDARY[0]
+    model, par, recs, adv = sdp_case(name)
+    pairs = [(r["query"], r["target"]) for r in recs]
+    hsps = [r["hsps"] for r in recs]
+    side = ex.Engine(0)
+    try:
+        side.own_stream()
+        side.sdp_reserve(1 << 30)
+        e2g = ex.Model("est2genome")
+        vp = workloads.est2genome_pairs(16, 600, 40000, seed=5)
+        alone = [a.vulgar("q", "t") for a in eng.find_path(e2g, vp, dpmemory=32)]
+        got, errs = {}, []
+
+        def flights():
+            try:
+                for k in range(6):
+                    got[k] = side.sdp(model, pairs, hsps, adv[0], adv[1], par["dropoff"], par["threshold"], 4)
+            except Exception as e:                      # (reported by the assertion below)
+                errs.append(e)
+        th = threading.Thread(target=flights)
+        th.start()
+        beside = [[a.vulgar("q", "t") for a in eng.find_path(e2g, vp, dpmemory=32)] for _ in range(4)]
+        th.join()
+        assert not errs, errs
+        assert all(b == alone for b in beside)
+        for k in range(6):
+            for r, alns in zip(recs, got[k]):
+                g = [{"score": a.score, "region": list(a.region), "ops": [list(o) for o in a.ops], "vulgar": a.vulgar(r["id"])}
+                     for a in alns]
+                assert g == expected(r), (k, r["id"])
+        side.sdp_reserve(0)
+    finally:
+        side.close()
