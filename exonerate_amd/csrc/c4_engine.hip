@@ -1126,6 +1126,7 @@ struct Engine {
     // the default parameters: 13 + 16 - 30) and the fewest target columns it takes: a path gains at most
     // (Q + 1) x pk16_match_max + (T / pk16_intron_cols + 1) x pk16_intron_gain (pk16_fits)
     int pk16_intron_gain = 0, pk16_intron_cols = 4;
+    int loop_tr_host[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};     // KParams::loop_tr
     DevBuf<KParams> kparams;
     // reusable device buffers
     DevBuf<DevJob> d_jobs;
@@ -1178,6 +1179,7 @@ struct Engine {
         }
         local = m->start_scope == C4GPU_SCOPE_ANYWHERE && m->end_scope == C4GPU_SCOPE_ANYWHERE;
         memset(&kp, 0, sizeof kp);
+        for (int i = 0; i < 16; i++) loop_tr_host[i] = -1;
         for (int i = 0; i < m->n_calcs; i++) kp.calc_value[i] = m->calcs[i].value;
         kp.min_intron = params->min_intron; kp.max_intron = params->max_intron;
         if (params->max_intron < params->min_intron) {
@@ -1251,8 +1253,63 @@ struct Engine {
                 }
                 pk16_intron_gain = (int)std::max<long long>(0, std::min<long long>(gain, 1 << 20));
                 pk16_intron_cols = std::max(4, params->min_intron);
+                // KParams::loop_tr (c4_viterbi_kernel.h, viterbi_kernel): a state s with a loop (0, 1) that adds nothing, entered
+                // by pre-splice and left by post-splice transitions only, where leaving and coming back cannot pay: the best
+                // 3' site + the best 5' site + the opening constant of s's own transitions is NEGATIVE (the sites at their best
+                // as the predictor rounds them, splice.c:379-381 -- without the + 1 of slack the 16-bit guard above allows
+                // itself, but with 0.001 for the float sums: 13 + 16 - 30 = -1 under the default parameters), and nothing
+                // else that moves along the target without a query row adds anything (gaps cost).  Then every cell of a
+                // one-row continuation from s takes the loop, whatever the order of the candidates.  C4GPU_LOOP_SHORTCUT=0: off.
+                const bool loop_on = !(getenv("C4GPU_LOOP_SHORTCUT") && atoi(getenv("C4GPU_LOOP_SHORTCUT")) == 0);
+                bool others_cost = true;
+                for (int k = 0; k < m->n_transitions; k++) {
+                    const c4gpu_transition &t = m->transitions[k];
+                    if (t.advance_query != 0 || t.calc < 0) continue;
+                    const c4gpu_calc &cc = m->calcs[t.calc];
+                    if (cc.kind == C4GPU_CALC_SPLICE_PRE || cc.kind == C4GPU_CALC_SPLICE_POST) continue;
+                    if (cc.kind != C4GPU_CALC_CONST || cc.value > 0) others_cost = false;
+                }
+                if (loop_on && family == FAM_EST2GENOME && others_cost && m->n_states <= 16) {
+                    int tight[4];
+                    for (int k = 0; k < 4; k++) {
+                        const c4gpu_splice_model &sp = params->splice[k];
+                        double sum = 0;
+                        for (int r = 0; r < sp.model_length && r < C4GPU_SPLICE_MAX_LEN; r++) {
+                            double mx = 0;
+                            for (int c = 0; c < 5; c++) mx = std::max(mx, (double)sp.data[r][c]);
+                            sum += mx;
+                        }
+                        tight[k] = (int)std::floor(sum + 0.5 + 1e-3);
+                    }
+                    for (int st = 0; st < m->n_states; st++) {
+                        long long pre = -0x40000000LL, post = -0x40000000LL;
+                        int loop = -1;
+                        bool clean = true;
+                        for (int k = 0; k < m->n_transitions; k++) {
+                            const c4gpu_transition &t = m->transitions[k];
+                            const c4gpu_calc *cc = t.calc >= 0 ? &m->calcs[t.calc] : nullptr;
+                            if (t.input == st && t.output == st) {
+                                if (t.advance_query == 0 && t.advance_target == 1 && !cc && loop < 0) loop = k; else clean = false;
+                            } else if (t.output == st) {
+                                if (cc && cc->kind == C4GPU_CALC_SPLICE_PRE) pre = std::max<long long>(pre, (long long)cc->value + tight[cc->param & 3]);
+                                else clean = false;
+                            } else if (t.input == st) {
+                                if (cc && cc->kind == C4GPU_CALC_SPLICE_POST) post = std::max<long long>(post, (long long)cc->value + tight[cc->param & 3]);
+                                else clean = false;
+                            }
+                        }
+                        loop_tr_host[st] = (clean && loop >= 0 && pre > -0x40000000LL && post > -0x40000000LL && pre + post < 0) ? loop : -1;
+                    }
+                }
             }
             if (getenv("C4GPU_LOCAL_EXACT") && atoi(getenv("C4GPU_LOCAL_EXACT")) == 0) local_exact = false;   // test hook
+        }
+        for (int i = 0; i < 16; i++) kp.loop_tr[i] = loop_tr_host[i];
+        if (getenv("C4GPU_TRACE") && family == FAM_EST2GENOME) {
+            std::string which;
+            for (int i = 0; i < 16; i++) if (loop_tr_host[i] >= 0) which += " " + std::to_string(i) + ":" + std::to_string(loop_tr_host[i]);
+            fprintf(stderr, "c4gpu trace: one-row sections answered without a DP for states (state:loop transition)%s\n",
+                    which.empty() ? " none" : which.c_str());
         }
         for (int c = 0; c < 4096; c++) {
             const uint8_t row = params->submat_index[params->aa[params->trans[c]]];

@@ -50,6 +50,10 @@ struct KParams {                 // uniform per launch (device memory, staged to
     int start_scope, end_scope;
     int submat[24 * 24];
     uint8_t codon_row[4096];             // split-codon calcs: 3 x 4-bit base masks -> Submat row of the residue
+    // loop_tr[s] >= 0: state s has a self-loop over one target column that adds nothing (an intron), and NO other way from s
+    // back to s without a query row can reach the loop's score (Engine::init_host proves it from the parameters): a path
+    // sub-alignment of no query rows from s to s is that loop, T times -- answered without running it (viterbi_kernel)
+    int loop_tr[16];
 };
 struct DevSeqs {
     const uint8_t *qcode, *tcode;        // residue -> submat row codes (tcode: codon codes for 1:3 match)
@@ -1311,6 +1315,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
         __syncthreads();
         if (jid >= n_jobs) break;
         const DevJob &job = jobs[jid];
+        if constexpr (MODE == MODE_PATH && CONT && !SUB && SPAN == 0) {
+            // A sub-alignment between two checkpoints of ONE query row that starts and ends in a state whose only way back to
+            // itself that costs nothing is its own loop (an intron across a whole section: about half of the sections of a
+            // chance alignment across a 100 kb window): the reference's continuation (viterbi.c:705-714) can only find the loop,
+            // T times -- every detour (3' site, gaps, 5' site back in) scores strictly less at every cell, so neither order nor
+            // ties matter -- and leaves the first cell's slots as they are.  One run, no DP (1 700 steps of a wave with one
+            // live lane otherwise).  KParams::loop_tr holds the proof's result per state; -1: run it.
+            const int fs = job.first_state;
+            const int ltr = (fs >= 0 && fs < 16) ? kp_lds.loop_tr[fs] : -1;
+            if (job.Q == 0 && job.T > 0 && job.T < (1 << 24) && fs == job.final_state && ltr >= 0) {
+                if (threadIdx.x == 0) {
+                    DevResult res;
+                    res.flags = 0; res.n_ops = 1; res.n_vsa = 0; res.last_srp = 0; res.qs = res.ts = 0; res.pad = 0;
+                    res.cell_size = DP::CS;
+                    for (int l = 0; l < CELL_MAX; l++) res.final_cell[l] = l < DP::CS ? job.first_cell[l] : 0;
+                    res.end_set = true; res.score = res.final_cell[0]; res.qe = 0; res.te = job.T;
+                    res.ops_off = (long long)atomicAdd(scratch.runs_used, 1ull);
+                    if (res.ops_off + 1 > scratch.runs_capacity) { res.flags |= FLAG_OPS_OVERFLOW; res.n_ops = 0; }
+                    else scratch.runs_out[res.ops_off] = ((uint32_t)ltr << 24) | (uint32_t)job.T;
+                    results[jid] = res;
+                }
+                continue;
+            }
+        }
         // every member starts defined.  Round 4: one set of the derived protein2genome vectors came out differently when the
         // suite's kernel-variant tests had run before it in the same process (and only then): an object left uninitialised is
         // undefined wherever a member is read before it is written, and what the registers held decided
