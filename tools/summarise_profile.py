@@ -88,5 +88,7 @@ out = {
             "is exact (profiles/r02_fetch_calibration.md: known-size reads in this kernel's own access widths). SQ_* are "
             "per-wave quad-cycles; simd_issue_utilisation = VALU-active share of a wave's cycles x resident waves per SIMD.",
 }
-json.dump(out, open(f"{dst}/traffic_latest.json", "w"), indent=1)
+# bench.py's roofline block reads traffic_latest.json for the launches IT times (two launch lanes): a one-lane profile
+# (C4GPU_LANES=1, tag *_lanes1) has launches twice the size and is kept under its own name only
+json.dump(out, open(f"{dst}/traffic_latest.json" if "lanes1" not in tag else f"{dst}/{tag}_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
