@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libc4gpu.so")
 
-ABI_VERSION = 7            # C4GPU_ABI_VERSION of include/c4gpu.h these structures mirror
+ABI_VERSION = 8            # C4GPU_ABI_VERSION of include/c4gpu.h these structures mirror
 MAX_STATES, MAX_TRANSITIONS, MAX_CALCS, MAX_SHADOWS, NAME_LEN = 16, 48, 16, 4, 48
 SPLICE_MAX_LEN = 32
 CELL_MAX = 1 + MAX_SHADOWS + 3
@@ -226,6 +226,7 @@ PROTOTYPES = [
     ("c4gpu_batch_kernel_stats", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double),
                                            C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("c4gpu_packed_route_fits", C.c_int, [C.POINTER(Model), C.POINTER(Params), C.c_int32, C.c_int32]),
+    ("c4gpu_loop_sections", C.c_int, [C.POINTER(Model), C.POINTER(Params), C.POINTER(C.c_int32), C.c_int32]),
     ("c4gpu_stage_create", C.c_void_p, [C.c_void_p, C.POINTER(Model), C.POINTER(Params)]),
     ("c4gpu_stage_load", C.c_int, [C.c_void_p, C.POINTER(Pair), C.c_int32]),
     ("c4gpu_stage_load_ms", C.c_double, [C.c_void_p]),

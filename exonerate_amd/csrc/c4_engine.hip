@@ -1257,7 +1257,7 @@ struct Engine {
                 // by pre-splice and left by post-splice transitions only, where leaving and coming back cannot pay: the best
                 // 3' site + the best 5' site + the opening constant of s's own transitions is NEGATIVE (the sites at their best
                 // as the predictor rounds them, splice.c:379-381 -- without the + 1 of slack the 16-bit guard above allows
-                // itself, but with 0.001 for the float sums: 13 + 16 - 30 = -1 under the default parameters), and nothing
+                // itself, but with 0.001 for the float sums: 13 + 15 - 30 = -2 under the default parameters), and nothing
                 // else that moves along the target without a query row adds anything (gaps cost).  Then every cell of a
                 // one-row continuation from s takes the loop, whatever the order of the candidates.  C4GPU_LOOP_SHORTCUT=0: off.
                 const bool loop_on = !(getenv("C4GPU_LOOP_SHORTCUT") && atoi(getenv("C4GPU_LOOP_SHORTCUT")) == 0);
@@ -2903,6 +2903,18 @@ int c4gpu_packed_route_fits(const c4gpu_model *model, const c4gpu_params *params
     std::unique_ptr<KParams> kp(new KParams);
     if (eng->init_host(nullptr, model, params, *kp)) return -1;
     return (eng->pk16_params_ok && eng->family == FAM_EST2GENOME && eng->pk16_fits(query_length, target_length)) ? 1 : 0;
+}
+
+int c4gpu_loop_sections(const c4gpu_model *model, const c4gpu_params *params, int32_t *loop_transition, int32_t n_states) {
+    std::unique_ptr<Engine> eng(new Engine);
+    std::unique_ptr<KParams> kp(new KParams);
+    if (eng->init_host(nullptr, model, params, *kp)) return -1;
+    int found = 0;
+    for (int s = 0; s < n_states; s++) {
+        loop_transition[s] = s < 16 ? kp->loop_tr[s] : -1;
+        found += loop_transition[s] >= 0;
+    }
+    return found;
 }
 
 int c4gpu_memrule_device(c4gpu_ctx *ctx, const c4gpu_model *model, int dpmemory_mb, const int32_t *query_length,

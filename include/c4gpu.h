@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define C4GPU_ABI_VERSION 7
+#define C4GPU_ABI_VERSION 8
 
 /* src/c4/c4.h:28-30 */
 typedef int32_t c4gpu_score;
@@ -333,6 +333,14 @@ void        c4gpu_alignment_clear(c4gpu_alignment *a);
  * launch will take; the results are the reference's either way. */
 int         c4gpu_packed_route_fits(const c4gpu_model *model, const c4gpu_params *params, int32_t query_length,
                                     int32_t target_length);
+/* Host only: for which states of (model, params) a path sub-alignment WITHOUT a query row that starts and ends in the state is
+ * answered without a dynamic programme -- the state's loop over one target column, repeated (csrc/c4_viterbi_kernel.h,
+ * KParams::loop_tr).  loop_transition[s] = the loop's transition id, or -1 where the parameters do not prove that nothing else
+ * can score as much: the state must be entered and left through splice calcs only, every other transition that moves without a
+ * query row must cost (constant <= 0), and the state's best 3' site + best 5' site + opening constant must be negative
+ * (13 + 15 - 30 under exonerate's defaults: the best 5' site sums to 13.09, the best 3' site to 15.50, rounded as the predictor rounds; optimal.c:266-313 runs a Viterbi over such a section like over any other).
+ * Returns the number of states with a loop, or -1 (last_error). */
+int         c4gpu_loop_sections(const c4gpu_model *model, const c4gpu_params *params, int32_t *loop_transition, int32_t n_states);
 
 /* Device-resident batches (bench / shim hot loop): upload once, run many times. */
 typedef struct c4gpu_batch c4gpu_batch;

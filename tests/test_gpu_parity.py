@@ -435,7 +435,7 @@ def test_score_offsets_and_repaired_tails_on_wide_chance_alignments(eng, monkeyp
 def test_one_row_sections_inside_an_intron_answered_without_a_dp(eng, monkeypatch, capfd):
     """A sub-alignment between two checkpoints that has no query row and starts and ends in one intron state can only be that
     state's loop, T times, when leaving the intron and coming back cannot pay (best 3' site + best 5' site + opening constant
-    < 0: 13 + 16 - 30 under the default parameters) -- the path kernel answers it without a DP (KParams::loop_tr).  Chance
+    < 0: 13 + 15 - 30 under the default parameters) -- the path kernel answers it without a DP (KParams::loop_tr).  Chance
     alignments across whole 100 kb windows are full of such sections: the same alignments with and without the shortcut, one
     shorter one against the oracle; with an opening constant of -20 an intron's two sites can pay for it and the shortcut must be off."""
     from exonerate_amd import workloads
