@@ -154,7 +154,8 @@ struct PinArenaRef {
     PinArena *get() { if (!a) a = g_pin_pool.take(); return a; }
 };
 static thread_local PinArenaRef t_pin;
-static const bool g_dl_eager = getenv("C4GPU_DL_EAGER") && atoi(getenv("C4GPU_DL_EAGER")) != 0;
+static const bool g_free_now = getenv("C4GPU_FREE_NOW") && atoi(getenv("C4GPU_FREE_NOW")) != 0;      // ~DevBuf frees at once (as before round 5's end)
+static const bool g_dl_sync_first = getenv("C4GPU_DL_SYNC_FIRST") && atoi(getenv("C4GPU_DL_SYNC_FIRST")) != 0;
 static const bool g_pin_off = getenv("C4GPU_PIN_XFER") && atoi(getenv("C4GPU_PIN_XFER")) == 0;       // 0: pageable copies, as before
 
 // every wait for a stream: the downloads of this thread that landed in its arena reach their destinations
@@ -195,7 +196,7 @@ struct DevBuf {
     // (retired, not freed: hipFree waits for every kernel on the device, those of other threads' batches included -- the HSP
     // extension of the drop-in's main thread waited 0.35 s for the SDP passes of the flight beside it at the end of each of
     // its calls; what is retired is freed at the next flush: context / batch / stage destroy, or once 16 GB are waiting)
-    ~DevBuf() { if (p) g_retired.retire(p, n * sizeof(T)); }
+    ~DevBuf() { if (p) { if (g_free_now) (void)hipFree(p); else g_retired.retire(p, n * sizeof(T)); } }
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
@@ -228,11 +229,15 @@ struct DevBuf {
     // the data is at `dst` after the next c4_stream_sync(s) of the calling thread
     int download(T *dst, size_t count, hipStream_t s) const {
         if (!count) return 0;
-        // a read-back is queued only once everything in front of it in its stream is over: a DMA copy that waits for a kernel
-        // waits in its engine's queue, and that queue is shared by all streams of the process -- the read-backs of the other
-        // launch lane, or of another thread's batch, then sit behind it until THIS stream's kernel ends (seen: a word scan's
-        // 8-byte read-back held up for the 0.36 s of another thread's SDP passes).  C4GPU_DL_EAGER=1: queue at once, as before
-        if (!g_dl_eager) (void)hipStreamSynchronize(s);
+        // C4GPU_DL_SYNC_FIRST=1: a read-back is queued only once everything in front of it in its stream is over.  A DMA copy that
+        // waits for a kernel waits in its engine's queue, and that queue is shared by all streams of the process: the read-backs
+        // of another thread's batch then sit behind it until THIS stream's kernel ends (seen: a word scan's 8-byte read-back held
+        // up for the 0.36 s of another thread's SDP passes).  The one place where that happened -- a batch of SDP passes beside
+        // the drop-in's main thread -- waits for its passes itself before it queues anything (sdp_run_device); doing it for
+        // every read-back costs nothing in a warm run (425.8 ms either way) but serialises the host's work between a launch and
+        // its wait with the kernel, and the first steps of a run, which still allocate their launch buffers there, took
+        // 805 ms instead of 417 (`bench.py` with its default three steps).  So: off by default.
+        if (g_dl_sync_first) (void)hipStreamSynchronize(s);
         if (uint8_t *slot = pin_slot(count * sizeof(T), s)) {
             HIP_OK(hipMemcpyAsync(slot, p, count * sizeof(T), hipMemcpyDeviceToHost, s));
             t_pin.a->pending.push_back(PinArena::Pending{dst, slot, count * sizeof(T)});
