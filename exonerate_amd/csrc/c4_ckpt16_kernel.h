@@ -66,6 +66,17 @@ struct Prof16 {
     static constexpr int INTS = NCODE * CODE / 4;         // ints per (wave, job)
 };
 
+// The column inputs of a step as a per-wave STAGE in LDS (round 6; the packed score pass has had one since round 4,
+// c4_viterbi16_kernel.h IO 1): 128 columns x 6 planes of one int -- the four splice values of both jobs already interleaved into
+// packed halves, and the byte offsets of the two dense residue codes into the query profile --, plane-major (the lanes of a wave
+// read consecutive columns: 64 consecutive words, no bank conflict).  The wave refills it once per chunk of 63 steps with 64
+// coalesced, clamped columns (one 8-byte and one 1-byte load per job and CHUNK where a step issued them per STEP, with their
+// clamps, 64-bit address arithmetic and four v_perm: 24 of ~200 VALU instructions of a step, four of its six vector memory
+// instructions and the wait for them at the top of every step), and a step reads its column with three ds_read2st64.
+struct Stage16 {
+    static constexpr int COLS = 128, PLANES = 6, INTS = COLS * 8;       // 4 KB per wave, 4 KB-aligned: the running address wraps with one v_and_or
+};
+
 template <class M, int R, int ROOT = -1>
 struct WaveCK16 {
     using F = Facts<M>;
@@ -90,6 +101,10 @@ struct WaveCK16 {
     static_assert(M::START == 0 && M::END == 1, "state numbering of the closed model");
     static_assert(!F::exported(M::START), "START advances nothing");
     struct C16 { int sc[NS]; int il[NS]; int srp[NS]; };
+    typedef __attribute__((address_space(3))) int lds_int;
+    __device__ __forceinline__ static lds_int *lds_at(int a) { return (lds_int *)(size_t)(unsigned)a; }
+    __device__ __forceinline__ static int lds_addr(const lds_int *p) { return (int)(unsigned)(size_t)p; }
+    using P16 = Prof16<R>;
 
     const KParams *kp;
     int lane;
@@ -106,8 +121,10 @@ struct WaveCK16 {
     C16 col[NCOL][R], nbr[NCOL], expo, nx_carry;
     int prof_a[2];                                        // LDS byte address of this lane's profile entry of dense code 0, per job
     const uint8_t *tdense;                                // the launch's code table: [24 + d] = matrix row code of dense index d
-    int nx_tcode[2];
-    uint2 nx_sp16[2];
+    // the next column, from the stage: packed splice values, the profile byte offsets of its two codes, and (fetched in the
+    // middle of a step, when those have arrived) the profile entries: job A's NP ints, then job B's
+    int nx_sp4[4], nx_off[2], nx_prof[2 * P16::NP];
+    int stage_a, stage_base;                              // LDS byte address of the next column's stage entry; of the wave's stage
     bool carry_cols;
     int corner_sc[2], corner_srp[2];
     bool corner_set[2];
@@ -156,18 +173,41 @@ struct WaveCK16 {
             });
         }
     }
-    __device__ __forceinline__ void prefetch_column(int j) {
+    // the next column's entry of the stage (a lane's columns follow each other: a running address)
+    __device__ __forceinline__ void prefetch_column() {
+        const lds_int *p = lds_at(stage_a);
+        static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; nx_sp4[K] = p[K * Stage16::COLS]; });
+        nx_off[0] = p[4 * Stage16::COLS]; nx_off[1] = p[5 * Stage16::COLS];
+        stage_a = ((stage_a + 4) & (Stage16::COLS * 4 - 1)) | stage_base;
+    }
+    // the profile entries of the next column's codes
+    __device__ __forceinline__ void prefetch_profile() {
+        const lds_int *pa = lds_at(prof_a[0] + nx_off[0]), *pb = lds_at(prof_a[1] + nx_off[1]);
+        static_for<P16::NP>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; nx_prof[K] = pa[K]; nx_prof[P16::NP + K] = pb[K]; });
+    }
+    // columns c0 + lane of both jobs into the stage: clamped as the per-step loads were, the splice values of the two jobs
+    // interleaved into packed halves, the dense residue codes as profile offsets
+    __device__ __forceinline__ void fill_stage(lds_int *stage, int c0) {
         constexpr int mat = F::match_at();
+        const int c = c0 + lane;
+        uint2 sv[2]; int off[2];
         static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
-            int ti = t0[H] + j - mat;
+            int ti = t0[H] + c - mat;
             ti = ti < 0 ? 0 : (ti > tlast[H] ? tlast[H] : ti);
-            nx_tcode[H] = tc[H][(unsigned)ti];
+            off[H] = (int)tc[H][(unsigned)ti] * P16::CODE;
+            sv[H] = uint2{0u, 0u};
             if constexpr (F::has_splice()) {
-                int tp = t0[H] + j - 2;
+                int tp = t0[H] + c - 2;
                 tp = tp < 0 ? 0 : (tp > tlast[H] ? tlast[H] : tp);
-                nx_sp16[H] = ss16[H][(unsigned)tp];
+                sv[H] = ss16[H][(unsigned)tp];
             }
         });
+        lds_int *p = stage + (c & (Stage16::COLS - 1));
+        p[0 * Stage16::COLS] = (int)__builtin_amdgcn_perm(sv[1].x, sv[0].x, 0x05040100u);
+        p[1 * Stage16::COLS] = (int)__builtin_amdgcn_perm(sv[1].x, sv[0].x, 0x07060302u);
+        p[2 * Stage16::COLS] = (int)__builtin_amdgcn_perm(sv[1].y, sv[0].y, 0x05040100u);
+        p[3 * Stage16::COLS] = (int)__builtin_amdgcn_perm(sv[1].y, sv[0].y, 0x07060302u);
+        p[4 * Stage16::COLS] = off[0]; p[5 * Stage16::COLS] = off[1];
     }
 
     // one cell of both jobs; ORIGIN: this instantiation can hold the origin cell (row 0 of the lane, steps before the
@@ -225,34 +265,26 @@ struct WaveCK16 {
     __device__ __forceinline__ void step(int s, int i0, bool first_strip, bool last_strip, const int *bnd_in, int *bnd_out) {
         const int j = s - lane;
         int ms[R];
-        {
-            using P16 = Prof16<R>;
-            typedef __attribute__((address_space(3))) int lds_int;
-            const lds_int *pa = (const lds_int *)(size_t)(unsigned)(prof_a[0] + nx_tcode[0] * P16::CODE);
-            const lds_int *pb = (const lds_int *)(size_t)(unsigned)(prof_a[1] + nx_tcode[1] * P16::CODE);
-            static_for<P16::NP>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
-                const int ea = pa[K], eb = pb[K];
-                ms[2 * K] = (int)__builtin_amdgcn_perm((unsigned)eb, (unsigned)ea, 0x05040100u);
-                if constexpr (2 * K + 1 < R) ms[2 * K + 1] = (int)__builtin_amdgcn_perm((unsigned)eb, (unsigned)ea, 0x07060302u);
-            });
-        }
-        int sp[4] = {0, 0, 0, 0};
-        if constexpr (F::has_splice()) {
-            sp[0] = (int)__builtin_amdgcn_perm(nx_sp16[1].x, nx_sp16[0].x, 0x05040100u);
-            sp[1] = (int)__builtin_amdgcn_perm(nx_sp16[1].x, nx_sp16[0].x, 0x07060302u);
-            sp[2] = (int)__builtin_amdgcn_perm(nx_sp16[1].y, nx_sp16[0].y, 0x05040100u);
-            sp[3] = (int)__builtin_amdgcn_perm(nx_sp16[1].y, nx_sp16[0].y, 0x07060302u);
-        }
+        static_for<P16::NP>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
+            const int ea = nx_prof[K], eb = nx_prof[P16::NP + K];
+            ms[2 * K] = (int)__builtin_amdgcn_perm((unsigned)eb, (unsigned)ea, 0x05040100u);
+            if constexpr (2 * K + 1 < R) ms[2 * K + 1] = (int)__builtin_amdgcn_perm((unsigned)eb, (unsigned)ea, 0x07060302u);
+        });
+        int sp[4];
+        static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; sp[K] = nx_sp4[K]; });
         for_exported([&](auto S_, int) __attribute__((always_inline)) { constexpr int S = S_;
             nbr[PH].sc[S] = dpp_shr1(nx_carry.sc[S], expo.sc[S]);
             nbr[PH].srp[S] = dpp_shr1(nx_carry.srp[S], expo.srp[S]);
             if constexpr (live(S)) nbr[PH].il[S] = dpp_shr1(nx_carry.il[S], expo.il[S]);
         });
         prefetch_carry(s + 1, bnd_in);
-        prefetch_column(j + 1);
+        prefetch_column();
         const bool origin = first_strip & (lane == 0) & (s == 0);
         static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
             eval_cell<RR, PH, JINT>(j, origin, ms[RR], sp);
+            // half-way through the step the stage entry read above has arrived; the profile entries it points to are then there
+            // when the next step starts
+            if constexpr (RR == (R + 1) / 2 - 1) prefetch_profile();
         });
         // the bottom row for the lane below, BEFORE any checkpoint edit (that lane still needs column j as it was)
         for_exported([&](auto S_, int) __attribute__((always_inline)) { constexpr int S = S_;
@@ -376,7 +408,7 @@ struct WaveCK16 {
     // chunk of steps once the strip above has finished the columns it reads (progress counters in LDS: c4_win16_kernel.h, run)
     template <int NW>
     __device__ __forceinline__ void run(const DevJob &ja, const DevJob &jb, const DevSeqs &seqs, int *bnd, int *ckpt_a, int *ckpt_b,
-                                        int wid, int *prog) {
+                                        int wid, int *prog, lds_int *stage) {
         const DevJob *jp[2] = {&ja, &jb};
         ckp[0] = ckpt_a; ckp[1] = ckpt_b;
         static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
@@ -407,10 +439,12 @@ struct WaveCK16 {
         const int main_lo = 63 + MAXAT, main_hi = Tm;
         const int nsteps_r = (nsteps + NCOL - 1) / NCOL * NCOL;
         const int main_lo_r = (main_lo + NCOL - 1) / NCOL * NCOL;
-        constexpr int CHK = (64 / NCOL) * NCOL;             // steps per chunk of the progress protocol
+        constexpr int CHK = (63 / NCOL) * NCOL;             // steps per chunk: of the progress protocol, and between two refills of the stage
         const int PS = nsteps_r + 1;
+        stage_base = lds_addr(stage);
         for (int b = wid; b < nstrips; b += NW) {
             const int i0 = b * W + lane * R;
+            stage_a = stage_base + ((0 - lane) & (Stage16::COLS - 1)) * 4;
             static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
                 build_profile<H>(i0);
                 cp_next_j[H] = section[H] > 0 ? section[H] : 0x7fffffff; cp_next_i[H] = 0;
@@ -437,35 +471,34 @@ struct WaveCK16 {
                     step<JI, P>(s0 + P, i0, first, last, bnd_in, bnd_out);
                 });
             };
-            if constexpr (NW == 1) {
-                prefetch_column(0 - lane);
-                prefetch_carry(0, bnd_in);
-                int s = 0;
-                for (; s < main_lo_r && s < nsteps_r; s += NCOL) group(IC<0>{}, s);
-                for (; s + NCOL - 1 <= main_hi; s += NCOL) group(IC<1>{}, s);
-                for (; s < nsteps_r; s += NCOL) group(IC<0>{}, s);
-            } else {
+            {
                 const int above = (wid + NW - 1) % NW, above_base = ((b - 1) / NW) * PS, my_base = (b / NW) * PS;
                 // the steps before c1 read carry columns up to c1 (one step ahead): written by the strip above in its step c1 + 63
                 auto wait_above = [&](int c1) __attribute__((always_inline)) {
+                    if constexpr (NW == 1) return;
                     if (first) return;
                     const int need = above_base + (c1 + 64 < nsteps_r ? c1 + 64 : nsteps_r);
                     while (__hip_atomic_load(prog + above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 };
+                fill_stage(stage, -63);                    // columns -63 ... 0: what the first steps of the lanes read
                 wait_above(CHK < nsteps_r ? CHK : nsteps_r);
-                prefetch_column(0 - lane);
+                prefetch_column();
+                prefetch_profile();
                 prefetch_carry(0, bnd_in);
                 for (int c0 = 0; c0 < nsteps_r; c0 += CHK) {
                     const int c1 = c0 + CHK < nsteps_r ? c0 + CHK : nsteps_r;
+                    fill_stage(stage, c0 + 1);             // columns c0 + 1 ... c0 + 64: what this chunk's steps read ahead
                     if (c0) wait_above(c1);
                     int s = c0;
                     for (; s < main_lo_r && s < c1; s += NCOL) group(IC<0>{}, s);
                     for (; s + NCOL - 1 <= main_hi && s < c1; s += NCOL) group(IC<1>{}, s);
                     for (; s < c1; s += NCOL) group(IC<0>{}, s);
-                    if (!last) {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        if (lane == 0) __hip_atomic_store(prog + wid, my_base + c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if constexpr (NW > 1) {
+                        if (!last) {
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            if (lane == 0) __hip_atomic_store(prog + wid, my_base + c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
                     }
                 }
             }
@@ -543,7 +576,7 @@ struct WaveCK16 {
 template <class M, int R, int ROOT, int NW>
 __device__ __forceinline__ void ckpt16_pair(const KParams *kp_lds, const DevSeqs &seqs, const DevJob *jobs, int ia, int ib,
                                             DevResult *results, DevVsa *vsas, int *bnd, int *ck_a, int *ck_b, int *prog,
-                                            int (*corner_lds)[4], int *prof_mem, const uint8_t *tdense) {
+                                            int (*corner_lds)[4], int *prof_mem, const uint8_t *tdense, int *stage_mem) {
     using DP = WaveCK16<M, R, ROOT>;
     if (threadIdx.x == 0) DP::write_empty_column(bnd);
     if constexpr (NW > 1) {
@@ -562,7 +595,10 @@ __device__ __forceinline__ void ckpt16_pair(const KParams *kp_lds, const DevSeqs
         for (int h = 0; h < 2; h++)
             dp.prof_a[h] = (int)(unsigned)(size_t)((lds_int *)prof_mem + (w * 2 + h) * Prof16<R>::INTS) + dp.lane * Prof16<R>::EB;
     }
-    dp.template run<NW>(jobs[ia], jobs[ib], seqs, bnd, ck_a, ck_b, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), prog);
+    {
+        const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        dp.template run<NW>(jobs[ia], jobs[ib], seqs, bnd, ck_a, ck_b, w, prog, (typename DP::lds_int *)stage_mem + w * Stage16::INTS);
+    }
     // the lane that owned a job's corner cell hands it to the lane that walks the job's checkpoints
     int sc[2], srp[2];
     bool set[2];
@@ -606,19 +642,17 @@ void ckpt16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, con
                    DevVsa *vsas, DevScratch scratch, int *queue) {
     using RT = Roots<M>;
     static_assert(!ROOTED || RT::disjoint(), "a rooted pass needs components to choose from");
-    __shared__ KParams kp_lds;
+    // the launch constants stay in memory (a strip reads them once, for its profile); the LDS goes to the column stages (4 KB per
+    // wave, 4 KB-aligned) and the query profiles: 48.3 KB per workgroup of four waves, three workgroups per CU
+    __shared__ __attribute__((aligned(4096))) int stage_mem[NW * Stage16::INTS];
     __shared__ int next_job;
     __shared__ int prog[NW];
     __shared__ int corner_lds[2][4];
     __shared__ __attribute__((aligned(16))) int prof_mem[NW * 2 * Prof16<R>::INTS];
     __shared__ uint8_t tdense_lds[32];
     if (threadIdx.x < 32) tdense_lds[threadIdx.x] = reinterpret_cast<const uint8_t *>(seqs.sub_colptr)[threadIdx.x];
-    {
-        const int *src = reinterpret_cast<const int *>(kparams);
-        int *dst = reinterpret_cast<int *>(&kp_lds);
-        for (int x = threadIdx.x; x < (int)(sizeof(KParams) / sizeof(int)); x += 64 * NW) dst[x] = src[x];
-    }
     __syncthreads();
+    const KParams *kp_lds = kparams;
     int *bnd = scratch.bnd + (long long)blockIdx.x * scratch.bnd_stride;
     int *ck_a = scratch.ckpt + (long long)blockIdx.x * 2 * scratch.ckpt_stride, *ck_b = ck_a + scratch.ckpt_stride;
     for (;;) {
@@ -634,7 +668,7 @@ void ckpt16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, con
             static_for<RT::count()>([&](auto X_) __attribute__((always_inline)) { constexpr int X = X_;
                 constexpr int ROOT = RT::root(X);
                 if (!ran && root == ROOT) {
-                    ckpt16_pair<M, R, ROOT, NW>(&kp_lds, seqs, jobs, ia, ib, results, vsas, bnd, ck_a, ck_b, prog, corner_lds, prof_mem, tdense_lds);
+                    ckpt16_pair<M, R, ROOT, NW>(kp_lds, seqs, jobs, ia, ib, results, vsas, bnd, ck_a, ck_b, prog, corner_lds, prof_mem, tdense_lds, stage_mem);
                     ran = true;
                 }
             });
@@ -646,7 +680,7 @@ void ckpt16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, con
                 results[threadIdx.x ? ib : ia] = res;
             }
         } else {
-            ckpt16_pair<M, R, -1, NW>(&kp_lds, seqs, jobs, ia, ib, results, vsas, bnd, ck_a, ck_b, prog, corner_lds, prof_mem, tdense_lds);
+            ckpt16_pair<M, R, -1, NW>(kp_lds, seqs, jobs, ia, ib, results, vsas, bnd, ck_a, ck_b, prog, corner_lds, prof_mem, tdense_lds, stage_mem);
         }
     }
 }

@@ -56,6 +56,10 @@ struct WaveWin16 {
     static_assert(!F::exported(M::START), "START advances nothing");
     static_assert(NS * DC < 0x8000, "entry-cell identity in 16 bits");
     struct C16 { int sc[NS]; int il[NS]; int rq[NS]; int rt[NS]; };
+    typedef __attribute__((address_space(3))) int lds_int;
+    __device__ __forceinline__ static lds_int *lds_at(int a) { return (lds_int *)(size_t)(unsigned)a; }
+    __device__ __forceinline__ static int lds_addr(const lds_int *p) { return (int)(unsigned)(size_t)p; }
+    using P16 = Prof16<R>;
 
     const KParams *kp;
     int lane;
@@ -71,8 +75,10 @@ struct WaveWin16 {
     C16 col[NCOL][R], nbr[NCOL], expo, nx_carry;
     int prof_a[2];                                        // this lane's query profile entry of dense code 0, per window (Prof16, c4_ckpt16_kernel.h)
     const uint8_t *tdense;
-    int nx_tcode[2];
-    uint2 nx_sp16[2];
+    // the next column, from the wave's column stage (Stage16, c4_ckpt16_kernel.h): packed splice values, profile offsets of its two
+    // codes and, fetched in the middle of a step, the profile entries (window A's NP ints, then window B's)
+    int nx_sp4[4], nx_off[2], nx_prof[2 * P16::NP];
+    int stage_a, stage_base;
     bool carry_cols;
     int corner_sc[2], corner_rq[2], corner_rt[2];
     bool corner_set[2];
@@ -121,18 +127,38 @@ struct WaveWin16 {
             });
         }
     }
-    __device__ __forceinline__ void prefetch_column(int j) {
+    __device__ __forceinline__ void prefetch_column() {
+        const lds_int *p = lds_at(stage_a);
+        static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; nx_sp4[K] = p[K * Stage16::COLS]; });
+        nx_off[0] = p[4 * Stage16::COLS]; nx_off[1] = p[5 * Stage16::COLS];
+        stage_a = ((stage_a + 4) & (Stage16::COLS * 4 - 1)) | stage_base;
+    }
+    __device__ __forceinline__ void prefetch_profile() {
+        const lds_int *pa = lds_at(prof_a[0] + nx_off[0]), *pb = lds_at(prof_a[1] + nx_off[1]);
+        static_for<P16::NP>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; nx_prof[K] = pa[K]; nx_prof[P16::NP + K] = pb[K]; });
+    }
+    // columns c0 + lane of both windows into the stage (WaveCK16::fill_stage)
+    __device__ __forceinline__ void fill_stage(lds_int *stage, int c0) {
         constexpr int mat = F::match_at();
+        const int c = c0 + lane;
+        uint2 sv[2]; int off[2];
         static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
-            int ti = t0[H] + j - mat;
+            int ti = t0[H] + c - mat;
             ti = ti < 0 ? 0 : (ti > tlast[H] ? tlast[H] : ti);
-            nx_tcode[H] = tc[H][(unsigned)ti];
+            off[H] = (int)tc[H][(unsigned)ti] * P16::CODE;
+            sv[H] = uint2{0u, 0u};
             if constexpr (F::has_splice()) {
-                int tp = t0[H] + j - 2;
+                int tp = t0[H] + c - 2;
                 tp = tp < 0 ? 0 : (tp > tlast[H] ? tlast[H] : tp);
-                nx_sp16[H] = ss16[H][(unsigned)tp];
+                sv[H] = ss16[H][(unsigned)tp];
             }
         });
+        lds_int *p = stage + (c & (Stage16::COLS - 1));
+        p[0 * Stage16::COLS] = (int)__builtin_amdgcn_perm(sv[1].x, sv[0].x, 0x05040100u);
+        p[1 * Stage16::COLS] = (int)__builtin_amdgcn_perm(sv[1].x, sv[0].x, 0x07060302u);
+        p[2 * Stage16::COLS] = (int)__builtin_amdgcn_perm(sv[1].y, sv[0].y, 0x05040100u);
+        p[3 * Stage16::COLS] = (int)__builtin_amdgcn_perm(sv[1].y, sv[0].y, 0x07060302u);
+        p[4 * Stage16::COLS] = off[0]; p[5 * Stage16::COLS] = off[1];
     }
 
     // one cell of both windows; ipk / jpk: the cell's own row and column in both halves (the payload of a path that starts here)
@@ -190,24 +216,13 @@ struct WaveWin16 {
     __device__ __forceinline__ void step(int s, int i0, bool last_strip, const int *bnd_in, int *bnd_out) {
         const int j = s - lane;
         int ms[R];
-        {
-            using P16 = Prof16<R>;
-            typedef __attribute__((address_space(3))) int lds_int;
-            const lds_int *pa = (const lds_int *)(size_t)(unsigned)(prof_a[0] + nx_tcode[0] * P16::CODE);
-            const lds_int *pb = (const lds_int *)(size_t)(unsigned)(prof_a[1] + nx_tcode[1] * P16::CODE);
-            static_for<P16::NP>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
-                const int ea = pa[K], eb = pb[K];
-                ms[2 * K] = (int)__builtin_amdgcn_perm((unsigned)eb, (unsigned)ea, 0x05040100u);
-                if constexpr (2 * K + 1 < R) ms[2 * K + 1] = (int)__builtin_amdgcn_perm((unsigned)eb, (unsigned)ea, 0x07060302u);
-            });
-        }
-        int sp[4] = {0, 0, 0, 0};
-        if constexpr (F::has_splice()) {
-            sp[0] = (int)__builtin_amdgcn_perm(nx_sp16[1].x, nx_sp16[0].x, 0x05040100u);
-            sp[1] = (int)__builtin_amdgcn_perm(nx_sp16[1].x, nx_sp16[0].x, 0x07060302u);
-            sp[2] = (int)__builtin_amdgcn_perm(nx_sp16[1].y, nx_sp16[0].y, 0x05040100u);
-            sp[3] = (int)__builtin_amdgcn_perm(nx_sp16[1].y, nx_sp16[0].y, 0x07060302u);
-        }
+        static_for<P16::NP>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_;
+            const int ea = nx_prof[K], eb = nx_prof[P16::NP + K];
+            ms[2 * K] = (int)__builtin_amdgcn_perm((unsigned)eb, (unsigned)ea, 0x05040100u);
+            if constexpr (2 * K + 1 < R) ms[2 * K + 1] = (int)__builtin_amdgcn_perm((unsigned)eb, (unsigned)ea, 0x07060302u);
+        });
+        int sp[4];
+        static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; sp[K] = nx_sp4[K]; });
         for_exported([&](auto S_, int) __attribute__((always_inline)) { constexpr int S = S_;
             nbr[PH].sc[S] = dpp_shr1(nx_carry.sc[S], expo.sc[S]);
             nbr[PH].rq[S] = dpp_shr1(nx_carry.rq[S], expo.rq[S]);
@@ -215,11 +230,12 @@ struct WaveWin16 {
             if constexpr (live(S)) nbr[PH].il[S] = dpp_shr1(nx_carry.il[S], expo.il[S]);
         });
         prefetch_carry(s + 1, bnd_in);
-        prefetch_column(j + 1);
+        prefetch_column();
         const int jpk = (j & 0xffff) | (j << 16);
         static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
             const int i = i0 + RR;
             eval_cell<RR, PH, JINT>(j, ms[RR], sp, i | (i << 16), jpk);
+            if constexpr (RR == (R + 1) / 2 - 1) prefetch_profile();       // the stage entry read above has arrived
         });
         // the window's first columns are the whole-rectangle pass's own cells, read from its dump; their payload is the
         // cell's identity (c4_viterbi_kernel.h, SEED 2).  Only in the steps that can hold those columns.
@@ -307,7 +323,7 @@ struct WaveWin16 {
     // of strip b + 1 is the one strip b - 1 wrote and strip b reads: b + 1 is at least 64 steps behind b, which has then read
     // (one step ahead) every column b + 1 overwrites.
     template <int NW>
-    __device__ __forceinline__ void run(const DevJob &ja, const DevJob &jb, const DevSeqs &seqs, int *bnd, int wid, int *prog) {
+    __device__ __forceinline__ void run(const DevJob &ja, const DevJob &jb, const DevSeqs &seqs, int *bnd, int wid, int *prog, lds_int *stage) {
         const DevJob *jp[2] = {&ja, &jb};
         static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
             const DevJob &jx = *jp[H];
@@ -339,10 +355,12 @@ struct WaveWin16 {
         const int main_lo = 63 + (MAXAT > DC ? MAXAT : DC), main_hi = Tm;
         const int nsteps_r = (nsteps + NCOL - 1) / NCOL * NCOL;
         const int main_lo_r = (main_lo + NCOL - 1) / NCOL * NCOL;
-        constexpr int CHK = (64 / NCOL) * NCOL;             // steps per chunk of the progress protocol
+        constexpr int CHK = (63 / NCOL) * NCOL;             // steps per chunk: of the progress protocol, and between two refills of the stage
         const int PS = nsteps_r + 1;
+        stage_base = lds_addr(stage);
         for (int b = wid; b < nstrips; b += NW) {
             const int i0 = b * W + lane * R;
+            stage_a = stage_base + ((0 - lane) & (Stage16::COLS - 1)) * 4;
             static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_; build_profile<H>(i0); });
             static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
                 expo.sc[S] = NEG16; expo.il[S] = 0; expo.rq[S] = 0; expo.rt[S] = 0;
@@ -365,35 +383,34 @@ struct WaveWin16 {
                     step<JI, P>(s0 + P, i0, last, bnd_in, bnd_out);
                 });
             };
-            if constexpr (NW == 1) {
-                prefetch_column(0 - lane);
-                prefetch_carry(0, bnd_in);
-                int s = 0;
-                for (; s < main_lo_r && s < nsteps_r; s += NCOL) group(IC<0>{}, s);
-                for (; s + NCOL - 1 <= main_hi; s += NCOL) group(IC<1>{}, s);
-                for (; s < nsteps_r; s += NCOL) group(IC<0>{}, s);
-            } else {
+            {
                 const int above = (wid + NW - 1) % NW, above_base = ((b - 1) / NW) * PS, my_base = (b / NW) * PS;
                 // the steps before c1 read carry columns up to c1 (one step ahead): written by the strip above in its step c1 + 63
                 auto wait_above = [&](int c1) __attribute__((always_inline)) {
+                    if constexpr (NW == 1) return;
                     if (first) return;
                     const int need = above_base + (c1 + 64 < nsteps_r ? c1 + 64 : nsteps_r);
                     while (__hip_atomic_load(prog + above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 };
+                fill_stage(stage, -63);                    // columns -63 ... 0: what the first steps of the lanes read
                 wait_above(CHK < nsteps_r ? CHK : nsteps_r);
-                prefetch_column(0 - lane);
+                prefetch_column();
+                prefetch_profile();
                 prefetch_carry(0, bnd_in);
                 for (int c0 = 0; c0 < nsteps_r; c0 += CHK) {
                     const int c1 = c0 + CHK < nsteps_r ? c0 + CHK : nsteps_r;
+                    fill_stage(stage, c0 + 1);             // columns c0 + 1 ... c0 + 64: what this chunk's steps read ahead
                     if (c0) wait_above(c1);
                     int s = c0;
                     for (; s < main_lo_r && s < c1; s += NCOL) group(IC<0>{}, s);
                     for (; s + NCOL - 1 <= main_hi && s < c1; s += NCOL) group(IC<1>{}, s);
                     for (; s < c1; s += NCOL) group(IC<0>{}, s);
-                    if (!last) {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        if (lane == 0) __hip_atomic_store(prog + wid, my_base + c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if constexpr (NW > 1) {
+                        if (!last) {
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            if (lane == 0) __hip_atomic_store(prog + wid, my_base + c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
                     }
                 }
             }
@@ -408,7 +425,7 @@ struct WaveWin16 {
 template <class M, int R, int ROOT, int NW>
 __device__ __forceinline__ void win16_chains(const KParams *kp_lds, const DevSeqs &seqs, DevJob *job_lds, int *more, int ia, int ib,
                                              DevResult *results, int *bnd, int *prog, int (*corner_lds)[4], int *prof_mem,
-                                             const uint8_t *tdense) {
+                                             const uint8_t *tdense, int *stage_mem) {
     using DP = WaveWin16<M, R, ROOT>;
     int hop = 0, first_score = 0;                      // threads 0 and 1: their window chain
     bool active = threadIdx.x < 2 && more[threadIdx.x & 1];
@@ -428,7 +445,7 @@ __device__ __forceinline__ void win16_chains(const KParams *kp_lds, const DevSeq
             if (threadIdx.x < 2) corner_lds[threadIdx.x][3] = 0;
             __syncthreads();
         }
-        dp.template run<NW>(job_lds[0], job_lds[1], seqs, bnd, wid, prog);
+        dp.template run<NW>(job_lds[0], job_lds[1], seqs, bnd, wid, prog, (typename DP::lds_int *)stage_mem + wid * Stage16::INTS);
         // the lane that owned a window's corner cell hands it to the thread that keeps that window's chain
         int sc[2], rq[2], rt[2];
         bool set[2];
@@ -498,7 +515,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, 8)
 void win16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, const int *pairs, int n_pairs, DevResult *results,
                   DevScratch scratch, int *queue) {
     using RT = Roots<M>;
-    __shared__ KParams kp_lds;
+    // (the launch constants stay in memory: a strip reads them once, for its profile)
+    __shared__ __attribute__((aligned(4096))) int stage_mem[NW * Stage16::INTS];
     __shared__ int next_job;
     __shared__ DevJob job_lds[2];
     __shared__ int more[2];
@@ -507,12 +525,8 @@ void win16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, cons
     __shared__ __attribute__((aligned(16))) int prof_mem[NW * 2 * Prof16<R>::INTS];
     __shared__ uint8_t tdense_lds[32];
     if (threadIdx.x < 32) tdense_lds[threadIdx.x] = reinterpret_cast<const uint8_t *>(seqs.sub_colptr)[threadIdx.x];
-    {
-        const int *src = reinterpret_cast<const int *>(kparams);
-        int *dst = reinterpret_cast<int *>(&kp_lds);
-        for (int x = threadIdx.x; x < (int)(sizeof(KParams) / sizeof(int)); x += 64 * NW) dst[x] = src[x];
-    }
     __syncthreads();
+    const KParams *kp_lds = kparams;
     int *bnd = scratch.bnd + (long long)blockIdx.x * scratch.bnd_stride;
     // the empty column: every exported state unset, in every root's layout (they differ in which states they hold, not in
     // what an unset state looks like: score -32 768 per slot group of 3 or 4 ints would need the layout; instead every int of
@@ -541,7 +555,7 @@ void win16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, cons
                     if (threadIdx.x == 0) WaveWin16<M, R, ROOT>::write_empty_column(bnd);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     __syncthreads();
-                    win16_chains<M, R, ROOT, NW>(&kp_lds, seqs, job_lds, more, ia, ib, results, bnd, prog, corner_lds, prof_mem, tdense_lds);
+                    win16_chains<M, R, ROOT, NW>(kp_lds, seqs, job_lds, more, ia, ib, results, bnd, prog, corner_lds, prof_mem, tdense_lds, stage_mem);
                     ran = true;
                 }
             });
@@ -550,7 +564,7 @@ void win16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, cons
             if (threadIdx.x == 0) WaveWin16<M, R, -1>::write_empty_column(bnd);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
-            win16_chains<M, R, -1, NW>(&kp_lds, seqs, job_lds, more, ia, ib, results, bnd, prog, corner_lds, prof_mem, tdense_lds);
+            win16_chains<M, R, -1, NW>(kp_lds, seqs, job_lds, more, ia, ib, results, bnd, prog, corner_lds, prof_mem, tdense_lds, stage_mem);
         } else if (!ran) {                                  // a root the model does not have: the host's mistake, say so
             if (threadIdx.x < 2 && more[threadIdx.x]) {
                 DevResult res;
