@@ -73,8 +73,13 @@ struct Prof16 {
 // coalesced, clamped columns (one 8-byte and one 1-byte load per job and CHUNK where a step issued them per STEP, with their
 // clamps, 64-bit address arithmetic and four v_perm: 24 of ~200 VALU instructions of a step, four of its six vector memory
 // instructions and the wait for them at the top of every step), and a step reads its column with three ds_read2st64.
+// The strip carry row rides in BND more planes of the same stage: the row above still travels through the workgroup's slab in
+// memory (written by lane 63 of the strip above, a store nobody waits for), but the strip below fetches the 64 columns a chunk
+// reads with ONE coalesced load per lane once the strip above has published them, and a step reads its column from LDS at a
+// wave-uniform address (a broadcast) -- the column loop issues no vector memory load at all.
+template <int BND>
 struct Stage16 {
-    static constexpr int COLS = 128, PLANES = 6, INTS = COLS * 8;       // 4 KB per wave, 4 KB-aligned: the running address wraps with one v_and_or
+    static constexpr int COLS = 128, CARRY0 = 6, PLANES = 6 + BND, INTS = COLS * PLANES;     // planes of 512 bytes, 512-byte aligned: a running address wraps with one v_and_or
 };
 
 template <class M, int R, int ROOT = -1>
@@ -105,6 +110,7 @@ struct WaveCK16 {
     __device__ __forceinline__ static lds_int *lds_at(int a) { return (lds_int *)(size_t)(unsigned)a; }
     __device__ __forceinline__ static int lds_addr(const lds_int *p) { return (int)(unsigned)(size_t)p; }
     using P16 = Prof16<R>;
+    using ST = Stage16<BND>;
 
     const KParams *kp;
     int lane;
@@ -125,6 +131,7 @@ struct WaveCK16 {
     // middle of a step, when those have arrived) the profile entries: job A's NP ints, then job B's
     int nx_sp4[4], nx_off[2], nx_prof[2 * P16::NP];
     int stage_a, stage_base;                              // LDS byte address of the next column's stage entry; of the wave's stage
+    int carry_a, carry_base;                              // ... of the next carry column's first plane (wave-uniform); of that plane
     bool carry_cols;
     int corner_sc[2], corner_srp[2];
     bool corner_set[2];
@@ -142,15 +149,27 @@ struct WaveCK16 {
             if constexpr (live(S)) colp[slot + 2] = 0;
         });
     }
-    __device__ __forceinline__ void prefetch_carry(int s_next, const int *bnd_in) {
-        const int jx = s_next < 0 ? 0 : (s_next > Tm ? Tm : s_next);
-        const int jc = carry_cols ? jx : 0;
+    // the next carry column, from the stage's carry planes (steps follow each other: a running, wave-uniform address)
+    __device__ __forceinline__ void prefetch_carry() {
+        const lds_int *p = lds_at(carry_a);
         for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
-            const int *p = bnd_in + (long long)jc * BND + slot;
-            nx_carry.sc[S] = p[0];
-            nx_carry.srp[S] = p[1];
-            if constexpr (live(S)) nx_carry.il[S] = p[2];
+            nx_carry.sc[S] = p[slot * ST::COLS];
+            nx_carry.srp[S] = p[(slot + 1) * ST::COLS];
+            if constexpr (live(S)) nx_carry.il[S] = p[(slot + 2) * ST::COLS];
         });
+        carry_a = ((carry_a + 4) & (ST::COLS * 4 - 1)) | carry_base;
+    }
+    // carry columns c0 + lane (clamped to the row's columns as the per-step loads were; the first strip: the empty column) into
+    // the stage -- after the strip above has published them
+    __device__ __forceinline__ void fill_carry(lds_int *stage, int c0, const int *bnd_in) {
+        const int c = c0 + lane;
+        const int jx = c < 0 ? 0 : (c > Tm ? Tm : c);
+        const int jc = carry_cols ? jx : 0;
+        const int *g = bnd_in + (long long)jc * BND;
+        int v[BND];
+        static_for<BND>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; v[K] = g[K]; });
+        lds_int *p = stage + ST::CARRY0 * ST::COLS + (c & (ST::COLS - 1));
+        static_for<BND>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; p[K * ST::COLS] = v[K]; });
     }
     // this lane's rows i0 .. i0 + R - 1 of job H against every dense code: the halves step() used to build from the matrix per
     // step (rows outside the job score as row code 0 did: they feed nothing a result reads)
@@ -176,9 +195,9 @@ struct WaveCK16 {
     // the next column's entry of the stage (a lane's columns follow each other: a running address)
     __device__ __forceinline__ void prefetch_column() {
         const lds_int *p = lds_at(stage_a);
-        static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; nx_sp4[K] = p[K * Stage16::COLS]; });
-        nx_off[0] = p[4 * Stage16::COLS]; nx_off[1] = p[5 * Stage16::COLS];
-        stage_a = ((stage_a + 4) & (Stage16::COLS * 4 - 1)) | stage_base;
+        static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; nx_sp4[K] = p[K * ST::COLS]; });
+        nx_off[0] = p[4 * ST::COLS]; nx_off[1] = p[5 * ST::COLS];
+        stage_a = ((stage_a + 4) & (ST::COLS * 4 - 1)) | stage_base;
     }
     // the profile entries of the next column's codes
     __device__ __forceinline__ void prefetch_profile() {
@@ -202,12 +221,12 @@ struct WaveCK16 {
                 sv[H] = ss16[H][(unsigned)tp];
             }
         });
-        lds_int *p = stage + (c & (Stage16::COLS - 1));
-        p[0 * Stage16::COLS] = (int)__builtin_amdgcn_perm(sv[1].x, sv[0].x, 0x05040100u);
-        p[1 * Stage16::COLS] = (int)__builtin_amdgcn_perm(sv[1].x, sv[0].x, 0x07060302u);
-        p[2 * Stage16::COLS] = (int)__builtin_amdgcn_perm(sv[1].y, sv[0].y, 0x05040100u);
-        p[3 * Stage16::COLS] = (int)__builtin_amdgcn_perm(sv[1].y, sv[0].y, 0x07060302u);
-        p[4 * Stage16::COLS] = off[0]; p[5 * Stage16::COLS] = off[1];
+        lds_int *p = stage + (c & (ST::COLS - 1));
+        p[0 * ST::COLS] = (int)__builtin_amdgcn_perm(sv[1].x, sv[0].x, 0x05040100u);
+        p[1 * ST::COLS] = (int)__builtin_amdgcn_perm(sv[1].x, sv[0].x, 0x07060302u);
+        p[2 * ST::COLS] = (int)__builtin_amdgcn_perm(sv[1].y, sv[0].y, 0x05040100u);
+        p[3 * ST::COLS] = (int)__builtin_amdgcn_perm(sv[1].y, sv[0].y, 0x07060302u);
+        p[4 * ST::COLS] = off[0]; p[5 * ST::COLS] = off[1];
     }
 
     // one cell of both jobs; ORIGIN: this instantiation can hold the origin cell (row 0 of the lane, steps before the
@@ -277,7 +296,7 @@ struct WaveCK16 {
             nbr[PH].srp[S] = dpp_shr1(nx_carry.srp[S], expo.srp[S]);
             if constexpr (live(S)) nbr[PH].il[S] = dpp_shr1(nx_carry.il[S], expo.il[S]);
         });
-        prefetch_carry(s + 1, bnd_in);
+        prefetch_carry();
         prefetch_column();
         const bool origin = first_strip & (lane == 0) & (s == 0);
         static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
@@ -442,9 +461,11 @@ struct WaveCK16 {
         constexpr int CHK = (63 / NCOL) * NCOL;             // steps per chunk: of the progress protocol, and between two refills of the stage
         const int PS = nsteps_r + 1;
         stage_base = lds_addr(stage);
+        carry_base = stage_base + ST::CARRY0 * ST::COLS * 4;
         for (int b = wid; b < nstrips; b += NW) {
             const int i0 = b * W + lane * R;
-            stage_a = stage_base + ((0 - lane) & (Stage16::COLS - 1)) * 4;
+            stage_a = stage_base + ((0 - lane) & (ST::COLS - 1)) * 4;
+            carry_a = carry_base;
             static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_;
                 build_profile<H>(i0);
                 cp_next_j[H] = section[H] > 0 ? section[H] : 0x7fffffff; cp_next_i[H] = 0;
@@ -483,13 +504,15 @@ struct WaveCK16 {
                 };
                 fill_stage(stage, -63);                    // columns -63 ... 0: what the first steps of the lanes read
                 wait_above(CHK < nsteps_r ? CHK : nsteps_r);
+                fill_carry(stage, -63, bnd_in);            // carry column 0
                 prefetch_column();
                 prefetch_profile();
-                prefetch_carry(0, bnd_in);
+                prefetch_carry();
                 for (int c0 = 0; c0 < nsteps_r; c0 += CHK) {
                     const int c1 = c0 + CHK < nsteps_r ? c0 + CHK : nsteps_r;
                     fill_stage(stage, c0 + 1);             // columns c0 + 1 ... c0 + 64: what this chunk's steps read ahead
                     if (c0) wait_above(c1);
+                    fill_carry(stage, c0 + 1, bnd_in);     // ... and the row above at those columns
                     int s = c0;
                     for (; s < main_lo_r && s < c1; s += NCOL) group(IC<0>{}, s);
                     for (; s + NCOL - 1 <= main_hi && s < c1; s += NCOL) group(IC<1>{}, s);
@@ -597,7 +620,7 @@ __device__ __forceinline__ void ckpt16_pair(const KParams *kp_lds, const DevSeqs
     }
     {
         const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        dp.template run<NW>(jobs[ia], jobs[ib], seqs, bnd, ck_a, ck_b, w, prog, (typename DP::lds_int *)stage_mem + w * Stage16::INTS);
+        dp.template run<NW>(jobs[ia], jobs[ib], seqs, bnd, ck_a, ck_b, w, prog, (typename DP::lds_int *)stage_mem + w * DP::ST::INTS);
     }
     // the lane that owned a job's corner cell hands it to the lane that walks the job's checkpoints
     int sc[2], srp[2];
@@ -642,9 +665,10 @@ void ckpt16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, con
                    DevVsa *vsas, DevScratch scratch, int *queue) {
     using RT = Roots<M>;
     static_assert(!ROOTED || RT::disjoint(), "a rooted pass needs components to choose from");
-    // the launch constants stay in memory (a strip reads them once, for its profile); the LDS goes to the column stages (4 KB per
-    // wave, 4 KB-aligned) and the query profiles: 48.3 KB per workgroup of four waves, three workgroups per CU
-    __shared__ __attribute__((aligned(4096))) int stage_mem[NW * Stage16::INTS];
+    // the launch constants stay in memory (a strip reads them once, for its profile); the LDS goes to the stages (column inputs and
+    // carry row: 5 KB per wave for one strand's states) and the query profiles: 52.3 KB per workgroup of four waves, three per CU
+    __shared__ __attribute__((aligned(512))) int stage_mem[NW * Stage16<WaveCK16<M, R, ROOTED ? Roots<M>::root(0) : -1>::BND>::INTS];
+    static_assert(!ROOTED || WaveCK16<M, R, Roots<M>::root(0)>::BND == WaveCK16<M, R, Roots<M>::root(Roots<M>::count() - 1)>::BND, "one stage layout for every root");
     __shared__ int next_job;
     __shared__ int prog[NW];
     __shared__ int corner_lds[2][4];

@@ -60,6 +60,7 @@ struct WaveWin16 {
     __device__ __forceinline__ static lds_int *lds_at(int a) { return (lds_int *)(size_t)(unsigned)a; }
     __device__ __forceinline__ static int lds_addr(const lds_int *p) { return (int)(unsigned)(size_t)p; }
     using P16 = Prof16<R>;
+    using ST = Stage16<BND>;
 
     const KParams *kp;
     int lane;
@@ -78,7 +79,7 @@ struct WaveWin16 {
     // the next column, from the wave's column stage (Stage16, c4_ckpt16_kernel.h): packed splice values, profile offsets of its two
     // codes and, fetched in the middle of a step, the profile entries (window A's NP ints, then window B's)
     int nx_sp4[4], nx_off[2], nx_prof[2 * P16::NP];
-    int stage_a, stage_base;
+    int stage_a, stage_base, carry_a, carry_base;
     bool carry_cols;
     int corner_sc[2], corner_rq[2], corner_rt[2];
     bool corner_set[2];
@@ -96,16 +97,26 @@ struct WaveWin16 {
             if constexpr (live(S)) colp[slot + 3] = 0;
         });
     }
-    __device__ __forceinline__ void prefetch_carry(int s_next, const int *bnd_in) {
-        const int jx = s_next < 0 ? 0 : (s_next > Tm ? Tm : s_next);
-        const int jc = carry_cols ? jx : 0;
+    // the next carry column from the stage's carry planes; the 64 columns a chunk reads into them (WaveCK16)
+    __device__ __forceinline__ void prefetch_carry() {
+        const lds_int *p = lds_at(carry_a);
         for_exported([&](auto S_, int slot) __attribute__((always_inline)) { constexpr int S = S_;
-            const int *p = bnd_in + (long long)jc * BND + slot;
-            nx_carry.sc[S] = p[0];
-            nx_carry.rq[S] = p[1];
-            nx_carry.rt[S] = p[2];
-            if constexpr (live(S)) nx_carry.il[S] = p[3];
+            nx_carry.sc[S] = p[slot * ST::COLS];
+            nx_carry.rq[S] = p[(slot + 1) * ST::COLS];
+            nx_carry.rt[S] = p[(slot + 2) * ST::COLS];
+            if constexpr (live(S)) nx_carry.il[S] = p[(slot + 3) * ST::COLS];
         });
+        carry_a = ((carry_a + 4) & (ST::COLS * 4 - 1)) | carry_base;
+    }
+    __device__ __forceinline__ void fill_carry(lds_int *stage, int c0, const int *bnd_in) {
+        const int c = c0 + lane;
+        const int jx = c < 0 ? 0 : (c > Tm ? Tm : c);
+        const int jc = carry_cols ? jx : 0;
+        const int *g = bnd_in + (long long)jc * BND;
+        int v[BND];
+        static_for<BND>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; v[K] = g[K]; });
+        lds_int *p = stage + ST::CARRY0 * ST::COLS + (c & (ST::COLS - 1));
+        static_for<BND>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; p[K * ST::COLS] = v[K]; });
     }
     // this lane's rows of window H against every dense code (Prof16, c4_ckpt16_kernel.h)
     template <int H>
@@ -129,9 +140,9 @@ struct WaveWin16 {
     }
     __device__ __forceinline__ void prefetch_column() {
         const lds_int *p = lds_at(stage_a);
-        static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; nx_sp4[K] = p[K * Stage16::COLS]; });
-        nx_off[0] = p[4 * Stage16::COLS]; nx_off[1] = p[5 * Stage16::COLS];
-        stage_a = ((stage_a + 4) & (Stage16::COLS * 4 - 1)) | stage_base;
+        static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; nx_sp4[K] = p[K * ST::COLS]; });
+        nx_off[0] = p[4 * ST::COLS]; nx_off[1] = p[5 * ST::COLS];
+        stage_a = ((stage_a + 4) & (ST::COLS * 4 - 1)) | stage_base;
     }
     __device__ __forceinline__ void prefetch_profile() {
         const lds_int *pa = lds_at(prof_a[0] + nx_off[0]), *pb = lds_at(prof_a[1] + nx_off[1]);
@@ -153,12 +164,12 @@ struct WaveWin16 {
                 sv[H] = ss16[H][(unsigned)tp];
             }
         });
-        lds_int *p = stage + (c & (Stage16::COLS - 1));
-        p[0 * Stage16::COLS] = (int)__builtin_amdgcn_perm(sv[1].x, sv[0].x, 0x05040100u);
-        p[1 * Stage16::COLS] = (int)__builtin_amdgcn_perm(sv[1].x, sv[0].x, 0x07060302u);
-        p[2 * Stage16::COLS] = (int)__builtin_amdgcn_perm(sv[1].y, sv[0].y, 0x05040100u);
-        p[3 * Stage16::COLS] = (int)__builtin_amdgcn_perm(sv[1].y, sv[0].y, 0x07060302u);
-        p[4 * Stage16::COLS] = off[0]; p[5 * Stage16::COLS] = off[1];
+        lds_int *p = stage + (c & (ST::COLS - 1));
+        p[0 * ST::COLS] = (int)__builtin_amdgcn_perm(sv[1].x, sv[0].x, 0x05040100u);
+        p[1 * ST::COLS] = (int)__builtin_amdgcn_perm(sv[1].x, sv[0].x, 0x07060302u);
+        p[2 * ST::COLS] = (int)__builtin_amdgcn_perm(sv[1].y, sv[0].y, 0x05040100u);
+        p[3 * ST::COLS] = (int)__builtin_amdgcn_perm(sv[1].y, sv[0].y, 0x07060302u);
+        p[4 * ST::COLS] = off[0]; p[5 * ST::COLS] = off[1];
     }
 
     // one cell of both windows; ipk / jpk: the cell's own row and column in both halves (the payload of a path that starts here)
@@ -229,7 +240,7 @@ struct WaveWin16 {
             nbr[PH].rt[S] = dpp_shr1(nx_carry.rt[S], expo.rt[S]);
             if constexpr (live(S)) nbr[PH].il[S] = dpp_shr1(nx_carry.il[S], expo.il[S]);
         });
-        prefetch_carry(s + 1, bnd_in);
+        prefetch_carry();
         prefetch_column();
         const int jpk = (j & 0xffff) | (j << 16);
         static_for<R>([&](auto RR_) __attribute__((always_inline)) { constexpr int RR = RR_;
@@ -358,9 +369,11 @@ struct WaveWin16 {
         constexpr int CHK = (63 / NCOL) * NCOL;             // steps per chunk: of the progress protocol, and between two refills of the stage
         const int PS = nsteps_r + 1;
         stage_base = lds_addr(stage);
+        carry_base = stage_base + ST::CARRY0 * ST::COLS * 4;
         for (int b = wid; b < nstrips; b += NW) {
             const int i0 = b * W + lane * R;
-            stage_a = stage_base + ((0 - lane) & (Stage16::COLS - 1)) * 4;
+            stage_a = stage_base + ((0 - lane) & (ST::COLS - 1)) * 4;
+            carry_a = carry_base;
             static_for<2>([&](auto H_) __attribute__((always_inline)) { constexpr int H = H_; build_profile<H>(i0); });
             static_for<NS>([&](auto S_) __attribute__((always_inline)) { constexpr int S = S_;
                 expo.sc[S] = NEG16; expo.il[S] = 0; expo.rq[S] = 0; expo.rt[S] = 0;
@@ -395,13 +408,15 @@ struct WaveWin16 {
                 };
                 fill_stage(stage, -63);                    // columns -63 ... 0: what the first steps of the lanes read
                 wait_above(CHK < nsteps_r ? CHK : nsteps_r);
+                fill_carry(stage, -63, bnd_in);            // carry column 0
                 prefetch_column();
                 prefetch_profile();
-                prefetch_carry(0, bnd_in);
+                prefetch_carry();
                 for (int c0 = 0; c0 < nsteps_r; c0 += CHK) {
                     const int c1 = c0 + CHK < nsteps_r ? c0 + CHK : nsteps_r;
                     fill_stage(stage, c0 + 1);             // columns c0 + 1 ... c0 + 64: what this chunk's steps read ahead
                     if (c0) wait_above(c1);
+                    fill_carry(stage, c0 + 1, bnd_in);     // ... and the row above at those columns
                     int s = c0;
                     for (; s < main_lo_r && s < c1; s += NCOL) group(IC<0>{}, s);
                     for (; s + NCOL - 1 <= main_hi && s < c1; s += NCOL) group(IC<1>{}, s);
@@ -445,7 +460,7 @@ __device__ __forceinline__ void win16_chains(const KParams *kp_lds, const DevSeq
             if (threadIdx.x < 2) corner_lds[threadIdx.x][3] = 0;
             __syncthreads();
         }
-        dp.template run<NW>(job_lds[0], job_lds[1], seqs, bnd, wid, prog, (typename DP::lds_int *)stage_mem + wid * Stage16::INTS);
+        dp.template run<NW>(job_lds[0], job_lds[1], seqs, bnd, wid, prog, (typename DP::lds_int *)stage_mem + wid * DP::ST::INTS);
         // the lane that owned a window's corner cell hands it to the thread that keeps that window's chain
         int sc[2], rq[2], rt[2];
         bool set[2];
@@ -516,7 +531,10 @@ void win16_kernel(const KParams *kparams, DevSeqs seqs, const DevJob *jobs, cons
                   DevScratch scratch, int *queue) {
     using RT = Roots<M>;
     // (the launch constants stay in memory: a strip reads them once, for its profile)
-    __shared__ __attribute__((aligned(4096))) int stage_mem[NW * Stage16::INTS];
+    // (one stage layout for every root)
+    constexpr int STAGE_BND = WaveWin16<M, R, RT::disjoint() ? RT::root(0) : -1>::BND;
+    static_assert(!RT::disjoint() || STAGE_BND == WaveWin16<M, R, RT::root(RT::count() - 1)>::BND, "one stage layout for every root");
+    __shared__ __attribute__((aligned(512))) int stage_mem[NW * Stage16<STAGE_BND>::INTS];
     __shared__ int next_job;
     __shared__ DevJob job_lds[2];
     __shared__ int more[2];
