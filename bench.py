@@ -332,6 +332,108 @@ def revcomp(seq):
     return seq.translate(bytes.maketrans(b"ACGTacgt", b"TGCAtgca"))[::-1]
 
 
+NOMINAL_VALU_G = 0.5 * 1024 * 2.4          # G wave-instructions/s: one wave64 VALU instruction per two cycles and SIMD, 1 024 SIMDs, 2.4 GHz
+
+
+def roofline_block(valu, hbm, extra):
+    """The line's `roofline`: the roof that binds these kernels is VALU issue, so that is what achieved /
+    peak / frac are; the HBM figures north_star asks for stay beside them under `hbm` (frac ~0 by construction: all live DP
+    state is in registers, the compulsory traffic is ~17 B per target COLUMN).  Without counter figures for this tree the VALU
+    numbers are null and the block says why (`counters`)."""
+    out = {"bound": "valu-issue", "achieved": valu["achieved"] if valu else None, "peak": valu["peak"] if valu else NOMINAL_VALU_G,
+           "unit": "G wave-inst/s", "frac": valu["frac"] if valu else None,
+           "traffic": hbm.get("traffic"), "hbm": hbm, "valu": valu,
+           "note": "integer max-plus with the whole anti-diagonal in VGPRs: achieved = the dominant kernel's wave-instructions per "
+                   "launch (its lane operations per cell from the SQ counters of the profiled run of the same source hash x the "
+                   "cells this run's launches covered) / this run's launch time (HIP events); peak = 0.5 wave-instructions per "
+                   "cycle and SIMD x 1 024 SIMDs x 2.4 GHz; `hbm`: algorithmic bytes per launch / the same time against 8 TB/s "
+                   "(DESIGN.md section 5)"}
+    out.update(extra)
+    return out
+
+
+def kernel_table(kernels_pmc, stats, n_pairs, launches_per_step):
+    """Per pass of the step: this run's launch time (HIP events) beside the profiled run's instruction count for the same code,
+    i.e. the fraction of the nominal VALU issue rate each kernel reaches.  kernels_pmc: profiles/traffic_latest.json `kernels`
+    (wave-instructions per PAIR of the north-star batch, registers, waiting share), None without counter figures."""
+    names = {0: "score", 2: "windows", 3: "checkpoint", 1: "path"}
+    table = {}
+    for mode, name in names.items():
+        st = stats[mode]
+        if not st["launches"]:
+            continue
+        ms = st["ms"] / st["launches"]
+        row = {"ms_per_launch": ms, "launches": st["launches"]}
+        pk = (kernels_pmc or {}).get(name)
+        if pk and ms > 0:
+            insts = pk["wave_insts_per_pair"] * n_pairs / launches_per_step
+            row.update({"wave_insts_per_launch": insts, "valu_frac_of_nominal": insts / (ms * 1e-3) / (NOMINAL_VALU_G * 1e9),
+                        "wait_frac_profiled": pk.get("wait_frac"), "vgprs_per_lane": pk.get("vgprs_per_lane"),
+                        "waves_per_simd": pk.get("waves_per_simd"), "kernel": pk.get("kernel")})
+        table[name] = row
+    return table
+
+
+class ClockSampler:
+    """Shader clock and package power of the GPU while the timed steps run (the packed score pass reaches
+    2.29 GHz in the microbenchmark and 1.70 GHz beside a second launch lane; is that the power cap?): a thread that reads the
+    driver's sysfs files four times a second -- no subprocess, nothing on the device."""
+    def __init__(self, period=0.25):
+        import glob
+        self.period, self.samples, self._stop, self._thread = period, [], None, None
+        self.sclk = self.power = None
+        for c in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+            self.sclk = c
+            pw = glob.glob(os.path.join(os.path.dirname(c), "hwmon", "hwmon*", "power1_average")) + \
+                 glob.glob(os.path.join(os.path.dirname(c), "hwmon", "hwmon*", "power1_input"))
+            self.power = pw[0] if pw else None
+            break
+
+    def _read(self):
+        mhz = watts = None
+        try:
+            for line in open(self.sclk):
+                if "*" in line:
+                    mhz = float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except (OSError, ValueError, IndexError, TypeError):
+            pass
+        try:
+            watts = float(open(self.power).read()) / 1e6
+        except (OSError, ValueError, TypeError):
+            pass
+        return mhz, watts
+
+    def __enter__(self):
+        import threading
+        if self.sclk is None:
+            return self
+        self._stop = threading.Event()
+        def loop():
+            while not self._stop.is_set():
+                self.samples.append(self._read())
+                self._stop.wait(self.period)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join()
+        return False
+
+    def report(self):
+        mhz = [a for a, _ in self.samples if a]
+        w = [b for _, b in self.samples if b]
+        if not mhz and not w:
+            return {"samples": 0, "note": "no readable shader clock / power file under /sys/class/drm (not a GPU box?)"}
+        return {"samples": len(self.samples), "period_s": self.period,
+                "sclk_mhz_mean": sum(mhz) / len(mhz) if mhz else None, "sclk_mhz_min": min(mhz) if mhz else None,
+                "sclk_mhz_max": max(mhz) if mhz else None,
+                "power_w_mean": sum(w) / len(w) if w else None, "power_w_max": max(w) if w else None,
+                "source": "%s, %s (read while the %s timed steps of the headline ran)" % (self.sclk, self.power, "K")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -572,7 +674,8 @@ def main():
         work["gathered_ints"] += int(flat.size)
 
     flush_c_stdio()
-    elapsed = timed(batch, host_batches, args.steps, args.warmup)
+    with ClockSampler() as clock_sampler:
+        elapsed = timed(batch, host_batches, args.steps, args.warmup)
     stats = {m: batch.kernel_stats(m) for m in range(4)}
     ranks_report = dict(per_rank)                                         # of the headline run (the legs below overwrite it)
     headline_work = dict(work)
@@ -712,13 +815,24 @@ def main():
         kname = ("viterbi16_kernel_mw<Est2GenomeDesc> (FIND_SCORE + column dumps, two jobs per lane in packed 16-bit halves)"
                  if dom_mode == 0 and os.environ.get("C4GPU_PK16", "1") != "0" else
                  "viterbi_kernel_mw<Est2GenomeDesc, %s>" % ("MODE_SCORE + column dumps" if dom_mode == 0 else "MODE_REGION"))
+        #  ... and only while the device code is the code that was profiled: the summary names the hash of
+        # exonerate_amd/csrc it was made from (exonerate_amd/srchash.py); another tree gets no counter figures at all
+        pmc_note, kernels_pmc = None, None
         try:
+            from exonerate_amd.srchash import csrc_hash
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-            if tj["config"] == {"pairs_per_gpu": n_local, "query_len": args.qlen, "target_len": args.tlen} \
+            here = csrc_hash()
+            if tj.get("csrc_hash") != here:
+                pmc_note = ("profiles/traffic_latest.json was made from csrc %s, this tree is %s: no counter figures quoted "
+                            "(tools/profile_round.sh + tools/summarise_profile.py make new ones)" % (tj.get("csrc_hash"), here))
+            elif tj["config"] == {"pairs_per_gpu": n_local, "query_len": args.qlen, "target_len": args.tlen} \
                     and tj.get("mode", 2) == dom_mode:
-                traffic, kname, valu_pmc = tj["bytes_per_launch"], tj["kernel"], tj.get("valu")
-        except (OSError, ValueError, KeyError):
-            pass
+                traffic, kname, valu_pmc, kernels_pmc = tj["bytes_per_launch"], tj["kernel"], tj.get("valu"), tj.get("kernels")
+                pmc_note = "counters of %s (csrc %s)" % (tj.get("source"), here)
+            else:
+                pmc_note = "profiles/traffic_latest.json is of another configuration: no counter figures quoted"
+        except (OSError, ValueError, KeyError, ImportError) as e:
+            pmc_note = "no usable profiles/traffic_latest.json (%s)" % type(e).__name__
         # the bound that matters for this kernel: VALU issue.  Peak = the MEASURED issue rate of the kernel's own
         # instruction mix at its occupancy (tools/valu_issue_microbench.hip -> profiles/valu_issue_latest.json),
         # instructions per launch from the SQ counters of the profiled run (profiles/traffic_latest.json),
@@ -733,10 +847,16 @@ def main():
                 peak_ipc = vj.get("nominal_wave_inst_per_clk_per_simd", vj["peak_wave_inst_per_clk_per_simd"])
                 clk = vj["clock_ghz"] * 1e9
                 peak = peak_ipc * vj["simds"] * clk                     # wave-instructions per second, whole chip
-                ach = valu_pmc["insts_per_launch"] / (avg_ms * 1e-3)
+                # instructions of THIS run's launches: the kernel's lane operations per cell (a property of the code: the SQ
+                # counters of the profiled run of the same source hash) x the cells this run's launches covered / 64 lanes;
+                # the time is this run's own (HIP events)
+                insts_here = valu_pmc["lane_ops_per_cell"] * (reg["cells"] / max(1, reg["launches"])) / 64.0
+                ach = insts_here / (avg_ms * 1e-3)
                 valu = {"bound": "valu-issue", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-inst/s",
                         "frac": ach / peak, "peak_wave_inst_per_clk_per_simd": peak_ipc, "clock_ghz": vj["clock_ghz"],
-                        "lane_ops_per_cell": valu_pmc["lane_ops_per_cell"], "source": vj["source"]}
+                        "lane_ops_per_cell": valu_pmc["lane_ops_per_cell"], "wave_insts_per_launch": insts_here,
+                        "wait_frac_of_wave_cycles_profiled": valu_pmc.get("wait_frac_of_wave_cycles"),
+                        "waves_per_simd": valu_pmc.get("waves_per_simd"), "source": vj["source"]}
                 w = str(int(round(valu_pmc.get("waves_per_simd", 0))))
                 if w in vj.get("wave_inst_per_clk_per_simd_by_waves", {}):
                     mix = vj["wave_inst_per_clk_per_simd_by_waves"][w] * vj["simds"] * vj["effective_clock_ghz_by_waves"][w] * 1e9
@@ -752,7 +872,7 @@ def main():
                       "bit-exact vulgar vs reference",
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "int32",
+            "vs_baseline": None, "dtype": "int32 (packed int16 where proven exact)",
             "dtype_note": "int32 as the reference (typedef gint C4_Score); the whole-rectangle score pass runs two jobs per lane in "
                           "saturating packed int16 halves where every score provably fits (bit-identical results; C4GPU_PK16=0 "
                           "keeps it in int32)", "data": "synthetic" if not stub else "stub (control-flow test, no device)",
@@ -775,16 +895,14 @@ def main():
                                    % (n_local, args.qlen, args.tlen),
                        "pairs_per_gpu": n_local, "pairs_per_step": n_step, "query_len": args.qlen, "target_len": args.tlen,
                        "aligned_in_sample": n_aligned},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": algo_bytes_per_launch,
-                         "launches_per_step": launches_per_step,
-                         "kernel": kname, "valu_pmc": valu_pmc, "valu": valu,
-                         "avg_launch_ms": avg_ms, "launches": reg["launches"],
-                         "kernel_cells_per_s": reg["cells"] / (reg["ms"] * 1e-3) if reg["ms"] else 0.0,
-                         "note": "integer max-plus with all live DP state in VGPRs: compulsory HBM traffic is "
-                                 "~17 B per target column, so the HBM fraction is ~0 by construction; `valu` is the "
-                                 "binding roof: measured issue rate of the kernel's instruction mix x 1024 SIMDs "
-                                 "(DESIGN.md section 5)"},
+            "roofline": roofline_block(valu, {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                                              "algorithmic_bytes": algo_bytes_per_launch},
+                                       {"launches_per_step": launches_per_step, "kernel": kname, "valu_pmc": valu_pmc,
+                                        "avg_launch_ms": avg_ms, "launches": reg["launches"],
+                                        "kernel_cells_per_s": reg["cells"] / (reg["ms"] * 1e-3) if reg["ms"] else 0.0,
+                                        "counters": pmc_note, "clock": clock_sampler.report(),
+                                        "kernels": kernel_table(kernels_pmc, stats, n_local, launches_per_step)}),
             "kernel_ms": {"score": stats[0]["ms"], "region": stats[2]["ms"], "checkpoint": stats[3]["ms"], "path": stats[1]["ms"]},
             # the step as a work-queue step: job header broadcast + work-item scatter + result gather (tensors over RCCL
             # when there is a process group), all inside the timed region

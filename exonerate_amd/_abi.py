@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libc4gpu.so")
 
-ABI_VERSION = 8            # C4GPU_ABI_VERSION of include/c4gpu.h these structures mirror
+ABI_VERSION = 9            # C4GPU_ABI_VERSION of include/c4gpu.h these structures mirror
 MAX_STATES, MAX_TRANSITIONS, MAX_CALCS, MAX_SHADOWS, NAME_LEN = 16, 48, 16, 4, 48
 SPLICE_MAX_LEN = 32
 CELL_MAX = 1 + MAX_SHADOWS + 3
@@ -150,6 +150,7 @@ class ViterbiResult(C.Structure):
 # (name, restype, argtypes) for every symbol include/*.h declares
 PROTOTYPES = [
     ("c4gpu_abi_version", C.c_int, []),
+    ("c4gpu_config_reload", C.c_int, []),
     ("c4gpu_last_error", C.c_char_p, []),
     ("c4gpu_ctx_create", C.c_void_p, [C.c_int]),
     ("c4gpu_ctx_destroy", None, [C.c_void_p]),
@@ -298,6 +299,42 @@ def load(path=None):
         fn = getattr(lib, name)          # AttributeError if the ABI header and the library diverge
         fn.restype = res
         fn.argtypes = args
+    lib = _EnvSynced(lib)
     if path is None:
         _lib = lib
     return lib
+
+
+class _EnvSynced:
+    """The library reads its C4GPU_* switches once (csrc/c4_config.h); tests flip them between two calls.  Every call through
+    this proxy first compares the process's C4GPU_* variables with what the library last read and asks it to read them again
+    (c4gpu_config_reload) when they differ -- the explicit hook, used by this plumbing and by nothing in the library."""
+
+    def __init__(self, cdll):
+        object.__setattr__(self, "_cdll", cdll)
+        object.__setattr__(self, "_seen", self._snapshot())
+        object.__setattr__(self, "_calls", {})
+
+    @staticmethod
+    def _snapshot():
+        return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("C4GPU_")))
+
+    def _sync(self):
+        now = self._snapshot()
+        if now != self._seen:
+            object.__setattr__(self, "_seen", now)
+            self._cdll.c4gpu_config_reload()
+
+    def __getattr__(self, name):
+        calls = object.__getattribute__(self, "_calls")
+        if name in calls:
+            return calls[name]
+        fn = getattr(self._cdll, name)
+
+        def call(*args, _fn=fn):
+            self._sync()
+            return _fn(*args)
+        call.__name__ = name
+        call.restype, call.argtypes = getattr(fn, "restype", None), getattr(fn, "argtypes", None)
+        calls[name] = call
+        return call

@@ -22,6 +22,7 @@
 
 #include "c4gpu.h"
 #include "c4_internal.h"
+#include "c4_config.h"
 #include "c4_memrule.h"
 #include "c4_launch.h"
 #include "c4_sdp_launch.h"
@@ -73,8 +74,7 @@ namespace {
 // works on its own items only.  C4GPU_HOST_THREADS=1 keeps everything on the calling thread.
 template <typename F> void parallel_for(long long n, long long min_per_thread, F &&fn) {
     static const int hw = [] {
-        const char *e = getenv("C4GPU_HOST_THREADS");
-        const int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        const int v = c4cfg::num(c4cfg::HOST_THREADS, (int)std::thread::hardware_concurrency());
         return std::max(1, std::min(v, 16));
     }();
     const int t = (int)std::min<long long>(hw, n / std::max<long long>(1, min_per_thread));
@@ -93,17 +93,25 @@ template <typename F> void parallel_for(long long n, long long min_per_thread, F
 // hipFree waits for the whole device: with two launch lanes and a staging stream in flight, a launch buffer that has to grow
 // in the middle of a step would stall its lane until the other lane's kernels (hundreds of ms) have finished.  A buffer that
 // is outgrown is therefore retired, not freed: it goes onto this list and is freed when its owner is (batch / stage / context
-// destruction: nothing is in flight then), or at once when the list holds more than 16 GB.
+// destruction: nothing is in flight then), or at once when the list holds more than its cap: 16 GB, or a tenth of the device's
+// memory where that is less (set when a context opens).  An allocation that fails frees the list and tries once more (DevBuf::alloc,
+// PinBuf::reserve, the SDP arena), and every sizing decision that asks the device how much is free counts the list as free
+// (dev_mem_info): what waits here is memory nobody uses.
 struct RetiredBuffers {
     std::mutex lock;
     std::vector<std::pair<void *, size_t>> list;
     size_t bytes = 0;
+    size_t cap = (size_t)16 << 30;
+    void set_cap_for(size_t device_bytes) {
+        std::lock_guard<std::mutex> hold(lock);
+        cap = std::min<size_t>((size_t)16 << 30, device_bytes / 10);
+    }
     void retire(void *p, size_t n) {
         std::vector<std::pair<void *, size_t>> drop;
         {
             std::lock_guard<std::mutex> hold(lock);
             list.emplace_back(p, n); bytes += n;
-            if (bytes > ((size_t)16 << 30)) { drop.swap(list); bytes = 0; }
+            if (bytes > cap) { drop.swap(list); bytes = 0; }
         }
         for (auto &d : drop) (void)hipFree(d.first);
     }
@@ -114,6 +122,24 @@ struct RetiredBuffers {
     }
 };
 static RetiredBuffers g_retired;
+// hipMalloc that gives the retired buffers back to the device before it gives up
+static hipError_t dev_malloc(void **p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
+        (void)hipGetLastError();
+        g_retired.flush();
+        e = hipMalloc(p, bytes);
+    }
+    return e;
+}
+// free / total device memory as a sizing decision should see them: what is only waiting to be freed counts as free (it is
+// NOT freed here: hipFree waits for every kernel in flight, which is why the buffers were retired; the allocation that follows
+// frees them if it has to)
+static hipError_t dev_mem_info(size_t *free_bytes, size_t *total_bytes) {
+    const hipError_t e = hipMemGetInfo(free_bytes, total_bytes);
+    if (e == hipSuccess) { std::lock_guard<std::mutex> hold(g_retired.lock); *free_bytes += g_retired.bytes; }
+    return e;
+}
 
 // Small transfers between the passes go through page-locked memory.  A copy to or from pageable memory is carried out by a
 // copy KERNEL of one workgroup (__amd_rocclr_copyBuffer), which needs a compute unit with room for it -- and while the other
@@ -154,9 +180,11 @@ struct PinArenaRef {
     PinArena *get() { if (!a) a = g_pin_pool.take(); return a; }
 };
 static thread_local PinArenaRef t_pin;
-static const bool g_free_now = getenv("C4GPU_FREE_NOW") && atoi(getenv("C4GPU_FREE_NOW")) != 0;      // ~DevBuf frees at once (as before round 5's end)
-static const bool g_dl_sync_first = getenv("C4GPU_DL_SYNC_FIRST") && atoi(getenv("C4GPU_DL_SYNC_FIRST")) != 0;
-static const bool g_pin_off = getenv("C4GPU_PIN_XFER") && atoi(getenv("C4GPU_PIN_XFER")) == 0;       // 0: pageable copies, as before
+// C4GPU_FREE_NOW=1: ~DevBuf frees at once (as before round 5's end); C4GPU_DL_SYNC_FIRST=1: see DevBuf::download;
+// C4GPU_PIN_XFER=0: pageable copies, as before round 5
+static inline bool g_free_now_q() { return c4cfg::nonzero(c4cfg::FREE_NOW); }
+static inline bool g_dl_sync_first_q() { return c4cfg::nonzero(c4cfg::DL_SYNC_FIRST); }
+static inline bool g_pin_off_q() { return c4cfg::is(c4cfg::PIN_XFER, 0); }
 
 // every wait for a stream: the downloads of this thread that landed in its arena reach their destinations
 static hipError_t c4_stream_sync(hipStream_t s) {
@@ -173,7 +201,7 @@ static hipError_t c4_stream_sync(hipStream_t s) {
 }
 // bytes of the calling thread's arena for a transfer on stream s (nullptr: too large, or no arena -- copy directly)
 static uint8_t *pin_slot(size_t bytes, hipStream_t s) {
-    if (g_pin_off || !bytes) return nullptr;
+    if (g_pin_off_q() || !bytes) return nullptr;
     PinArena *a = t_pin.get();
     if (!a->cap || bytes > a->cap / 4) return nullptr;
     if (a->stream_set && a->stream != s) { (void)c4_stream_sync(a->stream); }
@@ -196,7 +224,7 @@ struct DevBuf {
     // (retired, not freed: hipFree waits for every kernel on the device, those of other threads' batches included -- the HSP
     // extension of the drop-in's main thread waited 0.35 s for the SDP passes of the flight beside it at the end of each of
     // its calls; what is retired is freed at the next flush: context / batch / stage destroy, or once 16 GB are waiting)
-    ~DevBuf() { if (p) { if (g_free_now) (void)hipFree(p); else g_retired.retire(p, n * sizeof(T)); } }
+    ~DevBuf() { if (p) { if (g_free_now_q()) (void)hipFree(p); else g_retired.retire(p, n * sizeof(T)); } }
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
@@ -208,11 +236,11 @@ struct DevBuf {
         count += count / 8;
         if (count * sizeof(T) < ((size_t)1 << 20)) count *= 2;
         if (!count) count = 1;
-        HIP_OK(hipMalloc((void **)&p, count * sizeof(T)));
+        HIP_OK(dev_malloc((void **)&p, count * sizeof(T)));
         n = count;
         // C4GPU_FILL_ALLOC=<byte>: every new device buffer starts as that byte (a test hook: nothing may depend on what a
         // buffer held before its first write)
-        if (const char *fill = getenv("C4GPU_FILL_ALLOC")) HIP_OK(hipMemset(p, atoi(fill), count * sizeof(T)));
+        if (c4cfg::has(c4cfg::FILL_ALLOC)) HIP_OK(hipMemset(p, c4cfg::num(c4cfg::FILL_ALLOC, 0), count * sizeof(T)));
         return 0;
     }
     int upload(const T *src, size_t count, hipStream_t s) {
@@ -237,7 +265,7 @@ struct DevBuf {
         // every read-back costs nothing in a warm run (425.8 ms either way) but serialises the host's work between a launch and
         // its wait with the kernel, and the first steps of a run, which still allocate their launch buffers there, took
         // 805 ms instead of 417 (`bench.py` with its default three steps).  So: off by default.
-        if (g_dl_sync_first) (void)hipStreamSynchronize(s);
+        if (g_dl_sync_first_q()) (void)hipStreamSynchronize(s);
         if (uint8_t *slot = pin_slot(count * sizeof(T), s)) {
             HIP_OK(hipMemcpyAsync(slot, p, count * sizeof(T), hipMemcpyDeviceToHost, s));
             t_pin.a->pending.push_back(PinArena::Pending{dst, slot, count * sizeof(T)});
@@ -274,7 +302,9 @@ struct PinBuf {
         if (bytes <= n && p) return 0;
         if (p) { (void)hipHostFree(p); p = nullptr; n = 0; }
         bytes += bytes / 8;                      // the next batch of a stream of batches is about this size, rarely the same
-        HIP_OK(hipHostMalloc((void **)&p, bytes, hipHostMallocDefault));
+        hipError_t e = hipHostMalloc((void **)&p, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) { (void)hipGetLastError(); g_retired.flush(); e = hipHostMalloc((void **)&p, bytes, hipHostMallocDefault); }
+        HIP_OK(e);
         n = bytes;
         return 0;
     }
@@ -779,7 +809,7 @@ __host__ __device__ inline bool final_cell_equiv(const int *computed, const int 
     return true;
 }
 
-inline bool cell_strict() { return getenv("C4GPU_CELL_STRICT") && atoi(getenv("C4GPU_CELL_STRICT")) != 0; }      // read on every call: a test switches it
+inline bool cell_strict() { return c4cfg::nonzero(c4cfg::CELL_STRICT); }
 
 // one thread per checkpoint job: verify the chain of final cells, then Alignment_add (alignment.c:75-102) over the runs
 // of its sub-alignments in path order (each job's walk wrote its runs END -> START)
@@ -860,7 +890,7 @@ struct ResidentSeqs {
 
     int build(c4gpu_ctx *ctx, int family, const c4gpu_params *params, const c4gpu_pair *pairs, int n, bool pin = false,
               const SpliceFold *fold16 = nullptr) {
-        const bool trace = getenv("C4GPU_TRACE") != nullptr;          // read on every call: tests switch it
+        const bool trace = c4cfg::has(c4cfg::TRACE);
         const auto t_begin = std::chrono::steady_clock::now();
         auto lap = [&](const char *what) {
             if (trace) fprintf(stderr, "c4gpu trace: staging: %-24s at %.3f ms\n", what,
@@ -974,7 +1004,7 @@ struct ResidentSeqs {
         ss16_built = false;
         if (family_has_splice(family)) {
             if (splice_models.upload(params->splice, 4, s) || ss.alloc((size_t)4 * ht_n)) return -1;
-            bool tiled = !(getenv("C4GPU_SPLICE_TILE") && atoi(getenv("C4GPU_SPLICE_TILE")) == 0);     // 0: the one-position-per-thread kernel
+            bool tiled = !(c4cfg::is(c4cfg::SPLICE_TILE, 0));     // 0: the one-position-per-thread kernel
             for (int k = 0; k < 4; k++)
                 tiled = tiled && params->splice[k].splice_after >= 0 && params->splice[k].splice_after <= SPLICE_HALO &&
                         params->splice[k].model_length >= 0 && params->splice[k].model_length <= C4GPU_SPLICE_MAX_LEN;
@@ -1105,9 +1135,9 @@ struct SeedPlan {
 // cooperating waves per job of the region windows (SEED 2): two where the family has that form -- a job's later windows are
 // a few hundred rows high and leave fewer waves idle than with four (north-star batch: 846 against 867 ms per step) --
 // three waves: 894-916 ms, one wave with every strip boundary through HBM: 854-872 ms, four rows per lane on two waves:
-// 851-857 ms -- C4GPU_WIN_NW=4 keeps four (read on every call: a test switches it)
+// 851-857 ms -- C4GPU_WIN_NW=4 keeps four
 int window_waves(int family) {
-    int nw = getenv("C4GPU_WIN_NW") ? atoi(getenv("C4GPU_WIN_NW")) : 2;
+    int nw = c4cfg::num(c4cfg::WIN_NW, 2);
     if (nw != 2) nw = 4;
     return get_kernel_mw(family, MODE_REGION, true, true, nw, false, 2) ? nw : 4;
 }
@@ -1265,7 +1295,7 @@ struct Engine {
                 // itself, but with 0.001 for the float sums: 13 + 15 - 30 = -2 under the default parameters), and nothing
                 // else that moves along the target without a query row adds anything (gaps cost).  Then every cell of a
                 // one-row continuation from s takes the loop, whatever the order of the candidates.  C4GPU_LOOP_SHORTCUT=0: off.
-                const bool loop_on = !(getenv("C4GPU_LOOP_SHORTCUT") && atoi(getenv("C4GPU_LOOP_SHORTCUT")) == 0);
+                const bool loop_on = !(c4cfg::is(c4cfg::LOOP_SHORTCUT, 0));
                 bool others_cost = true;
                 for (int k = 0; k < m->n_transitions; k++) {
                     const c4gpu_transition &t = m->transitions[k];
@@ -1307,10 +1337,10 @@ struct Engine {
                     }
                 }
             }
-            if (getenv("C4GPU_LOCAL_EXACT") && atoi(getenv("C4GPU_LOCAL_EXACT")) == 0) local_exact = false;   // test hook
+            if (c4cfg::is(c4cfg::LOCAL_EXACT, 0)) local_exact = false;   // test hook
         }
         for (int i = 0; i < 16; i++) kp.loop_tr[i] = loop_tr_host[i];
-        if (getenv("C4GPU_TRACE") && family == FAM_EST2GENOME) {
+        if (c4cfg::has(c4cfg::TRACE) && family == FAM_EST2GENOME) {
             std::string which;
             for (int i = 0; i < 16; i++) if (loop_tr_host[i] >= 0) which += " " + std::to_string(i) + ":" + std::to_string(loop_tr_host[i]);
             fprintf(stderr, "c4gpu trace: one-row sections answered without a DP for states (state:loop transition)%s\n",
@@ -1326,9 +1356,9 @@ struct Engine {
     // The continuation kernels compiled without the row-0 validity mask (c4_viterbi_kernel.h, eval_cell: CONT && LOCAL)
     // hold, in states the reference leaves unset, -987654321 plus at most one calc per cell of a path: exact while
     // that stays far below every real score of the job, i.e. (Q + T + 2) x the largest calc well under 987654321 / 2.
-    // C4GPU_CONT_FREE=0 keeps the kernels with every mask (read on every call: a test switches it).
+    // C4GPU_CONT_FREE=0 keeps the kernels with every mask.
     bool cont_free_ok(long long q_plus_t) const {
-        if (getenv("C4GPU_CONT_FREE") && atoi(getenv("C4GPU_CONT_FREE")) == 0) return false;
+        if (c4cfg::is(c4cfg::CONT_FREE, 0)) return false;
         return (double)(q_plus_t + 2) * std::max(calc_bound, 1.0) < 4.0e8;
     }
 
@@ -1396,7 +1426,7 @@ struct Engine {
 
     int run_impl(const ResidentSeqs &seqs, int mode, bool cont, const std::vector<JobSpec> &specs,
                  std::vector<JobOut> &out, const std::vector<RegionPoints> *pts, SeedPlan *seed = nullptr) {
-        const bool trace = getenv("C4GPU_TRACE") != nullptr;          // read on every call: tests switch it
+        const bool trace = c4cfg::has(c4cfg::TRACE);
         const auto t_begin = std::chrono::steady_clock::now();
         struct Trace {
             bool on; std::chrono::steady_clock::time_point t0; int mode, n;
@@ -1420,10 +1450,10 @@ struct Engine {
         auto nbits = [](int v) { int b = 0; while ((1LL << b) <= v) b++; return b; };
         // C4GPU_PACK=0 forces the two-slot form (what targets beyond 2^31 / query-rows columns get): read on
         // every call so that a test can switch it
-        bool pack = (mode == MODE_REGION) && !(getenv("C4GPU_PACK") && atoi(getenv("C4GPU_PACK")) == 0);
+        bool pack = (mode == MODE_REGION) && !(c4cfg::is(c4cfg::PACK, 0));
         for (int i = 0; i < n && pack; i++)
             pack = nbits(specs[i].region.query_length) + nbits(specs[i].region.target_length) <= 31;
-        static const int wpe_env = getenv("C4GPU_WPE") ? atoi(getenv("C4GPU_WPE")) : 0;
+        const int wpe_env = c4cfg::num(c4cfg::WPE, 0);
         int span = 0;
         for (int i = 0; i < n; i++) {
             const int sp = specs[i].span_in ? 1 : (specs[i].span_out ? 2 : 0);
@@ -1447,7 +1477,7 @@ struct Engine {
         const int span_cs = 1 + model->total_shadow_designations;
         // whole-rectangle passes whose query spans several 64*R-row strips run on 4 cooperating waves per
         // job (strip carry rows stay in LDS instead of HBM); C4GPU_MW=0 forces the one-wave kernels
-        static const int mw_env = getenv("C4GPU_MW") ? atoi(getenv("C4GPU_MW")) : 1;
+        const int mw_env = c4cfg::num(c4cfg::MW, 1);
         if (seed) {
             int win_nw = seed->mode == 2 ? window_waves(family) : 4;
             // the score pass of a launch with too few jobs to occupy the device on four waves each (256 proteins against one
@@ -1458,7 +1488,7 @@ struct Engine {
             ki = get_kernel_mw(family, mode, true, mode == MODE_REGION, win_nw, false, seed->mode);
             if (!ki || !use_local || (mode == MODE_REGION && !pack)) { c4h::set_error("no seeded kernel for this launch"); return -1; }
             // the score pass with dumps: two jobs per lane in packed 16-bit halves where every score fits (C4GPU_PK16=0: never)
-            const int pk_env = getenv("C4GPU_PK16") ? atoi(getenv("C4GPU_PK16")) : 1;      // read on every call: a test switches it
+            const int pk_env = c4cfg::num(c4cfg::PK16, 1);
             const KernelInfo *kpk = (seed->mode == 1 && pk_env && pk16_params_ok && n >= 2) ? get_kernel_pk16(family, pk_env == 3 ? 0 : pk_env == 4 ? 2 : 1) : nullptr;      // 3: the all-asm form (c4_viterbi16_kernel.h, VAR 0)
             if (kpk) {
                 bool fits = true;
@@ -1468,7 +1498,7 @@ struct Engine {
                 if (fits) ki = kpk;
                 // ... and with the packed region windows behind it (c4_win16_kernel.h; C4GPU_WIN16=0: the 32-bit windows) it
                 // writes its dumps as 16-bit rows: window rows and columns must fit 15 / 16 bits
-                const int w16_env = getenv("C4GPU_WIN16") ? atoi(getenv("C4GPU_WIN16")) : 1;     // read on every call: a test switches it
+                const int w16_env = c4cfg::num(c4cfg::WIN16, 1);
                 const KernelInfo *kd = (fits && pk_env == 1 && w16_env) ? get_kernel_pk16(family, 3) : nullptr;
                 // (the packed windows index a query profile by the targets' dense codes: at most eight residue codes in the batch)
                 if (kd && get_kernel_win16(family, 0) && seed->kshift <= 15 && seqs.tdense_n > 0) {
@@ -1477,12 +1507,12 @@ struct Engine {
                     if (rows_ok) { ki = kd; seed->fmt16 = true; }
                     // ... and with its column loop fed from LDS alone (IO 1) where every query fits the strips of one workgroup
                     // and the targets hold few enough residue codes for the query profile (C4GPU_PK16_IO=0: never; 1: with a barrier per chunk instead of progress counters)
-                    const int io_env = getenv("C4GPU_PK16_IO") ? atoi(getenv("C4GPU_PK16_IO")) : 2;
+                    const int io_env = c4cfg::num(c4cfg::PK16_IO, 2);
                     const KernelInfo *ke = (rows_ok && io_env) ? get_kernel_pk16(family, io_env == 2 ? 5 : 4) : nullptr;     // 2 (default): progress counters between the cooperating waves; 1: a barrier per chunk
                     // seven or eight codes (IUPAC ambiguity codes in the targets): the staged form with the larger profile, where every
                     // query fits its four strips of 256 rows (C4GPU_PK16_C8=0: the form that loads per step)
                     if (ke && seqs.tdense_n > pk16_staged_codes() && seqs.tdense_n <= 8 && io_env == 2 &&
-                        !(getenv("C4GPU_PK16_C8") && atoi(getenv("C4GPU_PK16_C8")) == 0) && get_kernel_pk16(family, 8)) {
+                        !(c4cfg::is(c4cfg::PK16_C8, 0)) && get_kernel_pk16(family, 8)) {
                         bool strips_ok = true;
                         for (int i = 0; i < n && strips_ok; i++) strips_ok = specs[i].region.query_length + 1 <= pk16_staged_rows();
                         if (strips_ok) { ki = get_kernel_pk16(family, 8); staged_codes = seqs.tdense.p; }
@@ -1491,7 +1521,7 @@ struct Engine {
                         bool strips_ok = true;
                         for (int i = 0; i < n && strips_ok; i++) strips_ok = specs[i].region.query_length + 1 <= pk16_staged_rows();
                         if (strips_ok) { ki = ke; staged_codes = seqs.tdense.p; }
-                        else if (io_env == 2 && !(getenv("C4GPU_PK16_R6") && atoi(getenv("C4GPU_PK16_R6")) == 0)) {
+                        else if (io_env == 2 && !(c4cfg::is(c4cfg::PK16_R6, 0))) {
                             // queries of 1 024 .. 1 535 rows: six rows per lane put them into the four strips of one workgroup
                             // (C4GPU_PK16_R6=0: the form that loads per step, in two passes over the target)
                             const KernelInfo *kh = get_kernel_pk16(family, 7);
@@ -1499,13 +1529,13 @@ struct Engine {
                             for (int i = 0; i < n && six_ok; i++) six_ok = specs[i].region.query_length + 1 <= pk16_staged_rows6();
                             if (six_ok) { ki = kh; staged_codes = seqs.tdense.p; }
                             // ... longer ones in several super-strips of that form (C4GPU_PK16_LONG=0: the per-step form)
-                            else if (get_kernel_pk16(family, 9) && !(getenv("C4GPU_PK16_LONG") && atoi(getenv("C4GPU_PK16_LONG")) == 0)) {
+                            else if (get_kernel_pk16(family, 9) && !(c4cfg::is(c4cfg::PK16_LONG, 0))) {
                                 ki = get_kernel_pk16(family, 9); staged_codes = seqs.tdense.p;
                             }
                         }
                         // ... on eight waves of two rows per lane where the launch has at most one pair of jobs per compute unit (the
                         // shard of a strong-scaled run): twice the waves on the same rows (C4GPU_PK16_NW8=0: never; 1: always)
-                        const int nw8_env = getenv("C4GPU_PK16_NW8") ? atoi(getenv("C4GPU_PK16_NW8")) : -1;
+                        const int nw8_env = c4cfg::num(c4cfg::PK16_NW8, -1);
                         const KernelInfo *kg = (strips_ok && io_env == 2 && nw8_env != 0) ? get_kernel_pk16(family, 6) : nullptr;
                         if (kg && (nw8_env == 1 || (n + 1) / 2 <= ctx->prop.multiProcessorCount)) ki = kg;
                     }
@@ -1513,7 +1543,7 @@ struct Engine {
             }
             if (seed->mode == 1) { seed->seedw = ki->seedw; seed->dc = ki->max_at; }
             if (seed->mode == 2 && seed->fmt16) {
-                const int w16_env = getenv("C4GPU_WIN16") ? atoi(getenv("C4GPU_WIN16")) : 1;     // 2..9: one shape whatever the jobs (tests, measurement)
+                const int w16_env = c4cfg::num(c4cfg::WIN16, 1);     // 2..9: one shape whatever the jobs (tests, measurement)
                 int shape = w16_env == 9 ? 0 : w16_env - 1;
                 if (w16_env <= 1) {          // the strips of a window on two cooperating waves where the first windows have two strips and more
                     long long strips = 0;
@@ -1537,7 +1567,7 @@ struct Engine {
             const KernelInfo *kmw8 = (ki == kmw && mw_env != 4 && !pts) ? get_kernel_mw(family, mode, use_local, pack, 8) : nullptr;
             if (kmw8 && (long long)n * 8 <= 2LL * 4 * ctx->prop.multiProcessorCount) ki = kmw8;
         }
-        if (seed && getenv("C4GPU_TRACE")) fprintf(stderr, "c4gpu trace:   seeded pass %d with kernel %s\n", seed->mode, ki->name);
+        if (seed && c4cfg::has(c4cfg::TRACE)) fprintf(stderr, "c4gpu trace:   seeded pass %d with kernel %s\n", seed->mode, ki->name);
         // longest first (persistent waves pull from the queue head)
         std::vector<int> &order = h_order;
         order.resize(n);
@@ -1873,7 +1903,7 @@ int sequential_reduced_path(Engine &eng, const ResidentSeqs &seqs, int pair, int
 // handful of waves takes as long as thousands: 433 ms for 11 chance alignments across 1 kb x 93 kb).
 int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector<int> &red, const std::vector<PairPlan> &plan,
                         int dpmemory_mb, c4gpu_alignment *alignments, std::vector<char> &done, std::map<int, JobOut> &unfinished) {
-    const bool trace = getenv("C4GPU_TRACE") != nullptr;          // read on every call: tests switch it
+    const bool trace = c4cfg::has(c4cfg::TRACE);
     const auto t_begin = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (trace) fprintf(stderr, "c4gpu trace:   fused: %-22s at %.3f ms\n", what,
@@ -1883,8 +1913,8 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
     c4gpu_ctx *ctx = eng.ctx;
     const int n = (int)red.size();
     if (!n || eng.pair_sub) return 0;
-    if (getenv("C4GPU_FUSED") && atoi(getenv("C4GPU_FUSED")) == 0) return 0;         // read on every call: a test switches it
-    static const int wpe_env = getenv("C4GPU_WPE") ? atoi(getenv("C4GPU_WPE")) : 0;
+    if (c4cfg::is(c4cfg::FUSED, 0)) return 0;
+    const int wpe_env = c4cfg::num(c4cfg::WPE, 0);
     long long worst = 0;
     for (int i : red) worst = std::max(worst, (long long)plan[i].ar.query_length + plan[i].ar.target_length);
     const bool cont_free = eng.cont_free_ok(worst);              // the sub-alignments lie inside their pair's region
@@ -1898,12 +1928,12 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
     // from: one strand of est2genome) where the region pass reported that state, else over every inner state;
     // C4GPU_CK16=0: never, 2..8: one shape whatever the jobs (tests, measurement), C4GPU_CK16_ROOT=0: never the rooted form (read on every
     // call: a test switches them)
-    const int ck_env = getenv("C4GPU_CK16") ? atoi(getenv("C4GPU_CK16")) : 1;
-    const bool ck_root_env = !(getenv("C4GPU_CK16_ROOT") && atoi(getenv("C4GPU_CK16_ROOT")) == 0);
+    const int ck_env = c4cfg::num(c4cfg::CK16, 1);
+    const bool ck_root_env = !(c4cfg::is(c4cfg::CK16_ROOT, 0));
     const bool ck16_on = ck_env > 0 && cont_free && eng.pk16_params_ok && seqs.tdense_n > 0;      // (dense target codes: Prof16)
     const KernelInfo *kc16 = ck16_on ? get_kernel_ck16(eng.family, 0, false) : nullptr;
     const KernelInfo *kc16r = (ck16_on && ck_root_env) ? get_kernel_ck16(eng.family, ck_env == 8 ? 0 : ck_env - 1, true) : nullptr;   // 1: chosen below, 8: variant 0
-    const int ck16_tmax = getenv("C4GPU_CK16_TMAX") ? atoi(getenv("C4GPU_CK16_TMAX")) : 0x7fffffff;      // test hook
+    const int ck16_tmax = c4cfg::num(c4cfg::CK16_TMAX, 0x7fffffff);      // test hook
     hipStream_t s = ctx->stream;
     const c4h::MemRule rule{m->max_query_advance, m->max_target_advance, m->n_states, m->total_shadow_designations};
     // -- the checkpoint jobs: the rooted packed kernel's first (root by root), then the packed kernel's, then the 32-bit kernel's,
@@ -1957,7 +1987,7 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
         if (group[a] == 2 && root_of(a) != root_of(b)) return root_of(a) < root_of(b);
         return cells(a) > cells(b);
     });
-    if (getenv("C4GPU_TRACE"))
+    if (c4cfg::has(c4cfg::TRACE))
         fprintf(stderr, "c4gpu trace:   fused: kernels %s, %s\nc4gpu trace:   fused: packed checkpoint kernels %s for %d, %s for %d of %d jobs\n",
                 kc->name, kp->name, (kc16r && n16r) ? kc16r->name : "-", n16r, (kc16 && n16a) ? kc16->name : "-", n16a, n);
     std::vector<DevJob> &jobs = eng.hf_jobs;
@@ -2088,7 +2118,7 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
     if (eng.d_fflags.zero(n, s)) return -1;
     hipLaunchKernelGGL(fuse_expand_kernel, dim3(n), dim3(64), 0, s, eng.d_fjobs.p, eng.d_fvsa.p, eng.d_ffirst.p, n,
                        eng.d_fsub_jobs.p, rule, dpmemory_mb, kp->R, eng.d_fflags.p, eng.d_fstats.p,
-                       (getenv("C4GPU_BYROOT") && atoi(getenv("C4GPU_BYROOT")) == 0) ? 0 : 1);
+                       (c4cfg::is(c4cfg::BYROOT, 0)) ? 0 : 1);
     HIP_OK(hipGetLastError());
     if (eng.d_fstats.download(stats.data(), FUSE_STATS, s)) return -1;
     HIP_OK(c4_stream_sync(s));
@@ -2183,7 +2213,7 @@ int fused_reduced_paths(Engine &eng, const ResidentSeqs &seqs, const std::vector
             unfinished[red[order[x]]] = std::move(o);
         }
     }
-    if (getenv("C4GPU_TRACE"))               // read on every call: a test switches it on
+    if (c4cfg::has(c4cfg::TRACE))
         fprintf(stderr, "c4gpu trace:   fused: %d of %d pairs finished on the device route, %lld sub-alignments\n", n_done, n, n_sub);
     lap("alignments built");
     return 0;
@@ -2224,14 +2254,14 @@ int windowed_region_pass(Engine &eng, const ResidentSeqs &seqs, const std::vecto
     // them cost 127 ms per 1 024 pairs, the extra hops cost nothing: profiles/r03_step.md), at least 12, at most 64
     int need_hops = 12;
     for (int x : want) need_hops = std::max(need_hops, ((outs[x].res.te - 1) >> kshift) + 2);
-    const int max_hops = getenv("C4GPU_WINDOW_HOPS") ? atoi(getenv("C4GPU_WINDOW_HOPS")) : std::min(need_hops, 64);
+    const int max_hops = c4cfg::num(c4cfg::WINDOW_HOPS, std::min(need_hops, 64));
     std::vector<int> open;                                       // pairs whose path runs back further than the hop budget
     std::vector<char> demoted(n, 0);                             // ... and pairs the packed route could not serve (below)
     long long windows = 0;
     // C4GPU_STRICT=1 (debugging): a packed pass that disagrees with the 32-bit kernels fails the call instead of handing the
     // pair to them; C4GPU_FORCE_CORNER_MISMATCH=k (test hook): every k-th wanted pair is treated as such a disagreement
-    const bool strict = getenv("C4GPU_STRICT") && atoi(getenv("C4GPU_STRICT")) != 0;
-    const int force_miss = getenv("C4GPU_FORCE_CORNER_MISMATCH") ? atoi(getenv("C4GPU_FORCE_CORNER_MISMATCH")) : 0;
+    const bool strict = c4cfg::nonzero(c4cfg::STRICT);
+    const int force_miss = c4cfg::num(c4cfg::FORCE_CORNER_MISMATCH, 0);
     if (sp1.fmt16) {
         // the packed windows compute the component of the state END was entered from (DevResult::last_srp of the score pass);
         // a pair without one goes to the one-pass 32-bit kernel, which needs none
@@ -2239,7 +2269,7 @@ int windowed_region_pass(Engine &eng, const ResidentSeqs &seqs, const std::vecto
         for (int x : want) {
             if (outs[x].res.last_srp > 1) { keep.push_back(x); continue; }
             if (strict) { c4h::set_error("windowed region pass: the score pass did not say where END was entered from"); return -1; }
-            if (getenv("C4GPU_TRACE")) fprintf(stderr, "c4gpu trace:   pair %d: no root from the packed score pass, one-pass kernel\n", pairs[x]);
+            if (c4cfg::has(c4cfg::TRACE)) fprintf(stderr, "c4gpu trace:   pair %d: no root from the packed score pass, one-pass kernel\n", pairs[x]);
             open.push_back(x); demoted[x] = 1;
         }
         want.swap(keep);
@@ -2276,7 +2306,7 @@ int windowed_region_pass(Engine &eng, const ResidentSeqs &seqs, const std::vecto
             if (!r.end_set || r.score != o.score || (force_miss > 0 && h % (size_t)force_miss == 0)) {
                 // never seen outside the test hook; should a packed pass ever disagree with itself, the pair is the one-pass
                 // 32-bit kernel's (the other pairs of the call keep their results)
-                if (getenv("C4GPU_TRACE"))
+                if (c4cfg::has(c4cfg::TRACE))
                     fprintf(stderr, "c4gpu trace:   pair %d: score pass %d at (%d, %d), window corner %d (set %d): one-pass kernel\n", pairs[want[h]],
                             o.score, o.qe, o.te, r.score, (int)r.end_set);
                 if (strict) { c4h::set_error("windowed region pass: a window's corner cell differs from the score pass"); return -1; }
@@ -2298,7 +2328,7 @@ int windowed_region_pass(Engine &eng, const ResidentSeqs &seqs, const std::vecto
             const DevResult &r = outs[h].res;
             DevResult &o = out[open[h]];
             if (r.score != o.score || r.qe != o.qe || r.te != o.te) {
-                if (getenv("C4GPU_TRACE"))
+                if (c4cfg::has(c4cfg::TRACE))
                     fprintf(stderr, "c4gpu trace:   pair %d: score pass %d at (%d, %d), one-pass kernel %d at (%d, %d)\n", pairs[open[h]],
                             o.score, o.qe, o.te, r.score, r.qe, r.te);
                 if (strict || !demoted[open[h]]) {
@@ -2318,7 +2348,7 @@ int windowed_region_pass(Engine &eng, const ResidentSeqs &seqs, const std::vecto
         const double rate = 1.0 - (double)hops.size() / (double)wanted;
         eng.ctx->window_rate = eng.ctx->window_rate < 0 ? rate : 0.5 * eng.ctx->window_rate + 0.5 * rate;
     }
-    if (getenv("C4GPU_TRACE"))
+    if (c4cfg::has(c4cfg::TRACE))
         fprintf(stderr, "c4gpu trace: windowed region pass: %d pairs, dumps every %d columns, %lld windows in one launch, %zu of %zu "
                 "paths left to the one-pass kernel\n", n, 1 << kshift, round, hops.size(), wanted);
     return 0;
@@ -2346,7 +2376,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
         SubScope(Engine &e_, const std::vector<const c4gpu_subopt *> *s) : e(e_) { e.pair_sub = s; }
         ~SubScope() { e.pair_sub = nullptr; }
     } sub_scope(eng, subs);
-    const bool trace = getenv("C4GPU_TRACE") != nullptr;          // read on every call: tests switch it
+    const bool trace = c4cfg::has(c4cfg::TRACE);
     const auto t_begin = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (trace) fprintf(stderr, "c4gpu trace: find_path_batch: %-28s at %.3f ms\n", what,
@@ -2382,21 +2412,21 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
         // (4 096 only where the packed pass will really run: a call with a pair that does not fit its 16 bits -- a long query, a
         // small --intronpenalty -- or with C4GPU_PK16=0 dumps 32-bit rows, for which 8 192 is the better interval)
         bool pk16_serves = eng.family == FAM_EST2GENOME && eng.pk16_params_ok && region_pairs.size() >= 2 &&
-                           !(getenv("C4GPU_PK16") && atoi(getenv("C4GPU_PK16")) == 0) && get_kernel_pk16(eng.family, 1) != nullptr;
+                           !(c4cfg::is(c4cfg::PK16, 0)) && get_kernel_pk16(eng.family, 1) != nullptr;
         for (size_t x = 0; x < region_pairs.size() && pk16_serves; x++)
             pk16_serves = eng.pk16_fits(plan[region_pairs[x]].ar.query_length, plan[region_pairs[x]].ar.target_length);
         int kshift_env = pk16_serves ? 12 : 13;
         for (int i : region_pairs)
             if (plan[i].ar.target_length < (4 << 13) && plan[i].ar.target_length >= (4 << 12)) kshift_env = 12;
-        if (getenv("C4GPU_SEED_KSHIFT")) kshift_env = atoi(getenv("C4GPU_SEED_KSHIFT"));
+        kshift_env = c4cfg::num(c4cfg::SEED_KSHIFT, kshift_env);
         const int kshift = std::max(2, std::min(kshift_env, 20));
-        const bool off = getenv("C4GPU_WINDOWED") && atoi(getenv("C4GPU_WINDOWED")) == 0;
+        const bool off = c4cfg::is(c4cfg::WINDOWED, 0);
         const KernelInfo *k1 = get_kernel_mw(eng.family, MODE_SCORE, true, false, 4, false, 1);
         const KernelInfo *k2 = get_kernel_mw(eng.family, MODE_REGION, true, true, 4, false, 2);
         // where most alignments ran past the hop budget in the earlier batches of this context (chance alignments across
         // whole windows: all-against-all without a threshold), the one-pass kernel is the cheaper form
-        const bool pays = eng.ctx->window_rate < 0 || eng.ctx->window_rate >= 0.5 || getenv("C4GPU_SEED_KSHIFT");
-        if (!off && pays && !subs && eng.local && eng.local_exact && k1 && k2 && !(getenv("C4GPU_PACK") && atoi(getenv("C4GPU_PACK")) == 0)) {
+        const bool pays = eng.ctx->window_rate < 0 || eng.ctx->window_rate >= 0.5 || c4cfg::has(c4cfg::SEED_KSHIFT);
+        if (!off && pays && !subs && eng.local && eng.local_exact && k1 && k2 && !(c4cfg::is(c4cfg::PACK, 0))) {
             std::vector<int> win_pairs, rest;
             for (int i : region_pairs) {
                 const c4gpu_region &ar = plan[i].ar;
@@ -2418,7 +2448,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
     // the region pass.  Same recurrence, same score (FIND_SCORE and FIND_REGION differ in payload only); the
     // choice follows the hit rate of the previous batches of this context, sampled on the first large one.
     {
-        const char *sf_env = getenv("C4GPU_SCORE_FIRST");                  // 0 never, 1 always, unset adaptive
+        const bool sf_env = c4cfg::has(c4cfg::SCORE_FIRST);                // 0 never, 1 always, unset adaptive
         const bool can = threshold > C4GPU_IMPOSSIBLY_LOW_SCORE && region_pairs.size() >= 512;
         const size_t total = region_pairs.size();
         auto score_filter = [&](size_t first, size_t count, size_t *kept) -> int {
@@ -2434,7 +2464,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
         };
         bool score_first = false;
         size_t sampled = 0, kept = 0, all_kept = 0;
-        if (can && sf_env) score_first = atoi(sf_env) != 0;
+        if (can && sf_env) score_first = c4cfg::num(c4cfg::SCORE_FIRST, 0) != 0;
         else if (can && hit_rate >= 0) score_first = hit_rate < 0.3;
         else if (can) {
             // one device-filling launch costs about the same as a small one: sample that many pairs
@@ -2590,11 +2620,11 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
                 // sends the pair down the call-by-call route (one launch per section: 50 launches of 2 ms for a chance
                 // alignment across a 100 kb window, profiles/r05_wide_trace.md).
                 const bool next_in_round = x + 1 < group[g + 1] && refs[x + 1].seg == k + 1;
-                if (getenv("C4GPU_TRACE"))
+                if (c4cfg::has(c4cfg::TRACE))
                     fprintf(stderr, "c4gpu trace: pair %d nested segment %d: final cell %d/%d after the nested pass, %d/%d predicted%s\n",
                             refs[x].pair, k, children.back().final_cell[0], children.back().final_cell[1], sg[k].final_cell[0], sg[k].final_cell[1],
                             next_in_round ? ": the next segment's nested pass used the old cell, sequential route" : "");
-                if (next_in_round || (getenv("C4GPU_NESTED_REDO") && atoi(getenv("C4GPU_NESTED_REDO")) != 0)) redo[refs[x].pair] = 1;
+                if (next_in_round || c4cfg::nonzero(c4cfg::NESTED_REDO)) redo[refs[x].pair] = 1;
             }
             sg.erase(sg.begin() + k);
             sg.insert(sg.begin() + k, children.begin(), children.end());
@@ -2632,7 +2662,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
     {
         std::vector<int> cap(n, 0);
         const int path_cs = 1 + m->total_shadow_designations;
-        static const bool force_seq = getenv("C4GPU_FORCE_SEQUENTIAL") != nullptr;    // test hook
+        const bool force_seq = c4cfg::has(c4cfg::FORCE_SEQUENTIAL);    // test hook
         if (force_seq) for (int i : red) redo[i] = 1;
         // The reference threads the final cell of each sub-DP into the next one (optimal.c:283,301); we
         // predicted it from the checkpoint rows to run all sub-DPs in one launch.  Verify: up to and including
@@ -2657,7 +2687,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
             for (uint32_t r : outs[x].runs) c4h::alignment_add(&a, &cap[i], (int)(r >> 24), (int)(r & 0xffffff));
             if (!final_cell_equiv(outs[x].res.final_cell, sg[k].final_cell, path_cs,
                                   sg[k].region.target_start + sg[k].region.target_length, packed_pair[i] != 0, strict_cells)) {
-                if (getenv("C4GPU_TRACE"))
+                if (c4cfg::has(c4cfg::TRACE))
                     fprintf(stderr, "c4gpu trace: pair %d sub-alignment %d: final cell %d/%d computed, %d/%d predicted\n", i,
                             k, outs[x].res.final_cell[0], outs[x].res.final_cell[1], sg[k].final_cell[0], sg[k].final_cell[1]);
                 if (k + 1 < (int)sg.size()) {
@@ -2680,7 +2710,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
         // early in a wide region cost one launch per remaining section: 50 launches of 2 ms for a chance alignment across a
         // 100 kb window, profiles/r05_wide_trace.md; differences in a cell are mostly an intron start that the next match
         // state forgets.)  C4GPU_REPAIR_REJOIN=0: recompute every sub-alignment behind a miss (test hook).
-        const bool rejoin = !(getenv("C4GPU_REPAIR_REJOIN") && atoi(getenv("C4GPU_REPAIR_REJOIN")) == 0);
+        const bool rejoin = !(c4cfg::is(c4cfg::REPAIR_REJOIN, 0));
         std::vector<size_t> first_of(n, 0);
         for (size_t r = 0; r < red.size(); r++) first_of[red[r]] = seg_first[r];
         std::vector<JobOut> routs;
@@ -2726,7 +2756,7 @@ int find_path_batch(Engine &eng, const ResidentSeqs &seqs, int dpmemory_mb, c4gp
             }
             repairs.swap(next);
         }
-        if (repair_launches && getenv("C4GPU_TRACE"))
+        if (repair_launches && c4cfg::has(c4cfg::TRACE))
             fprintf(stderr, "c4gpu trace: stale tails: %lld sub-alignments recomputed in %lld launches, %lld re-joined the batch\n",
                     repaired, repair_launches, rejoined);
     }
@@ -2770,7 +2800,7 @@ struct SideLane {
 
 // would this call be cut in two?  (callers create the side lane only then)
 bool lanes_wanted(const ResidentSeqs &seqs, const uint8_t *active, bool blocking) {
-    const int env = getenv("C4GPU_LANES") ? atoi(getenv("C4GPU_LANES")) : 0;       // read on every call: a test switches it
+    const int env = c4cfg::num(c4cfg::LANES, 0);
     if (blocking || env == 1) return false;
     long long n_act = 0;
     double cells = 0;
@@ -2871,6 +2901,13 @@ struct c4gpu_stage {
 extern "C" {
 
 int c4gpu_abi_version(void) { return C4GPU_ABI_VERSION; }
+int c4gpu_config_reload(void) {
+    (void)c4cfg::get();                       // (the once-flag is spent before the table is written again)
+    c4cfg::load_from_environment();
+    int n = 0;
+    for (int k = 0; k < c4cfg::N_KEYS; k++) n += c4cfg::table().e[k].set ? 1 : 0;
+    return n;
+}
 const char *c4gpu_last_error(void) { return c4h::g_error.c_str(); }
 
 static std::atomic<int> g_warm_cancel{0};        // c4gpu_ctx_warm_cancel; reset by every c4gpu_ctx_create
@@ -2898,6 +2935,7 @@ c4gpu_ctx *c4gpu_ctx_create(int device_ordinal) {
         delete ctx;
         return nullptr;
     }
+    g_retired.set_cap_for(ctx->prop.totalGlobalMem);
     return ctx;
 }
 
@@ -2983,14 +3021,14 @@ int c4gpu_ctx_sdp_reserve(c4gpu_ctx *ctx, int64_t bytes) {
         return 0;
     }
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { c4h::set_error("c4gpu_ctx_sdp_reserve: hipMemGetInfo failed"); return -1; }
+    if (dev_mem_info(&free_b, &total_b) != hipSuccess) { c4h::set_error("c4gpu_ctx_sdp_reserve: hipMemGetInfo failed"); return -1; }
     size_t want = std::min<size_t>((size_t)bytes, (size_t)((double)(free_b + ctx->sdp_arena_bytes) * 0.6));
     want &= ~(((size_t)1 << 16) - 1);                     // whole 64 KB chunks
     ctx->sdp_arena_keep = true;
     if (ctx->sdp_arena_bytes >= want) return 0;
     if (ctx->sdp_arena) (void)hipFree(ctx->sdp_arena);
     ctx->sdp_arena = nullptr; ctx->sdp_arena_bytes = 0;
-    if (hipMalloc(&ctx->sdp_arena, want) != hipSuccess) {
+    if (dev_malloc(&ctx->sdp_arena, want) != hipSuccess) {
         (void)hipGetLastError();
         ctx->sdp_arena = nullptr;
         c4h::set_error("c4gpu_ctx_sdp_reserve: allocation failed");
@@ -3361,7 +3399,7 @@ int c4gpu_stage_load(c4gpu_stage *st, const c4gpu_pair *pairs, int32_t n_pairs) 
         // the packed passes' splice array: written by the splice kernel itself here (ss16_kernel's formula with the calc
         // constants of the pre-splice transitions as `fold`), where the first packed launch would otherwise build it inside
         // the step (C4GPU_PK16=0: no packed pass, no array)
-        const bool pk = !(getenv("C4GPU_PK16") && atoi(getenv("C4GPU_PK16")) == 0) && n_pairs >= 2 && st->eng.pk16_params_ok &&
+        const bool pk = !(c4cfg::is(c4cfg::PK16, 0)) && n_pairs >= 2 && st->eng.pk16_params_ok &&
                         st->eng.family == FAM_EST2GENOME;
         SpliceFold fold{{0, 0, 0, 0}};
         for (int i = 0; i < st->model.n_calcs; i++)
@@ -3369,7 +3407,7 @@ int c4gpu_stage_load(c4gpu_stage *st, const c4gpu_pair *pairs, int32_t n_pairs) 
             else if (st->model.calcs[i].kind == C4GPU_CALC_SPLICE_POST) fold.add[st->model.calcs[i].param & 3] = 0;
         if (st->seqs.build(&st->ctx, st->eng.family, &st->params, pairs, n_pairs, true, pk ? &fold : nullptr)) return -1;
         if (pk && st->eng.ensure_ss16(st->seqs)) return -1;            // (only where the tiled splice kernel did not run)
-        if (pk && getenv("C4GPU_SS16_CHECK")) {
+        if (pk && c4cfg::has(c4cfg::SS16_CHECK)) {
             // test hook: the array the splice kernel wrote against the one ss16_kernel builds from the int arrays
             DevBuf<uint2> chk;
             const size_t nn = (size_t)st->seqs.ss_len;

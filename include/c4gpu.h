@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define C4GPU_ABI_VERSION 8
+#define C4GPU_ABI_VERSION 9
 
 /* src/c4/c4.h:28-30 */
 typedef int32_t c4gpu_score;
@@ -205,6 +205,13 @@ typedef struct {
 typedef struct c4gpu_ctx c4gpu_ctx;
 
 int         c4gpu_abi_version(void);
+/* The library's C4GPU_* switches (shapes kept for measurement, test hooks, fallbacks kept for A/B runs: csrc/c4_config.h) are read
+ * from the environment ONCE -- when the first context opens, or at the first question -- by one function; no call path of the
+ * library calls getenv (the reference reads its own environment through its ArgumentSets at start-up, argument.c, and so does
+ * the drop-in, integration/c4gpu_shim.c: shim_env).  c4gpu_config_reload reads the environment again: the hook of a test that
+ * flips a variable between two calls.  Not to be called while another thread is inside the library.  Returns the number of
+ * C4GPU_* variables it found set. */
+int         c4gpu_config_reload(void);
 const char *c4gpu_last_error(void);
 
 /* Opens HIP device `device_ordinal`.  Returns NULL (and sets last_error) when no gfx950 device or the

@@ -21,7 +21,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert declared <= bound, sorted(declared - bound)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.c4gpu_abi_version() == _abi.ABI_VERSION == 8
+    assert lib.c4gpu_abi_version() == _abi.ABI_VERSION == 9
 
 
 def test_no_cpu_fallback(lib):

@@ -10,6 +10,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-revcomp --no-configs"
+(cd $ROOT && python -c "from exonerate_amd.srchash import csrc_hash; print(csrc_hash())") > "$OUT/csrc_hash.txt"
 cd /tmp
 # (C4GPU_LANES=1 in the environment: the whole round on one launch lane, so that per-kernel times and counters add up to the step)
 python $ROOT/bench.py --steps 2 --warmup 1 ${BENCH_EXTRA:-} > "$OUT/bench.json" 2> "$OUT/bench.err"

@@ -54,8 +54,37 @@ vj = json.load(open(f"{dst}/valu_issue_latest.json"))
 wave_cycles = 4.0 * v["SQ_WAVE_CYCLES"] / max(v["SQ_WAVES"], 1)          # shader cycles one wave lives (quad-cycle counter)
 waves_per_simd = waves / vj["simds"]
 ipc = (v["SQ_INSTS_VALU"] / max(v["SQ_WAVES"], 1)) / wave_cycles * waves_per_simd
+# every pass of the step: wave-instructions per PAIR of the batch (a dispatch covers pairs_per_gpu / launches_per_step pairs),
+# registers, waiting share, the trace's launch time -- what bench.py's roofline.kernels sets this run's launch times against
+sys.path.insert(0, root)
+from exonerate_amd.srchash import csrc_hash
+lps = max(1, bench["roofline"].get("launches_per_step", 2))
+pairs_per_dispatch = cfg["pairs_per_gpu"] / lps
+def is_path(k):
+    if not k.startswith("c4k::viterbi_kernel<"): return False
+    a = [x.strip() for x in k.split("<", 1)[1].rstrip(">").split(",")]
+    return len(a) > 2 and a[2] == "1"
+groups = {"score": lambda k: "viterbi16_kernel_mw" in k or ("viterbi_kernel_mw" in k), "windows": lambda k: "win16_kernel" in k,
+          "checkpoint": lambda k: "ckpt16_kernel" in k, "path": is_path}
+kernels = {}
+for gname, pred in groups.items():
+    ks = [k for k in agg if pred(k)]
+    if not ks: continue
+    k = max(ks, key=lambda k: agg[k].get("SQ_WAVE_CYCLES", 0))
+    a = agg[k]
+    nd = int(a.get("dispatches:SQ_WAVES", 0)) or 1
+    tr = [r for name, r in stats.items() if short(name) == k]
+    vg = int(meta[k][0]) * 2
+    kernels[gname] = {"kernel": k, "dispatches_in_pmc_run": nd,
+                      "wave_insts_per_pair": a["SQ_INSTS_VALU"] / nd / pairs_per_dispatch,
+                      "wait_frac": a["SQ_WAIT_ANY"] / a["SQ_WAVE_CYCLES"] if a.get("SQ_WAVE_CYCLES") else None,
+                      "vgprs_per_lane": vg, "waves_per_simd": 512 // vg if vg else None,
+                      "lds_bytes": int(meta[k][3]), "scratch_bytes_per_lane": int(meta[k][4]),
+                      "rocprof_avg_launch_ms": float(tr[0]["AverageNs"]) / 1e6 if tr else None,
+                      "valu_frac_of_nominal_in_trace": (a["SQ_INSTS_VALU"] / nd) / (float(tr[0]["AverageNs"]) * 1e-9) / (0.5 * 1024 * 2.4e9) if tr else None}
 out = {
     "source": f"profiles/{tag}_pmc.csv, profiles/{tag}_kernel_stats.csv (tools/profile_round.sh, tools/summarise_profile.py)",
+    "csrc_hash": open(src + "/csrc_hash.txt").read().strip() if os.path.exists(src + "/csrc_hash.txt") else csrc_hash(), "kernels": kernels,
     "config": {"pairs_per_gpu": cfg["pairs_per_gpu"], "query_len": cfg["query_len"], "target_len": cfg["target_len"]},
     "kernel": reg, "mode": mode, "dispatches_in_pmc_run": n,
     "fetch_kib": v["FETCH_SIZE"] / n, "write_kib": v["WRITE_SIZE"] / n,
