@@ -381,8 +381,20 @@ class ClockSampler:
     def __init__(self, period=0.25):
         import glob
         self.period, self.samples, self._stop, self._thread = period, [], None, None
+        self.pci = None
         self.sclk = self.power = None
-        for c in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+        # the card this process computes on: a box has eight, the process sees one -- found by its PCI address
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+            addr = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            mine = [c for c in cards if os.path.basename(os.path.realpath(os.path.dirname(c))) == addr]
+            cards = mine or cards
+            self.pci = addr if mine else None
+        except Exception:
+            self.pci = None
+        for c in cards:
             self.sclk = c
             pw = glob.glob(os.path.join(os.path.dirname(c), "hwmon", "hwmon*", "power1_average")) + \
                  glob.glob(os.path.join(os.path.dirname(c), "hwmon", "hwmon*", "power1_input"))
@@ -407,6 +419,10 @@ class ClockSampler:
         import threading
         if self.sclk is None:
             return self
+        try:
+            self.raw = open(self.sclk).read()[:160]
+        except OSError:
+            self.raw = None
         self._stop = threading.Event()
         def loop():
             while not self._stop.is_set():
@@ -431,7 +447,8 @@ class ClockSampler:
                 "sclk_mhz_mean": sum(mhz) / len(mhz) if mhz else None, "sclk_mhz_min": min(mhz) if mhz else None,
                 "sclk_mhz_max": max(mhz) if mhz else None,
                 "power_w_mean": sum(w) / len(w) if w else None, "power_w_max": max(w) if w else None,
-                "source": "%s, %s (read while the %s timed steps of the headline ran)" % (self.sclk, self.power, "K")}
+                "pci_address_matched": self.pci, "pp_dpm_sclk_as_read": getattr(self, "raw", None),
+                "source": "%s, %s (read while the K timed steps of the headline ran)" % (self.sclk, self.power)}
 
 
 def main():
