@@ -821,7 +821,7 @@ def main():
         # 4 splice arrays x 4 B x T, 32 B of result
         algo_bytes = sum(len(q) + len(t) + 16 * len(t) + 32 for q, t in pairs)
         avg_ms = reg["ms"] / max(1, reg["launches"])
-        # a large batch runs as two halves on two launch lanes (c4_engine.hip, find_path_lanes): two launches of this kernel
+        # a large batch runs as two halves on two launch lanes (c4_engine_find_path.inc, find_path_lanes): two launches of this kernel
         # per step, each over half of the pairs, sharing the device while they overlap; the roofline is per LAUNCH
         launches_per_step = max(1, round(reg["launches"] / max(1, args.steps)))
         algo_bytes_per_launch = algo_bytes / launches_per_step

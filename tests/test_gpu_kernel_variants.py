@@ -714,7 +714,7 @@ def test_packed_16_bit_checkpoint_pass_agrees_with_the_32_bit_pass(eng, monkeypa
 @pytest.mark.parametrize("model_type", ["est2genome", "affine:local", "protein2genome"])
 def test_two_launch_lanes_give_the_one_lane_results(eng, monkeypatch, model_type):
     """A large batch is cut into two halves of equal work that walk through the passes of Optimal_find_path on two streams
-    from two host threads over the same resident sequences (c4_engine.hip, find_path_lanes; default for 2 048 pairs and
+    from two host threads over the same resident sequences (c4_engine_find_path.inc, find_path_lanes; default for 2 048 pairs and
     more).  C4GPU_LANES=2 forces the cut on a small ragged batch: same alignments as one lane, through the one-shot entry
     point and through a resident batch (whose kernel statistics then count the launches of both lanes)."""
     rng = random.Random(991)

@@ -383,7 +383,7 @@ def test_stale_sub_alignment_tails_are_recomputed(eng, monkeypatch, capfd):
     monkeypatch.setenv("C4GPU_TRACE", "1")
     # C4GPU_CELL_STRICT=1: a final cell whose SCORE differs from the prediction counts as a miss (the form of rounds 1-4) and the
     # tail is recomputed; the default compares the shadow slots only (a score offset moves no decision of a continuation sub-DP:
-    # c4_engine.hip, final_cell_equiv) and keeps the batch's results -- both must give the oracle's alignments
+    # c4_engine_staging.inc, final_cell_equiv) and keeps the batch's results -- both must give the oracle's alignments
     monkeypatch.setenv("C4GPU_CELL_STRICT", "1")
     found = eng.find_all_paths(model, [(q, t)], dpmemory=32, threshold=300, max_paths=2)[0]
     err = capfd.readouterr().err

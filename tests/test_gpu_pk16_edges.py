@@ -1,4 +1,4 @@
-"""The packed 16-bit route at the edges of its guard (Engine::pk16_fits, c4_engine.hip): the host may only take the packed
+"""The packed 16-bit route at the edges of its guard (Engine::pk16_fits, c4_engine_launch.inc): the host may only take the packed
 score pass / region windows / checkpoint pass where every score a path can reach fits 16 000 and the intron length test
 cannot fail on the upper side.  Each case puts a WINDOWED launch (dumps every 256 columns, so that targets of a few thousand
 columns take the two-pass route) just inside and just outside one term of the guard, asserts from C4GPU_TRACE which score

@@ -1,4 +1,4 @@
-"""The host side of the path pass's shortcut for one-row sections inside an intron (csrc/c4_engine.hip Engine::init_host ->
+"""The host side of the path pass's shortcut for one-row sections inside an intron (csrc/c4_engine_launch.inc Engine::init_host ->
 KParams::loop_tr, csrc/c4_viterbi_kernel.h viterbi_kernel): which states the parameters prove it for.  No device needed
 (c4gpu_loop_sections); the device side is tests/test_gpu_parity.py::test_one_row_sections_inside_an_intron_answered_without_a_dp."""
 import ctypes as C
