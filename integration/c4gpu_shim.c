@@ -436,6 +436,8 @@ void shim_hsp_params(c4gpu_params *p){
 
 /* ---- one Viterbi call ----------------------------------------------------------------------------------- */
 
+static GMutex shim_device_lock[2];       /* one batch on a context at a time (the batching seam below; slot 1: C4GPU_SLOTS=2) */
+
 static C4_Score shim_dp(C4_Model *model, Region *region, Viterbi_Data *vd, SubOpt_Index *soi,
                         gpointer user_data, int mode, Viterbi_DP_Func cpu_func){
     Ungapped_Data *ud = user_data;
@@ -490,6 +492,12 @@ static C4_Score shim_dp(C4_Model *model, Region *region, Viterbi_Data *vd, SubOp
      * pair stays resident on the device between them.  Identity = content: the residues (a freed Sequence's
      * address may be reused), the whole flattened model (tables, calc values, scopes -- derived models share long
      * name prefixes) and the scoring parameters in force. */
+    /* The exhaustive seam may have batch N + 1 on the device (a `c4gpu-flush` thread inside c4gpu_batch_run on this very
+     * context) while the main thread replays batch N; a replay that leaves its recorded rounds lands here.  A context serves
+     * one batch at a time: this call takes the device lock of the seam's slot 0 (shim_ctx) for its device part, i.e. it waits
+     * for a flush in flight (rare: -S yes past the recorded rounds, a batch that failed, a region the dry run did
+     * not see). */
+    g_mutex_lock(&shim_device_lock[0]);
     {
         static c4gpu_batch *resident = NULL;
         static guint64 resident_key = 0;
@@ -526,6 +534,7 @@ static C4_Score shim_dp(C4_Model *model, Region *region, Viterbi_Data *vd, SubOp
             }
         i = resident ? c4gpu_batch_viterbi(resident, mode, &job, 1, &r) : -1;
     }
+    g_mutex_unlock(&shim_device_lock[0]);
     if(blocked)
         c4gpu_subopt_destroy(blocked);
     if(i != 0){
@@ -700,11 +709,14 @@ static gboolean shim_can_batch(GAM *gam, Sequence *query, Sequence *target){
     {   /* whether the model is one of the accelerated families does not depend on the pair: asked once per model (the
          * per-pair user data the flattening reads -- Match tables, splice predictors -- are the process's static argument
          * sets); at 4 096 pairs of a run the repeated check was 0.1 ms per pair */
+        static GAM *seen_gam = NULL;                 /* (pinned while pairs of it are pending: GAM_share below) */
         static C4_Model *seen_model = NULL;
         static gboolean seen_ok = FALSE;
         static Alphabet_Type seen_q, seen_t;
-        if((seen_model == gam->optimal->find_path->model) && (seen_q == query->alphabet->type) && (seen_t == target->alphabet->type))
+        if((seen_gam == gam) && (seen_model == gam->optimal->find_path->model) && (seen_q == query->alphabet->type)
+        && (seen_t == target->alphabet->type))
             return seen_ok;
+        seen_gam = gam;
         ud = Model_Type_create_data(gam->gas->type, query, target);
         ok = shim_flatten(gam->optimal->find_path->model, ud, &fm);
         Model_Type_destroy_data(gam->gas->type, ud);
@@ -769,7 +781,6 @@ typedef struct {
  * own.  Measured on config 4 through the command line (64 x 64, two flushes of 2 048): the two device parts take 841 + 941 ms side
  * by side against 709 + 627 ms one after the other -- end of the run at 1 675 / 1 957 / 3 067 ms against 1 751 / 1 833 / 1 907 ms:
  * 0.08-0.15 s gained at best, and one run in three lost a second in a stalled allocation beside the other batch's kernels. */
-static GMutex shim_device_lock[2];
 static c4gpu_ctx *shim_ctx2 = NULL;
 static guint shim_flush_seq = 0;
 static ShimFlushJob *shim_in_flight = NULL;
