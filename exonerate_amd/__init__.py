@@ -518,6 +518,18 @@ class ResidentBatch:
         if _lib().c4gpu_batch_run_regions(self.h, arr, act, dpmemory, threshold) != 0:
             raise _err("c4gpu_batch_run_regions")
 
+    def set_annotation(self, cds):
+        """exonerate's --annotation: cds[i] = (cds_start, cds_length) of pair i's query, or None (c4gpu_batch_set_annotation);
+        applies to the sequences the batch holds now."""
+        if cds is None:
+            rc = _lib().c4gpu_batch_set_annotation(self.h, None, None)
+        else:
+            st = (C.c_int32 * max(1, self.n))(*[(c[0] if c else 0) for c in cds])
+            ln = (C.c_int32 * max(1, self.n))(*[(c[1] if c else 0) for c in cds])
+            rc = _lib().c4gpu_batch_set_annotation(self.h, st, ln)
+        if rc != 0:
+            raise _err("c4gpu_batch_set_annotation")
+
     def set_thresholds(self, per_pair):
         """Per-pair score thresholds (exonerate's --percent); None switches them off."""
         arr = None if per_pair is None else (C.c_int32 * max(1, self.n))(*per_pair)

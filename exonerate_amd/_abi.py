@@ -227,6 +227,7 @@ PROTOTYPES = [
     ("c4gpu_batch_kernel_stats", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double),
                                            C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("c4gpu_packed_route_fits", C.c_int, [C.POINTER(Model), C.POINTER(Params), C.c_int32, C.c_int32]),
+    ("c4gpu_batch_set_annotation", C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("c4gpu_loop_sections", C.c_int, [C.POINTER(Model), C.POINTER(Params), C.POINTER(C.c_int32), C.c_int32]),
     ("c4gpu_stage_create", C.c_void_p, [C.c_void_p, C.POINTER(Model), C.POINTER(Params)]),
     ("c4gpu_stage_load", C.c_int, [C.c_void_p, C.POINTER(Pair), C.c_int32]),

@@ -42,7 +42,7 @@ inline void make_kparams(const c4gpu_model *m, const c4gpu_params *params, KPara
     bool protein = false;
     for (int i = 0; i < m->n_calcs; i++)
         if (m->calcs[i].kind == C4GPU_CALC_MATCH_PROTEIN || m->calcs[i].kind == C4GPU_CALC_MATCH_P2D) protein = true;
-    memcpy(kp->submat, protein ? &params->protein_submat[0][0] : &params->dna_submat[0][0], sizeof kp->submat);
+    memcpy(kp->submat, protein ? &params->protein_submat[0][0] : &params->dna_submat[0][0], sizeof(int) * 24 * 24);
     for (int c = 0; c < 4096; c++) {
         const uint8_t row = params->submat_index[params->aa[params->trans[c]]];
         kp->codon_row[c] = row < 24 ? row : 0;

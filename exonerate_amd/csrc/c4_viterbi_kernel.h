@@ -48,7 +48,8 @@ struct KParams {                 // uniform per launch (device memory, staged to
     int calc_value[16];
     int min_intron, max_intron;
     int start_scope, end_scope;
-    int submat[24 * 24];
+    int submat[25 * 24];                 // row 24: what a DNA query position inside an annotated CDS scores against every target code
+                                         // (MATCH_IMPOSSIBLY_LOW_SCORE, match.c:276-281; Engine::annotated, annotate_qcode_kernel)
     uint8_t codon_row[4096];             // split-codon calcs: 3 x 4-bit base masks -> Submat row of the residue
     // loop_tr[s] >= 0: state s has a self-loop over one target column that adds nothing (an intron), and NO other way from s
     // back to s without a query row can reach the loop's score (Engine::init_host proves it from the parameters): a path

@@ -363,6 +363,16 @@ int          c4gpu_batch_run(c4gpu_batch *b, int what, int dpmemory_mb, c4gpu_sc
  * c4gpu_batch_run(b, 2, ...): c4gpu_batch_alignment; alignment regions are in sequence coordinates. */
 int          c4gpu_batch_run_regions(c4gpu_batch *b, const c4gpu_region *regions, const uint8_t *active,
                                      int dpmemory_mb, c4gpu_score threshold);
+/* --annotation (src/comparison/match.c:276-281, Match_1_1_dna_score_func): a DNA query that carries a CDS annotation
+ * (Sequence_Annotation: cds_start, cds_length, sequence.h:49-54) may not take part in a 1:1 DNA match inside its CDS -- the match
+ * scores MATCH_IMPOSSIBLY_LOW_SCORE there.  cds_start[i] / cds_length[i]: the annotation of pair i's query (length <= 0: none;
+ * both NULL: no pair has one).  Applies to the sequences the batch holds NOW (after c4gpu_batch_create or
+ * c4gpu_batch_swap_stage; call it again after the next swap) and to every run that follows: annotated positions carry a matrix
+ * row of their own, the batch's passes take the kernels that keep every validity mask and the 32-bit arithmetic (a score of
+ * -987654321 is outside every packed-pass guard), one launch lane.  Models without a 1:1 DNA match calc are not affected (the
+ * reference's other match functions have their own, coding-model rules: match.c:490-546, not on the accelerated path). */
+int         c4gpu_batch_set_annotation(c4gpu_batch *b, const int32_t *cds_start, const int32_t *cds_length);
+
 /* Per-pair score thresholds for the full runs (what = 2) and c4gpu_batch_next_paths: what
  * GAM_get_query_threshold gives a query under --percent (gam.c:466-487,677-705; never below --score).  A pair
  * is held to max(threshold argument, per_pair[i]).  NULL switches them off. */

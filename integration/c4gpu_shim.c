@@ -276,6 +276,12 @@ c4gpu_ctx *shim_ctx_nowait(void){
 
 /* ---- C4_Model (closed) -> c4gpu_model ------------------------------------------------------------- */
 
+/* --annotation (match.c:276-281: no 1:1 DNA match inside a DNA query's CDS): the Optimal seams -- the per-call shim and the
+ * exhaustive batches -- hand the annotation to the library (c4gpu_batch_set_annotation) and set this around their flattening;
+ * the other seams (BSDP's sub-DPs, SDP, seeding: their kernels read their own tables) still leave such runs to the
+ * reference's functions. */
+static __thread gboolean shim_annotation_ok = FALSE;
+
 gboolean shim_flatten_any(C4_Model *m, Ungapped_Data *ud, c4gpu_model *out, gboolean allow_span){
     register guint i, j;
     memset(out, 0, sizeof(*out));
@@ -314,7 +320,7 @@ gboolean shim_flatten_any(C4_Model *m, Ungapped_Data *ud, c4gpu_model *out, gboo
             else if(out->query_alphabet && out->target_alphabet) o->kind = C4GPU_CALC_MATCH_PROTEIN;
             else if(!out->query_alphabet && !out->target_alphabet) o->kind = C4GPU_CALC_MATCH_DNA;
             else return FALSE;
-            if(ud->query->annotation) return FALSE; /* cds veto, match.c:276-281 */
+            if(ud->query->annotation && (!shim_annotation_ok)) return FALSE; /* cds veto, match.c:276-281 */
         } else if((!strcmp(c->name, "gap open")) || (!strcmp(c->name, "gap extend"))
                || (!strcmp(c->name, "frameshift"))){
             o->kind = C4GPU_CALC_CONST;
@@ -368,6 +374,23 @@ gboolean shim_flatten_any(C4_Model *m, Ungapped_Data *ud, c4gpu_model *out, gboo
 
 static gboolean shim_flatten(C4_Model *m, Ungapped_Data *ud, c4gpu_model *out){
     return shim_flatten_any(m, ud, out, FALSE);
+    }
+/* ... for a seam that passes a query's annotation on */
+static gboolean shim_flatten_annotated(C4_Model *m, Ungapped_Data *ud, c4gpu_model *out){
+    register gboolean ok;
+    shim_annotation_ok = TRUE;
+    ok = shim_flatten_any(m, ud, out, FALSE);
+    shim_annotation_ok = FALSE;
+    return ok;
+    }
+/* the annotation as the library takes it (only a DNA query's counts: match.c:277) */
+static void shim_cds(Sequence *query, int32_t *start, int32_t *length){
+    *start = 0; *length = 0;
+    if(query->annotation && (query->alphabet->type == Alphabet_Type_DNA)){
+        *start = query->annotation->cds_start;
+        *length = query->annotation->cds_length;
+        }
+    return;
     }
 
 /* the static ArgumentSets + Match tables -> c4gpu_params */
@@ -456,7 +479,7 @@ static C4_Score shim_dp(C4_Model *model, Region *region, Viterbi_Data *vd, SubOp
     /* a single small rectangle is faster on the host than one launch + copies (a batch is another matter) */
     if(cpu_func && (((gdouble)region->query_length + 1.0) * ((gdouble)region->target_length + 1.0) < min_cells))
         return cpu_func(model, region, vd, soi, user_data);
-    if((!shim_get_ctx()) || (!shim_flatten(model, ud, &fm))){
+    if((!shim_get_ctx()) || (!shim_flatten_annotated(model, ud, &fm))){
         if(!cpu_func)
             g_error("c4gpu shim: no CPU implementation to fall back to");
         return cpu_func(model, region, vd, soi, user_data);
@@ -510,6 +533,12 @@ static C4_Score shim_dp(C4_Model *model, Region *region, Viterbi_Data *vd, SubOp
         key = (key ^ 0xff) * 1099511628211ULL;
         for(c = (const guchar*)tstr; *c; c++) key = (key ^ *c) * 1099511628211ULL;
         key ^= ((guint64)ud->query->len << 32) ^ (guint64)ud->target->len;
+        {   /* (the resident copy of an annotated query carries the annotation in its residue codes) */
+            int32_t cs, cl;
+            shim_cds(ud->query, &cs, &cl);
+            key = (key ^ (guint64)(guint32)cs) * 1099511628211ULL;
+            key = (key ^ (guint64)(guint32)cl) * 1099511628211ULL;
+        }
         memset(&params, 0, sizeof(params));
         shim_params(ud, &params);
         /* a continuation copy differs from its model in the scopes only (viterbi.c:68-76) and the device picks the
@@ -528,6 +557,14 @@ static C4_Score shim_dp(C4_Model *model, Region *region, Viterbi_Data *vd, SubOp
             pair.query = (const uint8_t*)qstr;  pair.query_len = ud->query->len;
             pair.target = (const uint8_t*)tstr; pair.target_len = ud->target->len;
             resident = c4gpu_batch_create(shim_ctx, &fm, &params, &pair, 1);
+            if(resident){
+                int32_t cs, cl;
+                shim_cds(ud->query, &cs, &cl);
+                if((cl > 0) && (c4gpu_batch_set_annotation(resident, &cs, &cl) != 0)){
+                    c4gpu_batch_destroy(resident);
+                    resident = NULL;
+                    }
+                }
             resident_key = key;
             resident_failed = (resident == NULL);
             resident_scope[0] = fm.start_scope; resident_scope[1] = fm.end_scope;
@@ -718,7 +755,7 @@ static gboolean shim_can_batch(GAM *gam, Sequence *query, Sequence *target){
             return seen_ok;
         seen_gam = gam;
         ud = Model_Type_create_data(gam->gas->type, query, target);
-        ok = shim_flatten(gam->optimal->find_path->model, ud, &fm);
+        ok = shim_flatten_annotated(gam->optimal->find_path->model, ud, &fm);
         Model_Type_destroy_data(gam->gas->type, ud);
         seen_model = gam->optimal->find_path->model; seen_q = query->alphabet->type; seen_t = target->alphabet->type;
         seen_ok = ok;
@@ -769,6 +806,7 @@ typedef struct {
     c4gpu_pair *pair;
     gchar **str;
     c4gpu_score *per_pair;            /* --percent thresholds, or NULL */
+    int32_t *cds_start, *cds_length;  /* --annotation: per pair, or NULL where no query of the batch is annotated */
     GThread *thread;
     gint rounds_done;
     gint slot;                        /* which of the two resident batches carries it */
@@ -840,8 +878,22 @@ static ShimFlushJob *shim_flush_prepare(void){
     sp = todo->pdata[0];
     ud = Model_Type_create_data(job->gam->gas->type, sp->query, sp->target);
     memset(&job->fm, 0, sizeof(job->fm));
-    if((job->flattened = shim_flatten(job->gam->optimal->find_path->model, ud, &job->fm)))
+    if((job->flattened = shim_flatten_annotated(job->gam->optimal->find_path->model, ud, &job->fm)))
         shim_params(ud, &job->params);
+    /* --annotation: the CDS of every annotated DNA query of the batch (c4gpu_batch_set_annotation) */
+    job->cds_start = job->cds_length = NULL;
+    for(i = 0; i < n; i++){
+        int32_t cs, cl;
+        sp = todo->pdata[i];
+        shim_cds(sp->query, &cs, &cl);
+        if(cl > 0){
+            if(!job->cds_start){
+                job->cds_start = g_new0(int32_t, n);
+                job->cds_length = g_new0(int32_t, n);
+                }
+            job->cds_start[i] = cs; job->cds_length[i] = cl;
+            }
+        }
     Model_Type_destroy_data(job->gam->gas->type, ud);
     if(job->flattened && job->gam->gas->percent_threshold){
         /* one threshold per query (cached by Sequence): pairs below it stop after the score pass */
@@ -916,6 +968,9 @@ static gpointer shim_flush_device(gpointer data){
             if(res_batch && (c4gpu_batch_swap_stage(res_batch, res_stage) == 0)){
                 batch = res_batch;
                 c4gpu_batch_set_thresholds(batch, NULL);
+                /* (NULL, NULL where no query of this batch is annotated: the batch leaves its annotated form) */
+                if(c4gpu_batch_set_annotation(batch, job->cds_start, job->cds_length) != 0)
+                    batch = NULL;
                 }
             }
         }
@@ -974,6 +1029,8 @@ static void shim_flush_replay(ShimFlushJob *job){
     g_free(job->str);
     g_free(job->pair);
     g_free(job->per_pair);
+    g_free(job->cds_start);
+    g_free(job->cds_length);
     /* replay in submission order through the reference's own code */
     for(i = 0; i < n; i++){
         register GAM_Result *gam_result;

@@ -279,6 +279,14 @@ static void odata_clear(odata *od){
         free(od->ss[k]);
     }
 
+/* --annotation: the CDS of the query every following call aligns (Sequence_Annotation, sequence.h:49-54; length <= 0: none).
+ * Test infrastructure keeps it beside the calls instead of in their signatures. */
+static int32_t oracle_cds_start = 0, oracle_cds_length = 0;
+void oracle_set_annotation(int32_t cds_start, int32_t cds_length){
+    oracle_cds_start = cds_start;
+    oracle_cds_length = cds_length;
+    }
+
 /* C4_Calc_score, src/c4/c4.c:1700 + the calc functions of SURVEY.md section 8a-A4 */
 static c4gpu_score calc_score(odata *od, int calc, int32_t qpos, int32_t tpos){
     const c4gpu_params *p = od->params;
@@ -289,7 +297,9 @@ static c4gpu_score calc_score(odata *od, int calc, int32_t qpos, int32_t tpos){
     switch(c->kind){
         case C4GPU_CALC_CONST:
             return c->value;
-        case C4GPU_CALC_MATCH_DNA:       /* Match_1_1_dna_score_func, match.c:271 (no annotation) */
+        case C4GPU_CALC_MATCH_DNA:       /* Match_1_1_dna_score_func, match.c:271-285: inside an annotated CDS no 1:1 match */
+            if((oracle_cds_length > 0) && (qpos >= oracle_cds_start) && (qpos < oracle_cds_start + oracle_cds_length))
+                return LOW;
             return p->dna_submat[p->submat_index[od->query[qpos]]][p->submat_index[od->target[tpos]]];
         case C4GPU_CALC_MATCH_PROTEIN:   /* Match_1_1_protein_score_func, match.c:287 */
             return p->protein_submat[p->submat_index[od->query[qpos]]][p->submat_index[od->target[tpos]]];

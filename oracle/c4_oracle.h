@@ -31,6 +31,8 @@ int  oracle_find_path(const c4gpu_model *model, const c4gpu_params *params,
                       const uint8_t *query, int32_t qlen, const uint8_t *target, int32_t tlen,
                       int dpmemory_mb, c4gpu_score threshold, c4gpu_alignment *out);
 void oracle_alignment_clear(c4gpu_alignment *a);
+/* --annotation (match.c:276-281): the CDS of the query that the calls after this one align; cds_length <= 0: none */
+void oracle_set_annotation(int32_t cds_start, int32_t cds_length);
 
 /* SubOpt, src/c4/subopt.c: the blocked points of the alignments already reported for a pair (sequence
  * coordinates).  oracle_subopt_add_alignment = SubOpt_add_alignment (subopt.c:131); the _subopt variants

@@ -557,9 +557,19 @@ static void run_golden(gchar *model_name, gchar *input_path, gboolean with_splic
         g_strchomp(line);
         if((!line[0]) || (line[0] == '#'))
             continue;
-        f = g_strsplit(line, "\t", 3);
+        f = g_strsplit(line, "\t", 4);                 /* id, query, target[, "cds_start:cds_length"] */
         g_assert(f[0] && f[1] && f[2]);
         query = Sequence_create(f[0], NULL, f[1], 0, Sequence_Strand_FORWARD, qa);
+        if(f[3] && strchr(f[3], ':')){
+            /* --annotation: what Sequence_create attaches to a sequence whose id has an entry in the annotation file
+             * (sequence.c:51-88,176-178: a pointer into the file's tree, not owned by the sequence; here a record of its own,
+             * never freed: a dump tool) */
+            query->annotation = g_new0(Sequence_Annotation, 1);
+            query->annotation->id = g_strdup(f[0]);
+            query->annotation->strand = Sequence_Strand_FORWARD;
+            query->annotation->cds_start = atoi(f[3]);
+            query->annotation->cds_length = atoi(strchr(f[3], ':') + 1);
+            }
         tfwd = Sequence_create("tg", NULL, f[2], 0, Sequence_Strand_FORWARD, ta);
         if(revcomp_target){
             target = Sequence_revcomp(tfwd);

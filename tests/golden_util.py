@@ -40,6 +40,12 @@ for _tag, _bases in (("hugegap", ("affine_local_dna", "est2genome", "protein2dna
         SETS["%s_%s_D0" % (_b, _tag)] = SETS[_b]
 
 
+# --annotation (match.c:276-281): DNA queries with a CDS annotation, rec["cds"] = [cds_start, cds_length]; made by the reference
+# with the annotation attached to the query Sequence (oracle/refdump.c, tools/make_golden.py: annotated)
+ANNOT_SETS = {"est2genome_annot": ("est2genome", 0, 0), "est2genome_annot_D0": ("est2genome", 0, 0),
+              "affine_local_dna_annot": ("affine:local", 0, 0), "affine_local_dna_annot_D0": ("affine:local", 0, 0)}
+
+
 # sets with the GAM sub-optimal loop (rec["subopt"] = successive alignments, rec["threshold"])
 SUBOPT_SETS = {
     "affine_local_dna_subopt": ("affine:local", 0, 0), "affine_local_dna_subopt_D0": ("affine:local", 0, 0),
@@ -126,7 +132,7 @@ def get_model(lib, params, name):
         m = _abi.Model()
         assert lib.c4gpu_model_get_derived(mt.encode(), qa, ta, params, src, dst, ss, es, m, None) == 0
         return m
-    mt, qa, ta = SETS[name] if name in SETS else SUBOPT_SETS[name]
+    mt, qa, ta = SETS[name] if name in SETS else ANNOT_SETS[name] if name in ANNOT_SETS else SUBOPT_SETS[name]
     m = _abi.Model()
     assert lib.c4gpu_model_get(mt.encode(), qa, ta, params, m) == 0
     return m

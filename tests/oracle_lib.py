@@ -126,6 +126,14 @@ def find_score(model, params, q, t):
     return load().oracle_find_score(model, params, q, len(q), t, len(t))
 
 
+def set_annotation(cds):
+    """exonerate's --annotation for the calls that follow: cds = (cds_start, cds_length) of the query, or None."""
+    lib = load()
+    lib.oracle_set_annotation.argtypes = [C.c_int32, C.c_int32]
+    lib.oracle_set_annotation.restype = None
+    lib.oracle_set_annotation(*(cds if cds else (0, 0)))
+
+
 def subopt_points(so):
     lib = load()
     n = lib.oracle_subopt_points(so, None, None, 0)

@@ -237,11 +237,12 @@ def test_find_path_over_regions_of_resident_pairs(eng, model_type, dpm):
     assert got[0].as_dict() == full[0].as_dict()                           # the box holds the whole alignment
 
 
-@pytest.mark.parametrize("kshift", ["3", "5", "7"])
-@pytest.mark.parametrize("model_type,qlen,tlen,dpm", [
-    ("est2genome", 600, 6000, 32), ("est2genome", 1300, 5000, 1), ("affine:local", 700, 2500, 1),
-    ("affine:local", 2100, 2300, 32), ("protein2dna", 300, 3000, 32), ("protein2genome", 330, 5000, 32),
-])
+# (the 1 300-row est2genome case -- 10 s of oracle per run -- takes the smallest and the largest interval only: the GPU suite's time)
+@pytest.mark.parametrize("model_type,qlen,tlen,dpm,kshift", [
+    (m, q, t, d, k) for (m, q, t, d) in [("est2genome", 600, 6000, 32), ("est2genome", 1300, 5000, 1), ("affine:local", 700, 2500, 1),
+                                         ("affine:local", 2100, 2300, 32), ("protein2dna", 300, 3000, 32),
+                                         ("protein2genome", 330, 5000, 32)]
+    for k in ("3", "5", "7") if not (q == 1300 and k == "5")])
 def test_windowed_region_pass_matches_oracle(eng, monkeypatch, capfd, model_type, qlen, tlen, dpm, kshift):
     """FIND_REGION in two passes (score pass that dumps the DP state every 2^kshift columns, region-start payload
     passes over one dump interval at a time, walking left from the end cell): same scores, end cells and region starts

@@ -10,7 +10,7 @@ import pytest
 import exonerate_amd as ex
 from exonerate_amd import _abi
 import oracle_lib
-from golden_util import SETS, SUBOPT_SETS, DERIVED_SETS, SPAN_SETS, load_set, expected, set_params
+from golden_util import SETS, SUBOPT_SETS, DERIVED_SETS, SPAN_SETS, ANNOT_SETS, load_set, expected, set_params
 
 pytestmark = pytest.mark.gpu
 
@@ -26,7 +26,7 @@ def _model(name):
     if name in DERIVED_SETS:
         mt, qa, ta, (src, dst, ss, es) = DERIVED_SETS[name]
         return ex.Model.derived(mt, src, dst, ss, es, qa, ta)
-    mt, qa, ta = SETS[name] if name in SETS else SUBOPT_SETS[name]
+    mt, qa, ta = SETS[name] if name in SETS else ANNOT_SETS[name] if name in ANNOT_SETS else SUBOPT_SETS[name]
     return ex.Model(mt, qa, ta, params=set_params(_abi.load(), name))
 
 
@@ -44,6 +44,43 @@ def test_find_score_and_path_match_reference_vectors(eng, name):
             continue
         assert aln is not None, rec["id"]
         assert aln.as_dict(rec["id"]) == expected(rec), rec["id"]
+
+
+@pytest.mark.parametrize("name", sorted(ANNOT_SETS))
+def test_annotated_queries_match_reference_vectors(eng, name, monkeypatch, capfd):
+    """exonerate's --annotation (match.c:276-281): a DNA query's positions inside its annotated CDS cannot take part in a 1:1 DNA
+    match.  c4gpu_batch_set_annotation gives those positions a matrix row of their own (MATCH_IMPOSSIBLY_LOW_SCORE against
+    everything) and sends the batch's passes to the kernels that keep every validity mask; scores, regions, operations and printed
+    lines are the reference's (vectors made with the annotation attached to the query), on both memory routes; the same batch
+    without the annotation gives other alignments, and taking the annotation away again restores them."""
+    model = _model(name)
+    recs = load_set(name)
+    pairs = [(r["query"], r["target"]) for r in recs]
+    dpm = recs[0]["dpmemory"]
+    monkeypatch.setenv("C4GPU_TRACE", "1")
+    b = ex.ResidentBatch(eng, model, pairs)
+
+    def results():
+        b.run(2, dpmemory=dpm)
+        return [b.alignment(i) for i in range(len(recs))]
+    plain = [a.as_dict(r["id"]) if a else None for a, r in zip(results(), recs)]
+    capfd.readouterr()
+    b.set_annotation([tuple(r["cds"]) for r in recs])
+    got = results()
+    err = capfd.readouterr().err
+    launched = [l for l in err.splitlines() if "c4gpu trace:   kernel " in l]
+    assert launched and not any("_local" in l or "pk16" in l or "16_" in l for l in launched), launched     # every mask kept, 32-bit passes
+    differ = 0
+    for rec, aln, pl in zip(recs, got, plain):
+        if "path_score" not in rec:
+            assert aln is None, rec["id"]
+        else:
+            assert aln is not None and aln.as_dict(rec["id"]) == expected(rec), rec["id"]
+        differ += (aln.as_dict(rec["id"]) if aln else None) != pl
+    assert differ >= len(recs) // 3
+    b.set_annotation(None)
+    assert [a.as_dict(r["id"]) if a else None for a, r in zip(results(), recs)] == plain
+    b.close()
 
 
 def test_reference_known_answer_tests_on_gpu(eng):

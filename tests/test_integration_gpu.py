@@ -73,7 +73,9 @@ def test_exonerate_gpu_output_is_byte_identical(tmp_path, model, extra, batch):
             t = dna(400) + coding + dna(600)
         else:
             q = dna(500 + 100 * n)
-            if model == "est2genome":
+            if model == "est2genome" and "-S" in extra:     # (the reference's sub-optimal loop is the slow side of this test)
+                t = dna(1000) + q[:200] + "GT" + dna(800) + "AG" + q[200:420] + "GT" + dna(1500) + "AG" + q[420:] + dna(1200)
+            elif model == "est2genome":
                 t = dna(2000) + q[:200] + "GT" + dna(1500) + "AG" + q[200:420] + "GT" + dna(3000) + "AG" + q[420:] + dna(2500)
             else:
                 t = dna(100) + q[:250] + dna(3) + q[260:] + dna(150)
@@ -93,6 +95,49 @@ def test_exonerate_gpu_output_is_byte_identical(tmp_path, model, extra, batch):
     assert ref_out.count("vulgar:") >= (1 if "--bestn" in extra else 3)
     if "--percent" in extra:
         assert ref_out.count("vulgar:") < 9       # the unrelated query/target combinations are filtered
+
+
+@pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
+                    reason="reference binaries are built in the build container (make -C integration)")
+@pytest.mark.parametrize("model,batch", [("est2genome", "4096"), ("est2genome", "0"), ("affine:local", "4096")])
+def test_annotation_runs_are_served_by_the_device(tmp_path, model, batch):
+    """exonerate's --annotation (sequence.c:51-88): a cDNA with a CDS annotation may not take part in a 1:1 DNA match inside its
+    CDS (match.c:276-281).  Until round 5 the drop-in refused every model once a query carried an annotation; now the Optimal
+    seams hand it over (c4gpu_batch_set_annotation; pinned on the reference's own Optimal_find_path with the annotation attached
+    to the query: tests/golden/*_annot*.jsonl).  Through THIS reference's command line the option is accepted and changes
+    nothing: Sequence_Annotation_compare (sequence.c:45-50) compares the sequence id with the BYTES of the annotation record
+    (its first member is a pointer to the id, not the id), so Sequence_create_internal's tfind (sequence.c:176-178) never finds
+    an entry and no Sequence ever carries one.  What this test holds: such a run is served by the device, byte-identical --
+    and identical to the run without the option, as the reference's is (should the reference's lookup ever be repaired, this
+    assertion fails and the seam's annotation path gets its end-to-end case)."""
+    rng = random.Random(77 + len(model))
+    dna = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    qs, ts, ann = [], [], []
+    for n in range(3):
+        q = dna(420 + 60 * n)
+        if model == "est2genome":
+            t = dna(900) + q[:180] + "GT" + dna(700) + "AG" + q[180:] + dna(800)
+        else:
+            t = dna(100) + q[:200] + dna(4) + q[210:] + dna(150)
+        qs.append(("qy%d" % n, q))
+        ts.append(("tg%d" % n, t))
+        if n != 1:
+            ann.append("qy%d + %d %d" % (n, 121 + 30 * n, 150))        # id strand cds_start (1-based) cds_length
+    qf, tf, af = str(tmp_path / "q.fa"), str(tmp_path / "t.fa"), str(tmp_path / "q.annotation")
+    _fasta(qf, qs)
+    _fasta(tf, ts)
+    with open(af, "w") as f:
+        f.write("\n".join(ann) + "\n")
+    base = ["-m", model, "-E", "yes", "--showalignment", "yes", "--showvulgar", "yes", "-V", "0", "-S", "no"]
+    args = base + ["--annotation", af, qf, tf]
+    ref = _Ref(args)
+    plain = _Ref(base + [qf, tf])
+    gpu_out, gpu_err = _run(GPU_EXE, args, {"C4GPU_VERBOSE": "1", "C4GPU_BATCH": batch})
+    ref_out = ref.out()
+    assert "c4gpu:" in gpu_err and "using the CPU" not in gpu_err, "the GPU engine was not used:\n" + gpu_err[-1500:]
+    assert ("c4gpu: batch of" in gpu_err) == (batch != "0"), gpu_err[-1500:]
+    assert gpu_out == ref_out
+    assert ref_out.count("vulgar:") >= 3 and ref_out == plain.out()
 
 
 @pytest.mark.skipif(not (os.path.exists(GPU_EXE) and os.path.exists(CPU_EXE)),
@@ -215,8 +260,8 @@ def test_low_complexity_inputs_tie_everywhere(tmp_path, model):
     unit = dna(97)
     q3 = dna(600)
     qs = [("tandem", "ACGT" * 200), ("polya", "A" * 700), ("copies", q3), ("unit", (unit * 9)[:800])]
-    ts = [("tandem_t", "ACGT" * 10000), ("polya_t", "A" * 30000), ("copies_t", (q3[:300] + "GT" + "C" * 80 + "AG" + q3[300:]) * 30),
-          ("unit_t", unit * 300)]
+    ts = [("tandem_t", "ACGT" * 6000), ("polya_t", "A" * 18000), ("copies_t", (q3[:300] + "GT" + "C" * 80 + "AG" + q3[300:]) * 20),
+          ("unit_t", unit * 200)]
     qf, tf = str(tmp_path / "q.fa"), str(tmp_path / "t.fa")
     _fasta(qf, qs)
     _fasta(tf, ts)
@@ -478,9 +523,9 @@ def test_short_runs_leave_with_the_device_thread_joined(tmp_path):
     loads code objects stops that warm-up (c4gpu_ctx_warm_cancel) and joins the thread before it leaves -- round 3 left with
     _exit under a thread still inside the runtime, round 4 with _exit after the join.  Round 5: the ordinary exit(), handlers
     and all (the crash that _exit papered over was getenv racing with the HIP start-up's setenv: shim_env; 1 500 of 1 500 short
-    runs then left cleanly through exit()).  The 0.2 s heuristic est2genome run fifty times on the default way out, and the
+    runs then left cleanly through exit()).  The 0.2 s heuristic est2genome run thirty times on the default way out, and the
     error path (exit(1) from general/argument.c's handler, pointed at shim_exit by the Makefile) with the device thread
-    started: exit status and output as the reference's every time.  Ten more times through _exit (C4GPU_FAST_EXIT=1)."""
+    started: exit status and output as the reference's every time.  Six more times through _exit (C4GPU_FAST_EXIT=1)."""
     from exonerate_amd import workloads
     pairs = workloads.est2genome_pairs(8, 400, 40000, seed=123)
     qf, tf = str(tmp_path / "q.fa"), str(tmp_path / "t.fa")
@@ -490,9 +535,9 @@ def test_short_runs_leave_with_the_device_thread_joined(tmp_path):
     ref_out, _ = _run(CPU_EXE, args)
     assert ref_out.count("vulgar:") >= 4
     env = {k: v for k, v in os.environ.items() if k not in ("C4GPU_WAIT", "C4GPU_FAST_EXIT")}
-    for rep in range(60):
+    for rep in range(36):
         e = dict(env)
-        if rep >= 50:
+        if rep >= 30:
             e["C4GPU_FAST_EXIT"] = "1"
         r = subprocess.run([GPU_EXE] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=300)
         assert r.returncode == 0, (rep, r.returncode, r.stderr.decode()[-2000:])
@@ -502,7 +547,7 @@ def test_short_runs_leave_with_the_device_thread_joined(tmp_path):
     _fasta(pf, [("p", "MKVLAAGIVGLLLAQWERTYHSAAPPKKLMNDE")])
     bad = ["-m", "est2genome", "-V", "0", pf, tf]
     rr = subprocess.run([CPU_EXE] + bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
-    for rep in range(10):
+    for rep in range(6):
         r = subprocess.run([GPU_EXE] + bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
         assert r.returncode == rr.returncode == 1, (rep, r.returncode, r.stderr.decode()[-1000:])
         assert r.stdout == rr.stdout

@@ -7,7 +7,7 @@ inputs of the reference's model known-answer tests.  Integer work: every compari
 import pytest
 from exonerate_amd import _abi
 import oracle_lib
-from golden_util import SETS, SUBOPT_SETS, DERIVED_SETS, SPAN_SETS, load_set, get_model, set_params, expected
+from golden_util import SETS, SUBOPT_SETS, DERIVED_SETS, SPAN_SETS, ANNOT_SETS, load_set, get_model, set_params, expected
 
 
 @pytest.mark.parametrize("name", sorted(SETS) + sorted(DERIVED_SETS))
@@ -24,6 +24,33 @@ def test_oracle_matches_reference_vectors(lib, params, name):
             assert got is None
             continue
         assert got == expected(rec), rec["id"]
+
+
+@pytest.mark.parametrize("name", sorted(ANNOT_SETS))
+def test_oracle_matches_reference_vectors_with_annotation(lib, params, name):
+    """--annotation (match.c:276-281): a DNA query's positions inside its annotated CDS score MATCH_IMPOSSIBLY_LOW_SCORE in a
+    1:1 DNA match; the reference ran these pairs with the annotation attached to the query (rec["cds"])."""
+    params = set_params(lib, name)
+    model = get_model(lib, params, name)
+    recs = load_set(name)
+    assert recs and any(r["score"] == 0 for r in recs) and any(r["score"] > 0 for r in recs)
+    changed = 0
+    try:
+        for rec in recs:
+            q, t = rec["query"].encode(), rec["target"].encode()
+            oracle_lib.set_annotation(None)
+            plain = oracle_lib.find_score(model, params, q, t)
+            oracle_lib.set_annotation(rec["cds"])
+            assert oracle_lib.find_score(model, params, q, t) == rec["score"], rec["id"]
+            changed += plain != rec["score"]
+            got = oracle_lib.find_path(model, params, q, t, dpmemory=rec["dpmemory"], qid=rec["id"])
+            if "path_score" not in rec:
+                assert got is None
+                continue
+            assert got == expected(rec), rec["id"]
+    finally:
+        oracle_lib.set_annotation(None)
+    assert changed >= len(recs) // 3          # the annotation is what decides these records
 
 
 @pytest.mark.parametrize("name", sorted(SUBOPT_SETS))

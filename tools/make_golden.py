@@ -198,18 +198,21 @@ ALT_FLAGS = PARAM_VARIANTS["altparams"]
 
 
 def run(model, cases, dpmemory, extra=()):
+    # (a case may carry a fourth entry: the query's CDS annotation (cds_start, cds_length) -- exonerate's --annotation)
     with tempfile.NamedTemporaryFile("w", suffix=".tsv", delete=False) as f:
-        for cid, q, t in cases:
-            f.write("%s\t%s\t%s\n" % (cid, q, t))
+        for c in cases:
+            f.write("%s\t%s\t%s" % c[:3] + ("\t%d:%d" % c[3] if len(c) > 3 else "") + "\n")
         path = f.name
     cmd = [REFDUMP, "--cmd", "golden", "--model", model, "--input", path, "-D", str(dpmemory)] + list(extra)
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout.decode()
     os.unlink(path)
     recs = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
     assert len(recs) == len(cases), (model, len(recs), len(cases))
-    for r, (cid, q, t) in zip(recs, cases):
-        assert r["id"] == cid
-        r["query"], r["target"], r["dpmemory"] = q, t, dpmemory
+    for r, c in zip(recs, cases):
+        assert r["id"] == c[0]
+        r["query"], r["target"], r["dpmemory"] = c[1], c[2], dpmemory
+        if len(c) > 3:
+            r["cds"] = list(c[3])
     return recs
 
 
@@ -629,6 +632,22 @@ def main():
             for r in recs:
                 f.write(json.dumps(r, separators=(",", ":")) + "\n")
         print(name, len(recs), "dst scores", [r["dst_score"] for r in recs])
+    # --annotation (match.c:276-281): DNA queries with a CDS annotation -- no 1:1 DNA match inside it.  CDS in the middle, at
+    # either end, over the whole query, past its end, one residue long
+    def annotated(cases, seed):
+        ar = random.Random(seed)
+        out = []
+        for k, (cid, q, t) in enumerate(cases):
+            n = len(q)
+            kind = k % 6
+            cds = ((n // 3, max(1, n // 3)), (0, max(1, n // 4)), (max(0, n - max(1, n // 4)), max(1, n // 4)), (0, n + 5),
+                   (ar.randint(0, max(0, n - 1)), 1), (n // 2, n))[kind]
+            out.append((cid, q, t, cds))
+        return out
+    sets.append(("est2genome_annot", "est2genome", annotated([c for c in est if len(c[1]) >= 30][:14], 41), 32, ()))
+    sets.append(("est2genome_annot_D0", "est2genome", annotated([c for c in est if len(c[1]) >= 30 and len(c[2]) >= 13][:12], 42), 0, ()))
+    sets.append(("affine_local_dna_annot", "affine:local", annotated([c for c in d if len(c[1]) >= 13 and len(c[2]) >= 13][:14], 43), 32, ()))
+    sets.append(("affine_local_dna_annot_D0", "affine:local", annotated([c for c in d if len(c[1]) >= 13 and len(c[2]) >= 13][:12], 44), 0, ()))
     for name, model, cases, dpm, extra in sets:
         if only and name not in only:
             continue
