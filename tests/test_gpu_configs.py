@@ -3,6 +3,7 @@ C2 affine:local 1 kb x 1 kb, C3 protein2dna 500 aa x one shared 1 Mb contig, C5-
 against a shared contig.  Where the oracle cannot finish a full-size rectangle in seconds, parity goes
 through a size-independent property: a local alignment whose optimal path lies inside a window of the
 contig is the window's alignment shifted by the window offset (same ops, same score)."""
+import os
 import pytest
 
 import exonerate_amd as ex
@@ -60,6 +61,27 @@ def test_c5_shape_protein2genome_shared_contig(eng):
     """C5 shape at reduced contig length: proteins with intron-split genes against one shared 300 kb contig."""
     proteins, contig, places = workloads.protein_vs_contig(8, 300, 300000, seed=20260935, introns=True)
     _check_against_windows(eng, ex.Model("protein2genome"), proteins, contig, places, 1000)
+
+
+def test_c5_exhaustive_shape_at_full_size_against_the_reference_records(eng):
+    """BASELINE config 5's exhaustive shape at its size -- 256 proteins of 300 aa against ONE 10 Mb chromosome, protein2genome,
+    7.7 x 10^11 first-pass cells -- and every 64th alignment (score, region, operations) against the records the REFERENCE made for
+    them (tests/golden/bench_configs.json: refdump on each sampled protein and its window, tools/make_bench_golden.py).  Until
+    round 5 this comparison lived in bench.py only."""
+    import json
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_configs.json")))["c5"]
+    model_name, pairs, _ = workloads.bench_config("c5")
+    assert model_name == "protein2genome" and len(pairs) == 256 and len(pairs[0][1]) == 10000000
+    b = ex.ResidentBatch(eng, ex.Model(model_name), pairs)
+    try:
+        b.run(2)
+        assert len(want["sample"]) >= 4
+        for rec in want["sample"]:
+            a = b.alignment(rec["pair"])
+            assert a is not None and a.score == rec["score"], rec["pair"]
+            assert list(a.region) == rec["region"] and [list(o) for o in a.ops] == rec["ops"], rec["pair"]
+    finally:
+        b.close()
 
 
 def test_shared_buffers_give_the_same_results_as_private_copies(eng):
