@@ -700,8 +700,50 @@ struct WaveDP {
         }
     }
 
+    // The cooperating-wave kernels (run_mw, round 6) read their column inputs from a per-wave STAGE in LDS, as the packed passes do
+    // (c4_viterbi16_kernel.h IO 1, c4_ckpt16_kernel.h Stage16): one plane per input -- the residue / codon code, the base masks of
+    // the split-codon calcs, the four splice values -- of STG_COLS columns; the wave fetches the columns a chunk reads ahead with
+    // one coalesced, clamped load per array and lane once per chunk (fill_stage: what prefetch_column loaded per step), and a step
+    // reads its column from LDS.  Where a launch has one wave per SIMD (256 proteins against one chromosome: five working waves
+    // of a job, one row per lane) nothing hid the latency of six global loads per step behind a step of ~90 instructions.
+    static constexpr int STG_CH = (64 + NCOL - 1) / NCOL * NCOL;           // run_mw's chunk (CH below)
+    static constexpr int STG_COLS = STG_CH > 64 ? 256 : 128;              // a chunk reads 63 + CH columns
+    static constexpr int STG_PLANES = 1 + (F::has_phase() ? 1 : 0) + (F::has_splice() ? 4 : 0);
+    static constexpr int STG_INTS = STG_COLS * STG_PLANES;
+    static constexpr int STG_P_TN4 = 1, STG_P_SP = 1 + (F::has_phase() ? 1 : 0);
+    int stage_a, stage_base;                            // LDS byte address of the next column's entry; of the wave's stage
+    __device__ __forceinline__ void prefetch_staged() {
+        const lds_int *p = (const lds_int *)(size_t)(unsigned)stage_a;
+        nx_tcode = p[0];
+        if constexpr (F::has_phase()) nx_tn4 = p[STG_P_TN4 * STG_COLS];
+        if constexpr (F::has_splice())
+            static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; nx_sp[K] = p[(STG_P_SP + K) * STG_COLS]; });
+        stage_a = ((stage_a + 4) & (STG_COLS * 4 - 1)) | stage_base;
+    }
+    // columns c0 + lane (lanes below `count`) into the stage
+    __device__ __forceinline__ void fill_stage(lds_int *stage, int c0, int count) {
+        if (lane >= count) return;
+        constexpr int mat = F::match_at();
+        const int c = c0 + lane;
+        lds_int *p = stage + (c & (STG_COLS - 1));
+        int ti = t0 + c - mat;
+        ti = ti < 0 ? 0 : (ti > tlast ? tlast : ti);
+        p[0] = tc[(unsigned)ti];
+        if constexpr (F::has_phase()) {
+            int tq = t0 + c - 1;
+            tq = tq < 0 ? 0 : (tq > tlast ? tlast : tq);
+            p[STG_P_TN4 * STG_COLS] = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(tn4p) + ((unsigned)tq << 1));
+        }
+        if constexpr (F::has_splice()) {
+            int tp = t0 + c - 2;
+            tp = tp < 0 ? 0 : (tp > tlast ? tlast : tp);
+            const unsigned sp_off = (unsigned)tp << 2;
+            static_for<4>([&](auto K_) __attribute__((always_inline)) { constexpr int K = K_; p[(STG_P_SP + K) * STG_COLS] = splice(K, sp_off); });
+        }
+    }
+
     // ---- one wave step: every lane evaluates its R rows of column j = s - lane ---------------------------
-    template <bool JINT, int PH>
+    template <bool JINT, int PH, bool STG = false>
     __device__ __forceinline__ void step(int s, int i0, bool first_strip, bool last_strip, const int *bnd_in,
                                          int *bnd_out, uint32_t *tb_slab, long long tb_base, int *ckpt,
                                          int section_length, int cp_count) {
@@ -758,7 +800,7 @@ struct WaveDP {
         });
         // (2) request the next step's inputs
         prefetch_carry(s + 1, bnd_in);
-        prefetch_column(j + 1);
+        if constexpr (STG) prefetch_staged(); else prefetch_column(j + 1);
         // (3) the R cells of this lane, top to bottom
         uint32_t tbw[R];
         bool end_ok[R];
@@ -1041,9 +1083,13 @@ struct WaveDP {
     // Wave w at chunk c' reads columns [CH*c', CH*c'+CH] of the row above; wave w-1 has then finished
     // chunk c'+1, i.e. columns up to CH*(c'+2)-64: enough for CH >= 64.  Ring span <= 3*CH-64 < RING.
     static constexpr int CH = (64 + NCOL - 1) / NCOL * NCOL;
-    template <int NW>
+    template <int NW, bool STG_ = false>
     __device__ __forceinline__ void run_mw(const DevJob &job, const DevSeqs &seqs, int *bnd, lds_int *rings,
-                                           int wid) {
+                                           int wid, lds_int *stage) {
+        // STG_ (the kernel decides): not the blocking kernels -- the blocked-row entries of a column travel with their per-step
+        // loads -- and not where the rings of an unpacked region pass on eight waves leave no room in the CU's 160 KB
+        constexpr bool STG = STG_;
+        static_assert(STG_CH == CH, "the stage is sized for run_mw's chunk");
         static_assert(!CONT && (MODE == MODE_SCORE || MODE == MODE_REGION), "multi-wave: full-rectangle passes");
         Q = job.Q; T = job.T; q0 = job.q0; t0 = job.t0;
         tshift = job.tshift;
@@ -1111,8 +1157,15 @@ struct WaveDP {
             auto group = [&](auto JI_, int s0) __attribute__((always_inline)) {
                 constexpr bool JI = decltype(JI_)::value != 0;
                 static_for<NCOL>([&](auto P_) __attribute__((always_inline)) { constexpr int P = P_;
-                    step<JI, P>(s0 + P, i0, first, last, bnd_in, bnd_out, nullptr, 0, nullptr, 1, 0);
+                    step<JI, P, STG>(s0 + P, i0, first, last, bnd_in, bnd_out, nullptr, 0, nullptr, 1, 0);
                 });
+            };
+            // the columns chunk k's steps read ahead: k CH + 1 ... k CH + CH (the lanes' columns of earlier chunks are in the ring)
+            auto refill = [&](int k) __attribute__((always_inline)) {
+                if constexpr (STG) {
+                    fill_stage(stage, k * CH + 1, 64);
+                    if constexpr (CH > 64) fill_stage(stage, k * CH + 65, CH - 64);
+                }
             };
             // every wave executes exactly nticks barriers: 2*wid before its first chunk, one after each
             // of its nchunks chunks, 2*(NW-1-wid) after its last
@@ -1120,18 +1173,28 @@ struct WaveDP {
             if (idle) {
                 for (int k = 0; k < nchunks; k++) __syncthreads();
             } else {
+                if constexpr (STG) {
+                    stage_base = (int)(unsigned)(size_t)stage;
+                    stage_a = stage_base + ((0 - lane) & (STG_COLS - 1)) * 4;
+                    fill_stage(stage, -63, 64);          // columns -63 ... 0: what the first steps of the lanes read
+                    prefetch_staged();
+                } else {
                     prefetch_column(0 - lane);
+                }
                 prefetch_carry(0, bnd_in);
                 int k = 0;
                 for (; k < nchunks && k * CH < main_lo; k++) {
+                    refill(k);
                     for (int s = k * CH; s < k * CH + CH; s += NCOL) group(IC<0>{}, s);
                     __syncthreads();
                 }
                 for (; k < nchunks && k * CH + CH - 1 <= main_hi; k++) {
+                    refill(k);
                     for (int s = k * CH; s < k * CH + CH; s += NCOL) group(IC<1>{}, s);
                     __syncthreads();
                 }
                 for (; k < nchunks; k++) {
+                    refill(k);
                     for (int s = k * CH; s < k * CH + CH; s += NCOL) group(IC<0>{}, s);
                     __syncthreads();
                 }
@@ -1435,6 +1498,9 @@ void viterbi_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *jobs,
     __shared__ int next_job;
     __shared__ int rings[(NW > 1 ? NW - 1 : 1) * DP::RING * DP::BND];
     __shared__ int wave_best[NW][8];
+    // the column stages (WaveDP::fill_stage): a plane is STG_COLS ints, aligned to its own size for the running address
+    constexpr bool STG = !SUB && (sizeof(int) * ((NW > 1 ? NW - 1 : 1) * DP::RING * DP::BND + NW * DP::STG_INTS) + sizeof(KParams) + sizeof(DevJob) + 1024 <= 160 * 1024);
+    __shared__ __attribute__((aligned(1024))) int stage_mem[STG ? NW * DP::STG_INTS : 1];
     {
         const int *src = reinterpret_cast<const int *>(kparams);
         int *dst = reinterpret_cast<int *>(&kp_lds);
@@ -1467,7 +1533,7 @@ void viterbi_kernel_mw(const KParams *kparams, DevSeqs seqs, const DevJob *jobs,
             if (threadIdx.x == 0) { corner_lds[2] = 0; hop_more = 0; }
             __syncthreads();
         }
-        dp.template run_mw<NW>(job, seqs, bnd, (typename DP::lds_int *)rings, wid);
+        dp.template run_mw<NW, STG>(job, seqs, bnd, (typename DP::lds_int *)rings, wid, (typename DP::lds_int *)stage_mem + (STG ? wid * DP::STG_INTS : 0));
         if constexpr (SEED == 2) {
             if (dp.corner_set) { corner_lds[0] = dp.corner[0]; corner_lds[1] = dp.corner[1]; corner_lds[2] = 1; }
         }
