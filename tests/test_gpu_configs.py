@@ -63,15 +63,17 @@ def test_c5_shape_protein2genome_shared_contig(eng):
     _check_against_windows(eng, ex.Model("protein2genome"), proteins, contig, places, 1000)
 
 
-def test_c5_exhaustive_shape_at_full_size_against_the_reference_records(eng):
+@pytest.mark.parametrize("name,model_name,n,tlen", [("c5", "protein2genome", 256, 10000000), ("c3", "protein2dna", 1024, 1000000)])
+def test_protein_configs_at_full_size_against_the_reference_records(eng, name, model_name, n, tlen):
     """BASELINE config 5's exhaustive shape at its size -- 256 proteins of 300 aa against ONE 10 Mb chromosome, protein2genome,
-    7.7 x 10^11 first-pass cells -- and every 64th alignment (score, region, operations) against the records the REFERENCE made for
-    them (tests/golden/bench_configs.json: refdump on each sampled protein and its window, tools/make_bench_golden.py).  Until
-    round 5 this comparison lived in bench.py only."""
+    7.7 x 10^11 first-pass cells -- and config 3 -- 1 024 proteins of 500 aa against ONE 1 Mb contig, protein2dna --: every 64th
+    alignment (score, region, operations) against the records the REFERENCE made for them (tests/golden/bench_configs.json:
+    refdump on each sampled protein and its window, tools/make_bench_golden.py).  Until round 5 this comparison lived in
+    bench.py only."""
     import json
-    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_configs.json")))["c5"]
-    model_name, pairs, _ = workloads.bench_config("c5")
-    assert model_name == "protein2genome" and len(pairs) == 256 and len(pairs[0][1]) == 10000000
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_configs.json")))[name]
+    got_model, pairs, _ = workloads.bench_config(name)
+    assert got_model == model_name and len(pairs) == n and len(pairs[0][1]) == tlen
     b = ex.ResidentBatch(eng, ex.Model(model_name), pairs)
     try:
         b.run(2)
