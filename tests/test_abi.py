@@ -24,6 +24,28 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert lib.c4gpu_abi_version() == _abi.ABI_VERSION == 9
 
 
+def test_switches_are_read_once_and_reloaded_on_request(lib, monkeypatch):
+    """csrc/c4_config.h: the library reads its C4GPU_* switches once; c4gpu_config_reload reads them again and says how many it
+    found set (the tests' hook -- exonerate_amd/_abi.py calls it whenever the process's variables changed); no source file of the
+    engine calls getenv."""
+    for k in [k for k in os.environ if k.startswith("C4GPU_")]:
+        monkeypatch.delenv(k)
+    assert lib.c4gpu_config_reload() == 0
+    monkeypatch.setenv("C4GPU_TRACE", "1")
+    monkeypatch.setenv("C4GPU_PK16", "0")
+    monkeypatch.setenv("C4GPU_NOT_A_SWITCH", "1")           # (not in the table: not counted)
+    assert lib.c4gpu_config_reload() == 2
+    monkeypatch.delenv("C4GPU_TRACE")
+    monkeypatch.delenv("C4GPU_PK16")
+    assert lib.c4gpu_config_reload() == 0
+    csrc = os.path.join(ROOT, "exonerate_amd", "csrc")
+    users = []
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".inc", ".h", ".cc")) and "getenv(" in re.sub(r"//[^\n]*", "", open(os.path.join(csrc, f)).read()):
+            users.append(f)
+    assert users == ["c4_config.h"], users
+
+
 def test_no_cpu_fallback(lib):
     import torch
     if torch.cuda.is_available():
