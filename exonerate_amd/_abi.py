@@ -291,6 +291,14 @@ def load(path=None):
         raise RuntimeError(
             "libc4gpu.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
             "there is no Python/CPU fallback for the C4 engine" % p)
+    # torch first, where there is one: it brings its own copy of the HIP runtime, and a process in which libc4gpu.so has pulled in
+    # /opt/rocm's before torch loads its own ends up with two runtimes, the first of which no longer finds the device
+    # ("no ROCm-capable device is detected" from c4gpu_ctx_create after `build(); smoke()` in one process).  Loaded second, the
+    # library binds to the runtime that is already there (same soname).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(p)
     lib.c4gpu_abi_version.restype = C.c_int
     if lib.c4gpu_abi_version() != ABI_VERSION:
