@@ -30,6 +30,9 @@ R = {("est2genome", "MODE_REGION"): 4, ("est2genome", "MODE_CKPT"): 3, ("est2gen
 # R=2/3 uncapped and R=4 at 1 wave/SIMD, profiles/r01_variants.md)
 # est2genome FIND_SCORE: 174 registers uncapped (185 with the column dumps) = 2 waves/SIMD; held to 168 it runs 3 (a
 # handful of scratch accesses outside the column loop)
+# est2genome FIND_PATH (one row per lane): 140 registers uncapped; its column loop needs fewer than 80, and held to 80 (six waves per
+# SIMD instead of the four of rounds 1-5) the loops stay free of scratch -- the pass waits half of its cycles, more waves hide it
+# (round 6: path pass 5.5 -> 5.1 ms on the north-star launch, both strands +4 %)
 CAP = {("est2genome", "MODE_REGION"): 2, ("est2genome", "MODE_CKPT"): 2, ("est2genome", "MODE_PATH"): 6,
        ("est2genome", "MODE_SCORE"): 3}
 # the unpacked region-start form (targets too long for (query_start << bits) | target_start in 31 bits)
