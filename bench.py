@@ -938,6 +938,9 @@ def main():
             out["configs"] = other_configs(ex, eng)
             if shard:
                 shard["frac_of_4096_pair_rate"] = shard["value"] / value
+                # what eight ranks would reach on BASELINE config 4 as worded (4 096 cDNAs per step cut into eight shards) if
+                # each aligned its shard at this rate: the work-queue collectives aside, 8 x the fraction
+                shard["projected_speedup_8gpu_strong"] = 8.0 * shard["frac_of_4096_pair_rate"]
                 out["configs"]["c4_shard512"] = shard
             if robust:
                 for rec in robust.values():
