@@ -101,7 +101,10 @@ def test_c4_north_star_batch_against_the_reference_binary(eng):
     """C4 at BASELINE's size (the configuration bench.py times): 4 096 cDNAs of 1 kb against their 100 kb windows in one
     batch, est2genome, -D 32.  Every pair must align; the vulgar lines of a sample — one pair per two host cores, up to 32,
     spread over the batch — are compared with the reference's own compiled exonerate run here (oracle/_ref, travels as a
-    binary)."""
+    binary).  Round 6: four of the sampled cDNAs also on their REVERSE strand -- what the reference aligns by
+    default for a DNA query (fastapipe.c:42-44): chance alignments that span most of their window, i.e. the wide-region route
+    (two dozen window hops, a checkpoint pass over the whole rectangle) -- against the reference run on the reverse-complemented
+    query."""
     import os, subprocess, tempfile
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "exonerate-compiled")
     if not os.path.exists(exe):
@@ -116,15 +119,26 @@ def test_c4_north_star_batch_against_the_reference_binary(eng):
         cores = os.cpu_count() or 1
     n = max(4, min(cores // 2, 32))          # (one reference process per TWO cores: as many as cores made each take twice as long)
     sample = [(k * 4096) // n for k in range(n)]
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    rsample = sample[1::max(1, n // 4)][:4]
+    rpairs = [(pairs[k][0].translate(comp)[::-1], pairs[k][1]) for k in rsample]
+    ralns = eng.find_path(model, rpairs, dpmemory=32)
     with tempfile.TemporaryDirectory() as d:
         procs = []
-        for k in sample:
-            open(os.path.join(d, "q%d.fa" % k), "w").write(">qy\n%s\n" % pairs[k][0].decode())
-            open(os.path.join(d, "t%d.fa" % k), "w").write(">tg\n%s\n" % pairs[k][1].decode())
+        for tag, k, (q, t) in [("f", k, pairs[k]) for k in sample] + [("r", k, rp) for k, rp in zip(rsample, rpairs)]:
+            open(os.path.join(d, "q%s%d.fa" % (tag, k)), "w").write(">qy\n%s\n" % q.decode())
+            open(os.path.join(d, "t%s%d.fa" % (tag, k)), "w").write(">tg\n%s\n" % t.decode())
             procs.append(subprocess.Popen([exe, "-m", "est2genome", "-E", "yes", "-S", "no", "--revcomp", "no", "--showalignment", "no",
-                                           "--showvulgar", "yes", "-V", "0", os.path.join(d, "q%d.fa" % k), os.path.join(d, "t%d.fa" % k)],
+                                           "--showvulgar", "yes", "-V", "0", os.path.join(d, "q%s%d.fa" % (tag, k)),
+                                           os.path.join(d, "t%s%d.fa" % (tag, k))],
                                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL))
         outs = [p.communicate(timeout=1500)[0].decode() for p in procs]
-    for k, o in zip(sample, outs):
+    for k, o in zip(sample, outs[:n]):
         ref = [l.strip() for l in o.splitlines() if l.startswith("vulgar:")]
         assert ref and alns[k].vulgar("qy", "tg") == ref[0], k
+    wide = 0
+    for k, a, o in zip(rsample, ralns, outs[n:]):
+        ref = [l.strip() for l in o.splitlines() if l.startswith("vulgar:")]
+        assert ref and a is not None and a.vulgar("qy", "tg") == ref[0], ("reverse strand", k)
+        wide += a.region[3] > 50000
+    assert wide >= 2                       # (chance alignments across most of the 100 kb window)
